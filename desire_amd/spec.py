@@ -1,0 +1,206 @@
+"""Frozen dimension / weight contract of the DESIRE hot path (host side, numpy only).
+
+The reference never finishes its graph, so the arithmetic this build
+commits to is written down here and in DESIGN.md section 2 ("frozen spec").  Reference anchors:
+
+* args fields and defaults ............ /root/reference/train.py:30-88, model/model.py:44-60
+* weight names/shapes the ref defines .. model/model.py:420-451 (temporal_w, w_hidden_enc1,
+                                          w_post_vae) + implicit TF/prettytensor scopes
+                                          model/model.py:126,136,143,233,238,257,279
+* CVAE layer stack ..................... model/model.py:453-492
+* the IOC / scene / social block ....... absent in the reference (model/model.py:312-313);
+                                          paper-defined, frozen in DESIGN.md section 2.
+
+Nothing here touches the GPU.  `Dims` is mirrored 1:1 by `struct desire_dims` in
+include/desire_hip.h.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+BN_EPS = 1e-3  # variance_epsilon, model/model.py:460,479
+
+
+@dataclass(frozen=True)
+class Dims:
+    """Static sizes of one forward call.  Row index r = (scene*K + k)*mno + slot."""
+
+    n_scenes: int = 1      # windows per call (DataLoader batch entries), each its own scene
+    mno: int = 32          # agent slots per window (max_num_obj), must divide 64
+    K: int = 20            # samples per agent
+    T_obs: int = 8
+    T_pred: int = 40
+    H: int = 128           # GRU hidden = args.d_dim (model/model.py:51,137)
+    L: int = 128           # latent_size
+    S: int = 32            # CVAE image side = int(sqrt(2*rnn_size)) (model/model.py:57-58)
+    C: int = 32            # scene feature channels
+    Gh: int = 64           # scene grid rows
+    Gw: int = 64           # scene grid cols
+    n_grids: int = 1       # distinct scene feature grids resident
+    grid_size: int = 4     # social grid side (train.py:71-72), B = grid_size**2
+    E_v: int = 16          # velocity embedding width
+    iters: int = 1         # IOC refinement iterations
+    posterior: int = 1     # 1: z = mu + sigma*eps (needs future), 0: z = eps (prior)
+    nb_w: float = 0.25     # social window width  (normalised units, = neighborhood_size*sx)
+    nb_h: float = 0.25     # social window height (normalised units)
+    sx: float = 1.0        # pixel -> normalised scale, x
+    sy: float = 1.0        # pixel -> normalised scale, y
+
+    @property
+    def A(self) -> int:
+        return self.n_scenes * self.mno
+
+    @property
+    def R(self) -> int:
+        return self.A * self.K
+
+    @property
+    def V(self) -> int:
+        return self.S * self.S
+
+    @property
+    def B(self) -> int:
+        return self.grid_size * self.grid_size
+
+    @property
+    def E(self) -> int:
+        """IOC GRU input width: [velocity embed | scene feature | social embed]."""
+        return self.E_v + self.C + self.H
+
+    def validate(self) -> None:
+        if self.S != 32:
+            raise ValueError("CVAE stack closes only for S=32 (rnn_size=512), model/model.py:465-468")
+        if 64 % self.mno != 0:
+            raise ValueError("mno must divide 64 (host pads max_num_obj up)")
+        if self.H % 32 or self.L % 8 or self.C % 8 or self.E_v % 8:
+            raise ValueError("H%32, L%8, C%8, E_v%8 required by the MFMA tiling")
+        if self.H > 128:
+            raise ValueError("H<=128 in this round (register-resident recurrent tile)")
+        if min(self.n_scenes, self.K, self.T_obs, self.T_pred, self.n_grids, self.iters) < 1:
+            raise ValueError("sizes must be >= 1")
+
+    def replace(self, **kw) -> "Dims":
+        return dataclasses.replace(self, **kw)
+
+
+def flops_per_sample(d: Dims) -> float:
+    """Algorithmic FLOPs per agent-trajectory-sample (multiply-add = 2),
+    re-derived for this spec's dims.  Used by bench.py for the MFMA roofline."""
+    H, L, V, Tp, To, K = d.H, d.L, d.V, d.T_pred, d.T_obs, d.K
+    f_dec_cvae = 2.0 * (16 * L * 128 + 16 * 128 * 25 * 64 + 64 * 64 * 25 * 32 + 256 * 32 * 25 * 1)
+    f_mask = 2.0 * V * H
+    f_dec_gru = Tp * (6.0 * H * 2 * H + 4 * H)
+    f_ioc = d.iters * (Tp * (6.0 * H * (d.E + H) + 2.0 * d.B * H * H + 2 * H + 2 * 2 * d.E_v)
+                       + 2.0 * H * 2 * Tp)
+    f_enc_cvae = 2.0 * (256 * 25 * 32 + 64 * 25 * 32 * 64 + 16 * 25 * 64 * 128 + 2048 * 2 * L)
+    per_agent = To * 6.0 * H * (2 + H) + 4.0 * H * V
+    if d.posterior:
+        per_agent += Tp * 6.0 * H * (2 + H) + f_enc_cvae
+    return f_dec_cvae + f_mask + f_dec_gru + f_ioc + per_agent / K
+
+
+# ------------------------------------------------------------------------------------------------
+# weight registry: name -> shape.  All fp32.  GRU layout follows TF-1.x GRUCell:
+#   gates/kernel [(in+H), 2H] (columns r|u), gates/bias [2H] (init 1.0),
+#   candidate/kernel [(in+H), H], candidate/bias [H]; rows ordered [input ; state].
+# conv kernels HWIO; transposed-conv kernels [kh, kw, out, in] (conv2d_transpose layout,
+# utils/convolutional_vae_util.py:83).  bn = (beta, gamma, moving_mean, moving_var).
+# ------------------------------------------------------------------------------------------------
+def weight_shapes(d: Dims) -> Dict[str, Tuple[int, ...]]:
+    H, L, V = d.H, d.L, d.V
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def gru(prefix: str, n_in: int) -> None:
+        s[prefix + "/gates/kernel"] = (n_in + H, 2 * H)
+        s[prefix + "/gates/bias"] = (2 * H,)
+        s[prefix + "/candidate/kernel"] = (n_in + H, H)
+        s[prefix + "/candidate/bias"] = (H,)
+
+    def bn(prefix: str, c: int) -> None:
+        for n in ("beta", "gamma", "moving_mean", "moving_var"):
+            s[prefix + "/bn/" + n] = (c,)
+
+    gru("enc_x", 2)                      # model/model.py:136-141,233-236
+    gru("enc_y", 2)                      # model/model.py:143-148,238-241
+    s["fc_c/w"] = (2 * H, V)             # w_hidden_enc1, model/model.py:434-437
+    s["fc_c/b"] = (V,)
+    for name, kk, ci, co in (("conv1", 5, 1, 32), ("conv2", 5, 32, 64), ("conv3", 5, 64, 128)):
+        s[f"vae_enc/{name}/w"] = (kk, kk, ci, co)     # model/model.py:484-486
+        s[f"vae_enc/{name}/b"] = (co,)
+        bn(f"vae_enc/{name}", co)
+    s["vae_enc/fc/w"] = (2048, 2 * L)    # model/model.py:488
+    s["vae_enc/fc/b"] = (2 * L,)
+    for name, kk, co, ci in (("deconv1", 4, 128, L), ("deconv2", 5, 64, 128),
+                             ("deconv3", 5, 32, 64), ("deconv4", 5, 1, 32)):
+        s[f"vae_dec/{name}/w"] = (kk, kk, co, ci)     # model/model.py:465-468
+        s[f"vae_dec/{name}/b"] = (co,)
+        bn(f"vae_dec/{name}", co)
+    s["mask_fc/w"] = (V, H)              # w_post_vae, model/model.py:439-443
+    s["mask_fc/b"] = (H,)
+    gru("dec", H)                        # scope hidden_states, model/model.py:279-285
+    s["head/w"] = (H, 2)                 # the ref's commented-out output layer, :315-321,445-449
+    s["head/b"] = (2,)
+    # ---- IOC block (paper-defined) ----
+    s["ioc/vel_fc/w"] = (2, d.E_v)
+    s["ioc/vel_fc/b"] = (d.E_v,)
+    s["ioc/social_fc/w"] = (d.B * H, H)
+    s["ioc/social_fc/b"] = (H,)
+    gru("ioc", d.E)
+    s["ioc/score/w"] = (H, 1)
+    s["ioc/score/b"] = (1,)
+    s["ioc/reg/w"] = (H, 2 * d.T_pred)
+    s["ioc/reg/b"] = (2 * d.T_pred,)
+    return s
+
+
+def init_weights(d: Dims, seed: int = 0, ref_init: bool = False) -> Dict[str, np.ndarray]:
+    """Deterministic random-init weights.
+
+    ref_init=True reproduces the reference's literal initialisers where it states them
+    (N(0,1) for fc_c / mask_fc, model/model.py:434-443) -- those saturate every downstream
+    nonlinearity, so the default uses fan-in scaled normals (what xavier_init does for the
+    prettytensor layers, utils/convolutional_vae_util.py:86-90) everywhere.  GRU gate bias is
+    1.0 as in TF GRUCell (bias_start=1.0)."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    for name, shape in weight_shapes(d).items():
+        if name.endswith("gates/bias"):
+            a = np.ones(shape, np.float32)
+        elif name.endswith("/bn/gamma"):
+            a = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("/bn/moving_var"):
+            a = (0.5 + rng.random(shape)).astype(np.float32)
+        elif name.endswith("/bn/beta") or name.endswith("/bn/moving_mean"):
+            a = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("/b") or name.endswith("/bias"):
+            a = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        elif ref_init and name in ("fc_c/w", "mask_fc/w"):
+            a = rng.standard_normal(shape).astype(np.float32)
+        else:
+            if len(shape) == 4:          # conv / deconv: fan-in = kh*kw*in
+                fan_in = shape[0] * shape[1] * (shape[2] if "vae_enc" in name else shape[3])
+            else:
+                fan_in = shape[0]
+            a = (rng.standard_normal(shape) / np.sqrt(max(fan_in, 1))).astype(np.float32)
+        w[name] = np.ascontiguousarray(a)
+    return w
+
+
+def fold_bn(w: Dict[str, np.ndarray], prefix: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Frozen (inference-phase) batch-norm + layer bias folded to per-channel (scale, shift):
+    y = scale * conv + shift, scale = gamma/sqrt(var+eps), shift = beta + scale*(b - mean).
+    prettytensor batch_normalize with scale_after_normalization=True, variance_epsilon=1e-3
+    (model/model.py:457-462).  Computed in float64 then rounded once, identically on every
+    caller (oracle and product both call this function)."""
+    g = w[prefix + "/bn/gamma"].astype(np.float64)
+    beta = w[prefix + "/bn/beta"].astype(np.float64)
+    mean = w[prefix + "/bn/moving_mean"].astype(np.float64)
+    var = w[prefix + "/bn/moving_var"].astype(np.float64)
+    b = w[prefix + "/b"].astype(np.float64)
+    scale = g / np.sqrt(var + BN_EPS)
+    shift = beta + scale * (b - mean)
+    return scale.astype(np.float32), shift.astype(np.float32)
