@@ -1,0 +1,148 @@
+"""ctypes binding of libdesire_hip.so (include/desire_hip.h).  This is the ONLY compute path of
+the package: if the library is missing or no gfx950 device is present, calls raise -- there is
+no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .spec import Dims
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdesire_hip.so")
+
+EXPORTS = [
+    "desire_last_error", "desire_version", "desire_create", "desire_destroy", "desire_set_weight",
+    "desire_finalize_weights", "desire_set_scene_grids", "desire_encode", "desire_sample",
+    "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
+    "desire_scene_cells", "desire_set_profiling", "desire_get_profile",
+]
+
+
+class DesireDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_scenes", "mno", "K", "T_obs", "T_pred", "H", "L", "S", "C", "Gh", "Gw", "n_grids",
+                 "grid_size", "E_v", "iters", "posterior")] + \
+               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")]
+
+    @classmethod
+    def from_dims(cls, d: Dims) -> "DesireDims":
+        return cls(d.n_scenes, d.mno, d.K, d.T_obs, d.T_pred, d.H, d.L, d.S, d.C, d.Gh, d.Gw, d.n_grids,
+                   d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy)
+
+
+class DesireError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (building is __graft_entry__.build()'s job, never done here)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DesireError(
+            "libdesire_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "desire_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
+    lib.desire_last_error.restype = C.c_char_p
+    lib.desire_create.argtypes = [C.POINTER(DesireDims), C.POINTER(vp)]
+    lib.desire_destroy.argtypes = [vp]
+    lib.desire_set_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
+    lib.desire_finalize_weights.argtypes = [vp]
+    lib.desire_set_scene_grids.argtypes = [vp, f32p, C.POINTER(C.c_int32)]
+    lib.desire_encode.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_sample.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_ioc_refine.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_forward.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.desire_read_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
+    lib.desire_neighbor_bins.argtypes = [vp, f32p, vp, vp, i32, vp]
+    lib.desire_scene_cells.argtypes = [vp, f32p, vp, i32, vp]
+    lib.desire_set_profiling.argtypes = [vp, C.c_int]
+    lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
+    for n in EXPORTS:
+        if n != "desire_last_error":
+            getattr(lib, n).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _chk(rc: int) -> None:
+    if rc != 0:
+        raise DesireError("libdesire_hip error %d: %s" % (rc, load().desire_last_error().decode()))
+
+
+class Handle:
+    """Thin owner of one desire_handle*.  All device pointers are raw integers (torch .data_ptr())."""
+
+    def __init__(self, dims: Dims):
+        dims.validate()
+        self.dims = dims
+        self.lib = load()
+        self._h = C.c_void_p()
+        cd = DesireDims.from_dims(dims)
+        _chk(self.lib.desire_create(C.byref(cd), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.desire_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            _chk(self.lib.desire_set_weight(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+        _chk(self.lib.desire_finalize_weights(self._h))
+
+    def set_scene_grids(self, dev_grids_ptr: int, grid_of_scene) -> None:
+        g = np.ascontiguousarray(grid_of_scene, dtype=np.int32)
+        if g.size != self.dims.n_scenes:
+            raise DesireError("grid_of_scene must have n_scenes entries")
+        _chk(self.lib.desire_set_scene_grids(self._h, dev_grids_ptr, g.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def encode(self, past_ptr: int, fut_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_encode(self._h, past_ptr, fut_ptr or None, stream or None))
+
+    def sample(self, eps_ptr: int, yhat_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_sample(self._h, eps_ptr, yhat_ptr, stream or None))
+
+    def ioc_refine(self, yhat_ptr: int, score_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_ioc_refine(self._h, yhat_ptr, score_ptr, stream or None))
+
+    def forward(self, past_ptr: int, fut_ptr: int, eps_ptr: int, yhat_ptr: int, score_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_forward(self._h, past_ptr, fut_ptr or None, eps_ptr, yhat_ptr, score_ptr, stream or None))
+
+    def read_buffer(self, name: str, shape: Tuple[int, ...], stream: int = 0) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        _chk(self.lib.desire_read_buffer(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size,
+                                         stream or None))
+        return out
+
+    def neighbor_bins(self, pos_ptr: int, valid_ptr: int, bins_ptr: int, n_groups: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_neighbor_bins(self._h, pos_ptr, valid_ptr, bins_ptr, n_groups, stream or None))
+
+    def scene_cells(self, pos_ptr: int, cells_ptr: int, n: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_scene_cells(self._h, pos_ptr, cells_ptr, n, stream or None))
+
+    def set_profiling(self, on: bool) -> None:
+        _chk(self.lib.desire_set_profiling(self._h, int(on)))
+
+    def get_profile(self) -> List[Tuple[str, float]]:
+        cap = 64
+        ms = (C.c_float * cap)()
+        names = (C.c_char_p * cap)()
+        n = C.c_int32(cap)
+        _chk(self.lib.desire_get_profile(self._h, ms, names, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

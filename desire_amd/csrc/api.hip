@@ -1,0 +1,502 @@
+// api.hip -- C ABI of libdesire_hip.so (include/desire_hip.h): handle, weight repacking into MFMA
+// B-fragment order, workspace, and the launch sequence of the hot path.  Host code only.
+#include "../../include/desire_hip.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(DESIRE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+extern "C" const char* desire_last_error(void) { return g_err.c_str(); }
+extern "C" int desire_version(void) { return 1; }
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int alloc(size_t b) {
+        bytes = b;
+        hipError_t e = hipMalloc(&p, b ? b : 4);
+        return e == hipSuccess ? 0 : -1;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+struct Prof { std::string name; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct desire_ctx {
+    desire_dims d;
+    int A, R, V, B, E;
+    std::map<std::string, std::vector<float>> host_w;       // raw weights as set
+    std::map<std::string, size_t> want;                      // name -> element count
+    std::map<std::string, DevBuf> dev;                       // raw / packed / folded device tensors
+    std::map<std::string, DevBuf> ws;                        // workspace
+    bool finalized = false;
+    const float* grids = nullptr;
+    bool grids_set = false;
+    bool profiling = false;
+    std::vector<Prof> prof;
+    std::vector<float> prof_ms;
+    std::vector<const char*> prof_names;
+};
+
+namespace {
+
+// Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
+std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at) {
+    const int G = (K + 7) / 8, NT = (N + 31) / 32;
+    std::vector<float> out((size_t)NT * G * 64 * 4, 0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int g = 0; g < G; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 8 * g + 4 * (lane >> 5) + i, n = nt * 32 + (lane & 31);
+                    if (k < K && n < N) out[(((size_t)nt * G + g) * 64 + lane) * 4 + i] = at(k, n);
+                }
+    return out;
+}
+
+int upload(desire_ctx* h, const std::string& name, const std::vector<float>& v) {
+    DevBuf& b = h->dev[name];
+    b.release();
+    if (b.alloc(v.size() * sizeof(float))) return -1;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
+const float* D(desire_ctx* h, const char* name) { return h->dev.at(name).f(); }
+const float4* D4(desire_ctx* h, const char* name) { return reinterpret_cast<const float4*>(h->dev.at(name).f()); }
+float* W(desire_ctx* h, const char* name) { return h->ws.at(name).f(); }
+
+void shapes(desire_ctx* h) {
+    const desire_dims& d = h->d;
+    const int H = d.H, L = d.L, V = h->V;
+    auto& s = h->want;
+    auto gru = [&](const std::string& p, int n_in) {
+        s[p + "/gates/kernel"] = (size_t)(n_in + H) * 2 * H;
+        s[p + "/gates/bias"] = 2 * H;
+        s[p + "/candidate/kernel"] = (size_t)(n_in + H) * H;
+        s[p + "/candidate/bias"] = H;
+    };
+    auto bn = [&](const std::string& p, int c) {
+        for (const char* n : {"beta", "gamma", "moving_mean", "moving_var"}) s[p + "/bn/" + n] = c;
+    };
+    gru("enc_x", 2); gru("enc_y", 2);
+    s["fc_c/w"] = (size_t)2 * H * V; s["fc_c/b"] = V;
+    struct CL { const char* n; int k, ci, co; };
+    for (CL c : {CL{"conv1", 5, 1, 32}, CL{"conv2", 5, 32, 64}, CL{"conv3", 5, 64, 128}}) {
+        const std::string p = std::string("vae_enc/") + c.n;
+        s[p + "/w"] = (size_t)c.k * c.k * c.ci * c.co; s[p + "/b"] = c.co; bn(p, c.co);
+    }
+    s["vae_enc/fc/w"] = (size_t)2048 * 2 * L; s["vae_enc/fc/b"] = 2 * L;
+    for (CL c : {CL{"deconv1", 4, L, 128}, CL{"deconv2", 5, 128, 64}, CL{"deconv3", 5, 64, 32}, CL{"deconv4", 5, 32, 1}}) {
+        const std::string p = std::string("vae_dec/") + c.n;
+        s[p + "/w"] = (size_t)c.k * c.k * c.ci * c.co; s[p + "/b"] = c.co; bn(p, c.co);
+    }
+    s["mask_fc/w"] = (size_t)V * H; s["mask_fc/b"] = H;
+    gru("dec", H);
+    s["head/w"] = 2 * H; s["head/b"] = 2;
+    s["ioc/vel_fc/w"] = 2 * d.E_v; s["ioc/vel_fc/b"] = d.E_v;
+    s["ioc/social_fc/w"] = (size_t)h->B * H * H; s["ioc/social_fc/b"] = H;
+    gru("ioc", h->E);
+    s["ioc/score/w"] = H; s["ioc/score/b"] = 1;
+    s["ioc/reg/w"] = (size_t)H * 2 * d.T_pred; s["ioc/reg/b"] = 2 * d.T_pred;
+}
+
+// frozen batch-norm + bias -> (scale, shift); float64 then one rounding (desire_amd/spec.py:fold_bn)
+void fold_bn(desire_ctx* h, const std::string& p, std::vector<float>& scale, std::vector<float>& shift) {
+    const auto& g = h->host_w.at(p + "/bn/gamma"); const auto& be = h->host_w.at(p + "/bn/beta");
+    const auto& mu = h->host_w.at(p + "/bn/moving_mean"); const auto& var = h->host_w.at(p + "/bn/moving_var");
+    const auto& b = h->host_w.at(p + "/b");
+    scale.resize(g.size()); shift.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        const double sc = (double)g[i] / std::sqrt((double)var[i] + 1e-3);
+        scale[i] = (float)sc;
+        shift[i] = (float)((double)be[i] + sc * ((double)b[i] - (double)mu[i]));
+    }
+}
+
+int check_dims(const desire_dims& d) {
+    if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
+    if (d.mno < 1 || d.mno > 64 || 64 % d.mno) return fail(DESIRE_ERR_ARG, "mno must divide 64");
+    if (d.H != 32 && d.H != 64 && d.H != 128) return fail(DESIRE_ERR_ARG, "H must be 32, 64 or 128 in this round");
+    if (d.L % 8 || d.L < 8) return fail(DESIRE_ERR_ARG, "L must be a positive multiple of 8");
+    if (d.C != 32 || d.E_v != 16) return fail(DESIRE_ERR_ARG, "C=32 and E_v=16 are the instantiated IOC widths in this round");
+    if (d.n_scenes < 1 || d.K < 1 || d.T_obs < 1 || d.T_pred < 1 || d.n_grids < 1 || d.iters < 1 || d.Gh < 1 || d.Gw < 1)
+        return fail(DESIRE_ERR_ARG, "sizes must be >= 1");
+    if (d.grid_size < 1 || d.grid_size > 4) return fail(DESIRE_ERR_ARG, "grid_size 1..4 in this round (LDS budget)");
+    if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
+    return 0;
+}
+
+struct Timer {
+    desire_ctx* h; hipStream_t s; bool on;
+    Timer(desire_ctx* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profiling) {
+        if (!on) return;
+        Prof p; p.name = name;
+        (void)hipEventCreate(&p.e0); (void)hipEventCreate(&p.e1);
+        (void)hipEventRecord(p.e0, s);
+        h->prof.push_back(p);
+    }
+    ~Timer() { if (on) (void)hipEventRecord(h->prof.back().e1, s); }
+};
+
+}  // namespace
+
+extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
+    if (!dims || !out) return fail(DESIRE_ERR_ARG, "null argument");
+    if (int rc = check_dims(*dims)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(DESIRE_ERR_NODEV, "no HIP device: libdesire_hip has no CPU path");
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DESIRE_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    desire_ctx* h = new desire_ctx();
+    h->d = *dims;
+    h->A = dims->n_scenes * dims->mno;
+    h->R = h->A * dims->K;
+    h->V = dims->S * dims->S;
+    h->B = dims->grid_size * dims->grid_size;
+    h->E = dims->E_v + dims->C + dims->H;
+    shapes(h);
+    const desire_dims& d = h->d;
+    const size_t A = h->A, R = h->R, f = sizeof(float);
+    struct WS { const char* n; size_t bytes; };
+    const WS list[] = {
+        {"HxHy", A * 2 * d.H * f}, {"p_last", A * 2 * f}, {"valid", A}, {"vae_in", A * h->V * f},
+        {"c1", A * 8192 * f}, {"c2", A * 4096 * f}, {"c3", A * 2048 * f}, {"params", A * 2 * d.L * f},
+        {"z", R * d.L * f}, {"d1", R * 2048 * f}, {"d2", R * 4096 * f}, {"d3", R * 8192 * f},
+        {"xhat", R * 1024 * f}, {"xz", R * d.H * f}, {"Y0", R * d.T_pred * 2 * f},
+        {"grid_of_scene", (size_t)d.n_scenes * sizeof(int32_t)},
+    };
+    for (const WS& w : list) {
+        if (h->ws[w.n].alloc(w.bytes)) { desire_destroy(h); return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n); }
+        (void)hipMemset(h->ws[w.n].p, 0, w.bytes);
+    }
+    *out = h;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_destroy(desire_handle* h) {
+    if (!h) return DESIRE_OK;
+    for (auto& kv : h->dev) kv.second.release();
+    for (auto& kv : h->ws) kv.second.release();
+    for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    delete h;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_set_weight(desire_handle* h, const char* name, const float* host_data, size_t n) {
+    if (!h || !name || !host_data) return fail(DESIRE_ERR_ARG, "null argument");
+    auto it = h->want.find(name);
+    if (it == h->want.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
+    if (it->second != n)
+        return fail(DESIRE_ERR_ARG, std::string("weight ") + name + ": expected " + std::to_string(it->second) +
+                                        " values, got " + std::to_string(n));
+    h->host_w[name].assign(host_data, host_data + n);
+    h->finalized = false;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_finalize_weights(desire_handle* h) {
+    if (!h) return fail(DESIRE_ERR_ARG, "null handle");
+    for (auto& kv : h->want)
+        if (!h->host_w.count(kv.first)) return fail(DESIRE_ERR_STATE, "weight not set: " + kv.first);
+    const desire_dims& d = h->d;
+    const int H = d.H, L = d.L, V = h->V, E = h->E, B = h->B;
+    auto& hw = h->host_w;
+    auto up = [&](const std::string& n, const std::vector<float>& v) { return upload(h, n, v); };
+    auto rowmajor = [](const std::vector<float>& w, int ldw, int k0) {
+        return [&w, ldw, k0](int k, int n) { return w[(size_t)(k0 + k) * ldw + n]; };
+    };
+    int bad = 0;
+    // GRUs: raw kernels/biases + packed sub-blocks
+    for (const char* p : {"enc_x", "enc_y"}) {
+        const std::string s(p);
+        bad |= up(s + "/gk", hw[s + "/gates/kernel"]);   bad |= up(s + "/gb", hw[s + "/gates/bias"]);
+        bad |= up(s + "/ck", hw[s + "/candidate/kernel"]); bad |= up(s + "/cb", hw[s + "/candidate/bias"]);
+        bad |= up(s + "/Whg", pack_b(H, 2 * H, rowmajor(hw[s + "/gates/kernel"], 2 * H, 2)));
+        bad |= up(s + "/Whc", pack_b(H, H, rowmajor(hw[s + "/candidate/kernel"], H, 2)));
+    }
+    bad |= up("dec/gb", hw["dec/gates/bias"]); bad |= up("dec/cb", hw["dec/candidate/bias"]);
+    bad |= up("dec/Wxg", pack_b(H, 2 * H, rowmajor(hw["dec/gates/kernel"], 2 * H, 0)));
+    bad |= up("dec/Whg", pack_b(H, 2 * H, rowmajor(hw["dec/gates/kernel"], 2 * H, H)));
+    bad |= up("dec/Wxc", pack_b(H, H, rowmajor(hw["dec/candidate/kernel"], H, 0)));
+    bad |= up("dec/Whc", pack_b(H, H, rowmajor(hw["dec/candidate/kernel"], H, H)));
+    bad |= up("head/w", hw["head/w"]); bad |= up("head/b", hw["head/b"]);
+    bad |= up("ioc/gb", hw["ioc/gates/bias"]); bad |= up("ioc/cb", hw["ioc/candidate/bias"]);
+    bad |= up("ioc/Wg", pack_b(E + H, 2 * H, rowmajor(hw["ioc/gates/kernel"], 2 * H, 0)));
+    bad |= up("ioc/Wc", pack_b(E + H, H, rowmajor(hw["ioc/candidate/kernel"], H, 0)));
+    bad |= up("ioc/vel_w", hw["ioc/vel_fc/w"]); bad |= up("ioc/vel_b", hw["ioc/vel_fc/b"]);
+    {
+        std::vector<float> all;
+        for (int b = 0; b < B; ++b) {
+            auto pk = pack_b(H, H, rowmajor(hw["ioc/social_fc/w"], H, b * H));
+            all.insert(all.end(), pk.begin(), pk.end());
+        }
+        bad |= up("ioc/Wsoc", all);
+    }
+    bad |= up("ioc/soc_b", hw["ioc/social_fc/b"]);
+    bad |= up("ioc/score_w", hw["ioc/score/w"]); bad |= up("ioc/score_b", hw["ioc/score/b"]);
+    bad |= up("ioc/Wreg", pack_b(H, 2 * d.T_pred, rowmajor(hw["ioc/reg/w"], 2 * d.T_pred, 0)));
+    bad |= up("ioc/reg_b", hw["ioc/reg/b"]);
+    // dense layers
+    bad |= up("fc_c/W", pack_b(2 * H, V, rowmajor(hw["fc_c/w"], V, 0)));  bad |= up("fc_c/b", hw["fc_c/b"]);
+    bad |= up("vae_enc/fc/W", pack_b(2048, 2 * L, rowmajor(hw["vae_enc/fc/w"], 2 * L, 0)));
+    bad |= up("vae_enc/fc/b", hw["vae_enc/fc/b"]);
+    bad |= up("mask/W", pack_b(V, H, rowmajor(hw["mask_fc/w"], H, 0)));  bad |= up("mask/b", hw["mask_fc/b"]);
+    // conv stack: folded batch-norm + packed taps
+    std::vector<float> sc, sh;
+    for (const char* n : {"vae_enc/conv1", "vae_enc/conv2", "vae_enc/conv3", "vae_dec/deconv1", "vae_dec/deconv2",
+                          "vae_dec/deconv3", "vae_dec/deconv4"}) {
+        fold_bn(h, n, sc, sh);
+        bad |= up(std::string(n) + "/scale", sc); bad |= up(std::string(n) + "/shift", sh);
+    }
+    bad |= up("vae_enc/conv1/raw", hw["vae_enc/conv1/w"]);
+    bad |= up("vae_dec/deconv4/raw", hw["vae_dec/deconv4/w"]);
+    auto pack_taps = [&](const std::vector<float>& w, int CI, int CO, bool transposed) {
+        std::vector<float> all;   // forward conv: w[tap][ci][co]; transposed conv: w[tap][co][ci]
+        for (int tap = 0; tap < 25; ++tap) {
+            const float* base = w.data() + (size_t)tap * CI * CO;
+            auto pk = pack_b(CI, CO, [&](int k, int n) { return transposed ? base[(size_t)n * CI + k] : base[(size_t)k * CO + n]; });
+            all.insert(all.end(), pk.begin(), pk.end());
+        }
+        return all;
+    };
+    bad |= up("vae_enc/conv2/W", pack_taps(hw["vae_enc/conv2/w"], 32, 64, false));
+    bad |= up("vae_enc/conv3/W", pack_taps(hw["vae_enc/conv3/w"], 64, 128, false));
+    bad |= up("vae_dec/deconv2/W", pack_taps(hw["vae_dec/deconv2/w"], 128, 64, true));
+    bad |= up("vae_dec/deconv3/W", pack_taps(hw["vae_dec/deconv3/w"], 64, 32, true));
+    {   // deconv1 as GEMM: B(k = ci, n = (ky*4+kx)*128 + co) = w[n*L + k]
+        const auto& w1 = hw["vae_dec/deconv1/w"];
+        bad |= up("vae_dec/deconv1/W", pack_b(L, 2048, [&](int k, int n) { return w1[(size_t)n * L + k]; }));
+    }
+    if (bad) return fail(DESIRE_ERR_HIP, "weight upload failed");
+    HIPCHK(hipDeviceSynchronize());
+    h->finalized = true;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_set_scene_grids(desire_handle* h, const float* dev_grids, const int32_t* host_grid_of_scene) {
+    if (!h || !dev_grids || !host_grid_of_scene) return fail(DESIRE_ERR_ARG, "null argument");
+    for (int i = 0; i < h->d.n_scenes; ++i)
+        if (host_grid_of_scene[i] < 0 || host_grid_of_scene[i] >= h->d.n_grids)
+            return fail(DESIRE_ERR_ARG, "grid_of_scene entry out of range");
+    HIPCHK(hipMemcpy(h->ws["grid_of_scene"].p, host_grid_of_scene, h->d.n_scenes * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->grids = dev_grids;
+    h->grids_set = true;
+    return DESIRE_OK;
+}
+
+static int ready(desire_handle* h) {
+    if (!h) return fail(DESIRE_ERR_ARG, "null handle");
+    if (!h->finalized) return fail(DESIRE_ERR_STATE, "weights not finalized (desire_finalize_weights)");
+    return 0;
+}
+
+extern "C" int desire_encode(desire_handle* h, const float* dev_past, const float* dev_fut, void* stream) {
+    if (int rc = ready(h)) return rc;
+    const desire_dims& d = h->d;
+    if (!dev_past) return fail(DESIRE_ERR_ARG, "dev_past is null");
+    if (d.posterior && !dev_fut) return fail(DESIRE_ERR_ARG, "dims.posterior=1 needs dev_fut");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = d.H, A = h->A;
+    EncArgs e{};
+    e.n_scenes = d.n_scenes; e.mno = d.mno; e.sx = d.sx; e.sy = d.sy; e.H = H;
+    e.frames = dev_past; e.T = d.T_obs;
+    e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
+    e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
+    e.out = W(h, "HxHy"); e.ldo = 2 * H; e.p_last = W(h, "p_last"); e.valid = static_cast<uint8_t*>(h->ws["valid"].p);
+    { Timer t(h, s, "encoder_x"); launch_encoder(e, s); }
+    if (d.posterior) {
+        e.frames = dev_fut; e.T = d.T_pred;
+        e.wx_g = D(h, "enc_y/gk"); e.b_g = D(h, "enc_y/gb"); e.wx_c = D(h, "enc_y/ck"); e.b_c = D(h, "enc_y/cb");
+        e.Whg = D4(h, "enc_y/Whg"); e.Whc = D4(h, "enc_y/Whc");
+        e.out = W(h, "HxHy") + H; e.p_last = nullptr; e.valid = nullptr;
+        { Timer t(h, s, "encoder_y"); launch_encoder(e, s); }
+        GemmArgs g{};
+        g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
+        g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");
+        { Timer t(h, s, "fc_c"); launch_gemm_rows(g, EPI_BIAS_RELU, s); }
+        ConvArgs c{};
+        c.n = A;
+        c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
+        c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
+        { Timer t(h, s, "conv1"); launch_conv1(c, s); }
+        c.in = W(h, "c1"); c.out = W(h, "c2"); c.Wp = D4(h, "vae_enc/conv2/W");
+        c.scale = D(h, "vae_enc/conv2/scale"); c.shift = D(h, "vae_enc/conv2/shift");
+        { Timer t(h, s, "conv2"); launch_conv2(c, s); }
+        c.in = W(h, "c2"); c.out = W(h, "c3"); c.Wp = D4(h, "vae_enc/conv3/W");
+        c.scale = D(h, "vae_enc/conv3/scale"); c.shift = D(h, "vae_enc/conv3/shift");
+        { Timer t(h, s, "conv3"); launch_conv3(c, s); }
+        g = GemmArgs{};
+        g.A = W(h, "c3"); g.lda = 2048; g.M = A; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
+        g.NT = (2 * d.L + 31) / 32; g.out = W(h, "params"); g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
+        { Timer t(h, s, "vae_enc_fc"); launch_gemm_rows(g, EPI_BIAS, s); }
+    }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_Yhat, void* stream) {
+    if (int rc = ready(h)) return rc;
+    if (!dev_eps || !dev_Yhat) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = d.H, R = h->R;
+    { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
+    GemmArgs g{};
+    g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
+    g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
+    g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
+    { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
+    ConvArgs c{};
+    c.n = R;
+    c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
+    c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
+    { Timer t(h, s, "deconv2"); launch_deconv2(c, s); }
+    c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
+    c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
+    { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
+    c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
+    c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
+    { Timer t(h, s, "deconv4"); launch_deconv4(c, s); }
+    MaskArgs m{};
+    m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;
+    m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
+    { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
+    DecArgs a{};
+    a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");
+    a.R = R; a.K = d.K; a.mno = d.mno; a.H = H; a.T = d.T_pred;
+    a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
+    a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
+    a.Y = W(h, "Y0"); a.hdump = nullptr;
+    { Timer t(h, s, "decoder"); launch_decoder(a, s); }
+    HIPCHK(hipMemcpyAsync(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream) {
+    if (int rc = ready(h)) return rc;
+    if (!dev_Yhat || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!h->grids_set) return fail(DESIRE_ERR_STATE, "scene grids not set (desire_set_scene_grids)");
+    const desire_dims& d = h->d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    IocArgs a{};
+    a.Y = dev_Yhat; a.score = dev_score; a.Hx = W(h, "HxHy"); a.ldhx = 2 * d.H; a.p_last = W(h, "p_last");
+    a.valid = static_cast<const uint8_t*>(h->ws["valid"].p);
+    a.R = h->R; a.K = d.K; a.mno = d.mno; a.H = d.H; a.T = d.T_pred; a.iters = d.iters;
+    a.C = d.C; a.Gh = d.Gh; a.Gw = d.Gw; a.E_v = d.E_v; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;
+    a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
+    a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b");
+    a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b");
+    a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
+    a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
+    a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
+    { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_forward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps,
+                              float* dev_Yhat, float* dev_score, void* stream) {
+    if (h && h->profiling) {
+        for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+        h->prof.clear();
+    }
+    if (int rc = desire_encode(h, dev_past, dev_fut, stream)) return rc;
+    if (int rc = desire_sample(h, dev_eps, dev_Yhat, stream)) return rc;
+    return desire_ioc_refine(h, dev_Yhat, dev_score, stream);
+}
+
+extern "C" int desire_read_buffer(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
+    if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(hipStreamSynchronize(s));
+    const desire_dims& d = h->d;
+    const size_t A = h->A, R = h->R, f = sizeof(float);
+    const std::string nm(name);
+    auto strided = [&](const float* src, size_t cols, size_t pitch_cols, size_t rows) -> int {
+        if (n != rows * cols) return fail(DESIRE_ERR_ARG, nm + ": expected " + std::to_string(rows * cols) + " values");
+        HIPCHK(hipMemcpy2D(host_out, cols * f, src, pitch_cols * f, cols * f, rows, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    if (nm == "Hx") return strided(W(h, "HxHy"), d.H, 2 * d.H, A);
+    if (nm == "Hy") return strided(W(h, "HxHy") + d.H, d.H, 2 * d.H, A);
+    if (nm == "z_mean") return strided(W(h, "params"), d.L, 2 * d.L, A);
+    if (nm == "z_log_sigma_sq") return strided(W(h, "params") + d.L, d.L, 2 * d.L, A);
+    struct P { const char* n; size_t cnt; };
+    const P plain[] = {{"vae_in", A * h->V}, {"c1", A * 8192}, {"c2", A * 4096}, {"c3", A * 2048}, {"z", R * d.L},
+                       {"d1", R * 2048}, {"d2", R * 4096}, {"d3", R * 8192}, {"xhat", R * 1024}, {"xz", R * d.H},
+                       {"Y0", R * d.T_pred * 2}, {"p_last", A * 2}};
+    for (const P& p : plain)
+        if (nm == p.n) {
+            if (n != p.cnt) return fail(DESIRE_ERR_ARG, nm + ": expected " + std::to_string(p.cnt) + " values");
+            HIPCHK(hipMemcpy(host_out, W(h, p.n), p.cnt * f, hipMemcpyDeviceToHost));
+            return DESIRE_OK;
+        }
+    return fail(DESIRE_ERR_ARG, "unknown buffer: " + nm);
+}
+
+extern "C" int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* dev_valid,
+                                    int32_t* dev_bins, int32_t n_groups, void* stream) {
+    if (!h || !dev_pos || !dev_valid || !dev_bins || n_groups < 0) return fail(DESIRE_ERR_ARG, "bad argument");
+    if (n_groups == 0) return DESIRE_OK;
+    launch_neighbor_bins(dev_pos, dev_valid, dev_bins, n_groups, h->d.mno, h->d.nb_w, h->d.nb_h, h->d.grid_size,
+                         static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_t* dev_cells, int32_t n, void* stream) {
+    if (!h || !dev_pos || !dev_cells || n < 0) return fail(DESIRE_ERR_ARG, "bad argument");
+    if (n == 0) return DESIRE_OK;
+    launch_scene_cells(dev_pos, dev_cells, n, h->d.Gh, h->d.Gw, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_set_profiling(desire_handle* h, int enable) {
+    if (!h) return fail(DESIRE_ERR_ARG, "null handle");
+    h->profiling = enable != 0;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_get_profile(desire_handle* h, float* host_ms, const char** host_names, int32_t* count) {
+    if (!h || !count) return fail(DESIRE_ERR_ARG, "null argument");
+    const int cap = *count;
+    int n = 0;
+    for (auto& p : h->prof) {
+        if (n >= cap) break;
+        HIPCHK(hipEventSynchronize(p.e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.e0, p.e1));
+        if (host_ms) host_ms[n] = ms;
+        if (host_names) host_names[n] = p.name.c_str();
+        ++n;
+    }
+    *count = n;
+    return DESIRE_OK;
+}

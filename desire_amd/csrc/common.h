@@ -1,0 +1,139 @@
+// common.h -- gfx950 device primitives shared by every DESIRE kernel.
+//
+// All contractions run on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32: 32x32 output
+// tile, K=2 per instruction, 64 cycles/SIMD, bitwise an fmaf chain).  One wave owns one or
+// more 32x32 accumulator tiles; A fragments come from LDS as one ds_read_b128 per four MFMAs,
+// B fragments come from HBM/L2 as one global_load_dwordx4 per four MFMAs out of weights that
+// the host has re-laid in "fragment order" (see PackedB in api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DS_WG 256          // every kernel runs 4 waves per workgroup, one per SIMD
+#define DS_TM 64           // rows per workgroup tile (2 MFMA M-tiles)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Accumulator element i (0..15) of this lane sits at row acc_row(i), column lane&31.
+__device__ __forceinline__ int acc_row(int i) { return (i & 3) + 8 * (i >> 2) + 4 * (lane_id() >> 5); }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// K-group g (8 consecutive k) of the contraction: lane (hi = lane>>5, c = lane&31) holds
+//   A: A[row][8g + 4hi + i]      i = 0..3   (one 16-byte LDS read)
+//   B: W[8g + 4hi + i][n0 + c]   i = 0..3   (one 16-byte global read from packed weights)
+// and MFMA step i contracts k = {8g + i (lanes 0-31), 8g + 4 + i (lanes 32-63)}.
+//
+// The K loop runs in chunks of 4 groups (16 MFMAs per M-tile) with the next chunk's B fragments
+// prefetched into registers while the current chunk computes; the loop is kept rolled so the
+// compiler cannot hoist a whole K extent of loads (38 groups at K=304 would need 300+ VGPRs).
+template <int MT>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const (&ap)[MT], int g,
+                                          const float4 (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(ap[m] + (g + j) * 8);
+            acc[m] = mfma32(a.x, b[j].x, acc[m]);
+            acc[m] = mfma32(a.y, b[j].y, acc[m]);
+            acc[m] = mfma32(a.z, b[j].z, acc[m]);
+            acc[m] = mfma32(a.w, b[j].w, acc[m]);
+        }
+    }
+}
+
+// ap[m]: LDS pointer to A[row = lane&31 of M-tile m][4*(lane>>5)]; rows may be gathered (convs).
+template <int MT>
+__device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
+                                               const float4* __restrict__ b_lane, int G) {
+    int g = 0;
+    if (G >= 4) {
+        float4 cur[4], nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = b_lane[j * 64];
+#pragma clang loop unroll(disable)
+        for (; g + 8 <= G; g += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = b_lane[(g + 4 + j) * 64];
+            mma_chunk<MT>(acc, ap, g, cur);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+        mma_chunk<MT>(acc, ap, g, cur);
+        g += 4;
+    }
+#pragma clang loop unroll(disable)
+    for (; g < G; ++g) {
+        const float4 b = b_lane[g * 64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(ap[m] + g * 8);
+            acc[m] = mfma32(a.x, b.x, acc[m]);
+            acc[m] = mfma32(a.y, b.y, acc[m]);
+            acc[m] = mfma32(a.z, b.z, acc[m]);
+            acc[m] = mfma32(a.w, b.w, acc[m]);
+        }
+    }
+}
+
+// a_lane: LDS pointer to A[lane&31][4*(lane>>5)] of M-tile 0 (row stride lda floats,
+//         lda % 4 == 0 and (lda/4) odd keeps ds_read_b128 conflict-free).
+// b_lane: packed weights of this n-tile, already offset by +lane (float4 units).
+template <int MT>
+__device__ __forceinline__ void mma_groups(f32x16 (&acc)[MT], const float* a_lane, int lda,
+                                           const float4* __restrict__ b_lane, int G) {
+    const float* ap[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ap[m] = a_lane + m * 32 * lda;
+    mma_groups_ptr<MT>(acc, ap, b_lane, G);
+}
+
+// elementwise (accurate libm forms; parity with the numpy oracle is 1e-6 class)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
+
+// ---- integer paths: every float op is ONE IEEE fp32 operation (no contraction) ----------------
+// scene cell: cy = clamp(floor(y*Gh), 0, Gh-1), cx likewise (oracle: scene_cell)
+__device__ __forceinline__ void scene_cell_dev(float x, float y, int Gh, int Gw, int& cy, int& cx) {
+    float fy = floorf(__fmul_rn(y, (float)Gh));
+    float fx = floorf(__fmul_rn(x, (float)Gw));
+    fy = fminf(fmaxf(fy, 0.f), (float)(Gh - 1));
+    fx = fminf(fmaxf(fx, 0.f), (float)(Gw - 1));
+    cy = (int)fy;
+    cx = (int)fx;
+}
+
+// neighbour bin of `other` (xj,yj) seen from centre (xi,yi); -1 when outside the window
+// (oracle: neighbor_bins; lineage: Social-LSTM getGridMask, the reference's missing grid.py)
+__device__ __forceinline__ int neighbor_bin_dev(float xi, float yi, float xj, float yj,
+                                                float nb_w, float nb_h, int G) {
+    const float hw = __fdiv_rn(nb_w, 2.0f), hh = __fdiv_rn(nb_h, 2.0f);
+    const float lx = __fsub_rn(xi, hw), hx = __fadd_rn(xi, hw);
+    const float ly = __fsub_rn(yi, hh), hy = __fadd_rn(yi, hh);
+    if (!(xj < hx) || !(xj >= lx) || !(yj < hy) || !(yj >= ly)) return -1;
+    float cx = floorf(__fmul_rn(__fdiv_rn(__fsub_rn(xj, lx), nb_w), (float)G));
+    float cy = floorf(__fmul_rn(__fdiv_rn(__fsub_rn(yj, ly), nb_h), (float)G));
+    cx = fminf(fmaxf(cx, 0.f), (float)(G - 1));
+    cy = fminf(fmaxf(cy, 0.f), (float)(G - 1));
+    return (int)cx + (int)cy * G;
+}
+
+// row r = (scene*K + k)*mno + slot  ->  agent = scene*mno + slot
+__device__ __forceinline__ int agent_of_row(int r, int K, int mno) {
+    const int per_scene = K * mno;
+    const int scene = r / per_scene;
+    return scene * mno + (r % mno);
+}

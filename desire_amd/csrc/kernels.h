@@ -1,0 +1,89 @@
+// kernels.h -- host-visible launchers and argument blocks (internal to libdesire_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// dynamic LDS above 64 KiB must be opted into once per kernel
+template <class F>
+inline void allow_big_lds(F* f) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_SCALE_SHIFT_ELU = 2 };
+
+// out[M, N] = epi(A[M, K] @ W[K, N]); W in packed fragment order [NT][G][64] float4.
+struct GemmArgs {
+    const float* A; int lda; int M; int K;
+    const float4* Bp; int G; int NT;
+    float* out; int ldo; int N;
+    const float* p0; const float* p1; int chmod;
+};
+void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s);
+
+void launch_reparam(const float* params, const float* eps, float* z, int R, int L, int K, int mno,
+                    int posterior, hipStream_t s);
+
+struct MaskArgs {
+    const float* xhat; int R; int V; int H; int K; int mno;
+    const float4* Wp; const float* bias; const float* Hx; int ldhx; float* xz;
+};
+void launch_mask(const MaskArgs& a, hipStream_t s);
+
+// ---- CVAE conv / deconv stack (kernels_conv.hip) ----
+struct ConvArgs {
+    const float* in; float* out; int n;            // n = samples (agents or rows)
+    const float4* Wp; const float* w_raw;          // packed taps / raw weights (VALU kernels)
+    const float* scale; const float* shift;        // folded bias + frozen batch-norm
+};
+void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
+void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
+void launch_conv3(const ConvArgs& a, hipStream_t s);     // [n,8,8,64]   -> [n,4,4,128]
+void launch_deconv2(const ConvArgs& a, hipStream_t s);   // [n,4,4,128]  -> [n,8,8,64]
+void launch_deconv3(const ConvArgs& a, hipStream_t s);   // [n,8,8,64]   -> [n,16,16,32]
+void launch_deconv4(const ConvArgs& a, hipStream_t s);   // [n,16,16,32] -> [n,32,32] (+sigmoid)
+
+// ---- recurrent kernels (kernels_rnn.hip) ----
+struct EncArgs {
+    const float* frames; int n_scenes; int T; int mno;     // [n_scenes, T, mno, 3]
+    float sx, sy; int H;
+    const float* wx_g; const float* b_g;                   // x rows of gates kernel [2, 2H], bias
+    const float* wx_c; const float* b_c;                   // x rows of candidate kernel [2, H]
+    const float4* Whg; const float4* Whc;                  // packed h rows [H,2H], [H,H]
+    float* out; int ldo;                                   // final state -> out[a*ldo + c]
+    float* p_last;                                         // optional [A,2]: normalised last pos
+    uint8_t* valid;                                        // optional [A]: id != 0 at last frame
+};
+void launch_encoder(const EncArgs& a, hipStream_t s);
+
+struct DecArgs {
+    const float* xz; const float* Hx; int ldhx; const float* p_last;
+    int R; int K; int mno; int H; int T;
+    const float4* Wxg; const float4* Wxc; const float4* Whg; const float4* Whc;
+    const float* b_g; const float* b_c;
+    const float* w_head; const float* b_head;              // [H,2], [2]
+    float* Y;                                              // [R, T, 2]
+    float* hdump;                                          // optional [R, T, H]
+};
+void launch_decoder(const DecArgs& a, hipStream_t s);
+
+struct IocArgs {
+    float* Y; float* score;                                // [R,T,2] in/out, [R]
+    const float* Hx; int ldhx; const float* p_last; const uint8_t* valid;
+    int R; int K; int mno; int H; int T; int iters;
+    int C; int Gh; int Gw; int E_v; int G; float nb_w, nb_h;   // G = social grid side
+    const float* grids; const int32_t* grid_of_scene;
+    const float* w_vel; const float* b_vel;                // [2,E_v], [E_v]
+    const float4* Wsoc; const float* b_soc;                // packed per bin: [B][NT][H/8][64]
+    const float4* Wg; const float4* Wc; const float* b_g; const float* b_c;   // K = E+H
+    const float* w_score; const float* b_score;            // [H], [1]
+    const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed
+};
+void launch_ioc(const IocArgs& a, hipStream_t s);
+
+void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
+                          float nb_w, float nb_h, int G, hipStream_t s);
+void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw, hipStream_t s);

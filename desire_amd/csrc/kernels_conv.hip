@@ -1,0 +1,290 @@
+// kernels_conv.hip -- the conv-CVAE stack of DESIRE on the fp32 matrix pipe.
+// Replaces vae_encoder (model/model.py:471-492) and vae_decoder (model/model.py:453-469 +
+// utils/convolutional_vae_util.py:27-135), batched over agents / (agent,k) rows instead of the
+// reference's one-object-at-a-time unroll (model/model.py:211).  NHWC activations, frozen
+// batch-norm + bias folded to per-channel (scale, shift), ELU / sigmoid fused in the epilogue.
+//
+//   conv1   VALU   [32,32,1]  -s2 SAME->  [16,16,32]     (0.4 MF/agent)
+//   conv2   MFMA   gather, rows = output pixels, K = 25 taps x 32 ci
+//   conv3   MFMA   gather, VALID, K = 25 taps x 64 ci
+//   deconv2 MFMA   scatter: G[(sample,in-pixel), (tap,co)] = In @ W, accumulated into an
+//                  LDS output tile (gather form would waste 75% of the MFMAs on a 4->8 VALID
+//                  transposed conv); each wave owns (sample-pair, co-half) so the read-modify-
+//                  write is race-free and deterministic
+//   deconv3 MFMA   stride-2 transposed conv split in its 4 output-parity classes, each a
+//                  stride-1 gather conv with 2x2 / 2x3 / 3x2 / 3x3 taps: accumulators ARE the
+//                  output, no scatter
+//   deconv4 VALU   one output channel: 32-wide dot per tap, parity class per wave (+sigmoid)
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// conv1 (VALU): one workgroup per agent
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_conv1(ConvArgs a) {
+    __shared__ float in_s[32 * 32];
+    __shared__ float w_s[25 * 32];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += DS_WG) in_s[i] = a.in[(size_t)n * 1024 + i];
+    for (int i = tid; i < 800; i += DS_WG) w_s[i] = a.w_raw[i];      // [ky][kx][0][co]
+    __syncthreads();
+    const int co = tid & 31, pg = tid >> 5;
+    const float sc = a.scale[co], sh = a.shift[co];
+    for (int p = pg; p < 256; p += 8) {
+        const int oy = p >> 4, ox = p & 15;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            if (iy < 0 || iy >= 32) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int ix = 2 * ox + kx - 1;
+                if (ix < 0 || ix >= 32) continue;
+                acc = fmaf(in_s[iy * 32 + ix], w_s[(ky * 5 + kx) * 32 + co], acc);
+            }
+        }
+        a.out[((size_t)n * 256 + p) * 32 + co] = eluf_(acc * sc + sh);
+    }
+}
+void launch_conv1(const ConvArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv1, dim3(a.n), dim3(DS_WG), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward conv, gather form.  Workgroup = 64 output rows = SPW samples x OW*OW pixels.
+// NT = CO/32 n-tiles:  NT==2 -> wave = (nt = w&1, m-tile = w>>1), MT = 1
+//                      NT==4 -> wave = (nt = w), MT = 2
+// ------------------------------------------------------------------------------------------------
+template <int CI, int IW, int OW, int STRIDE, int PAD, int CO>
+__global__ __launch_bounds__(DS_WG) void k_conv_gather(ConvArgs a) {
+    constexpr int PIX = OW * OW, SPW = DS_TM / PIX, LDP = CI + 4, NT = CO / 32, G = CI / 8;
+    constexpr int MT = (NT == 4) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* zero_row = smem;                       // LDP zeros
+    float* in_s = smem + LDP;                     // [SPW][IW*IW][LDP]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * SPW;
+    for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
+    constexpr int Q = CI / 4;
+    for (int i = tid; i < SPW * IW * IW * Q; i += DS_WG) {
+        const int pix = i / Q, c4 = i - pix * Q;
+        const int smp = s0 + pix / (IW * IW);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * IW * IW + pix) * CI + c4 * 4);
+        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int nt = (NT == 4) ? w : (w & 1);
+    const int mt0 = (NT == 4) ? 0 : (w >> 1);
+    f32x16 acc[MT];
+    int oy[MT], ox[MT], sm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc[m] = zero16();
+        const int r = (mt0 + m) * 32 + (lane & 31);
+        sm[m] = r / PIX;
+        const int q = r - sm[m] * PIX;
+        oy[m] = q / OW;
+        ox[m] = q - oy[m] * OW;
+    }
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) {
+            const float* ap[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
+                const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
+                ap[m] = (ok ? in_s + ((sm[m] * IW + iy) * IW + ix) * LDP : zero_row) + 4 * (lane >> 5);
+            }
+            mma_groups_ptr<MT>(acc, ap, a.Wp + ((size_t)((ky * 5 + kx) * NT + nt) * G) * 64 + lane, G);
+        }
+    const int co = nt * 32 + (lane & 31);
+    const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (mt0 + m) * 32 + acc_row(i);
+            const int smp = s0 + r / PIX;
+            if (smp < a.n) a.out[((size_t)s0 * PIX + r) * CO + co] = eluf_(acc[m][i] * sc + sh);
+        }
+}
+void launch_conv2(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (36 + 256 * 36) * sizeof(float);
+    hipLaunchKernelGGL((k_conv_gather<32, 16, 8, 2, 1, 64>), dim3(a.n), dim3(DS_WG), lds, s, a);
+}
+void launch_conv3(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (68 + 4 * 64 * 68) * sizeof(float);
+    allow_big_lds(k_conv_gather<64, 8, 4, 1, 0, 128>);
+    hipLaunchKernelGGL((k_conv_gather<64, 8, 4, 1, 0, 128>), dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deconv2: [n,4,4,128] -> [n,8,8,64], 5x5 VALID stride 1, scatter form.
+// Workgroup = 4 samples; wave = (co-half hf = w&1, sample pair sp = w>>1).
+// M-tile rows = (sample s in {0,1}, input pixel p in 0..15); A (K=128) lives in 64 VGPRs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float out_s[];     // [4][64 px][64 co]
+    const int lane = lane_id(), w = wave_id();
+    const int hf = w & 1, sp = w >> 1;
+    const int s0 = blockIdx.x * 4 + sp * 2;
+    const int c = lane & 31, hi = lane >> 5;
+    float* my = out_s + (sp * 2) * 4096;
+    // zero this wave's region: 2 samples x 64 px x 32 co
+    for (int i = 0; i < 64; ++i) {
+        const int sp_px = i * 2 + hi;                                  // 0..127 = (s, px)
+        my[sp_px * 64 + hf * 32 + c] = 0.f;
+    }
+    // A fragments: row = lane&31 -> (s = row>>4, p = row&15)
+    float4 af[16];
+    {
+        const int row = lane & 31;
+        const int smp = min(s0 + (row >> 4), a.n - 1);
+        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
+    }
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) {
+            f32x16 acc = zero16();
+            const float4* bp = a.Wp + ((size_t)((ky * 5 + kx) * 2 + hf) * 16) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 b = bp[g * 64];
+                acc = mfma32(af[g].x, b.x, acc);
+                acc = mfma32(af[g].y, b.y, acc);
+                acc = mfma32(af[g].z, b.z, acc);
+                acc = mfma32(af[g].w, b.w, acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = acc_row(i);
+                const int s = rr >> 4, p = rr & 15;
+                const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+                float* dst = my + (s * 64 + o) * 64 + hf * 32 + c;
+                *dst = *dst + acc[i];
+            }
+        }
+    const int co = hf * 32 + c;
+    const float sc = a.scale[co], sh = a.shift[co];
+    for (int i = 0; i < 64; ++i) {
+        const int sp_px = i * 2 + hi;
+        const int smp = s0 + (sp_px >> 6);
+        if (smp < a.n)
+            a.out[((size_t)smp * 64 + (sp_px & 63)) * 64 + co] = eluf_(my[sp_px * 64 + co] * sc + sh);
+    }
+}
+void launch_deconv2(const ConvArgs& a, hipStream_t s) {
+    allow_big_lds(k_deconv2);
+    hipLaunchKernelGGL(k_deconv2, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2:  o = 2i + k - 1.
+// Output parity class p = o&1 uses taps k with k = p+1 (mod 2): p=0 -> k in {1,3}, p=1 -> {0,2,4};
+// input shift d = (p + 1 - k)/2, i = q + d for o = 2q + p.  One wave per sample, MT = 2 covers the
+// 64 outputs of a class.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
+    constexpr int LDP = 68;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* zero_row = smem;
+    float* in_s = smem + LDP;                                          // [4][64][LDP]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * 4;
+    for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
+    for (int i = tid; i < 4 * 64 * 16; i += DS_WG) {
+        const int pix = i >> 4, c4 = i & 15;
+        const int smp = s0 + (pix >> 6);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
+        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int smp = s0 + w;
+    const float* mine = in_s + w * 64 * LDP;
+    const int c = lane & 31, hi = lane >> 5;
+    const float sc = a.scale[c], sh = a.shift[c];
+    int qy[2], qx[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            f32x16 acc[2] = {zero16(), zero16()};
+            for (int ky = 1 - py; ky < 5; ky += 2)
+                for (int kx = 1 - px; kx < 5; kx += 2) {
+                    const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+                    const float* ap[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int iy = qy[m] + dy, ix = qx[m] + dx;
+                        const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                        ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 4 * hi;
+                    }
+                    mma_groups_ptr<2>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
+                }
+            if (smp < a.n) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int q = m * 32 + acc_row(i);
+                        const int oy = 2 * (q >> 3) + py, ox = 2 * (q & 7) + px;
+                        a.out[((size_t)smp * 256 + oy * 16 + ox) * 32 + c] = eluf_(acc[m][i] * sc + sh);
+                    }
+            }
+        }
+}
+void launch_deconv3(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (68 + 4 * 64 * 68) * sizeof(float);
+    allow_big_lds(k_deconv3);
+    hipLaunchKernelGGL(k_deconv3, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deconv4 (VALU): [n,16,16,32] -> [n,32,32], 5x5 SAME stride 2, BN + sigmoid.
+// One workgroup per sample; wave = output parity class (uniform tap set), 4 pixels per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_deconv4(ConvArgs a) {
+    constexpr int LDP = 36;
+    __shared__ __attribute__((aligned(16))) float in_s[256 * LDP];
+    __shared__ __attribute__((aligned(16))) float w_s[25 * 32];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    for (int i = tid; i < 256 * 8; i += DS_WG) {
+        const int pix = i >> 3, c4 = i & 7;
+        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) =
+            *reinterpret_cast<const float4*>(a.in + ((size_t)n * 256 + pix) * 32 + c4 * 4);
+    }
+    for (int i = tid; i < 800; i += DS_WG) w_s[i] = a.w_raw[i];        // [ky][kx][0][ci]
+    __syncthreads();
+    const int py = w >> 1, px = w & 1;
+    const float sc = a.scale[0], sh = a.shift[0];
+    for (int j = 0; j < 4; ++j) {
+        const int q = j * 64 + lane;                                   // 0..255 within the class
+        const int qy = q >> 4, qx = q & 15;
+        float acc = 0.f;
+        for (int ky = 1 - py; ky < 5; ky += 2) {
+            const int iy = qy + (py + 1 - ky) / 2;
+            if (iy < 0 || iy >= 16) continue;
+            for (int kx = 1 - px; kx < 5; kx += 2) {
+                const int ix = qx + (px + 1 - kx) / 2;
+                if (ix < 0 || ix >= 16) continue;
+                const float* ip = in_s + (iy * 16 + ix) * LDP;
+                const float* wp = w_s + (ky * 5 + kx) * 32;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 x = *reinterpret_cast<const float4*>(ip + c4 * 4);
+                    const float4 ww = *reinterpret_cast<const float4*>(wp + c4 * 4);
+                    acc = fmaf(x.x, ww.x, acc); acc = fmaf(x.y, ww.y, acc);
+                    acc = fmaf(x.z, ww.z, acc); acc = fmaf(x.w, ww.w, acc);
+                }
+            }
+        }
+        a.out[(size_t)n * 1024 + (2 * qy + py) * 32 + 2 * qx + px] = sigmoidf_(acc * sc + sh);
+    }
+}
+void launch_deconv4(const ConvArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_deconv4, dim3(a.n), dim3(DS_WG), 0, s, a);
+}

@@ -1,0 +1,167 @@
+// kernels_gemm.hip -- row-tiled fp32-MFMA GEMMs with fused epilogues, reparameterisation and
+// the mask fc (+softmax, *Hx).  Replaces, batched over all agents / all (agent,k) rows:
+//   fc_c          model/model.py:243-251      relu([Hx,Hy] W + b)
+//   vae_enc fc    model/model.py:488          flat W + b
+//   deconv1       model/model.py:465          1x1 -> 4x4 transposed conv == GEMM [R,L]x[L,2048]
+//   reparam       model/model.py:260-264      z = mu + sqrt(exp(logsig2)) * eps
+//   mask fc       model/model.py:271-280      x_z = softmax(relu(xhat W + b)) * Hx
+#include "common.h"
+#include "kernels.h"
+
+#define KC 256            // K-chunk staged in LDS per pass
+#define LDA_C (KC + 4)    // 260 = 4*65: ds_read_b128 conflict-free
+
+template <int EPI, int NTW>
+__global__ __launch_bounds__(DS_WG) void k_gemm_rows(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * DS_TM;
+    f32x16 acc[NTW][2];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { acc[j][0] = zero16(); acc[j][1] = zero16(); }
+    const float* a_lane = smem + (lane & 31) * LDA_C + 4 * (lane >> 5);
+
+    for (int k0 = 0; k0 < a.K; k0 += KC) {
+        const int kc = min(KC, a.K - k0);
+        const int q = kc >> 2;                      // float4 per row
+        for (int i = tid; i < DS_TM * q; i += DS_WG) {
+            const int r = i / q, c4 = i - r * q;
+            const int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.M) v = *reinterpret_cast<const float4*>(a.A + (size_t)row * a.lda + k0 + c4 * 4);
+            *reinterpret_cast<float4*>(smem + r * LDA_C + c4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int nt = (blockIdx.y * NTW + j) * 4 + w;
+            if (nt < a.NT)
+                mma_groups<2>(acc[j], a_lane, LDA_C, a.Bp + ((size_t)nt * a.G + (k0 >> 3)) * 64 + lane, kc >> 3);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = (blockIdx.y * NTW + j) * 4 + w;
+        if (nt >= a.NT) continue;
+        const int col = nt * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        float p0 = 0.f, p1 = 0.f;
+        if (EPI == EPI_SCALE_SHIFT_ELU) { const int ch = col % a.chmod; p0 = a.p0[ch]; p1 = a.p1[ch]; }
+        else p0 = a.p0[col];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + m * 32 + acc_row(i);
+                if (row >= a.M) continue;
+                float v = acc[j][m][i];
+                if (EPI == EPI_BIAS) v = v + p0;
+                else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + p0, 0.f);
+                else v = eluf_(v * p0 + p1);
+                a.out[(size_t)row * a.ldo + col] = v;
+            }
+    }
+}
+
+void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s) {
+    const int NTW = 4;
+    dim3 grid((a.M + DS_TM - 1) / DS_TM, (a.NT + 4 * NTW - 1) / (4 * NTW));
+    const size_t lds = DS_TM * LDA_C * sizeof(float);
+    allow_big_lds(k_gemm_rows<EPI_BIAS, 4>); allow_big_lds(k_gemm_rows<EPI_BIAS_RELU, 4>);
+    allow_big_lds(k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>);
+    if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS, 4>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS_RELU, 4>), grid, dim3(DS_WG), lds, s, a);
+    else hipLaunchKernelGGL((k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>), grid, dim3(DS_WG), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// z = mu[agent] + sqrt(exp(logsig2[agent])) * eps[row]      (posterior)   |   z = eps   (prior)
+// params [A, 2L] = (mu | logsig2) as written by the vae_enc fc.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_reparam(const float* __restrict__ params, const float* __restrict__ eps,
+                          float* __restrict__ z, int R, int L, int K, int mno, int posterior) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * L) return;
+    const int r = i / L, l = i - r * L;
+    float e = eps[i];
+    if (posterior) {
+        const int a = agent_of_row(r, K, mno);
+        const float mu = params[(size_t)a * 2 * L + l], ls = params[(size_t)a * 2 * L + L + l];
+        e = mu + sqrtf(expf(ls)) * e;
+    }
+    z[i] = e;
+}
+
+void launch_reparam(const float* params, const float* eps, float* z, int R, int L, int K, int mno,
+                    int posterior, hipStream_t s) {
+    const int n = R * L;
+    hipLaunchKernelGGL(k_reparam, dim3((n + 255) / 256), dim3(256), 0, s, params, eps, z, R, L, K, mno, posterior);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask fc: xz[r,:] = softmax(relu(xhat[r,:] @ Wm + bm)) * Hx[agent(r),:]
+// one workgroup = 64 rows x all H (<=128) columns, K = V = 1024 in 4 chunks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_mask(MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * DS_TM;
+    const int NT = a.H >> 5;
+    f32x16 acc[2] = {zero16(), zero16()};
+    const float* a_lane = smem + (lane & 31) * LDA_C + 4 * (lane >> 5);
+    const int G = a.V >> 3;
+    for (int k0 = 0; k0 < a.V; k0 += KC) {
+        const int q = KC >> 2;
+        for (int i = tid; i < DS_TM * q; i += DS_WG) {
+            const int r = i / q, c4 = i - r * q;
+            const int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.R) v = *reinterpret_cast<const float4*>(a.xhat + (size_t)row * a.V + k0 + c4 * 4);
+            *reinterpret_cast<float4*>(smem + r * LDA_C + c4 * 4) = v;
+        }
+        __syncthreads();
+        if (w < NT) mma_groups<2>(acc, a_lane, LDA_C, a.Wp + ((size_t)w * G + (k0 >> 3)) * 64 + lane, KC >> 3);
+        __syncthreads();
+    }
+    // relu(acc + b) -> LDS tile [64][132]
+    const int LDT = 132;
+    if (w < NT) {
+        const int col = w * 32 + (lane & 31);
+        const float b = a.bias[col];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) smem[(m * 32 + acc_row(i)) * LDT + col] = fmaxf(acc[m][i] + b, 0.f);
+    }
+    __syncthreads();
+    // softmax over H per row: 4 threads per row
+    const int r = tid >> 2, q4 = tid & 3;
+    const int row = row0 + r;
+    const int per = a.H >> 2;                   // columns per thread (<= 32)
+    float mx = -3.0e38f;
+    for (int c = 0; c < per; ++c) mx = fmaxf(mx, smem[r * LDT + q4 * per + c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float sum = 0.f;
+    for (int c = 0; c < per; ++c) {
+        const float e = expf(smem[r * LDT + q4 * per + c] - mx);
+        smem[r * LDT + q4 * per + c] = e;
+        sum += e;
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (row < a.R) {
+        const int ag = agent_of_row(row, a.K, a.mno);
+        for (int c = 0; c < per; ++c) {
+            const int col = q4 * per + c;
+            a.xz[(size_t)row * a.H + col] = (smem[r * LDT + col] / sum) * a.Hx[(size_t)ag * a.ldhx + col];
+        }
+    }
+}
+
+void launch_mask(const MaskArgs& a, hipStream_t s) {
+    const size_t lds = DS_TM * LDA_C * sizeof(float);
+    allow_big_lds(k_mask);
+    hipLaunchKernelGGL(k_mask, dim3((a.R + DS_TM - 1) / DS_TM), dim3(DS_WG), lds, s, a);
+}

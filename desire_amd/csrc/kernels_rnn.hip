@@ -1,0 +1,468 @@
+// kernels_rnn.hip -- persistent recurrent kernels: one workgroup owns a 64-row tile for the whole
+// sequence, hidden state lives in registers (accumulator layout) + LDS (A-operand layout), the
+// per-step contractions run on the fp32 matrix pipe with weights streamed from L2 in fragment
+// order.  Wave w owns hidden columns [32w, 32w+32) of all 64 rows, so the r / u / candidate /
+// blend arithmetic of the TF GRUCell is register-local.
+//
+//   k_encoder   GRU encoders X and Y      model/model.py:136-167,233-241   (static_rnn, zero state)
+//   k_decoder   GRU decoder + head        model/model.py:279-289 (+ commented head :315-321)
+//   k_ioc       IOC scoring/refinement    absent in the reference (model/model.py:312-313): paper
+//   k_neighbor_bins / k_scene_cells       integer paths, bit-exact vs oracle
+//
+// TF GRUCell: [r,u] = sigmoid([x,h] Wg + bg); c = tanh([x, r*h] Wc + bc); h' = u*h + (1-u)*c.
+#include "common.h"
+#include "kernels.h"
+
+#define RNN_WG 512         // 8 waves: wave = (column block cb = w&3, M-tile mt = w>>2), two per SIMD
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = v;
+    return z;
+}
+
+// one 32x32 output tile of this wave: acc += A[32 rows][K] . Wp(ntile)
+__device__ __forceinline__ void mma1(f32x16& acc, const float* a_lane, const float4* __restrict__ b_lane, int G) {
+    f32x16 t[1] = {acc};
+    mma_groups<1>(t, a_lane, 0, b_lane, G);
+    acc = t[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder: tile = 64 agents, T steps, input (x,y) normalised in-kernel: one fp32 multiply each.
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(RNN_WG) void k_encoder(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3;
+    float* hs = smem;                      // [64][LDH]
+    float* xs = smem + DS_TM * LDH;        // [64][2]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w & 3, mt = w >> 2;
+    const int A = a.n_scenes * a.mno;
+    const int a0 = blockIdx.x * DS_TM;
+    const bool active = cb < NT;
+    const int col = cb * 32 + (lane & 31);
+    float wr0 = 0, wr1 = 0, wu0 = 0, wu1 = 0, wc0 = 0, wc1 = 0, br = 0, bu = 0, bc = 0;
+    if (active) {
+        wr0 = a.wx_g[col]; wr1 = a.wx_g[2 * H + col];
+        wu0 = a.wx_g[H + col]; wu1 = a.wx_g[2 * H + H + col];
+        wc0 = a.wx_c[col]; wc1 = a.wx_c[H + col];
+        br = a.b_g[col]; bu = a.b_g[H + col]; bc = a.b_c[col];
+    }
+    f32x16 h = zero16();
+    for (int i = tid; i < DS_TM * LDH; i += RNN_WG) hs[i] = 0.f;
+    const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
+    float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;       // + acc-row offset * LDH
+
+    for (int t = 0; t < a.T; ++t) {
+        if (tid < DS_TM) {
+            const int ag = min(a0 + tid, A - 1);
+            const int sc = ag / a.mno, slot = ag - sc * a.mno;
+            const float* f = a.frames + (((size_t)sc * a.T + t) * a.mno + slot) * 3;
+            xs[tid * 2 + 0] = __fmul_rn(f[1], a.sx);
+            xs[tid * 2 + 1] = __fmul_rn(f[2], a.sy);
+            if (t == a.T - 1 && a0 + tid < A) {
+                if (a.p_last) { a.p_last[(size_t)ag * 2] = xs[tid * 2]; a.p_last[(size_t)ag * 2 + 1] = xs[tid * 2 + 1]; }
+                if (a.valid) a.valid[ag] = (f[0] != 0.f) ? 1 : 0;
+            }
+        }
+        __syncthreads();                                   // xs ready, hs holds h_{t-1}
+        f32x16 rh, u;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + acc_row(i);
+                rh[i] = fmaf(xs[row * 2 + 1], wr1, fmaf(xs[row * 2], wr0, br));
+                u[i] = fmaf(xs[row * 2 + 1], wu1, fmaf(xs[row * 2], wu0, bu));
+            }
+            mma1(rh, a_lane, a.Whg + ((size_t)cb * G) * 64 + lane, G);
+            mma1(u, a_lane, a.Whg + ((size_t)(cb + NT) * G) * 64 + lane, G);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
+        }
+        __syncthreads();                                   // every wave done reading h_{t-1}
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = rh[i];
+        }
+        __syncthreads();
+        if (active) {
+            f32x16 ac;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + acc_row(i);
+                ac[i] = fmaf(xs[row * 2 + 1], wc1, fmaf(xs[row * 2], wc0, bc));
+            }
+            mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+        }
+        __syncthreads();                                   // every wave done reading r*h
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ag = a0 + mt * 32 + acc_row(i);
+            if (ag < A) a.out[(size_t)ag * a.ldo + col] = h[i];
+        }
+    }
+}
+void launch_encoder(const EncArgs& a, hipStream_t s) {
+    const int A = a.n_scenes * a.mno;
+    const size_t lds = (DS_TM * (a.H + 4) + DS_TM * 2) * sizeof(float);
+    const dim3 grid((A + DS_TM - 1) / DS_TM);
+    if (a.H == 128) hipLaunchKernelGGL(k_encoder<128>, grid, dim3(RNN_WG), lds, s, a);
+    else if (a.H == 64) hipLaunchKernelGGL(k_encoder<64>, grid, dim3(RNN_WG), lds, s, a);
+    else hipLaunchKernelGGL(k_encoder<32>, grid, dim3(RNN_WG), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder: tile = 64 rows; constant input x_z => its contribution (and the biases) is computed once
+// and kept in 48 accumulator-layout registers per wave; per step only the h-part contracts (K = H).
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3;
+    float* hs = smem;                          // [64][LDH]  h / r*h as A operand
+    float* xs = smem + DS_TM * LDH;            // [64][LDH]  x_z tile (prologue only)
+    float* wo = xs + DS_TM * LDH;              // [H][2] head weights
+    float* pl = wo + 2 * H;                    // [64][2] last observed position
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w & 3, mt = w >> 2;
+    const int row0 = blockIdx.x * DS_TM;
+    const bool active = cb < NT;
+    const int col = cb * 32 + (lane & 31);
+    for (int i = tid; i < DS_TM * (H >> 2); i += RNN_WG) {
+        const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+        const int row = min(row0 + r, a.R - 1);
+        *reinterpret_cast<float4*>(xs + r * LDH + c4 * 4) =
+            *reinterpret_cast<const float4*>(a.xz + (size_t)row * H + c4 * 4);
+        const int ag = agent_of_row(row, a.K, a.mno);
+        *reinterpret_cast<float4*>(hs + r * LDH + c4 * 4) =
+            *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
+    }
+    for (int i = tid; i < 2 * H; i += RNN_WG) wo[i] = a.w_head[i];
+    if (tid < DS_TM) {
+        const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
+        pl[tid * 2] = a.p_last[(size_t)ag * 2];
+        pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+    }
+    __syncthreads();
+    const float* x_lane = xs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
+    const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
+    float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;
+    f32x16 xr, xu, xc, h;
+    if (active) {
+        xr = splat16(a.b_g[col]); xu = splat16(a.b_g[H + col]); xc = splat16(a.b_c[col]);
+        mma1(xr, x_lane, a.Wxg + ((size_t)cb * G) * 64 + lane, G);
+        mma1(xu, x_lane, a.Wxg + ((size_t)(cb + NT) * G) * 64 + lane, G);
+        mma1(xc, x_lane, a.Wxc + ((size_t)cb * G) * 64 + lane, G);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = my_h[((i & 3) + 8 * (i >> 2)) * LDH];
+    }
+    const float bh0 = a.b_head[0], bh1 = a.b_head[1];
+    for (int t = 0; t < a.T; ++t) {
+        f32x16 rh, u;
+        if (active) {
+            rh = xr; u = xu;
+            mma1(rh, a_lane, a.Whg + ((size_t)cb * G) * 64 + lane, G);
+            mma1(u, a_lane, a.Whg + ((size_t)(cb + NT) * G) * 64 + lane, G);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = rh[i];
+        }
+        __syncthreads();
+        if (active) {
+            f32x16 ac = xc;
+            mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
+                const int rl = mt * 32 + acc_row(i);
+                if (a.hdump && row0 + rl < a.R) a.hdump[((size_t)(row0 + rl) * a.T + t) * H + col] = h[i];
+            }
+        }
+        __syncthreads();
+        {   // head: y = p_last + h W_o + b_o ; 8 threads per row
+            const int r = tid >> 3, q8 = tid & 7, per = H >> 3;
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = q8 * per; c < (q8 + 1) * per; ++c) {
+                const float hv = hs[r * LDH + c];
+                s0 = fmaf(hv, wo[c * 2], s0);
+                s1 = fmaf(hv, wo[c * 2 + 1], s1);
+            }
+            s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
+            s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+            s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4);
+            if (q8 == 0 && row0 + r < a.R) {
+                float2 y = make_float2(pl[r * 2] + (s0 + bh0), pl[r * 2 + 1] + (s1 + bh1));
+                *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + r) * a.T + t) * 2) = y;
+            }
+        }
+        // next step's first barrier (after the gate contraction) orders these reads before the r*h write
+    }
+}
+void launch_decoder(const DecArgs& a, hipStream_t s) {
+    const size_t lds = (2 * DS_TM * (a.H + 4) + 2 * a.H + DS_TM * 2) * sizeof(float);
+    const dim3 grid((a.R + DS_TM - 1) / DS_TM);
+    if (a.H == 128) { allow_big_lds(k_decoder<128>); hipLaunchKernelGGL(k_decoder<128>, grid, dim3(RNN_WG), lds, s, a); }
+    else if (a.H == 64) hipLaunchKernelGGL(k_decoder<64>, grid, dim3(RNN_WG), lds, s, a);
+    else hipLaunchKernelGGL(k_decoder<32>, grid, dim3(RNN_WG), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// IOC scoring / refinement.  Tile = 64 rows = 64/mno complete (scene,k) groups, so social pooling
+// never leaves the workgroup.  Per step:
+//   e_v = relu(v W_v + b_v)                       VALU
+//   e_s = grid[cell(y_t)]                         coalesced 128-B gather, cell index bit-exact
+//   e_r = relu(sum_b pool_b(h_{t-1}) W_b + b_s)   per bin: VALU builds the pooled operand from a
+//                                                 neighbour bitmask, MFMA contracts it (K = H)
+//   h_t = GRU([e_v|e_s|e_r], h_{t-1})             K = E + H
+//   score += h_t . w_s + b_s
+// after T steps: dY = h_T W_r + b_r ; Y += dY.
+// ------------------------------------------------------------------------------------------------
+template <int H, int EV, int C>
+__global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
+    constexpr int G8 = KX >> 3, GH = H >> 3;
+    const int B = a.G * a.G;
+    float* XH = smem;                                   // [64][LDX]   [e_v | e_s | e_r | h]
+    float* AB = XH + DS_TM * LDX;                       // [2][64][LDB] pooled operand, double buffered
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * DS_TM * LDB);   // [64][B]
+    float* pc = reinterpret_cast<float*>(masks + DS_TM * B);   // [64][2] current position
+    float* pp = pc + DS_TM * 2;                         // [64][2] previous position
+    float* wv = pp + DS_TM * 2;                         // [2][E_v] + [E_v]
+    float* red = wv + 3 * EV;                           // [4][64] score reduction
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + 4 * DS_TM);   // [64]
+
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w & 3, mt = w >> 2;
+    const int row0 = blockIdx.x * DS_TM;
+    const bool active = cb < NT;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid >> 3, q8 = tid & 7;              // 8 threads per row for the VALU phases
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int my_scene = my_row / (a.K * a.mno);
+    const int grp_base = (r8 / a.mno) * a.mno;          // first local row of my (scene,k) group
+    const int my_slot = r8 - grp_base;
+
+    for (int i = tid; i < 3 * EV; i += RNN_WG) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < DS_TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+
+    float bgr = 0, bgu = 0, bcc = 0, bso = 0, wsc = 0;
+    if (active) { bgr = a.b_g[col]; bgu = a.b_g[H + col]; bcc = a.b_c[col]; bso = a.b_soc[col]; wsc = a.w_score[col]; }
+    const float* x_lane = XH + (mt * 32 + (lane & 31)) * LDX + 4 * (lane >> 5);
+    float* my_x = XH + (mt * 32 + 4 * (lane >> 5)) * LDX + col;        // + acc-row * LDX (+ column base)
+    const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
+
+    for (int it = 0; it < a.iters; ++it) {
+        // h_0 = Hx[agent]
+        for (int i = tid; i < DS_TM * (H >> 2); i += RNN_WG) {
+            const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+            const int ag = agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno);
+            *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
+                *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
+        }
+        if (tid < DS_TM) {
+            const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
+            pp[tid * 2] = a.p_last[(size_t)ag * 2];
+            pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+        }
+        __syncthreads();
+        f32x16 h = zero16(), sp = zero16();
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = my_x[((i & 3) + 8 * (i >> 2)) * LDX + E];
+        }
+
+        for (int t = 0; t < a.T; ++t) {
+            // ---- P0: positions, clear masks ----
+            if (tid < DS_TM) {
+                const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
+                pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
+            }
+            for (int i = tid; i < DS_TM * B; i += RNN_WG) masks[i] = 0ull;
+            __syncthreads();
+            // ---- P1: e_v, e_s, neighbour masks ----
+            {
+                const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+                const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                constexpr int per = EV >> 3;
+#pragma unroll
+                for (int j = q8 * per; j < (q8 + 1) * per; ++j)
+                    XH[r8 * LDX + j] = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                int cy, cx;
+                scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                constexpr int cper = C >> 3;
+#pragma unroll
+                for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4)
+                    *reinterpret_cast<float4*>(XH + r8 * LDX + EV + j) = *reinterpret_cast<const float4*>(gsrc + j);
+                for (int j = q8; j < a.mno; j += 8) {
+                    if (j == my_slot || !vld[grp_base + j]) continue;
+                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
+                                                   a.nb_w, a.nb_h, a.G);
+                    if (b >= 0) atomicOr(&masks[r8 * B + b], 1ull << j);
+                }
+            }
+            __syncthreads();
+            // ---- P2: social pooling, one bin at a time ----
+            f32x16 soc = splat16(bso);
+            for (int b = 0; b < B; ++b) {
+                float* ab = AB + (b & 1) * DS_TM * LDB;
+                {
+                    constexpr int per = H >> 3;            // columns per thread (16 at H=128)
+                    const unsigned long long mk = masks[r8 * B + b];
+#pragma unroll
+                    for (int c0 = 0; c0 < per; c0 += 4) {
+                        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        unsigned long long m2 = mk;
+                        while (m2) {
+                            const int j = __ffsll((long long)m2) - 1;
+                            m2 &= m2 - 1;
+                            const float4 v0 = *reinterpret_cast<const float4*>(XH + (grp_base + j) * LDX + E + q8 * per + c0);
+                            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+                        }
+                        *reinterpret_cast<float4*>(ab + r8 * LDB + q8 * per + c0) = s0;
+                    }
+                }
+                __syncthreads();
+                if (active)
+                    mma1(soc, ab + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
+                         a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+            }
+            // ---- P3: e_r ----
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+            }
+            __syncthreads();
+            // ---- P4: gates ----
+            f32x16 rh, u;
+            if (active) {
+                rh = splat16(bgr); u = splat16(bgu);
+                mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
+                mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = rh[i];
+            }
+            __syncthreads();
+            // ---- P5: candidate, blend, score ----
+            if (active) {
+                f32x16 ac = splat16(bcc);
+                mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, G8);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+                    sp[i] = fmaf(h[i], wsc, sp[i]);
+                }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
+            }
+            if (tid < DS_TM) { pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1]; }
+            __syncthreads();
+        }
+        // ---- score: sum the per-lane partials over the 32 columns of this wave, then over column blocks ----
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = active ? sp[i] : 0.f;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+            if ((lane & 31) == 0) red[cb * DS_TM + mt * 32 + acc_row(i)] = v;
+        }
+        __syncthreads();
+        if (tid < DS_TM && row0 + tid < a.R && it == a.iters - 1) {
+            float sc = red[tid] + red[DS_TM + tid] + red[2 * DS_TM + tid] + red[3 * DS_TM + tid];
+            a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+        }
+        // ---- regression: Y += h_T W_r + b_r   (columns = (t, xy) flattened) ----
+        for (int nt = cb; nt < a.NTreg; nt += 4) {
+            f32x16 acc = zero16();
+            mma1(acc, x_lane + E, a.Wreg + ((size_t)nt * GH) * 64 + lane, GH);
+            const int cc = nt * 32 + (lane & 31);
+            if (cc < 2 * a.T) {
+                const float bb = a.b_reg[cc];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + mt * 32 + acc_row(i);
+                    if (row < a.R) {
+                        float* y = a.Y + (size_t)row * 2 * a.T + cc;
+                        *y = *y + (acc[i] + bb);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+size_t ioc_lds_bytes(const IocArgs& a) {
+    const int EV = 16, H = a.H, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
+    size_t f = (size_t)DS_TM * LDX + 2 * DS_TM * LDB + (size_t)DS_TM * B * 2 + DS_TM * 4 + 3 * EV + 4 * DS_TM;
+    return f * sizeof(float) + DS_TM + 64;
+}
+void launch_ioc(const IocArgs& a, hipStream_t s) {
+    const size_t lds = ioc_lds_bytes(a);
+    const dim3 grid((a.R + DS_TM - 1) / DS_TM);
+    if (a.H == 128) { allow_big_lds(k_ioc<128, 16, 32>); hipLaunchKernelGGL((k_ioc<128, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
+    else if (a.H == 64) { allow_big_lds(k_ioc<64, 16, 32>); hipLaunchKernelGGL((k_ioc<64, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
+    else { allow_big_lds(k_ioc<32, 16, 32>); hipLaunchKernelGGL((k_ioc<32, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// integer paths (standalone, for bit-exact tests)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_neighbor_bins(const float* __restrict__ pos, const uint8_t* __restrict__ valid,
+                                int32_t* __restrict__ bins, int n_groups, int mno, float nb_w, float nb_h, int G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_groups * mno * mno) return;
+    const int g = idx / (mno * mno), ij = idx - g * mno * mno;
+    const int i = ij / mno, j = ij - i * mno;
+    int b = -1;
+    if (i != j && valid[g * mno + j]) {
+        const float* p = pos + (size_t)g * mno * 2;
+        b = neighbor_bin_dev(p[i * 2], p[i * 2 + 1], p[j * 2], p[j * 2 + 1], nb_w, nb_h, G);
+    }
+    bins[idx] = b;
+}
+void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
+                          float nb_w, float nb_h, int G, hipStream_t s) {
+    const int n = n_groups * mno * mno;
+    hipLaunchKernelGGL(k_neighbor_bins, dim3((n + 255) / 256), dim3(256), 0, s, pos, valid, bins, n_groups, mno, nb_w, nb_h, G);
+}
+
+__global__ void k_scene_cells(const float* __restrict__ pos, int32_t* __restrict__ cells, int n, int Gh, int Gw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cy, cx;
+    scene_cell_dev(pos[i * 2], pos[i * 2 + 1], Gh, Gw, cy, cx);
+    cells[i * 2] = cy;
+    cells[i * 2 + 1] = cx;
+}
+void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw, hipStream_t s) {
+    hipLaunchKernelGGL(k_scene_cells, dim3((n + 255) / 256), dim3(256), 0, s, pos, cells, n, Gh, Gw);
+}

@@ -1,0 +1,163 @@
+"""DESIREModel -- host-side mirror of the reference's model/model.py:29-688 public surface, backed
+by libdesire_hip.so.
+
+Kept from the reference:
+  * constructor takes the argparse Namespace of train.py:30-88 (seq_length, d_dim, rnn_size,
+    latent_size, max_num_obj, learning_rate, grad_clip, neighborhood_size, grid_size, ...);
+  * attribute names input_data / target_data / cost / learning_rate / gru_states / final_states /
+    final_output exist (here: the last fed arrays / last results, not TF tensors);
+  * sample(sess, traj, grid, dimensions, true_traj, num) -> ndarray [obs+num, max_num_obj, 3]
+    (model/model.py:613-688).
+
+New (the reference has one seq_length, K hard-coded to 7, no IOC): args.pred_length, args.num_samples,
+args.ioc_iters, args.img_width/img_height, and forward() that returns all K refined samples + scores.
+
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .spec import Dims, init_weights
+
+
+def _next_divisor_of_64(n: int) -> int:
+    for m in (1, 2, 4, 8, 16, 32, 64):
+        if m >= n:
+            return m
+    raise ValueError("max_num_obj > 64 is not supported in this round (IOC tile = 64 rows)")
+
+
+def dims_from_args(args, n_scenes: int, posterior: bool = True) -> Dims:
+    S = int(np.sqrt(2 * args.rnn_size))                       # model/model.py:57-58
+    mno = _next_divisor_of_64(int(args.max_num_obj))
+    w_img = float(getattr(args, "img_width", 2048.0))
+    h_img = float(getattr(args, "img_height", 2048.0))
+    nb = float(getattr(args, "neighborhood_size", 32))
+    return Dims(
+        n_scenes=n_scenes, mno=mno, K=int(getattr(args, "num_samples", 20)),
+        T_obs=int(args.seq_length), T_pred=int(getattr(args, "pred_length", args.seq_length)),
+        H=int(args.d_dim), L=int(args.latent_size), S=S,
+        C=int(getattr(args, "scene_channels", 32)), Gh=int(getattr(args, "scene_grid", 64)),
+        Gw=int(getattr(args, "scene_grid", 64)), n_grids=int(getattr(args, "n_grids", 1)),
+        grid_size=int(getattr(args, "grid_size", 4)), E_v=16, iters=int(getattr(args, "ioc_iters", 1)),
+        posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img)
+
+
+class DESIREModel(object):
+    """Drop-in for model/model.py:29 DESIREModel(args)."""
+
+    def __init__(self, args, weights: Optional[Dict[str, np.ndarray]] = None, seed: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.DesireError("DESIREModel needs an MI355X: there is no CPU path (oracle/ is test-only)")
+        self.args = args
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.learning_rate = float(args.learning_rate)
+        self.max_num_obj = int(args.max_num_obj)
+        self.seq_length = int(args.seq_length)
+        self.batch_size = int(getattr(args, "batch_size", 1))
+        self._weights = weights
+        self._seed = seed
+        self._handles: Dict[Tuple[int, int], _lib.Handle] = {}
+        self._grids = None
+        self._grid_of_scene = None
+        # reference attribute names (model/model.py:62-75)
+        self.input_data = None
+        self.target_data = None
+        self.cost = None
+        self.gru_states = None
+        self.final_states = None
+        self.final_output = None
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _handle(self, n_scenes: int, posterior: bool) -> _lib.Handle:
+        key = (n_scenes, int(posterior))
+        if key not in self._handles:
+            d = dims_from_args(self.args, n_scenes, posterior)
+            h = _lib.Handle(d)
+            if self._weights is None:
+                self._weights = init_weights(d, self._seed)
+            h.set_weights(self._weights)
+            self._handles[key] = h
+        return self._handles[key]
+
+    def set_scene_grids(self, grids: np.ndarray, grid_of_scene: Sequence[int]) -> None:
+        """grids [n_grids, Gh, Gw, C] scene features rho(I); grid_of_scene[i] = grid index of window i."""
+        self._grids = self.torch.as_tensor(np.ascontiguousarray(grids, np.float32), device=self.device)
+        self._grid_of_scene = np.asarray(grid_of_scene, np.int32)
+
+    def _pad_windows(self, batch: Sequence[np.ndarray], mno: int):
+        x = np.stack([np.asarray(b) for b in batch]).astype(np.float32)      # [n, T, MNO, 3]
+        if x.shape[2] < mno:
+            x = np.concatenate([x, np.zeros(x.shape[:2] + (mno - x.shape[2], 3), np.float32)], axis=2)
+        return self.torch.as_tensor(np.ascontiguousarray(x), device=self.device)
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def forward(self, x_batch: Sequence[np.ndarray], y_batch: Optional[Sequence[np.ndarray]] = None,
+                eps: Optional[np.ndarray] = None, seed: int = 0):
+        """x_batch: loader windows [T_obs, MNO, 3] (DataLoader.next_batch x); y_batch: future windows
+        [T_pred, MNO, 3] or None (prior sampling).  Returns (Yhat [n, K, mno, T_pred, 2] normalised,
+        score [n, K, mno]) as torch tensors on the GPU."""
+        torch = self.torch
+        n = len(x_batch)
+        posterior = y_batch is not None
+        h = self._handle(n, posterior)
+        d = h.dims
+        past = self._pad_windows(x_batch, d.mno)
+        fut = self._pad_windows(y_batch, d.mno) if posterior else None
+        if past.shape[1] != d.T_obs or (posterior and fut.shape[1] != d.T_pred):
+            raise ValueError("window lengths must be (seq_length, pred_length)")
+        if eps is None:
+            g = torch.Generator(device=self.device).manual_seed(seed)
+            eps_t = torch.randn((d.R, d.L), generator=g, device=self.device, dtype=torch.float32)
+        else:
+            eps_t = torch.as_tensor(np.ascontiguousarray(eps, np.float32), device=self.device).reshape(d.R, d.L)
+        if self._grids is None:
+            self._grids = torch.zeros((d.n_grids, d.Gh, d.Gw, d.C), device=self.device)
+            self._grid_of_scene = np.zeros(n, np.int32)
+        gos = self._grid_of_scene if len(self._grid_of_scene) == n else np.resize(self._grid_of_scene, n)
+        h.set_scene_grids(self._grids.data_ptr(), gos)
+        Y = torch.empty((n, d.K, d.mno, d.T_pred, 2), device=self.device, dtype=torch.float32)
+        score = torch.empty((n, d.K, d.mno), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream().cuda_stream
+        h.forward(past.data_ptr(), fut.data_ptr() if posterior else 0, eps_t.data_ptr(), Y.data_ptr(),
+                  score.data_ptr(), stream)
+        self._keep = (past, fut, eps_t)            # keep inputs alive until the stream has consumed them
+        self.input_data, self.target_data = x_batch, y_batch
+        self.final_output, self.final_states = Y, score
+        return Y, score
+
+    # ---- reference-shaped sampling API (model/model.py:613-688) ------------------------------------
+    def sample(self, sess, traj, grid, dimensions, true_traj, num=10):
+        """traj [obs, MNO, 3] observed frames; returns [obs+num, MNO, 3]: the observed frames followed by
+        the top-scored (IOC) refined sample per object, in pixel units, ids carried over
+        (model/model.py:680-688).  `sess` is ignored; `grid` may be a [Gh,Gw,C] scene feature grid;
+        `dimensions` = (width, height) of the frame in pixels."""
+        torch = self.torch
+        traj = np.asarray(traj, np.float64)
+        args = SimpleNamespace(**vars(self.args))
+        args.seq_length, args.pred_length = traj.shape[0], int(num)
+        if dimensions is not None:
+            args.img_width, args.img_height = float(dimensions[0]), float(dimensions[1])
+        sub = DESIREModel(args, self._weights, self._seed)
+        if grid is not None and np.ndim(grid) == 3:
+            sub.set_scene_grids(np.asarray(grid, np.float32)[None], [0])
+        Y, score = sub.forward([traj], None)
+        d = sub._handle(1, False).dims
+        best = score[0].argmax(dim=0)                                        # [mno]
+        idx = best.view(1, -1, 1, 1).expand(1, d.mno, d.T_pred, 2)
+        top = torch.gather(Y[0], 0, idx)[0].cpu().numpy()                    # [mno, T_pred, 2]
+        out = np.zeros((traj.shape[0] + num, traj.shape[1], 3))
+        out[: traj.shape[0]] = traj
+        m = traj.shape[1]
+        out[traj.shape[0]:, :, 0] = traj[-1, :, 0]
+        out[traj.shape[0]:, :, 1] = (top[:m, :, 0] / d.sx).T
+        out[traj.shape[0]:, :, 2] = (top[:m, :, 1] / d.sy).T
+        out[traj.shape[0]:][:, traj[-1, :, 0] == 0] = 0
+        return out

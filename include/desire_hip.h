@@ -1,0 +1,112 @@
+/* desire_hip.h -- C ABI of libdesire_hip.so: DESIRE sample-generation + ranking/refinement hot
+ * path on MI355X (gfx950).
+ *
+ * The reference (tdavchev/DESIRE) has NO FFI / plugin / operator interface: its hot path is
+ * one Python function that unrolls a per-object loop into a TF1 graph
+ * (/root/reference/model/model.py:79-403, loop at :211) behind two Python classes
+ * (DESIREModel model/model.py:29, DataLoader utils/data_loader.py:20).  This ABI is therefore
+ * the boundary a maintainer would bind with ctypes from model/model.py; each entry point
+ * below names the reference lines whose work it replaces.  See INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer named dev_* is a DEVICE pointer owned by the
+ *     caller (e.g. torch tensor .data_ptr()), every pointer named host_* is host memory.
+ *   - all tensors fp32, C-contiguous, layouts given per argument.
+ *   - row index r = (scene*K + k)*mno + slot   (R = n_scenes*K*mno rows);
+ *     agent index a = scene*mno + slot          (A = n_scenes*mno agents).
+ *   - every call returns 0 on success, <0 on error; desire_last_error() gives the text.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     stream-ordered and asynchronous; one handle per device, not thread-safe per handle.
+ *   - there is no CPU path: on a machine without a gfx950 device desire_create fails.
+ */
+#ifndef DESIRE_HIP_H
+#define DESIRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DESIRE_OK 0
+#define DESIRE_ERR_ARG (-1)     /* bad argument / dims */
+#define DESIRE_ERR_STATE (-2)   /* weights missing, grids missing, ... */
+#define DESIRE_ERR_HIP (-3)     /* a HIP runtime call failed */
+#define DESIRE_ERR_NODEV (-4)   /* no gfx950 device */
+
+/* Mirrors desire_amd/spec.py:Dims.  Field meaning and the reference args they come from:
+ * mno=max_num_obj, T_obs/T_pred (ref: one seq_length), H=d_dim, L=latent_size,
+ * S=int(sqrt(2*rnn_size)) (model/model.py:44-60); grid_size (train.py:71-72);
+ * nb_w/nb_h = neighborhood_size (train.py:68-70) in normalised units; sx/sy pixel scale. */
+typedef struct desire_dims {
+    int32_t n_scenes, mno, K, T_obs, T_pred;
+    int32_t H, L, S, C, Gh, Gw, n_grids;
+    int32_t grid_size, E_v, iters, posterior;
+    float nb_w, nb_h, sx, sy;
+} desire_dims;
+
+typedef struct desire_ctx desire_handle;
+
+const char* desire_last_error(void);
+int desire_version(void);
+
+/* Replaces DESIREModel.__init__/build_model graph construction (model/model.py:36-77). */
+int desire_create(const desire_dims* dims, desire_handle** out);
+int desire_destroy(desire_handle* h);
+
+/* Weights by name (names/shapes: desire_amd/spec.py:weight_shapes; the reference's own names
+ * are define_weights model/model.py:420-451 plus the implicit TF/prettytensor scopes).
+ * host_data is n fp32 values in the natural (TF) layout; the library repacks GEMM operands
+ * into MFMA B-fragment order and uploads.  desire_finalize_weights folds frozen batch-norm
+ * (model/model.py:457-462) into per-channel scale/shift and verifies every tensor is set. */
+int desire_set_weight(desire_handle* h, const char* name, const float* host_data, size_t n);
+int desire_finalize_weights(desire_handle* h);
+
+/* Scene feature grids rho(I) (absent in the reference, model/model.py:312-313; the `grid`
+ * argument of sample(), :613).  dev_grids [n_grids, Gh, Gw, C]; host_grid_of_scene [n_scenes].
+ * The device buffer is referenced, not copied: keep it alive while the handle uses it. */
+int desire_set_scene_grids(desire_handle* h, const float* dev_grids, const int32_t* host_grid_of_scene);
+
+/* Encoders + CVAE encoder (model/model.py:233-259,471-492).
+ * dev_past [n_scenes, T_obs, mno, 3] and dev_fut [n_scenes, T_pred, mno, 3] are stacks of the
+ * loader's windows (id, x_px, y_px; utils/data_loader.py:212-229).  dev_fut may be NULL when
+ * dims.posterior == 0. */
+int desire_encode(desire_handle* h, const float* dev_past, const float* dev_fut, void* stream);
+
+/* Reparameterise + CVAE decoder + mask fc + GRU decoder (model/model.py:260-289).
+ * dev_eps [R, L]; dev_Yhat [R, T_pred, 2] out (normalised coordinates). */
+int desire_sample(desire_handle* h, const float* dev_eps, float* dev_Yhat, void* stream);
+
+/* IOC scoring + regression refinement, dims.iters passes (paper; model/model.py:312-313).
+ * dev_Yhat [R, T_pred, 2] in/out; dev_score [R] out. */
+int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream);
+
+/* encode + sample + ioc_refine, the unit bench.py times. */
+int desire_forward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps,
+                   float* dev_Yhat, float* dev_score, void* stream);
+
+/* Intermediates kept in the handle's workspace, for parity tests:
+ * "Hx" [A,H], "Hy" [A,H], "vae_in" [A,V], "z_mean" [A,L], "z_log_sigma_sq" [A,L], "z" [R,L],
+ * "d1" [R,2048], "d2" [R,4096], "d3" [R,8192], "xhat" [R,1024], "xz" [R,H], "Y0" [R,T_pred,2].
+ * Copies n floats to host_out after synchronising the stream. */
+int desire_read_buffer(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
+
+/* Integer paths, exposed for bit-exact tests (the same device functions the IOC kernel uses).
+ * dev_pos [n_groups, mno, 2] normalised; dev_valid [n_groups, mno] uint8;
+ * dev_bins [n_groups, mno, mno] int32 out (-1 = not pooled). */
+int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* dev_valid,
+                         int32_t* dev_bins, int32_t n_groups, void* stream);
+/* dev_pos [n, 2] -> dev_cells [n, 2] = (cy, cx). */
+int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_t* dev_cells, int32_t n, void* stream);
+
+/* Per-kernel GPU time of the last desire_forward on this handle, measured with hipEvents on
+ * `stream` (enabled by desire_set_profiling(h,1); adds event records only).
+ * host_ms[i] / host_names[i] for i < *count. */
+int desire_set_profiling(desire_handle* h, int enable);
+int desire_get_profile(desire_handle* h, float* host_ms, const char** host_names, int32_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESIRE_HIP_H */

@@ -1,0 +1,186 @@
+"""GPU parity: the HIP path (through the C ABI, via ctypes) against the CPU oracle on identical
+seeded inputs.  Tolerances: fp32 trajectory coordinates 1e-3 abs in normalised units (the bar
+BASELINE.json states); intermediates 2e-4 abs; integer indices bit-exact."""
+import numpy as np
+import pytest
+
+from desire_amd.spec import Dims, init_weights
+from tests.helpers import make_case, small_dims, to_oracle_layout
+
+pytestmark = pytest.mark.gpu
+
+TOL_Y = 1e-3
+TOL_MID = 2e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch
+
+
+def run_gpu(torch, d, w, past, fut, eps, grids, gos, Y_in=None):
+    from desire_amd import _lib
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past_t, eps_t, grids_t = t(past), t(eps), t(grids)
+    fut_t = t(fut) if d.posterior else None
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    if Y_in is None:
+        h.forward(past_t.data_ptr(), fut_t.data_ptr() if fut_t is not None else 0, eps_t.data_ptr(),
+                  Y.data_ptr(), score.data_ptr(), stream)
+    else:
+        h.encode(past_t.data_ptr(), fut_t.data_ptr() if fut_t is not None else 0, stream)
+        Y.copy_(t(Y_in))
+        h.ioc_refine(Y.data_ptr(), score.data_ptr(), stream)
+    torch.cuda.synchronize()
+    return h, Y.cpu().numpy(), score.cpu().numpy()
+
+
+def oracle_forward(d, w, past, fut, eps, grids, gos, **kw):
+    from oracle import desire_oracle as O
+    return O.forward(to_oracle_layout(past), to_oracle_layout(fut) if d.posterior else None, eps, grids, gos, w, d, **kw)
+
+
+def test_stagewise_parity_small(torch_cuda):
+    from oracle import desire_oracle as O
+    d = small_dims()
+    w = init_weights(d, 1)
+    past, fut, eps, grids, gos = make_case(d, seed=2)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    A, R = d.A, d.R
+    shapes = {"Hx": (A, d.H), "Hy": (A, d.H), "vae_in": (A, d.V), "z_mean": (A, d.L), "z_log_sigma_sq": (A, d.L),
+              "z": (R, d.L), "d1": (R, 2048), "d2": (R, 4096), "d3": (R, 8192), "xhat": (R, 1024), "xz": (R, d.H),
+              "Y0": (R, d.T_pred, 2)}
+    report = {}
+    for name, shp in shapes.items():
+        got = h.read_buffer(name, shp)
+        report[name] = float(np.abs(got - ref[name].reshape(shp)).max())
+    print("max abs err per stage:", report)
+    for name, err in report.items():
+        assert err < (TOL_Y if name == "Y0" else TOL_MID), (name, err, report)
+    # IOC stage on identical inputs (the oracle's decoder output) -> identical bins by construction
+    margin = O.bin_margin(ref["Y0"].reshape(d.n_scenes * d.K, d.mno, d.T_pred, 2).transpose(0, 2, 1, 3), d.nb_w, d.nb_h, d.grid_size)
+    ref2 = oracle_forward(d, w, past, fut, eps, grids, gos)
+    _, Y2, score2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref2["Y"]).max() < TOL_Y
+    assert np.abs(score2 - ref2["score"]).max() < 5e-3
+    # end to end (GPU decoder output feeds GPU IOC); bins can only differ if a pair sits within ~1e-6 of an edge
+    if margin > 1e-5:
+        assert np.abs(Y - ref["Y"]).max() < TOL_Y
+        assert np.abs(score - ref["score"]).max() < 5e-3
+
+
+@pytest.mark.parametrize("kw", [
+    dict(posterior=0),                                   # prior sampling: z = eps, no future
+    dict(mno=16, n_scenes=3, K=5),                       # 4 groups per tile, ragged last tile (R=240)
+    dict(mno=64, n_scenes=1, K=2, n_grids=1),            # one group per tile
+    dict(H=64, T_pred=7, K=3),                           # smaller hidden, odd horizon
+    dict(iters=2, K=2),                                  # two refinement passes
+    dict(grid_size=2, nb_w=0.6, nb_h=0.6, K=2),          # 2x2 social grid, wide window
+])
+def test_end_to_end_variants(torch_cuda, kw):
+    d = small_dims(**kw)
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos = make_case(d, seed=4)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    assert np.abs(Y0 - ref["Y0"]).max() < TOL_Y
+    _, Y2, score2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref["Y"]).max() < TOL_Y, np.abs(Y2 - ref["Y"]).max()
+    assert np.abs(score2 - ref["score"]).max() < 5e-3
+
+
+def test_neighbor_bins_and_scene_cells_bit_exact(torch_cuda):
+    torch = torch_cuda
+    from desire_amd import _lib
+    from oracle import desire_oracle as O
+    d = small_dims(mno=32)
+    h = _lib.Handle(d)
+    rng = np.random.default_rng(7)
+    n_groups = 257
+    pos = rng.uniform(-0.1, 1.1, (n_groups, d.mno, 2)).astype(np.float32)
+    # adversarial: exact window edges, bin edges, coincident agents
+    pos[0, 1] = pos[0, 0] + np.float32([d.nb_w / 2, 0])          # x_j == high  -> excluded
+    pos[0, 2] = pos[0, 0] - np.float32([d.nb_w / 2, 0])          # x_j == low   -> included, cell 0
+    pos[0, 3] = pos[0, 0]                                         # coincident   -> centre cell
+    pos[0, 4] = pos[0, 0] + np.float32([d.nb_w / 4, d.nb_h / 4])  # bin edge
+    pos[1] = np.float32(0.5) + np.float32(d.nb_w / d.grid_size) * rng.integers(-2, 3, (d.mno, 2)).astype(np.float32)
+    valid = (rng.random((n_groups, d.mno)) > 0.2).astype(np.uint8)
+    dev = torch.device("cuda")
+    pos_t = torch.as_tensor(pos, device=dev)
+    valid_t = torch.as_tensor(valid, device=dev)
+    bins_t = torch.full((n_groups, d.mno, d.mno), -7, dtype=torch.int32, device=dev)
+    h.neighbor_bins(pos_t.data_ptr(), valid_t.data_ptr(), bins_t.data_ptr(), n_groups)
+    torch.cuda.synchronize()
+    ref = O.neighbor_bins(pos, valid.astype(bool), d.nb_w, d.nb_h, d.grid_size)
+    np.testing.assert_array_equal(bins_t.cpu().numpy(), ref)
+    assert (ref >= 0).mean() > 0.02
+    # scene cells incl. out-of-range and exact cell edges
+    p = rng.uniform(-0.2, 1.2, (5000, 2)).astype(np.float32)
+    p[:64, 0] = np.arange(64, dtype=np.float32) / np.float32(64)
+    p[64:128, 1] = np.arange(64, dtype=np.float32) / np.float32(64)
+    p_t = torch.as_tensor(p, device=dev)
+    cells_t = torch.zeros((5000, 2), dtype=torch.int32, device=dev)
+    h.scene_cells(p_t.data_ptr(), cells_t.data_ptr(), 5000)
+    torch.cuda.synchronize()
+    cy, cx = O.scene_cell(p, d.Gh, d.Gw)
+    np.testing.assert_array_equal(cells_t.cpu().numpy(), np.stack([cy, cx], -1))
+
+
+def test_config1_shape_properties(torch_cuda):
+    """BASELINE configs[1] dims (32 agents, K=20, T=8/40, H=128) x 4 windows: size-independent checks --
+    determinism (bitwise), K-permutation equivariance of the sampler, padding agents never pooled."""
+    torch = torch_cuda
+    d = Dims(n_scenes=4, mno=32, K=20, T_obs=8, T_pred=40, n_grids=1, nb_w=0.2, nb_h=0.2, sx=1 / 1400.0, sy=1 / 1100.0)
+    w = init_weights(d, 5)
+    past, fut, eps, grids, gos = make_case(d, seed=6)
+    _, Y1, s1 = run_gpu(torch, d, w, past, fut, eps, grids, gos)
+    _, Y2, s2 = run_gpu(torch, d, w, past, fut, eps, grids, gos)
+    np.testing.assert_array_equal(Y1, Y2)
+    np.testing.assert_array_equal(s1, s2)
+    assert np.isfinite(Y1).all() and np.isfinite(s1).all()
+    # permuting the K draws of eps permutes the outputs (rows of different k never interact)
+    perm = np.random.default_rng(0).permutation(d.K)
+    e4 = eps.reshape(d.n_scenes, d.K, d.mno, d.L)[:, perm].reshape(d.R, d.L)
+    _, Y3, s3 = run_gpu(torch, d, w, past, fut, e4, grids, gos)
+    Y1r = Y1.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2)[:, perm].reshape(Y1.shape)
+    np.testing.assert_array_equal(Y3, Y1r)
+    np.testing.assert_array_equal(s3, s1.reshape(d.n_scenes, d.K, d.mno)[:, perm].reshape(-1))
+    # against the oracle on the first window only (oracle at full size takes too long for CI)
+    from oracle import desire_oracle as O
+    d1 = d.replace(n_scenes=1)
+    r1 = d1.R
+    ref = O.forward(to_oracle_layout(past[:1]), to_oracle_layout(fut[:1]), eps[:r1], grids, gos[:1], w, d1)
+    _, Yw, sw = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1], Y_in=ref["Y0"])
+    assert np.abs(Yw - ref["Y"]).max() < TOL_Y
+    np.testing.assert_array_equal(Y1[:r1], run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1])[1])
+
+
+def test_model_api_and_sample_layout(torch_cuda):
+    import argparse
+    from desire_amd.model import DESIREModel
+    args = argparse.Namespace(rnn_size=512, num_layers=1, batch_size=2, seq_length=8, pred_length=12, d_dim=128, e_dim=256,
+                              latent_size=128, max_num_obj=30, learning_rate=0.005, grad_clip=10.0, stride=1,
+                              neighborhood_size=300, grid_size=4, num_samples=3, img_width=1400.0, img_height=1100.0)
+    m = DESIREModel(args)
+    d = small_dims(n_scenes=2, mno=30 if False else 32)
+    past, fut, _, _, _ = make_case(d, seed=8)
+    x = [p[:, :30].astype(np.float64) for p in past]
+    y = [f[:, :30].astype(np.float64) for f in fut]
+    Y, score = m.forward(x, y)
+    assert tuple(Y.shape) == (2, 3, 32, 12, 2) and tuple(score.shape) == (2, 3, 32)
+    assert bool(torch_cuda.isfinite(Y).all())
+    out = m.sample(None, x[0], None, (1400.0, 1100.0), np.concatenate([x[0], y[0]]), num=10)
+    assert out.shape == (18, 30, 3)
+    np.testing.assert_array_equal(out[:8], x[0])
+    np.testing.assert_array_equal(out[8:, :, 0], np.broadcast_to(x[0][-1, :, 0], (10, 30)))
+    assert (out[8:][:, x[0][-1, :, 0] == 0] == 0).all()
