@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-trajectory-samples/s of the DESIRE hot path on MI355X.
+
+A "step" = one pass of the hot path (encode -> K-sample decode -> IOC score + one refinement)
+over one batch of loader windows already resident in HBM.  Workload = BASELINE.json configs[1]:
+32 agent slots per window, K=20, T_obs=8 / T_pred=40, H=128, L=128, fp32, social grid 4x4, scene
+grid 64x64x32; `--windows` windows (DataLoader batch entries, each its own scene) per step per GPU.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: windows are independent scenes (social pooling never crosses a window), so they shard
+across ranks with NO data-path collective; weak scaling (fixed windows per GPU).  Timing: barrier +
+torch.cuda.synchronize() on both sides of exactly K steps, max over ranks, rank 0 prints one JSON
+line.  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
+hipEvents on the launch stream over the timed steps) and `cpu_baseline` (the numpy oracle timed on
+this host on a bounded sample: ONE window = 640 samples).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def ioc_flops_per_row(d):
+    """Algorithmic FLOPs of k_ioc per row (one (agent,k) trajectory), SURVEY.md 8(d) D4 IOC terms."""
+    H, E, B, T = d.H, d.E, d.B, d.T_pred
+    return d.iters * (T * (6.0 * H * (E + H) + 2.0 * B * H * H + 2 * H + 4 * d.E_v) + 2.0 * H * 2 * T)
+
+
+def cpu_baseline(d_full, seed):
+    """The CPU restatement (oracle, NOT TF1 -- the reference cannot run) on one window."""
+    from oracle import desire_oracle as O                      # cpu_baseline leg: allowed importer
+    from desire_amd.spec import init_weights
+    from desire_amd.synth import make_case
+    d = d_full.replace(n_scenes=1, n_grids=1)
+    w = init_weights(d, seed)
+    past, fut, eps, grids, gos = make_case(d, seed=seed + 1)
+    tr = lambda x: np.ascontiguousarray(x.transpose(1, 0, 2, 3).reshape(x.shape[1], -1, 3))
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
+    dt = time.perf_counter() - t0
+    return {"value": d.R / dt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 1 window = %d samples, "
+                      "%.1f s; CPU restatement, not TF1 (reference graph does not build)" % (d.R, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=64, help="loader windows (scenes) per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from desire_amd import _lib
+    from desire_amd.spec import Dims, flops_per_sample, init_weights
+    from desire_amd.synth import make_case
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    d = Dims(n_scenes=a.windows, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4,
+             nb_w=0.15, nb_h=0.15, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
+    w = init_weights(d, a.seed)
+    past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    h.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    h.set_profiling(False)
+    prof = h.get_profile()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(Y).all()) and bool(torch.isfinite(score).all())
+
+    per_kernel = {}
+    for name, ms in prof:
+        per_kernel.setdefault(name, []).append(ms)
+    kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+    ioc_ms = kern_ms.get("ioc", float("nan"))
+    ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12
+    whole_tflops = flops_per_sample(d) * d.R * a.steps / dt / 1e12
+
+    if rank == 0:
+        samples = d.R * world * a.steps
+        out = {
+            "metric": "agent-trajectory-samples/sec (K=20, T_pred=40)",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SDD-like synthetic windows, 32 agent slots/window, K=20, "
+                                   "T_obs=8/T_pred=40, H=128, L=128, fp32, posterior CVAE, IOC 1 refinement, "
+                                   "social grid 4x4, scene grid 64x64x32; %d windows/step/GPU" % a.windows,
+                       "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d" % world,
+                       "flops_per_sample": flops_per_sample(d)},
+            "roofline": {"bound": "mfma", "kernel": "k_ioc<128,16,32>", "achieved": ioc_tflops,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ioc_tflops / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": ioc_ms,
+                         "algorithmic_flops_per_launch": ioc_flops_per_row(d) * d.R,
+                         "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / FP32_MFMA_PEAK_TFLOPS},
+            "kernel_ms": kern_ms,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, a.seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

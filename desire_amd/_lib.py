@@ -140,7 +140,9 @@ class Handle:
         _chk(self.lib.desire_set_profiling(self._h, int(on)))
 
     def get_profile(self) -> List[Tuple[str, float]]:
-        cap = 64
+        n0 = C.c_int32(1 << 30)
+        _chk(self.lib.desire_get_profile(self._h, None, None, C.byref(n0)))
+        cap = max(int(n0.value), 1)
         ms = (C.c_float * cap)()
         names = (C.c_char_p * cap)()
         n = C.c_int32(cap)

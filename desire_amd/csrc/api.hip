@@ -54,8 +54,7 @@ struct desire_ctx {
     bool grids_set = false;
     bool profiling = false;
     std::vector<Prof> prof;
-    std::vector<float> prof_ms;
-    std::vector<const char*> prof_names;
+    std::vector<std::string> prof_name_store;
 };
 
 namespace {
@@ -422,10 +421,6 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
 
 extern "C" int desire_forward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps,
                               float* dev_Yhat, float* dev_score, void* stream) {
-    if (h && h->profiling) {
-        for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
-        h->prof.clear();
-    }
     if (int rc = desire_encode(h, dev_past, dev_fut, stream)) return rc;
     if (int rc = desire_sample(h, dev_eps, dev_Yhat, stream)) return rc;
     return desire_ioc_refine(h, dev_Yhat, dev_score, stream);
@@ -498,5 +493,11 @@ extern "C" int desire_get_profile(desire_handle* h, float* host_ms, const char**
         ++n;
     }
     *count = n;
+    if (!host_ms && !host_names) return DESIRE_OK;      // count query only
+    h->prof_name_store.clear();
+    for (auto& p : h->prof) h->prof_name_store.push_back(p.name);
+    if (host_names) for (int i = 0; i < n; ++i) host_names[i] = h->prof_name_store[i].c_str();
+    for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    h->prof.clear();
     return DESIRE_OK;
 }

@@ -142,7 +142,11 @@ class DESIREModel(object):
         torch = self.torch
         traj = np.asarray(traj, np.float64)
         args = SimpleNamespace(**vars(self.args))
-        args.seq_length, args.pred_length = traj.shape[0], int(num)
+        t_pred = int(getattr(self.args, "pred_length", self.args.seq_length))
+        if num > t_pred:
+            raise ValueError("num=%d exceeds the model's pred_length=%d (the IOC regression head is sized by it)"
+                             % (num, t_pred))
+        args.seq_length, args.pred_length = traj.shape[0], t_pred
         if dimensions is not None:
             args.img_width, args.img_height = float(dimensions[0]), float(dimensions[1])
         sub = DESIREModel(args, self._weights, self._seed)
@@ -152,7 +156,7 @@ class DESIREModel(object):
         d = sub._handle(1, False).dims
         best = score[0].argmax(dim=0)                                        # [mno]
         idx = best.view(1, -1, 1, 1).expand(1, d.mno, d.T_pred, 2)
-        top = torch.gather(Y[0], 0, idx)[0].cpu().numpy()                    # [mno, T_pred, 2]
+        top = torch.gather(Y[0], 0, idx)[0].cpu().numpy()[:, :num]           # [mno, num, 2]
         out = np.zeros((traj.shape[0] + num, traj.shape[1], 3))
         out[: traj.shape[0]] = traj
         m = traj.shape[1]

@@ -100,9 +100,11 @@ int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* 
 /* dev_pos [n, 2] -> dev_cells [n, 2] = (cy, cx). */
 int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_t* dev_cells, int32_t n, void* stream);
 
-/* Per-kernel GPU time of the last desire_forward on this handle, measured with hipEvents on
- * `stream` (enabled by desire_set_profiling(h,1); adds event records only).
- * host_ms[i] / host_names[i] for i < *count. */
+/* Per-kernel GPU time measured with hipEvents on the launch stream (enabled by
+ * desire_set_profiling(h,1); adds two event records per kernel, nothing else).  Entries accumulate
+ * over calls; desire_get_profile synchronises on them, copies up to *count (in: capacity) entries
+ * to host_ms[i] / host_names[i], sets *count, and clears the list.  With host_ms == host_names ==
+ * NULL it only reports the pending entry count. */
 int desire_set_profiling(desire_handle* h, int enable);
 int desire_get_profile(desire_handle* h, float* host_ms, const char** host_names, int32_t* count);
 
