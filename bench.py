@@ -15,7 +15,7 @@ across ranks with NO data-path collective; weak scaling (fixed windows per GPU).
 torch.cuda.synchronize() on both sides of exactly K steps, max over ranks, rank 0 prints one JSON
 line.  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
 hipEvents on the launch stream over the timed steps) and `cpu_baseline` (the numpy oracle timed on
-this host on a bounded sample: ONE window = 640 samples).
+this host on a bounded sample: 4 windows = 2560 samples).
 """
 import argparse
 import json
@@ -44,7 +44,7 @@ def cpu_baseline(d_full, seed):
     from oracle import desire_oracle as O                      # cpu_baseline leg: allowed importer
     from desire_amd.spec import init_weights
     from desire_amd.synth import make_case
-    d = d_full.replace(n_scenes=1, n_grids=1)
+    d = d_full.replace(n_scenes=4, n_grids=1)
     w = init_weights(d, seed)
     past, fut, eps, grids, gos = make_case(d, seed=seed + 1)
     tr = lambda x: np.ascontiguousarray(x.transpose(1, 0, 2, 3).reshape(x.shape[1], -1, 3))
@@ -57,7 +57,7 @@ def cpu_baseline(d_full, seed):
     O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
     dt = time.perf_counter() - t0
     return {"value": d.R / dt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
-            "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 1 window = %d samples, "
+            "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 4 windows = %d samples, "
                       "%.1f s; CPU restatement, not TF1 (reference graph does not build)" % (d.R, dt)}
 
 
