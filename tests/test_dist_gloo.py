@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo.  The compute itself needs a GPU; what is covered here is the
+sharding + gather logic bench.py / DESIREModel use between ranks (windows block-sharded, results
+all-gathered in global window order, max-over-ranks timing reduction)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from desire_amd.dist import gather_results, shard_batch, shard_windows
+
+
+def test_shard_windows_covers_everything():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_windows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_windows(4, 2, 2)
+
+
+def _worker(rank, world, port, n_windows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch = [np.full((3, 2), i, np.float32) for i in range(n_windows)]
+        mine = shard_batch(batch, rank, world)
+        # stand-in for the per-window hot-path result: f(window) known in closed form
+        local = torch.stack([torch.as_tensor(b) * 2 + 1 for b in mine]) if mine else torch.zeros((0, 3, 2))
+        full = gather_results(local, n_windows)
+        t = torch.tensor([0.5 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # bench.py's max-over-ranks step time
+        dist.barrier()
+        q.put((rank, full.numpy(), float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_windows", [5, 8])
+def test_gloo_world2_gather_matches_single_process(n_windows):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_windows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([np.full((3, 2), i, np.float32) * 2 + 1 for i in range(n_windows)])
+    for rank, full, tmax in res:
+        np.testing.assert_array_equal(full, want)
+        assert tmax == 1.5
