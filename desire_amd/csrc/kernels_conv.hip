@@ -146,27 +146,44 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
     }
-    for (int ky = 0; ky < 5; ++ky)
-        for (int kx = 0; kx < 5; ++kx) {
-            f32x16 acc = zero16();
-            const float4* bp = a.Wp + ((size_t)((ky * 5 + kx) * 2 + hf) * 16) * 64 + lane;
+    // taps: B fragments of tap t+1 are fetched while tap t contracts (two register sets, loop unrolled
+    // by 2 so the sets are addressed statically); the scatter is an LDS float add without return
+    // (ds_add_f32) -- this wave is the only writer of its region, so the order is deterministic.
+    auto load_b = [&](float4 (&b)[16], int tap) {
+        const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16) * 64 + lane;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float4 b = bp[g * 64];
-                acc = mfma32(af[g].x, b.x, acc);
-                acc = mfma32(af[g].y, b.y, acc);
-                acc = mfma32(af[g].z, b.z, acc);
-                acc = mfma32(af[g].w, b.w, acc);
-            }
+        for (int g = 0; g < 16; ++g) b[g] = bp[g * 64];
+    };
+    auto do_tap = [&](const float4 (&b)[16], int tap) {
+        const int ky = tap / 5, kx = tap - ky * 5;
+        f32x16 acc = zero16();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = acc_row(i);
-                const int s = rr >> 4, p = rr & 15;
-                const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-                float* dst = my + (s * 64 + o) * 64 + hf * 32 + c;
-                *dst = *dst + acc[i];
-            }
+        for (int g = 0; g < 16; ++g) {
+            acc = mfma32(af[g].x, b[g].x, acc);
+            acc = mfma32(af[g].y, b[g].y, acc);
+            acc = mfma32(af[g].z, b[g].z, acc);
+            acc = mfma32(af[g].w, b[g].w, acc);
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = acc_row(i);
+            const int s = rr >> 4, p = rr & 15;
+            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+            __hip_atomic_fetch_add(my + (s * 64 + o) * 64 + hf * 32 + c, acc[i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    float4 b0[16], b1[16];
+    load_b(b0, 0);
+#pragma clang loop unroll(disable)
+    for (int tap = 0; tap < 24; tap += 2) {
+        load_b(b1, tap + 1);
+        do_tap(b0, tap);
+        load_b(b0, tap + 2);
+        do_tap(b1, tap + 1);
+    }
+    do_tap(b0, 24);
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): all LDS adds of this wave have landed
     const int co = hf * 32 + c;
     const float sc = a.scale[co], sh = a.shift[co];
     for (int i = 0; i < 64; ++i) {

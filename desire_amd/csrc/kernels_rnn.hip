@@ -237,24 +237,29 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 //   score += h_t . w_s + b_s
 // after T steps: dY = h_T W_r + b_r ; Y += dY.
 // ------------------------------------------------------------------------------------------------
-template <int H, int EV, int C>
-__global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
+// TM = rows per workgroup (32 or 64; must hold whole (scene,k) groups: TM % mno == 0), 8 threads per
+// row.  TM=32 runs 4 waves and ~77 KB of LDS so that TWO workgroups share a CU: their barrier/VALU
+// phases interleave with each other's MFMA phases.
+template <int H, int EV, int C, int TM>
+__global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = TM * 8;
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
     constexpr int G8 = KX >> 3, GH = H >> 3;
+    constexpr int NCH = H >> 5;                          // float4 chunks per thread in the pooled build
     const int B = a.G * a.G;
-    float* XH = smem;                                   // [64][LDX]   [e_v | e_s | e_r | h]
-    float* AB = XH + DS_TM * LDX;                       // [2][64][LDB] pooled operand, double buffered
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * DS_TM * LDB);   // [64][B]
-    float* pc = reinterpret_cast<float*>(masks + DS_TM * B);   // [64][2] current position
-    float* pp = pc + DS_TM * 2;                         // [64][2] previous position
-    float* wv = pp + DS_TM * 2;                         // [2][E_v] + [E_v]
-    float* red = wv + 3 * EV;                           // [4][64] score reduction
-    unsigned char* vld = reinterpret_cast<unsigned char*>(red + 4 * DS_TM);   // [64]
+    float* XH = smem;                                   // [TM][LDX]   [e_v | e_s | e_r | h]
+    float* AB = XH + TM * LDX;                          // [2][TM][LDB] pooled operand, double buffered
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B]
+    float* pc = reinterpret_cast<float*>(masks + TM * B);      // [TM][2] current position
+    float* pp = pc + TM * 2;                            // [TM][2] previous position
+    float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
+    float* red = wv + 3 * EV;                           // [4][TM] score reduction
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + 4 * TM);   // [TM]
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w & 3, mt = w >> 2;
-    const int row0 = blockIdx.x * DS_TM;
+    const int row0 = blockIdx.x * TM;
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid >> 3, q8 = tid & 7;              // 8 threads per row for the VALU phases
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
     const int grp_base = (r8 / a.mno) * a.mno;          // first local row of my (scene,k) group
     const int my_slot = r8 - grp_base;
 
-    for (int i = tid; i < 3 * EV; i += RNN_WG) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
-    if (tid < DS_TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
 
     float bgr = 0, bgu = 0, bcc = 0, bso = 0, wsc = 0;
     if (active) { bgr = a.b_g[col]; bgu = a.b_g[H + col]; bcc = a.b_c[col]; bso = a.b_soc[col]; wsc = a.w_score[col]; }
@@ -272,15 +277,38 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
     float* my_x = XH + (mt * 32 + 4 * (lane >> 5)) * LDX + col;        // + acc-row * LDX (+ column base)
     const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
 
+    // pooled operand of bin b: ab[r8][:] = sum_{j in mask} h_{t-1}[group row j][:]; thread q8 owns the
+    // float4 chunks q8, q8+8, ... so the 8 lanes of a row touch 128 contiguous bytes (no bank conflicts)
+    auto build = [&](int b) {
+        float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+        const unsigned long long mk = masks[r8 * B + b];
+        float4 s[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long m2 = mk;
+        while (m2) {
+            const int j = __ffsll((long long)m2) - 1;
+            m2 &= m2 - 1;
+            const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c * 32);
+                s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 32) = s[c];
+    };
+
     for (int it = 0; it < a.iters; ++it) {
         // h_0 = Hx[agent]
-        for (int i = tid; i < DS_TM * (H >> 2); i += RNN_WG) {
+        for (int i = tid; i < TM * (H >> 2); i += NTHR) {
             const int r = i / (H >> 2), c4 = i - r * (H >> 2);
             const int ag = agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno);
             *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
                 *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
         }
-        if (tid < DS_TM) {
+        if (tid < TM) {
             const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
             pp[tid * 2] = a.p_last[(size_t)ag * 2];
             pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
@@ -294,11 +322,11 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
 
         for (int t = 0; t < a.T; ++t) {
             // ---- P0: positions, clear masks ----
-            if (tid < DS_TM) {
+            if (tid < TM) {
                 const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
                 pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
             }
-            for (int i = tid; i < DS_TM * B; i += RNN_WG) masks[i] = 0ull;
+            for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
             __syncthreads();
             // ---- P1: e_v, e_s, neighbour masks ----
             {
@@ -323,30 +351,17 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
                 }
             }
             __syncthreads();
-            // ---- P2: social pooling, one bin at a time ----
+            // ---- P2: social pooling.  build(b+1) and the contraction of bin b sit between the same two
+            //      barriers, so waves that finish building early start their MFMAs while others still build
             f32x16 soc = splat16(bso);
+            build(0);
+            __syncthreads();
             for (int b = 0; b < B; ++b) {
-                float* ab = AB + (b & 1) * DS_TM * LDB;
-                {
-                    constexpr int per = H >> 3;            // columns per thread (16 at H=128)
-                    const unsigned long long mk = masks[r8 * B + b];
-#pragma unroll
-                    for (int c0 = 0; c0 < per; c0 += 4) {
-                        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        unsigned long long m2 = mk;
-                        while (m2) {
-                            const int j = __ffsll((long long)m2) - 1;
-                            m2 &= m2 - 1;
-                            const float4 v0 = *reinterpret_cast<const float4*>(XH + (grp_base + j) * LDX + E + q8 * per + c0);
-                            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-                        }
-                        *reinterpret_cast<float4*>(ab + r8 * LDB + q8 * per + c0) = s0;
-                    }
-                }
-                __syncthreads();
+                if (b + 1 < B) build(b + 1);
                 if (active)
-                    mma1(soc, ab + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
+                    mma1(soc, AB + (b & 1) * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
                          a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                __syncthreads();
             }
             // ---- P3: e_r ----
             if (active) {
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
             }
-            if (tid < DS_TM) { pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1]; }
+            if (tid < TM) { pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1]; }
             __syncthreads();
         }
         // ---- score: sum the per-lane partials over the 32 columns of this wave, then over column blocks ----
@@ -393,11 +408,11 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
             float v = active ? sp[i] : 0.f;
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-            if ((lane & 31) == 0) red[cb * DS_TM + mt * 32 + acc_row(i)] = v;
+            if ((lane & 31) == 0) red[cb * TM + mt * 32 + acc_row(i)] = v;
         }
         __syncthreads();
-        if (tid < DS_TM && row0 + tid < a.R && it == a.iters - 1) {
-            float sc = red[tid] + red[DS_TM + tid] + red[2 * DS_TM + tid] + red[3 * DS_TM + tid];
+        if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
+            float sc = red[tid] + red[TM + tid] + red[2 * TM + tid] + red[3 * TM + tid];
             a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
         }
         // ---- regression: Y += h_T W_r + b_r   (columns = (t, xy) flattened) ----
@@ -420,17 +435,21 @@ __global__ __launch_bounds__(RNN_WG) void k_ioc(IocArgs a) {
         __syncthreads();
     }
 }
-size_t ioc_lds_bytes(const IocArgs& a) {
+static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
     const int EV = 16, H = a.H, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
-    size_t f = (size_t)DS_TM * LDX + 2 * DS_TM * LDB + (size_t)DS_TM * B * 2 + DS_TM * 4 + 3 * EV + 4 * DS_TM;
-    return f * sizeof(float) + DS_TM + 64;
+    size_t f = (size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + 4 * TM;
+    return f * sizeof(float) + TM + 64;
+}
+template <int H, int TM>
+static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
+    allow_big_lds(k_ioc<H, 16, 32, TM>);
+    hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3(TM * 8), ioc_lds_bytes(a, TM), s, a);
 }
 void launch_ioc(const IocArgs& a, hipStream_t s) {
-    const size_t lds = ioc_lds_bytes(a);
-    const dim3 grid((a.R + DS_TM - 1) / DS_TM);
-    if (a.H == 128) { allow_big_lds(k_ioc<128, 16, 32>); hipLaunchKernelGGL((k_ioc<128, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
-    else if (a.H == 64) { allow_big_lds(k_ioc<64, 16, 32>); hipLaunchKernelGGL((k_ioc<64, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
-    else { allow_big_lds(k_ioc<32, 16, 32>); hipLaunchKernelGGL((k_ioc<32, 16, 32>), grid, dim3(RNN_WG), lds, s, a); }
+    const bool small = (a.mno <= 32) && !a.force_tm64;          // whole groups must fit the tile
+    if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
+    else if (a.H == 64) { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
+    else { if (small) launch_ioc_t<32, 32>(a, s); else launch_ioc_t<32, 64>(a, s); }
 }
 
 // ------------------------------------------------------------------------------------------------
