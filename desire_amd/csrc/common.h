@@ -56,27 +56,37 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const 
 }
 
 // ap[m]: LDS pointer to A[row = lane&31 of M-tile m][4*(lane>>5)]; rows may be gathered (convs).
+// Two statically named B register sets ping-pong (no copies): the loads of chunk c+1 are issued,
+// fenced with sched_barrier so hipcc cannot sink them to their use, then chunk c computes; a load is
+// therefore in flight for a whole 16*MT-MFMA chunk (>= 1024 cycles) before anything waits on it.
+__device__ __forceinline__ void load_b4(float4 (&b)[4], const float4* __restrict__ b_lane, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = b_lane[(g + j) * 64];
+}
+
 template <int MT>
 __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
                                                const float4* __restrict__ b_lane, int G) {
-    int g = 0;
-    if (G >= 4) {
-        float4 cur[4], nxt[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = b_lane[j * 64];
+    const int nch = G >> 2;
+    int c = 0;
+    if (nch > 0) {
+        float4 b0[4], b1[4];
+        load_b4(b0, b_lane, 0);
 #pragma clang loop unroll(disable)
-        for (; g + 8 <= G; g += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nxt[j] = b_lane[(g + 4 + j) * 64];
-            mma_chunk<MT>(acc, ap, g, cur);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        for (; c + 2 <= nch; c += 2) {
+            load_b4(b1, b_lane, 4 * c + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk<MT>(acc, ap, 4 * c, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nch) load_b4(b0, b_lane, 4 * c + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk<MT>(acc, ap, 4 * c + 4, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        mma_chunk<MT>(acc, ap, g, cur);
-        g += 4;
+        if (c < nch) { mma_chunk<MT>(acc, ap, 4 * c, b0); ++c; }
     }
 #pragma clang loop unroll(disable)
-    for (; g < G; ++g) {
+    for (int g = 4 * c; g < G; ++g) {
         const float4 b = b_lane[g * 64];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {

@@ -178,9 +178,13 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
 #pragma clang loop unroll(disable)
     for (int tap = 0; tap < 24; tap += 2) {
         load_b(b1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
         do_tap(b0, tap);
+        __builtin_amdgcn_sched_barrier(0);
         load_b(b0, tap + 2);
+        __builtin_amdgcn_sched_barrier(0);
         do_tap(b1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     do_tap(b0, 24);
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): all LDS adds of this wave have landed

@@ -118,8 +118,7 @@ void launch_encoder(const EncArgs& a, hipStream_t s) {
     const size_t lds = (DS_TM * (a.H + 4) + DS_TM * 2) * sizeof(float);
     const dim3 grid((A + DS_TM - 1) / DS_TM);
     if (a.H == 128) hipLaunchKernelGGL(k_encoder<128>, grid, dim3(RNN_WG), lds, s, a);
-    else if (a.H == 64) hipLaunchKernelGGL(k_encoder<64>, grid, dim3(RNN_WG), lds, s, a);
-    else hipLaunchKernelGGL(k_encoder<32>, grid, dim3(RNN_WG), lds, s, a);
+    else hipLaunchKernelGGL(k_encoder<64>, grid, dim3(RNN_WG), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,8 +221,7 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
     const size_t lds = (2 * DS_TM * (a.H + 4) + 2 * a.H + DS_TM * 2) * sizeof(float);
     const dim3 grid((a.R + DS_TM - 1) / DS_TM);
     if (a.H == 128) { allow_big_lds(k_decoder<128>); hipLaunchKernelGGL(k_decoder<128>, grid, dim3(RNN_WG), lds, s, a); }
-    else if (a.H == 64) hipLaunchKernelGGL(k_decoder<64>, grid, dim3(RNN_WG), lds, s, a);
-    else hipLaunchKernelGGL(k_decoder<32>, grid, dim3(RNN_WG), lds, s, a);
+    else hipLaunchKernelGGL(k_decoder<64>, grid, dim3(RNN_WG), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -448,8 +446,7 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
 void launch_ioc(const IocArgs& a, hipStream_t s) {
     const bool small = (a.mno <= 32) && !a.force_tm64;          // whole groups must fit the tile
     if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
-    else if (a.H == 64) { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
-    else { if (small) launch_ioc_t<32, 32>(a, s); else launch_ioc_t<32, 64>(a, s); }
+    else { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
 }
 
 // ------------------------------------------------------------------------------------------------
