@@ -147,8 +147,9 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
         for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
     }
     // taps: B fragments of tap t+1 are fetched while tap t contracts (two register sets, loop unrolled
-    // by 2 so the sets are addressed statically); the scatter is an LDS float add without return
-    // (ds_add_f32) -- this wave is the only writer of its region, so the order is deterministic.
+    // by 2 so the sets are addressed statically).  The scatter is a plain LDS read-add-write: this wave
+    // is the only writer of its region (deterministic), and ds_add_f32 measured 1.4x SLOWER on the whole
+    // kernel (LDS atomics retire at a fraction of the plain ds_read/ds_write rate).
     auto load_b = [&](float4 (&b)[16], int tap) {
         const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16) * 64 + lane;
 #pragma unroll
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
             const int rr = acc_row(i);
             const int s = rr >> 4, p = rr & 15;
             const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-            __hip_atomic_fetch_add(my + (s * 64 + o) * 64 + hf * 32 + c, acc[i], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            float* dst = my + (s * 64 + o) * 64 + hf * 32 + c;
+            *dst = *dst + acc[i];
         }
     };
     float4 b0[16], b1[16];
@@ -187,7 +188,6 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     do_tap(b0, 24);
-    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): all LDS adds of this wave have landed
     const int co = hf * 32 + c;
     const float sc = a.scale[co], sh = a.shift[co];
     for (int i = 0; i < 64; ++i) {
