@@ -415,7 +415,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
-    a.force_tm64 = getenv("DESIRE_IOC_TM64") ? 1 : 0;
+    { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;

@@ -81,7 +81,7 @@ struct IocArgs {
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c;   // K = E+H
     const float* w_score; const float* b_score;            // [H], [1]
     const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed
-    int force_tm64;                                        // debug/A-B: use the 64-row tile even when mno <= 32
+    int variant;                                           // A/B switch, see launch_ioc
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 

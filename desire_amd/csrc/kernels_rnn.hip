@@ -97,7 +97,7 @@ __global__ __launch_bounds__(RNN_WG) void k_encoder(EncArgs a) {
             }
             mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
         }
         __syncthreads();                                   // every wave done reading r*h
         if (active) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
             f32x16 ac = xc;
             mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
         }
         __syncthreads();
         if (active) {
@@ -349,22 +349,24 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
                 }
             }
             __syncthreads();
-            // ---- P2: social pooling.  build(b+1) and the contraction of bin b sit between the same two
-            //      barriers, so waves that finish building early start their MFMAs while others still build
-            f32x16 soc = splat16(bso);
-            build(0);
-            __syncthreads();
-            for (int b = 0; b < B; ++b) {
-                if (b + 1 < B) build(b + 1);
-                if (active)
-                    mma1(soc, AB + (b & 1) * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
-                         a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+            // ---- P2/P3: social pooling -> e_r ----
+            {
+                // build(b+1) and the contraction of bin b sit between the same two barriers, so waves that
+                // finish building early start their MFMAs while others still build
+                f32x16 soc = splat16(bso);
+                build(0);
                 __syncthreads();
-            }
-            // ---- P3: e_r ----
-            if (active) {
+                for (int b = 0; b < B; ++b) {
+                    if (b + 1 < B) build(b + 1);
+                    if (active)
+                        mma1(soc, AB + (b & 1) * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
+                             a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                    __syncthreads();
+                }
+                if (active) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+                    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+                }
             }
             __syncthreads();
             // ---- P4: gates ----
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
                 mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, G8);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(ac[i]);
+                    h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                 }
             }
@@ -444,7 +446,8 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3(TM * 8), ioc_lds_bytes(a, TM), s, a);
 }
 void launch_ioc(const IocArgs& a, hipStream_t s) {
-    const bool small = (a.mno <= 32) && !a.force_tm64;          // whole groups must fit the tile
+    // 32-row tiles (two workgroups per CU) whenever whole (scene,k) groups fit; variant=2 forces 64 rows (A/B)
+    const bool small = (a.mno <= 32) && a.variant != 2;
     if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
     else { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
 }
