@@ -17,7 +17,8 @@ EXPORTS = [
     "desire_last_error", "desire_version", "desire_create", "desire_destroy", "desire_set_weight",
     "desire_finalize_weights", "desire_set_scene_grids", "desire_encode", "desire_sample",
     "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
-    "desire_scene_cells", "desire_set_profiling", "desire_get_profile",
+    "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
+    "desire_temporal_conv", "desire_feature_pooling",
 ]
 
 
@@ -64,6 +65,10 @@ def load() -> C.CDLL:
     lib.desire_read_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_neighbor_bins.argtypes = [vp, f32p, vp, vp, i32, vp]
     lib.desire_scene_cells.argtypes = [vp, f32p, vp, i32, vp]
+    lib.desire_scene_cnn.argtypes = [vp, f32p, i32, i32, f32p, vp]
+    lib.desire_losses.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, vp]
+    lib.desire_temporal_conv.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_feature_pooling.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
@@ -135,6 +140,18 @@ class Handle:
 
     def scene_cells(self, pos_ptr: int, cells_ptr: int, n: int, stream: int = 0) -> None:
         _chk(self.lib.desire_scene_cells(self._h, pos_ptr, cells_ptr, n, stream or None))
+
+    def scene_cnn(self, image_ptr: int, Hi: int, Wi: int, grids_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_scene_cnn(self._h, image_ptr, Hi, Wi, grids_ptr, stream or None))
+
+    def losses(self, fut_ptr: int, yhat_ptr: int, kld_ptr: int, recon_ptr: int, cost_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_losses(self._h, fut_ptr, yhat_ptr, kld_ptr, recon_ptr, cost_ptr, stream or None))
+
+    def temporal_conv(self, past_ptr: int, rho_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_temporal_conv(self._h, past_ptr, rho_ptr, stream or None))
+
+    def feature_pooling(self, yhat_ptr: int, rho_ptr: int, out_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_feature_pooling(self._h, yhat_ptr, rho_ptr, out_ptr, stream or None))
 
     def set_profiling(self, on: bool) -> None:
         _chk(self.lib.desire_set_profiling(self._h, int(on)))

@@ -118,6 +118,10 @@ void shapes(desire_ctx* h) {
     gru("ioc", h->E);
     s["ioc/score/w"] = H; s["ioc/score/b"] = 1;
     s["ioc/reg/w"] = (size_t)H * 2 * d.T_pred; s["ioc/reg/b"] = 2 * d.T_pred;
+    s["scene_cnn/conv1/w"] = 25 * 3 * 16; s["scene_cnn/conv1/b"] = 16;
+    s["scene_cnn/conv2/w"] = 25 * 16 * 32; s["scene_cnn/conv2/b"] = 32;
+    s["scene_cnn/conv3/w"] = (size_t)25 * 32 * d.C; s["scene_cnn/conv3/b"] = d.C;
+    s["temporal/w"] = (size_t)d.T_obs * 2 * 100; s["temporal/b"] = 200;
 }
 
 // frozen batch-norm + bias -> (scale, shift); float64 then one rounding (desire_amd/spec.py:fold_bn)
@@ -292,6 +296,9 @@ extern "C" int desire_finalize_weights(desire_handle* h) {
         const auto& w1 = hw["vae_dec/deconv1/w"];
         bad |= up("vae_dec/deconv1/W", pack_b(L, 2048, [&](int k, int n) { return w1[(size_t)n * L + k]; }));
     }
+    for (const char* n : {"scene_cnn/conv1/w", "scene_cnn/conv1/b", "scene_cnn/conv2/w", "scene_cnn/conv2/b",
+                          "scene_cnn/conv3/w", "scene_cnn/conv3/b", "temporal/w", "temporal/b"})
+        bad |= up(n, hw[n]);
     if (bad) return fail(DESIRE_ERR_HIP, "weight upload failed");
     HIPCHK(hipDeviceSynchronize());
     h->finalized = true;
@@ -471,6 +478,55 @@ extern "C" int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_
     if (!h || !dev_pos || !dev_cells || n < 0) return fail(DESIRE_ERR_ARG, "bad argument");
     if (n == 0) return DESIRE_OK;
     launch_scene_cells(dev_pos, dev_cells, n, h->d.Gh, h->d.Gw, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_scene_cnn(desire_handle* h, const float* dev_image, int32_t Hi, int32_t Wi, float* dev_grids, void* stream) {
+    if (int rc = ready(h)) return rc;
+    if (!dev_image || !dev_grids) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    if (Hi != 4 * d.Gh || Wi != 4 * d.Gw) return fail(DESIRE_ERR_ARG, "scene image must be [n_grids, 4*Gh, 4*Gw, 3]");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n1 = (size_t)d.n_grids * (Hi / 2) * (Wi / 2) * 16, n2 = (size_t)d.n_grids * d.Gh * d.Gw * 32;
+    if (!h->ws.count("scnn1")) {
+        if (h->ws["scnn1"].alloc(n1 * sizeof(float)) || h->ws["scnn2"].alloc(n2 * sizeof(float)))
+            return fail(DESIRE_ERR_HIP, "hipMalloc failed for the scene CNN workspace");
+    }
+    { Timer t(h, s, "scene_cnn");
+      launch_conv_direct(dev_image, D(h, "scene_cnn/conv1/w"), D(h, "scene_cnn/conv1/b"), W(h, "scnn1"), d.n_grids, Hi, Wi, 3, 16, 2, 1, s);
+      launch_conv_direct(W(h, "scnn1"), D(h, "scene_cnn/conv2/w"), D(h, "scene_cnn/conv2/b"), W(h, "scnn2"), d.n_grids, Hi / 2, Wi / 2, 16, 32, 2, 1, s);
+      launch_conv_direct(W(h, "scnn2"), D(h, "scene_cnn/conv3/w"), D(h, "scene_cnn/conv3/b"), dev_grids, d.n_grids, d.Gh, d.Gw, 32, d.C, 1, 0, s); }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_losses(desire_handle* h, const float* dev_fut, const float* dev_Yhat, float* dev_kld,
+                             float* dev_recon, float* dev_cost, void* stream) {
+    if (int rc = ready(h)) return rc;
+    if (!dev_fut || !dev_Yhat || !dev_kld || !dev_recon || !dev_cost) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    if (!d.posterior) return fail(DESIRE_ERR_STATE, "losses need the posterior path (dims.posterior = 1)");
+    launch_losses(W(h, "params"), dev_Yhat, dev_fut, static_cast<const uint8_t*>(h->ws["valid"].p), dev_kld, dev_recon,
+                  dev_cost, d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_temporal_conv(desire_handle* h, const float* dev_past, float* dev_rho, void* stream) {
+    if (int rc = ready(h)) return rc;
+    if (!dev_past || !dev_rho) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    launch_temporal_conv(dev_past, D(h, "temporal/w"), D(h, "temporal/b"), dev_rho, d.n_scenes, d.T_obs, d.mno,
+                         static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float* dev_rho, float* dev_out, void* stream) {
+    if (!h || !dev_Yhat || !dev_rho || !dev_out) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    launch_feature_pooling(dev_Yhat, dev_rho, dev_out, h->R, d.T_pred, d.K, d.mno, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

@@ -88,3 +88,12 @@ void launch_ioc(const IocArgs& a, hipStream_t s);
 void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
                           float nb_w, float nb_h, int G, hipStream_t s);
 void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw, hipStream_t s);
+
+// ---- cold rows (kernels_aux.hip) ----
+void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
+                        int Co, int stride, int relu, hipStream_t s);
+void launch_temporal_conv(const float* frames, const float* w, const float* b, float* rho, int n_scenes, int T, int mno,
+                          hipStream_t s);
+void launch_feature_pooling(const float* Y, const float* rho, float* out, int R, int T, int K, int mno, hipStream_t s);
+void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, float* kld, float* recon,
+                   float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s);

@@ -1,0 +1,132 @@
+// kernels_aux.hip -- the cold rows of the hot-path scope table: losses, the
+// reference's temporal conv O1 / feature pooling O11 (A4, A11; no consumer in the reference, kept as
+// ops), and the scene-context CNN rho(I) (A14, once per scene).  All VALU: none of them is on the
+// per-sample critical path (0.35 GFLOP per scene image, O(A) scalars).
+#include "common.h"
+#include "kernels.h"
+
+// ---- scene CNN: direct NHWC conv, SAME padding (TF rule), stride S, optional ReLU ----------------
+// one thread per (pixel, 4 output channels)
+__global__ void k_conv_direct(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                              float* __restrict__ out, int n, int Hi, int Wi, int Ci, int Co, int stride, int relu) {
+    const int Ho = (Hi + stride - 1) / stride, Wo = (Wi + stride - 1) / stride;
+    const int pad_t = max((Ho - 1) * stride + 5 - Hi, 0) / 2, pad_l = max((Wo - 1) * stride + 5 - Wi, 0) / 2;
+    const int cq = Co >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * Ho * Wo * cq) return;
+    const int c4 = idx % cq;
+    const long pix = idx / cq;
+    const int ox = pix % Wo, oy = (pix / Wo) % Ho, img = pix / ((long)Wo * Ho);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 5; ++ky) {
+        const int iy = oy * stride + ky - pad_t;
+        if (iy < 0 || iy >= Hi) continue;
+        for (int kx = 0; kx < 5; ++kx) {
+            const int ix = ox * stride + kx - pad_l;
+            if (ix < 0 || ix >= Wi) continue;
+            const float* ip = in + (((size_t)img * Hi + iy) * Wi + ix) * Ci;
+            const float* wp = w + ((size_t)(ky * 5 + kx) * Ci) * Co + c4 * 4;
+            for (int ci = 0; ci < Ci; ++ci) {
+                const float x = ip[ci];
+                const float4 ww = *reinterpret_cast<const float4*>(wp + (size_t)ci * Co);
+                acc.x = fmaf(x, ww.x, acc.x); acc.y = fmaf(x, ww.y, acc.y);
+                acc.z = fmaf(x, ww.z, acc.z); acc.w = fmaf(x, ww.w, acc.w);
+            }
+        }
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(b + c4 * 4);
+    acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w;
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(out + ((((size_t)img * Ho + oy) * Wo + ox) * Co) + c4 * 4) = acc;
+}
+void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
+                        int Co, int stride, int relu, hipStream_t s) {
+    const int Ho = (Hi + stride - 1) / stride, Wo = (Wi + stride - 1) / stride;
+    const long total = (long)n * Ho * Wo * (Co / 4);
+    hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, w, b, out, n, Hi, Wi,
+                       Ci, Co, stride, relu);
+}
+
+// ---- O1 temporal conv: rho[a, c*100+q] = relu(sum_t X[a,t,c] * W[t,c,q] + b[c*100+q]),  c in {id, x} ----
+__global__ void k_temporal_conv(const float* __restrict__ frames, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ rho, int n_scenes, int T, int mno) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = n_scenes * mno;
+    if (idx >= A * 200) return;
+    const int a = idx / 200, o = idx - a * 200;
+    const int c = o / 100, q = o - c * 100;
+    const int sc = a / mno, slot = a - sc * mno;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t)
+        acc = fmaf(frames[(((size_t)sc * T + t) * mno + slot) * 3 + c], w[(t * 2 + c) * 100 + q], acc);
+    rho[idx] = fmaxf(acc + b[o], 0.f);
+}
+void launch_temporal_conv(const float* frames, const float* w, const float* b, float* rho, int n_scenes, int T, int mno,
+                          hipStream_t s) {
+    const int n = n_scenes * mno * 200;
+    hipLaunchKernelGGL(k_temporal_conv, dim3((n + 255) / 256), dim3(256), 0, s, frames, w, b, rho, n_scenes, T, mno);
+}
+
+// ---- O11 feature pooling: f[r,t,:100] = y_x * rho[a,:100], f[r,t,100:] = y_y * rho[a,100:] ----
+__global__ void k_feature_pooling(const float* __restrict__ Y, const float* __restrict__ rho, float* __restrict__ out,
+                                  int R, int T, int K, int mno) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * T * 200) return;
+    const int o = idx % 200;
+    const long rt = idx / 200;
+    const int r = rt / T;
+    const int a = agent_of_row(r, K, mno);
+    out[idx] = Y[rt * 2 + (o >= 100)] * rho[(size_t)a * 200 + o];
+}
+void launch_feature_pooling(const float* Y, const float* rho, float* out, int R, int T, int K, int mno, hipStream_t s) {
+    const long n = (long)R * T * 200;
+    hipLaunchKernelGGL(k_feature_pooling, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Y, rho, out, R, T, K, mno);
+}
+
+// ---- losses: one workgroup per agent; cost reduced by a single-block second kernel (deterministic) ----
+__global__ void k_losses(const float* __restrict__ params, const float* __restrict__ Y, const float* __restrict__ fut,
+                         float* __restrict__ kld, float* __restrict__ recon, int n_scenes, int mno, int K, int T, int L,
+                         float sx, float sy) {
+    __shared__ float red[256];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const int sc = a / mno, slot = a - sc * mno;
+    float s = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float mu = params[(size_t)a * 2 * L + l], ls = params[(size_t)a * 2 * L + L + l];
+        s += 1.0f + ls - mu * mu - expf(ls);
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    if (tid == 0) kld[a] = -0.5f * red[0];
+    __syncthreads();
+    float d = 0.f;
+    for (int i = tid; i < K * T; i += 256) {
+        const int k = i / T, t = i - k * T;
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+        const float dx = Y[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+        d += sqrtf(dx * dx + dy * dy);
+    }
+    red[tid] = d;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    if (tid == 0) recon[a] = red[0] / (float)(K * T);
+}
+__global__ void k_cost(const float* __restrict__ kld, const float* __restrict__ recon, const uint8_t* __restrict__ valid,
+                       float* __restrict__ cost, int A) {
+    __shared__ float rs[256], rn[256];
+    const int tid = threadIdx.x;
+    float s = 0.f, n = 0.f;
+    for (int a = tid; a < A; a += 256) if (valid[a]) { s += recon[a] + kld[a]; n += 1.f; }
+    rs[tid] = s; rn[tid] = n;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) { rs[tid] += rs[tid + st]; rn[tid] += rn[tid + st]; } __syncthreads(); }
+    if (tid == 0) { cost[0] = rs[0] / fmaxf(rn[0], 1.f); cost[1] = rn[0]; }
+}
+void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, float* kld, float* recon,
+                   float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s) {
+    const int A = n_scenes * mno;
+    hipLaunchKernelGGL(k_losses, dim3(A), dim3(256), 0, s, params, Y, fut, kld, recon, n_scenes, mno, K, T, L, sx, sy);
+    hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, s, kld, recon, valid, cost, A);
+}

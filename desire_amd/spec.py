@@ -156,6 +156,16 @@ def weight_shapes(d: Dims) -> Dict[str, Tuple[int, ...]]:
     s["ioc/score/b"] = (1,)
     s["ioc/reg/w"] = (H, 2 * d.T_pred)
     s["ioc/reg/b"] = (2 * d.T_pred,)
+    # ---- scene-context CNN rho(I) (paper; absent in the reference): image [4Gh,4Gw,3] -> [Gh,Gw,C] ----
+    s["scene_cnn/conv1/w"] = (5, 5, 3, 16)
+    s["scene_cnn/conv1/b"] = (16,)
+    s["scene_cnn/conv2/w"] = (5, 5, 16, 32)
+    s["scene_cnn/conv2/b"] = (32,)
+    s["scene_cnn/conv3/w"] = (5, 5, 32, d.C)
+    s["scene_cnn/conv3/b"] = (d.C,)
+    # ---- temporal convolution O1 (model/model.py:116-133, weights :427-431) ----
+    s["temporal/w"] = (1, d.T_obs, 2, 100)
+    s["temporal/b"] = (200,)
     return s
 
 
@@ -183,8 +193,10 @@ def init_weights(d: Dims, seed: int = 0, ref_init: bool = False) -> Dict[str, np
         elif ref_init and name in ("fc_c/w", "mask_fc/w"):
             a = rng.standard_normal(shape).astype(np.float32)
         else:
-            if len(shape) == 4:          # conv / deconv: fan-in = kh*kw*in
-                fan_in = shape[0] * shape[1] * (shape[2] if "vae_enc" in name else shape[3])
+            if name == "temporal/w":
+                fan_in = shape[1]
+            elif len(shape) == 4:        # conv / deconv: fan-in = kh*kw*in
+                fan_in = shape[0] * shape[1] * (shape[3] if "vae_dec" in name else shape[2])
             else:
                 fan_in = shape[0]
             a = (rng.standard_normal(shape) / np.sqrt(max(fan_in, 1))).astype(np.float32)

@@ -100,6 +100,23 @@ int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* 
 /* dev_pos [n, 2] -> dev_cells [n, 2] = (cy, cx). */
 int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_t* dev_cells, int32_t n, void* stream);
 
+/* Scene-context CNN rho(I) (paper; the reference has no image input, model/model.py:312-313):
+ * dev_image [n_grids, Hi=4*Gh, Wi=4*Gw, 3] -> dev_grids [n_grids, Gh, Gw, C] (then pass dev_grids to
+ * desire_set_scene_grids).  conv5x5/16/s2+ReLU, conv5x5/32/s2+ReLU, conv5x5/C/s1, TF SAME padding. */
+int desire_scene_cnn(desire_handle* h, const float* dev_image, int32_t Hi, int32_t Wi, float* dev_grids, void* stream);
+
+/* Train-path scalars after desire_forward (posterior mode): dev_kld [A] (model/model.py:587-589 per agent),
+ * dev_recon [A] = mean_k mean_t ||Y_gt - Yhat_k|| (paper; the reference's NLL has undefined inputs, :342),
+ * dev_cost [2] = {mean over existing agents of recon+kld (masking rule :351-366,374-376), #agents}. */
+int desire_losses(desire_handle* h, const float* dev_fut, const float* dev_Yhat, float* dev_kld, float* dev_recon,
+                  float* dev_cost, void* stream);
+
+/* The reference's temporal convolution O1 (model/model.py:116-133; channels are (id, x), its quirk) ->
+ * dev_rho [A, 200], and feature pooling O11 (:291-311) -> dev_out [R, T_pred, 200].  No consumer exists in
+ * the reference; exposed as ops for callers that want the literal tensors. */
+int desire_temporal_conv(desire_handle* h, const float* dev_past, float* dev_rho, void* stream);
+int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float* dev_rho, float* dev_out, void* stream);
+
 /* Per-kernel GPU time measured with hipEvents on the launch stream (enabled by
  * desire_set_profiling(h,1); adds two event records per kernel, nothing else).  Entries accumulate
  * over calls; desire_get_profile synchronises on them, copies up to *count (in: capacity) entries

@@ -213,16 +213,23 @@ def neighbor_bins(pos, valid, nb_w, nb_h, G):
     return np.where(inside, cx + cy * G, -1).astype(np.int32)
 
 
-def bin_margin(pos, nb_w, nb_h, G):
-    """Smallest distance (normalised units) of any pair to a bin/window boundary -- tests use
-    it to pick seeds where a 1e-6 coordinate difference cannot flip an index."""
+def bin_margin(pos, nb_w, nb_h, G, valid=None):
+    """Smallest distance (normalised units) of any (valid centre, valid other) pair to a bin/window
+    boundary -- tests use it to know when a 1e-6 coordinate difference cannot flip an index."""
     p = pos.astype(np.float64)
     dx = (p[..., None, :, 0] - p[..., :, None, 0] + nb_w / 2) / (nb_w / G)
     dy = (p[..., None, :, 1] - p[..., :, None, 1] + nb_h / 2) / (nb_h / G)
     M = p.shape[-2]
-    off = ~np.eye(M, dtype=bool)
-    mx = np.abs(dx - np.round(dx))[..., off].min() * (nb_w / G)
-    my = np.abs(dy - np.round(dy))[..., off].min() * (nb_h / G)
+    use = np.broadcast_to(~np.eye(M, dtype=bool), dx.shape).copy()
+    if valid is not None:
+        v = np.asarray(valid, bool)
+        use &= v[..., :, None] & v[..., None, :]
+    near = (np.abs(dx - G / 2) <= G / 2 + 1) & (np.abs(dy - G / 2) <= G / 2 + 1)     # only pairs near the window
+    use &= near
+    if not use.any():
+        return float("inf")
+    mx = np.abs(dx - np.round(dx))[use].min() * (nb_w / G)
+    my = np.abs(dy - np.round(dy))[use].min() * (nb_h / G)
     return float(min(mx, my))
 
 
@@ -383,6 +390,40 @@ def temporal_conv(temporal_data, w_t, b_t, stride=1):
         win = x[0, :, o * stride:o * stride + kw, :]          # [M, kw, 2]
         out[0, :, o, :] = np.einsum("mkc,kcq->mcq", win, w_t[0]).reshape(M, -1)
     return relu(out + b_t)
+
+
+def scene_cnn(image, w, dt=np.float32):
+    """Scene-context CNN rho(I) (paper section 3.3; the reference has no image input at all,
+    model/model.py:312-313).  image [n, 4Gh, 4Gw, 3] -> [n, Gh, Gw, C]:
+    conv5x5/16/s2 SAME + ReLU -> conv5x5/32/s2 SAME + ReLU -> conv5x5/C/s1 SAME (linear)."""
+    x = image.astype(dt)
+    x = relu(conv2d(x, w["scene_cnn/conv1/w"].astype(dt), 2, "SAME") + w["scene_cnn/conv1/b"].astype(dt))
+    x = relu(conv2d(x, w["scene_cnn/conv2/w"].astype(dt), 2, "SAME") + w["scene_cnn/conv2/b"].astype(dt))
+    return (conv2d(x, w["scene_cnn/conv3/w"].astype(dt), 1, "SAME") + w["scene_cnn/conv3/b"].astype(dt)).astype(dt)
+
+
+def feature_pooling(Y, rho, d):
+    """O11, model/model.py:291-311: f[r,t] = concat(y_x * rho[agent,:100], y_y * rho[agent,100:]).
+    Y [R,T,2], rho [A,200] -> [R,T,200]."""
+    rr = rows_from_agents(rho.astype(np.float32), d)                     # [R,200]
+    return np.concatenate([Y[..., 0:1] * rr[:, None, :100], Y[..., 1:2] * rr[:, None, 100:]], -1).astype(np.float32)
+
+
+def losses(z_mean, z_log_sigma_sq, Y, fut_n, valid, d, dt=np.float32):
+    """Train-path scalars.  kld[a]: model/model.py:587-589 per agent (the reference then means over
+    its batch of 1).  recon[a]: the paper's sample-generation loss, mean over k and t of
+    ||Y_gt - Yhat_k||_2 (the reference's Gaussian NLL has undefined inputs, :342).  cost: mean of
+    (recon + kld) over agents that exist (id != 0), the reference's masking rule :351-366,374-376.
+    Y [R,T,2], fut_n [T,A,2] normalised, valid [A]."""
+    kld = (-0.5 * np.sum(1.0 + z_log_sigma_sq - np.square(z_mean) - np.exp(z_log_sigma_sq), axis=1)).astype(dt)
+    Yk = Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2).astype(dt)
+    gt = fut_n.transpose(1, 0, 2).reshape(d.n_scenes, 1, d.mno, d.T_pred, 2).astype(dt)
+    dist = np.sqrt(np.square(Yk - gt).sum(-1))                           # [n,K,mno,T]
+    recon = dist.mean(axis=(1, 3)).reshape(d.A).astype(dt)
+    v = np.asarray(valid, bool)
+    n = int(v.sum())
+    cost = float(((recon + kld) * v).sum() / max(n, 1))
+    return kld, recon, cost, n
 
 
 def ade_fde(Y, gt):

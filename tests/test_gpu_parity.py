@@ -184,3 +184,53 @@ def test_model_api_and_sample_layout(torch_cuda):
     np.testing.assert_array_equal(out[:8], x[0])
     np.testing.assert_array_equal(out[8:, :, 0], np.broadcast_to(x[0][-1, :, 0], (10, 30)))
     assert (out[8:][:, x[0][-1, :, 0] == 0] == 0).all()
+
+
+def test_cold_rows_scene_cnn_losses_temporal_pooling(torch_cuda):
+    """scene CNN, losses, temporal conv O1, feature pooling O11."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    from oracle import desire_oracle as O
+    d = small_dims(K=3, n_grids=2)
+    w = init_weights(d, 9)
+    past, fut, eps, _, gos = make_case(d, seed=10)
+    rng = np.random.default_rng(11)
+    image = rng.uniform(0, 1, (d.n_grids, 4 * d.Gh, 4 * d.Gw, 3)).astype(np.float32)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    # scene CNN -> grids, used by the forward below
+    image_t = t(image)
+    grids_t = torch.zeros((d.n_grids, d.Gh, d.Gw, d.C), device=dev)
+    h.scene_cnn(image_t.data_ptr(), 4 * d.Gh, 4 * d.Gw, grids_t.data_ptr())
+    torch.cuda.synchronize()
+    grids_ref = O.scene_cnn(image, w)
+    assert np.abs(grids_t.cpu().numpy() - grids_ref).max() < 1e-4
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    past_t, fut_t, eps_t = t(past), t(fut), t(eps)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    # losses on the GPU outputs vs the oracle formulas evaluated on the SAME outputs
+    kld = torch.zeros(d.A, device=dev); recon = torch.zeros(d.A, device=dev); cost = torch.zeros(2, device=dev)
+    h.losses(fut_t.data_ptr(), Y.data_ptr(), kld.data_ptr(), recon.data_ptr(), cost.data_ptr())
+    torch.cuda.synchronize()
+    zm, zl = h.read_buffer("z_mean", (d.A, d.L)), h.read_buffer("z_log_sigma_sq", (d.A, d.L))
+    futn = O.normalise(to_oracle_layout(fut), d)
+    valid = to_oracle_layout(past)[d.T_obs - 1, :, 0] != 0
+    k_ref, r_ref, c_ref, n_ref = O.losses(zm, zl, Y.cpu().numpy(), futn, valid, d)
+    assert np.abs(kld.cpu().numpy() - k_ref).max() < 1e-3 * max(1.0, np.abs(k_ref).max())
+    assert np.abs(recon.cpu().numpy() - r_ref).max() < 1e-5
+    assert abs(float(cost[0]) - c_ref) < 1e-3 * max(1.0, abs(c_ref)) and int(cost[1]) == n_ref
+    # O1 / O11
+    rho = torch.zeros((d.A, 200), device=dev)
+    h.temporal_conv(past_t.data_ptr(), rho.data_ptr())
+    fp = torch.zeros((d.R, d.T_pred, 200), device=dev)
+    h.feature_pooling(Y.data_ptr(), rho.data_ptr(), fp.data_ptr())
+    torch.cuda.synchronize()
+    td = to_oracle_layout(past).transpose(1, 0, 2)[None]              # [1, A, T, 3]
+    rho_ref = O.temporal_conv(td, w["temporal/w"], w["temporal/b"])[0, :, 0, :]
+    np.testing.assert_allclose(rho.cpu().numpy(), rho_ref, rtol=1e-5, atol=1e-3)   # inputs are raw ids/pixels
+    fp_ref = O.feature_pooling(Y.cpu().numpy(), rho.cpu().numpy(), d)
+    np.testing.assert_array_equal(fp.cpu().numpy(), fp_ref)
