@@ -11,7 +11,7 @@ import numpy as np
 
 from .spec import Dims
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdesire_hip.so")
+LIB_PATH = os.environ.get("DESIRE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdesire_hip.so")
 
 EXPORTS = [
     "desire_last_error", "desire_version", "desire_create", "desire_destroy", "desire_set_weight",

@@ -423,7 +423,22 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
+#ifdef DESIRE_IOC_TIMING
+    if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
+    a.dbg = static_cast<long long*>(h->ws["dbg"].p);
+#endif
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+#ifdef DESIRE_IOC_TIMING
+    {
+        long long host[10];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
+        const char* names[10] = {"P0 pos+clear", "P1 ev/es/masks", "build0+bar", "build(b+1)", "mma bin", "bin barrier",
+                                 "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
+        long long tot = 0; for (int k = 0; k < 9; ++k) tot += host[k];
+        for (int k = 0; k < 9; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
+    }
+#endif
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

@@ -82,6 +82,7 @@ struct IocArgs {
     const float* w_score; const float* b_score;            // [H], [1]
     const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed
     int variant;                                           // A/B switch, see launch_ioc
+    long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 

@@ -238,16 +238,26 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 // TM = rows per workgroup (32 or 64; must hold whole (scene,k) groups: TM % mno == 0), 8 threads per
 // row.  TM=32 runs 4 waves and ~77 KB of LDS so that TWO workgroups share a CU: their barrier/VALU
 // phases interleave with each other's MFMA phases.
+#ifdef DESIRE_IOC_TIMING
+#define TICK(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICK(k)
+#endif
 template <int H, int EV, int C, int TM>
 __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTHR = TM * 8;
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
     constexpr int G8 = KX >> 3, GH = H >> 3;
     constexpr int NCH = H >> 5;                          // float4 chunks per thread in the pooled build
     const int B = a.G * a.G;
-    float* XH = smem;                                   // [TM][LDX]   [e_v | e_s | e_r | h]
-    float* AB = XH + TM * LDX;                          // [2][TM][LDB] pooled operand, double buffered
+    float* XH = smem;                                   // [TM+1][LDX] [e_v | e_s | e_r | h]; row TM stays zero
+    float* AB = XH + (TM + 1) * LDX;                    // [2][TM][LDB] pooled operand, double buffered;
+                                                        //   buffer 0 doubles as the r*h operand of the candidate
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B]
     float* pc = reinterpret_cast<float*>(masks + TM * B);      // [TM][2] current position
     float* pp = pc + TM * 2;                            // [TM][2] previous position
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
     const int my_slot = r8 - grp_base;
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    for (int i = tid; i < LDX; i += NTHR) XH[TM * LDX + i] = 0.f;
     if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
 
     float bgr = 0, bgu = 0, bcc = 0, bso = 0, wsc = 0;
@@ -275,23 +286,38 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
     float* my_x = XH + (mt * 32 + 4 * (lane >> 5)) * LDX + col;        // + acc-row * LDX (+ column base)
     const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
 
-    // pooled operand of bin b: ab[r8][:] = sum_{j in mask} h_{t-1}[group row j][:]; thread q8 owns the
-    // float4 chunks q8, q8+8, ... so the 8 lanes of a row touch 128 contiguous bytes (no bank conflicts)
+    // pooled operand of bin b: ab[r8][:] = sum_{j in mask} h_{t-1}[group row j][:].  Thread q8 owns the
+    // float4 chunks q8, q8+8, ... so the 8 lanes of a row touch 128 contiguous bytes (no bank conflicts).
+    // Branch-free for up to NS neighbours per (row, bin): the s-th set bit selects a source row, a missing
+    // one selects the all-zero row TM, so the 4*NS LDS reads are independent and issue back to back; the
+    // (rare) overflow is finished by a wave-uniform loop.  Summation order = ascending slot: deterministic.
+    constexpr int NS = 2;
     auto build = [&](int b) {
         float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
-        const unsigned long long mk = masks[r8 * B + b];
+        unsigned long long m2 = masks[r8 * B + b];
+        int off[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            off[sl] = m2 ? (grp_base + __ffsll((long long)m2) - 1) * LDX : TM * LDX;
+            m2 &= m2 - 1;
+        }
         float4 s[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned long long m2 = mk;
-        while (m2) {
-            const int j = __ffsll((long long)m2) - 1;
-            m2 &= m2 - 1;
-            const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
+        for (int c = 0; c < NCH; ++c) {
+            const float4 v0 = *reinterpret_cast<const float4*>(XH + off[0] + E + q8 * 4 + c * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(XH + off[1] + E + q8 * 4 + c * 32);
+            s[c].x = v0.x + v1.x; s[c].y = v0.y + v1.y; s[c].z = v0.z + v1.z; s[c].w = v0.w + v1.w;
+        }
+        if (__any(m2 != 0ull)) {
+            while (m2) {
+                const int j = __ffsll((long long)m2) - 1;
+                m2 &= m2 - 1;
+                const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(src + c * 32);
-                s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + c * 32);
+                    s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                }
             }
         }
 #pragma unroll
@@ -318,14 +344,23 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
             for (int i = 0; i < 16; ++i) h[i] = my_x[((i & 3) + 8 * (i >> 2)) * LDX + E];
         }
 
+        // positions of step 0 / cleared masks before the first P1
+        float2 ynext = make_float2(0.f, 0.f);
+        if (tid < TM) {
+            const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T) * 2);
+            pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
+        }
+        for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
+        __syncthreads();
+        const float* rh_lane = AB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5);     // r*h operand (AB buffer 0)
+        float* my_rh = AB + (mt * 32 + 4 * (lane >> 5)) * LDB + col;
+        constexpr int GX = E >> 3;                                                        // x-part groups
+
         for (int t = 0; t < a.T; ++t) {
-            // ---- P0: positions, clear masks ----
-            if (tid < TM) {
-                const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
-                pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
-            }
-            for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
-            __syncthreads();
+            TICK(0)
+            // prefetch next step's positions (consumed at the end of this step)
+            if (tid < TM && t + 1 < a.T)
+                ynext = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t + 1) * 2);
             // ---- P1: e_v, e_s, neighbour masks ----
             {
                 const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
@@ -349,19 +384,23 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
                 }
             }
             __syncthreads();
-            // ---- P2/P3: social pooling -> e_r ----
+            TICK(1)
+            // ---- P2/P3: social pooling -> e_r.  build(b+1) and the contraction of bin b sit between the same
+            //      two barriers, so waves that finish building early start their MFMAs while others still build
             {
-                // build(b+1) and the contraction of bin b sit between the same two barriers, so waves that
-                // finish building early start their MFMAs while others still build
                 f32x16 soc = splat16(bso);
                 build(0);
                 __syncthreads();
+                TICK(2)
                 for (int b = 0; b < B; ++b) {
                     if (b + 1 < B) build(b + 1);
+                    TICK(3)
                     if (active)
                         mma1(soc, AB + (b & 1) * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
                              a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                    TICK(4)
                     __syncthreads();
+                    TICK(5)
                 }
                 if (active) {
 #pragma unroll
@@ -369,38 +408,44 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
                 }
             }
             __syncthreads();
-            // ---- P4: gates ----
+            TICK(6)
+            // ---- P4: gates over [x | h]; r*h goes to its own LDS tile so no "done reading h" barrier is needed ----
             f32x16 rh, u;
             if (active) {
                 rh = splat16(bgr); u = splat16(bgu);
                 mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
                 mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
-            }
-            __syncthreads();
-            if (active) {
+                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = rh[i];
+                for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
             }
             __syncthreads();
-            // ---- P5: candidate, blend, score ----
+            TICK(7)
+            // ---- P5: candidate over [x | r*h], blend, score ----
             if (active) {
                 f32x16 ac = splat16(bcc);
-                mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, G8);
+                mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
+                mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                 }
-            }
-            __syncthreads();
-            if (active) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
+                for (int i = 0; i < 16; ++i)                               // h slot: last read by the gates, one barrier ago
+                    my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
             }
-            if (tid < TM) { pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1]; }
+            // next step's P0: positions and cleared masks (masks were last read in the bin loop)
+            if (tid < TM) {
+                pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
+                pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
+            }
+            for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
             __syncthreads();
+            TICK(8)
         }
         // ---- score: sum the per-lane partials over the 32 columns of this wave, then over column blocks ----
 #pragma unroll
@@ -434,10 +479,14 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
         }
         __syncthreads();
     }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
+#endif
 }
 static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
     const int EV = 16, H = a.H, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
-    size_t f = (size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + 4 * TM;
+    size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + 4 * TM;
     return f * sizeof(float) + TM + 64;
 }
 template <int H, int TM>
