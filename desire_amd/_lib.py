@@ -18,7 +18,7 @@ EXPORTS = [
     "desire_finalize_weights", "desire_set_scene_grids", "desire_encode", "desire_sample",
     "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
     "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
-    "desire_temporal_conv", "desire_feature_pooling",
+    "desire_temporal_conv", "desire_feature_pooling", "desire_build_windows", "desire_gaussian_sample", "desire_ade_fde",
 ]
 
 
@@ -69,6 +69,9 @@ def load() -> C.CDLL:
     lib.desire_losses.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, vp]
     lib.desire_temporal_conv.argtypes = [vp, f32p, f32p, vp]
     lib.desire_feature_pooling.argtypes = [vp, f32p, f32p, f32p, vp]
+    lib.desire_build_windows.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), i32, f32p, f32p, vp]
+    lib.desire_gaussian_sample.argtypes = [vp, f32p, f32p, f32p, i32, vp]
+    lib.desire_ade_fde.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
@@ -152,6 +155,17 @@ class Handle:
 
     def feature_pooling(self, yhat_ptr: int, rho_ptr: int, out_ptr: int, stream: int = 0) -> None:
         _chk(self.lib.desire_feature_pooling(self._h, yhat_ptr, rho_ptr, out_ptr, stream or None))
+
+    def build_windows(self, frames_ptr: int, n_frames: int, mno_in: int, starts, past_ptr: int, fut_ptr: int, stream: int = 0) -> None:
+        st = np.ascontiguousarray(starts, dtype=np.int32)
+        _chk(self.lib.desire_build_windows(self._h, frames_ptr, n_frames, mno_in, st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           st.size, past_ptr, fut_ptr, stream or None))
+
+    def gaussian_sample(self, params_ptr: int, normals_ptr: int, out_ptr: int, n: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_gaussian_sample(self._h, params_ptr, normals_ptr, out_ptr, n, stream or None))
+
+    def ade_fde(self, yhat_ptr: int, fut_ptr: int, out_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_ade_fde(self._h, yhat_ptr, fut_ptr, out_ptr, stream or None))
 
     def set_profiling(self, on: bool) -> None:
         _chk(self.lib.desire_set_profiling(self._h, int(on)))

@@ -546,6 +546,49 @@ extern "C" int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, c
     return DESIRE_OK;
 }
 
+extern "C" int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
+                                    const int32_t* host_starts, int32_t n_windows, float* dev_past, float* dev_fut, void* stream) {
+    if (!h || !dev_frames || !host_starts || !dev_past || !dev_fut) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    if (n_windows < 1 || n_windows > d.n_scenes) return fail(DESIRE_ERR_ARG, "n_windows must be 1..n_scenes");
+    if (mno_in < 1 || n_frames < d.T_obs + d.T_pred) return fail(DESIRE_ERR_ARG, "video shorter than one window");
+    for (int i = 0; i < n_windows; ++i)
+        if (host_starts[i] < 0 || host_starts[i] + d.T_obs + d.T_pred > n_frames)
+            return fail(DESIRE_ERR_ARG, "window start out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->ws.count("bw_starts")) {
+        if (h->ws["bw_starts"].alloc((size_t)d.n_scenes * sizeof(int32_t)) || h->ws["bw_err"].alloc(sizeof(int32_t)))
+            return fail(DESIRE_ERR_HIP, "hipMalloc failed");
+    }
+    HIPCHK(hipMemcpyAsync(h->ws["bw_starts"].p, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->ws["bw_err"].p, 0, sizeof(int32_t), s));
+    launch_build_windows(dev_frames, n_frames, mno_in, static_cast<const int32_t*>(h->ws["bw_starts"].p), n_windows, d.T_obs,
+                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws["bw_err"].p), s);
+    int32_t err = 0;
+    HIPCHK(hipMemcpyAsync(&err, h->ws["bw_err"].p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (err & 2) return fail(DESIRE_ERR_ARG, "a window holds more unique ids than max_num_obj slots (utils/data_loader.py:227 IndexError)");
+    if (err & 1) return fail(DESIRE_ERR_ARG, "track id outside [0, 65536)");
+    return DESIRE_OK;
+}
+
+extern "C" int desire_gaussian_sample(desire_handle* h, const float* dev_params, const float* dev_normals, float* dev_out,
+                                      int32_t n, void* stream) {
+    if (!h || !dev_params || !dev_normals || !dev_out || n < 0) return fail(DESIRE_ERR_ARG, "bad argument");
+    if (n == 0) return DESIRE_OK;
+    launch_gaussian_sample(dev_params, dev_normals, dev_out, n, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream) {
+    if (!h || !dev_Yhat || !dev_fut || !dev_out) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    launch_ade_fde(dev_Yhat, dev_fut, dev_out, d.n_scenes, d.mno, d.K, d.T_pred, d.sx, d.sy, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
 extern "C" int desire_set_profiling(desire_handle* h, int enable) {
     if (!h) return fail(DESIRE_ERR_ARG, "null handle");
     h->profiling = enable != 0;

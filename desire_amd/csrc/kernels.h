@@ -98,3 +98,8 @@ void launch_temporal_conv(const float* frames, const float* w, const float* b, f
 void launch_feature_pooling(const float* Y, const float* rho, float* out, int R, int T, int K, int mno, hipStream_t s);
 void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, float* kld, float* recon,
                    float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s);
+void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,
+                          int mno, float* past, float* fut, int32_t* err, hipStream_t s);
+void launch_gaussian_sample(const float* p, const float* nrm, float* out, int n, hipStream_t s);
+void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, int mno, int K, int T, float sx, float sy,
+                    hipStream_t s);

@@ -130,3 +130,118 @@ void launch_losses(const float* params, const float* Y, const float* fut, const 
     hipLaunchKernelGGL(k_losses, dim3(A), dim3(256), 0, s, params, Y, fut, kld, recon, n_scenes, mno, K, T, L, sx, sy);
     hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, s, kld, recon, valid, cost, A);
 }
+
+// ------------------------------------------------------------------------------------------------
+// N1: window + slot builder (utils/data_loader.py:203-229 on the device).  One workgroup per window:
+// the ids of the W = T_obs+T_pred frames go into a presence bitmap, slot = rank of the id among the
+// window's sorted unique ids (0 counts when any padding row exists, exactly like np.unique), rows
+// are copied.  Pure integer/copy work: bit-exact against DataLoader.window_to_slots.
+// err[0] |= 1: id out of bitmap range, |= 2: more unique ids than slots (the reference's IndexError).
+// ------------------------------------------------------------------------------------------------
+#define BW_WORDS 2048        // ids < 65536
+__global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__ frames, int F, int mno_in,
+                                                       const int32_t* __restrict__ starts, int T_obs, int T_pred, int mno,
+                                                       float* __restrict__ past, float* __restrict__ fut,
+                                                       int32_t* __restrict__ err) {
+    __shared__ unsigned int bits[BW_WORDS];
+    __shared__ unsigned int pref[BW_WORDS];
+    __shared__ unsigned int part[256];
+    const int wdw = blockIdx.x, tid = threadIdx.x;
+    const int W = T_obs + T_pred;
+    const int f0 = starts[wdw];
+    for (int i = tid; i < BW_WORDS; i += 256) bits[i] = 0u;
+    for (int i = tid; i < T_obs * mno * 3; i += 256) past[(size_t)wdw * T_obs * mno * 3 + i] = 0.f;
+    for (int i = tid; i < T_pred * mno * 3; i += 256) fut[(size_t)wdw * T_pred * mno * 3 + i] = 0.f;
+    __syncthreads();
+    const int n = W * mno_in;
+    for (int i = tid; i < n; i += 256) {
+        const int t = i / mno_in, s = i - t * mno_in;
+        const int f = min(f0 + t, F - 1);
+        const float idf = frames[((size_t)f * mno_in + s) * 3];
+        const unsigned id = (unsigned)idf;
+        if (idf < 0.f || id >= BW_WORDS * 32u) { atomicOr(err, 1); continue; }
+        atomicOr(&bits[id >> 5], 1u << (id & 31));
+    }
+    __syncthreads();
+    // exclusive prefix of popcounts over the bitmap words: 8 words per thread, then a block scan
+    unsigned local[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { local[k] = sum; sum += __popc(bits[tid * 8 + k]); }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned base = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pref[tid * 8 + k] = base + local[k];
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int t = i / mno_in, s = i - t * mno_in;
+        const int f = min(f0 + t, F - 1);
+        const float* src = frames + ((size_t)f * mno_in + s) * 3;
+        const float idf = src[0];
+        if (idf == 0.f || idf < 0.f) continue;
+        const unsigned id = (unsigned)idf;
+        if (id >= BW_WORDS * 32u) continue;
+        const unsigned slot = pref[id >> 5] + __popc(bits[id >> 5] & ((1u << (id & 31)) - 1u));
+        if (slot >= (unsigned)mno) { atomicOr(err, 2); continue; }
+        float* dst = (t < T_obs) ? past + (((size_t)wdw * T_obs + t) * mno + slot) * 3
+                                 : fut + (((size_t)wdw * T_pred + (t - T_obs)) * mno + slot) * 3;
+        dst[0] = idf; dst[1] = src[1]; dst[2] = src[2];
+    }
+}
+void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,
+                          int mno, float* past, float* fut, int32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_windows, dim3(n), dim3(256), 0, s, frames, F, mno_in, starts, T_obs, T_pred, mno, past, fut, err);
+}
+
+// ---- N3: bivariate-Gaussian head of sample() (model/model.py:552-565,595-611,661-669) ----------------
+// params [n,5] = (mux, muy, log sx, log sy, atanh-space corr); normals [n,2] ~ N(0,1) supplied by the caller;
+// out [n,2] = sample, clipped to <= 1.0 like the reference.  Cholesky form of the covariance at :608.
+__global__ void k_gaussian_sample(const float* __restrict__ p, const float* __restrict__ nrm, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mux = p[i * 5], muy = p[i * 5 + 1];
+    const float sx = expf(p[i * 5 + 2]), sy = expf(p[i * 5 + 3]), rho = tanhf(p[i * 5 + 4]);
+    const float n0 = nrm[i * 2], n1 = nrm[i * 2 + 1];
+    const float x = mux + sx * n0;
+    const float y = muy + sy * (rho * n0 + sqrtf(fmaxf(1.0f - rho * rho, 0.f)) * n1);
+    out[i * 2] = fminf(x, 1.0f);
+    out[i * 2 + 1] = fminf(y, 1.0f);
+}
+void launch_gaussian_sample(const float* p, const float* nrm, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gaussian_sample, dim3((n + 255) / 256), dim3(256), 0, s, p, nrm, out, n);
+}
+
+// ---- N4: ADE / FDE evaluation, best-of-K and mean-of-K, per agent ------------------------------------
+// out [A,4] = (ade_mean, fde_mean, ade_min, fde_min) in the units of Y (normalised).
+__global__ void k_ade_fde(const float* __restrict__ Y, const float* __restrict__ fut, float* __restrict__ out, int n_scenes,
+                          int mno, int K, int T, float sx, float sy) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_scenes * mno) return;
+    const int sc = a / mno, slot = a - sc * mno;
+    float am = 0.f, fm = 0.f, amin = 3.0e38f, fmin_ = 3.0e38f;
+    for (int k = 0; k < K; ++k) {
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        float s = 0.f, last = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+            const float dx = Y[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+            last = sqrtf(dx * dx + dy * dy);
+            s += last;
+        }
+        s /= (float)T;
+        am += s; fm += last;
+        amin = fminf(amin, s); fmin_ = fminf(fmin_, last);
+    }
+    out[a * 4] = am / (float)K; out[a * 4 + 1] = fm / (float)K; out[a * 4 + 2] = amin; out[a * 4 + 3] = fmin_;
+}
+void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, int mno, int K, int T, float sx, float sy,
+                    hipStream_t s) {
+    const int A = n_scenes * mno;
+    hipLaunchKernelGGL(k_ade_fde, dim3((A + 127) / 128), dim3(128), 0, s, Y, fut, out, n_scenes, mno, K, T, sx, sy);
+}

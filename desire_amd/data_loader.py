@@ -31,9 +31,13 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
-def frames_from_csv(data: np.ndarray, max_num_obj: int) -> Tuple[np.ndarray, List[float], List[int]]:
-    """Vectorised utils/data_loader.py:98-146 for one video.  data [4, N]."""
+def frames_from_csv(data: np.ndarray, max_num_obj: int, fix_id0: bool = False) -> Tuple[np.ndarray, List[float], List[int]]:
+    """Vectorised utils/data_loader.py:98-146 for one video.  data [4, N].
+    fix_id0=True renames track id 0 (every SDD video has one) to max_id+1, so it is no longer mistaken for
+    padding and silently dropped by next_batch (utils/data_loader.py:221-222); default keeps the reference."""
     frames, ids, xs, ys = data[0], data[1], data[2], data[3]
+    if fix_id0 and ids.size:
+        ids = np.where(ids == 0, ids.max() + 1, ids)
     frame_list = np.unique(frames)
     fidx = np.searchsorted(frame_list, frames)
     order = np.argsort(fidx, kind="stable")           # CSV column order inside each frame
@@ -60,6 +64,7 @@ def frames_from_csv(data: np.ndarray, max_num_obj: int) -> Tuple[np.ndarray, Lis
 
 def window_to_slots(window: np.ndarray, seq_length: int, max_num_obj: int) -> Tuple[np.ndarray, np.ndarray]:
     """Vectorised utils/data_loader.py:205-229.  window [T+1, MNO, 3] -> (source, target)."""
+    window = np.asarray(window, np.float64)
     ids = window[:, :, 0]
     uniq = np.unique(ids)
     slot = np.searchsorted(uniq, ids)
@@ -82,7 +87,8 @@ class DataLoader(object):
 
     def __init__(self, batch_size=50, seq_length=5, max_num_obj=40, leave_dataset=1,
                  preprocess=False, data_dir: str = "data/",
-                 frames: Optional[Sequence[np.ndarray]] = None):
+                 frames: Optional[Sequence[np.ndarray]] = None, traj_bin: Optional[str] = None,
+                 fix_id0: bool = False):
         self.leave_dataset = leave_dataset
         self.data_dir = data_dir
         self.frame_pointer = 0
@@ -90,8 +96,14 @@ class DataLoader(object):
         self.max_num_obj = max_num_obj
         self.batch_size = batch_size
         self.seq_length = seq_length
+        self.fix_id0 = fix_id0
+        if traj_bin is not None:                     # memory-mapped DSRTRJ1 container (desire_amd/formats.py)
+            from .formats import read_traj_bin
+            frames = read_traj_bin(traj_bin)
+            if frames[0].shape[1] != max_num_obj:
+                raise ValueError("traj_bin holds max_num_obj=%d, loader asked for %d" % (frames[0].shape[1], max_num_obj))
         if frames is not None:                       # already-preprocessed (frames, MNO, 3) arrays
-            self.raw_data = ([np.asarray(f, np.float64) for f in frames],
+            self.raw_data = ([f if isinstance(f, np.memmap) else np.asarray(f, np.float64) for f in frames],
                              [list(range(len(f))) for f in frames],
                              [[int((fr[:, 0] != 0).sum()) for fr in f] for f in frames])
             self._index()
@@ -118,7 +130,7 @@ class DataLoader(object):
         all_frame_data, frame_list_data, num_obj_data = [], [], []
         for path in self._csv_paths()[: self.leave_dataset]:   # flag used as a COUNT (:91)
             data = np.genfromtxt(path, delimiter=",")
-            arr, fl, no = frames_from_csv(data, self.max_num_obj)
+            arr, fl, no = frames_from_csv(data, self.max_num_obj, self.fix_id0)
             all_frame_data.append(arr)
             frame_list_data.append(fl)
             num_obj_data.append(no)

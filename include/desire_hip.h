@@ -117,6 +117,22 @@ int desire_losses(desire_handle* h, const float* dev_fut, const float* dev_Yhat,
 int desire_temporal_conv(desire_handle* h, const float* dev_past, float* dev_rho, void* stream);
 int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float* dev_rho, float* dev_out, void* stream);
 
+/* ---- rows "next" of the scope table ----
+ * N1: device-side window + slot builder = DataLoader.next_batch's inner loop (utils/data_loader.py:203-229).
+ * dev_frames [n_frames, mno_in, 3] is one preprocessed video (frames_from_csv layout); host_starts[i] is the
+ * first frame of window i; each window spans T_obs+T_pred consecutive frames; slot = rank of the id among the
+ * window's sorted unique ids (np.unique semantics, 0 included when padding exists).  Outputs
+ * dev_past [n_windows, T_obs, mno, 3], dev_fut [n_windows, T_pred, mno, 3].  Returns DESIRE_ERR_ARG where the
+ * reference raises IndexError (:227).  Synchronises the stream (error word read-back). */
+int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
+                         const int32_t* host_starts, int32_t n_windows, float* dev_past, float* dev_fut, void* stream);
+/* N3: bivariate-Gaussian head of sample() (model/model.py:552-565,595-611,661-669): dev_params [n,5] raw head
+ * outputs, dev_normals [n,2] ~ N(0,1); dev_out [n,2] sample clipped to <= 1.0. */
+int desire_gaussian_sample(desire_handle* h, const float* dev_params, const float* dev_normals, float* dev_out,
+                           int32_t n, void* stream);
+/* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K). */
+int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);
+
 /* Per-kernel GPU time measured with hipEvents on the launch stream (enabled by
  * desire_set_profiling(h,1); adds two event records per kernel, nothing else).  Entries accumulate
  * over calls; desire_get_profile synchronises on them, copies up to *count (in: capacity) entries

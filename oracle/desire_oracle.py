@@ -426,6 +426,28 @@ def losses(z_mean, z_log_sigma_sq, Y, fut_n, valid, d, dt=np.float32):
     return kld, recon, cost, n
 
 
+def gaussian_sample(params, normals):
+    """sample() head (model/model.py:661-669): get_coef, then a draw from the bivariate normal at :608 in
+    Cholesky form with caller-supplied N(0,1) normals, clipped to <= 1.0."""
+    p = params.astype(np.float32)
+    mux, muy = p[:, 0], p[:, 1]
+    sx, sy, rho = np.exp(p[:, 2]), np.exp(p[:, 3]), np.tanh(p[:, 4])
+    n0, n1 = normals[:, 0].astype(np.float32), normals[:, 1].astype(np.float32)
+    x = mux + sx * n0
+    y = muy + sy * (rho * n0 + np.sqrt(np.maximum(1 - rho * rho, 0)) * n1)
+    return np.stack([np.minimum(x, 1.0), np.minimum(y, 1.0)], -1).astype(np.float32)
+
+
+def ade_fde_k(Y, fut_n, d):
+    """Y [R,T,2], fut_n [T,A,2] -> [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K)."""
+    Yk = Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2).astype(np.float32)
+    gt = fut_n.transpose(1, 0, 2).reshape(d.n_scenes, 1, d.mno, d.T_pred, 2).astype(np.float32)
+    e = np.sqrt(np.square(Yk - gt).sum(-1))                    # [n,K,mno,T]
+    ade, fde = e.mean(-1), e[..., -1]
+    out = np.stack([ade.mean(1), fde.mean(1), ade.min(1), fde.min(1)], -1)
+    return out.reshape(d.A, 4).astype(np.float32)
+
+
 def ade_fde(Y, gt):
     """Y [..., T, 2], gt broadcastable -> (ADE, FDE) in the units of Y."""
     e = np.linalg.norm(Y - gt, axis=-1)

@@ -234,3 +234,68 @@ def test_cold_rows_scene_cnn_losses_temporal_pooling(torch_cuda):
     np.testing.assert_allclose(rho.cpu().numpy(), rho_ref, rtol=1e-5, atol=1e-3)   # inputs are raw ids/pixels
     fp_ref = O.feature_pooling(Y.cpu().numpy(), rho.cpu().numpy(), d)
     np.testing.assert_array_equal(fp.cpu().numpy(), fp_ref)
+
+
+def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
+    """N1 device window+slot builder (bit-exact vs the loader, incl. the reference's
+    golden windows), N3 Gaussian head, N4 ADE/FDE."""
+    import os
+    torch = torch_cuda
+    from desire_amd import _lib
+    from desire_amd.data_loader import DataLoader, window_to_slots
+    from oracle import desire_oracle as O
+    g = np.load(os.path.join(golden_dir, "loader_bookstore6_T8.npz"))
+    frames = g["data0"].astype(np.float32)                       # [160, 32, 3] preprocessed by the REFERENCE loader
+    d = small_dims(n_scenes=6, mno=32, K=2, T_obs=8, T_pred=12)
+    h = _lib.Handle(d)
+    dev = torch.device("cuda")
+    fr_t = torch.as_tensor(frames, device=dev)
+    starts = np.array([0, 8, 16, 40, 100, 140], np.int32)
+    past = torch.full((6, d.T_obs, d.mno, 3), -1.0, device=dev)
+    fut = torch.full((6, d.T_pred, d.mno, 3), -1.0, device=dev)
+    h.build_windows(fr_t.data_ptr(), frames.shape[0], frames.shape[1], starts, past.data_ptr(), fut.data_ptr())
+    W = d.T_obs + d.T_pred
+    for i, s0 in enumerate(starts):
+        src, tgt = window_to_slots(g["data0"][s0:s0 + W], W - 1, d.mno)       # reference semantics on W frames
+        full = np.concatenate([src, tgt[-1:]], 0)
+        np.testing.assert_array_equal(past[i].cpu().numpy(), full[:d.T_obs].astype(np.float32))
+        np.testing.assert_array_equal(fut[i].cpu().numpy(), full[d.T_obs:].astype(np.float32))
+    # the reference's own golden batch (T=8 -> 9-frame windows, x = first 8 frames)
+    d9 = small_dims(n_scenes=4, mno=32, K=2, T_obs=8, T_pred=1)
+    h9 = _lib.Handle(d9)
+    p9 = torch.zeros((4, 8, 32, 3), device=dev); f9 = torch.zeros((4, 1, 32, 3), device=dev)
+    h9.build_windows(fr_t.data_ptr(), 160, 32, np.array([0, 8, 16, 24], np.int32), p9.data_ptr(), f9.data_ptr())
+    np.testing.assert_array_equal(p9.cpu().numpy(), g["x"][0].astype(np.float32))
+    np.testing.assert_array_equal(f9.cpu().numpy()[:, 0], g["y"][0][:, -1].astype(np.float32))
+    # IndexError path: more unique ids than slots
+    d4 = small_dims(n_scenes=1, mno=4, K=1, T_obs=8, T_pred=12)
+    h4 = _lib.Handle(d4)
+    with pytest.raises(_lib.DesireError, match="more unique ids"):
+        h4.build_windows(fr_t.data_ptr(), 160, 32, np.array([0], np.int32), past.data_ptr(), fut.data_ptr())
+    with pytest.raises(_lib.DesireError, match="out of range"):
+        h.build_windows(fr_t.data_ptr(), 160, 32, np.array([150] * 6, np.int32), past.data_ptr(), fut.data_ptr())
+    # N3 Gaussian head
+    rng = np.random.default_rng(5)
+    params = rng.normal(0, 0.7, (1000, 5)).astype(np.float32)
+    normals = rng.standard_normal((1000, 2)).astype(np.float32)
+    out = torch.zeros((1000, 2), device=dev)
+    pt, nt = torch.as_tensor(params, device=dev), torch.as_tensor(normals, device=dev)
+    h.gaussian_sample(pt.data_ptr(), nt.data_ptr(), out.data_ptr(), 1000)
+    torch.cuda.synchronize()
+    ref = O.gaussian_sample(params, normals)
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-5 and out.max().item() <= 1.0
+    # N4 ADE/FDE on a real forward
+    w = init_weights(d, 2)
+    h.set_weights(w)
+    pst, ft, eps, grids, gos = make_case(d, seed=3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    pst_t, ft_t, eps_t, grids_t = t(pst), t(ft), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev); score = torch.zeros((d.R,), device=dev)
+    h.forward(pst_t.data_ptr(), ft_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    af = torch.zeros((d.A, 4), device=dev)
+    h.ade_fde(Y.data_ptr(), ft_t.data_ptr(), af.data_ptr())
+    torch.cuda.synchronize()
+    ref = O.ade_fde_k(Y.cpu().numpy(), O.normalise(to_oracle_layout(ft), d), d)
+    assert np.abs(af.cpu().numpy() - ref).max() < 1e-5
+    assert (af[:, 2] <= af[:, 0] + 1e-6).all() and (af[:, 3] <= af[:, 1] + 1e-6).all()
