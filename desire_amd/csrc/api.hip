@@ -140,7 +140,8 @@ void fold_bn(desire_ctx* h, const std::string& p, std::vector<float>& scale, std
 int check_dims(const desire_dims& d) {
     if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
     if (d.mno < 1 || d.mno > 64 || 64 % d.mno) return fail(DESIRE_ERR_ARG, "mno must divide 64");
-    if (d.H != 64 && d.H != 128) return fail(DESIRE_ERR_ARG, "H must be 64 or 128 in this round");
+    if (d.H != 64 && d.H != 128 && d.H != 256) return fail(DESIRE_ERR_ARG, "H must be 64, 128 or 256");
+    if (d.H == 256 && d.mno > 32) return fail(DESIRE_ERR_ARG, "H=256 needs mno <= 32 in this round (64 rows x (E+2H) floats exceed the 160 KB LDS tile)");
     if (d.L % 8 || d.L < 8) return fail(DESIRE_ERR_ARG, "L must be a positive multiple of 8");
     if (d.C != 32 || d.E_v != 16) return fail(DESIRE_ERR_ARG, "C=32 and E_v=16 are the instantiated IOC widths in this round");
     if (d.n_scenes < 1 || d.K < 1 || d.T_obs < 1 || d.T_pred < 1 || d.n_grids < 1 || d.iters < 1 || d.Gh < 1 || d.Gw < 1)

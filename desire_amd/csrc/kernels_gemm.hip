@@ -107,8 +107,8 @@ __global__ __launch_bounds__(DS_WG) void k_mask(MaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * DS_TM;
-    const int NT = a.H >> 5;
-    f32x16 acc[2] = {zero16(), zero16()};
+    const int NT = a.H >> 5;                                 // 2, 4 or 8 column tiles; wave w takes w, w+4
+    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     const float* a_lane = smem + (lane & 31) * LDA_C + 4 * (lane >> 5);
     const int G = a.V >> 3;
     for (int k0 = 0; k0 < a.V; k0 += KC) {
@@ -121,24 +121,31 @@ __global__ __launch_bounds__(DS_WG) void k_mask(MaskArgs a) {
             *reinterpret_cast<float4*>(smem + r * LDA_C + c4 * 4) = v;
         }
         __syncthreads();
-        if (w < NT) mma_groups<2>(acc, a_lane, LDA_C, a.Wp + ((size_t)w * G + (k0 >> 3)) * 64 + lane, KC >> 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nt = w + 4 * j;
+            if (nt < NT) mma_groups<2>(acc[j], a_lane, LDA_C, a.Wp + ((size_t)nt * G + (k0 >> 3)) * 64 + lane, KC >> 3);
+        }
         __syncthreads();
     }
-    // relu(acc + b) -> LDS tile [64][132]
-    const int LDT = 132;
-    if (w < NT) {
-        const int col = w * 32 + (lane & 31);
+    // relu(acc + b) -> LDS tile [64][H+4]
+    const int LDT = a.H + 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nt = w + 4 * j;
+        if (nt >= NT) continue;
+        const int col = nt * 32 + (lane & 31);
         const float b = a.bias[col];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) smem[(m * 32 + acc_row(i)) * LDT + col] = fmaxf(acc[m][i] + b, 0.f);
+            for (int i = 0; i < 16; ++i) smem[(m * 32 + acc_row(i)) * LDT + col] = fmaxf(acc[j][m][i] + b, 0.f);
     }
     __syncthreads();
     // softmax over H per row: 4 threads per row
     const int r = tid >> 2, q4 = tid & 3;
     const int row = row0 + r;
-    const int per = a.H >> 2;                   // columns per thread (<= 32)
+    const int per = a.H >> 2;                   // columns per thread (<= 64)
     float mx = -3.0e38f;
     for (int c = 0; c < per; ++c) mx = fmaxf(mx, smem[r * LDT + q4 * per + c]);
     mx = fmaxf(mx, __shfl_xor(mx, 1));

@@ -32,16 +32,16 @@ __device__ __forceinline__ void mma1(f32x16& acc, const float* a_lane, const flo
 // ------------------------------------------------------------------------------------------------
 // Encoder: tile = 64 agents, T steps, input (x,y) normalised in-kernel: one fp32 multiply each.
 // ------------------------------------------------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(RNN_WG) void k_encoder(EncArgs a) {
+template <int H, int TM>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3;
+    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64;
     float* hs = smem;                      // [64][LDH]
-    float* xs = smem + DS_TM * LDH;        // [64][2]
+    float* xs = smem + TM * LDH;        // [64][2]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int cb = w & 3, mt = w >> 2;
+    const int cb = w % NT, mt = w / NT;
     const int A = a.n_scenes * a.mno;
-    const int a0 = blockIdx.x * DS_TM;
+    const int a0 = blockIdx.x * TM;
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
     float wr0 = 0, wr1 = 0, wu0 = 0, wu1 = 0, wc0 = 0, wc1 = 0, br = 0, bu = 0, bc = 0;
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(RNN_WG) void k_encoder(EncArgs a) {
         br = a.b_g[col]; bu = a.b_g[H + col]; bc = a.b_c[col];
     }
     f32x16 h = zero16();
-    for (int i = tid; i < DS_TM * LDH; i += RNN_WG) hs[i] = 0.f;
+    for (int i = tid; i < TM * LDH; i += NTHR) hs[i] = 0.f;
     const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
     float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;       // + acc-row offset * LDH
 
     for (int t = 0; t < a.T; ++t) {
-        if (tid < DS_TM) {
+        if (tid < TM) {
             const int ag = min(a0 + tid, A - 1);
             const int sc = ag / a.mno, slot = ag - sc * a.mno;
             const float* f = a.frames + (((size_t)sc * a.T + t) * a.mno + slot) * 3;
@@ -114,31 +114,34 @@ __global__ __launch_bounds__(RNN_WG) void k_encoder(EncArgs a) {
     }
 }
 void launch_encoder(const EncArgs& a, hipStream_t s) {
+    // 32-agent tiles: the encoders are latency-bound (A/32 workgroups of H/32 waves), smaller tiles = more CUs busy
     const int A = a.n_scenes * a.mno;
-    const size_t lds = (DS_TM * (a.H + 4) + DS_TM * 2) * sizeof(float);
-    const dim3 grid((A + DS_TM - 1) / DS_TM);
-    if (a.H == 128) hipLaunchKernelGGL(k_encoder<128>, grid, dim3(RNN_WG), lds, s, a);
-    else hipLaunchKernelGGL(k_encoder<64>, grid, dim3(RNN_WG), lds, s, a);
+    constexpr int TM = 32;
+    const size_t lds = (TM * (a.H + 4) + TM * 2) * sizeof(float);
+    const dim3 grid((A + TM - 1) / TM);
+    if (a.H == 256) hipLaunchKernelGGL((k_encoder<256, TM>), grid, dim3(512), lds, s, a);
+    else if (a.H == 128) hipLaunchKernelGGL((k_encoder<128, TM>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_encoder<64, TM>), grid, dim3(128), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Decoder: tile = 64 rows; constant input x_z => its contribution (and the biases) is computed once
 // and kept in 48 accumulator-layout registers per wave; per step only the h-part contracts (K = H).
 // ------------------------------------------------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
+template <int H, int TM>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_decoder(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3;
+    constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM;
     float* hs = smem;                          // [64][LDH]  h / r*h as A operand
-    float* xs = smem + DS_TM * LDH;            // [64][LDH]  x_z tile (prologue only)
-    float* wo = xs + DS_TM * LDH;              // [H][2] head weights
+    float* xs = smem + TM * LDH;            // [64][LDH]  x_z tile (prologue only)
+    float* wo = xs + TM * LDH;              // [H][2] head weights
     float* pl = wo + 2 * H;                    // [64][2] last observed position
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int cb = w & 3, mt = w >> 2;
-    const int row0 = blockIdx.x * DS_TM;
+    const int cb = w % NT, mt = w / NT;
+    const int row0 = blockIdx.x * TM;
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
-    for (int i = tid; i < DS_TM * (H >> 2); i += RNN_WG) {
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
         const int row = min(row0 + r, a.R - 1);
         *reinterpret_cast<float4*>(xs + r * LDH + c4 * 4) =
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
         *reinterpret_cast<float4*>(hs + r * LDH + c4 * 4) =
             *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
     }
-    for (int i = tid; i < 2 * H; i += RNN_WG) wo[i] = a.w_head[i];
-    if (tid < DS_TM) {
+    for (int i = tid; i < 2 * H; i += NTHR) wo[i] = a.w_head[i];
+    if (tid < TM) {
         const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
         pl[tid * 2] = a.p_last[(size_t)ag * 2];
         pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
@@ -198,8 +201,9 @@ __global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
             }
         }
         __syncthreads();
-        {   // head: y = p_last + h W_o + b_o ; 8 threads per row
-            const int r = tid >> 3, q8 = tid & 7, per = H >> 3;
+        {   // head: y = p_last + h W_o + b_o ; TPR threads per row
+            const int r = tid / TPR, q8 = tid % TPR;
+            constexpr int per = H / TPR;
             float s0 = 0.f, s1 = 0.f;
             for (int c = q8 * per; c < (q8 + 1) * per; ++c) {
                 const float hv = hs[r * LDH + c];
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
             }
             s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
             s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
-            s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4);
+            if (TPR >= 8) { s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4); }
+            if (TPR >= 16) { s0 += __shfl_xor(s0, 8); s1 += __shfl_xor(s1, 8); }
             if (q8 == 0 && row0 + r < a.R) {
                 float2 y = make_float2(pl[r * 2] + (s0 + bh0), pl[r * 2 + 1] + (s1 + bh1));
                 *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + r) * a.T + t) * 2) = y;
@@ -217,11 +222,16 @@ __global__ __launch_bounds__(RNN_WG) void k_decoder(DecArgs a) {
         // next step's first barrier (after the gate contraction) orders these reads before the r*h write
     }
 }
+template <int H, int TM>
+static void launch_decoder_t(const DecArgs& a, hipStream_t s) {
+    const size_t lds = (2 * TM * (H + 4) + 2 * H + TM * 2) * sizeof(float);
+    allow_big_lds(k_decoder<H, TM>);
+    hipLaunchKernelGGL((k_decoder<H, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64), lds, s, a);
+}
 void launch_decoder(const DecArgs& a, hipStream_t s) {
-    const size_t lds = (2 * DS_TM * (a.H + 4) + 2 * a.H + DS_TM * 2) * sizeof(float);
-    const dim3 grid((a.R + DS_TM - 1) / DS_TM);
-    if (a.H == 128) { allow_big_lds(k_decoder<128>); hipLaunchKernelGGL(k_decoder<128>, grid, dim3(RNN_WG), lds, s, a); }
-    else hipLaunchKernelGGL(k_decoder<64>, grid, dim3(RNN_WG), lds, s, a);
+    if (a.H == 256) launch_decoder_t<256, 32>(a, s);
+    else if (a.H == 128) launch_decoder_t<128, 64>(a, s);
+    else launch_decoder_t<64, 64>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,16 +254,16 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 #define TICK(k)
 #endif
 template <int H, int EV, int C, int TM>
-__global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, (H / 32) * (TM / 32) <= 2 ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTHR = TM * 8;
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
+    constexpr int NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM;      // TPR threads per row in the VALU phases (8 or 16)
     constexpr int G8 = KX >> 3, GH = H >> 3;
-    constexpr int NCH = H >> 5;                          // float4 chunks per thread in the pooled build
+    constexpr int NCH = H / (4 * TPR);                   // float4 chunks per thread in the pooled build
     const int B = a.G * a.G;
     float* XH = smem;                                   // [TM+1][LDX] [e_v | e_s | e_r | h]; row TM stays zero
     float* AB = XH + (TM + 1) * LDX;                    // [2][TM][LDB] pooled operand, double buffered;
@@ -262,15 +272,15 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
     float* pc = reinterpret_cast<float*>(masks + TM * B);      // [TM][2] current position
     float* pp = pc + TM * 2;                            // [TM][2] previous position
     float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
-    float* red = wv + 3 * EV;                           // [4][TM] score reduction
-    unsigned char* vld = reinterpret_cast<unsigned char*>(red + 4 * TM);   // [TM]
+    float* red = wv + 3 * EV;                           // [NT][TM] score reduction
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);  // [TM]
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int cb = w & 3, mt = w >> 2;
+    const int cb = w % NT, mt = w / NT;
     const int row0 = blockIdx.x * TM;
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
-    const int r8 = tid >> 3, q8 = tid & 7;              // 8 threads per row for the VALU phases
+    const int r8 = tid / TPR, q8 = tid % TPR;           // TPR threads per row for the VALU phases
     const int my_row = min(row0 + r8, a.R - 1);
     const int my_scene = my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;          // first local row of my (scene,k) group
@@ -304,8 +314,8 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
         float4 s[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const float4 v0 = *reinterpret_cast<const float4*>(XH + off[0] + E + q8 * 4 + c * 32);
-            const float4 v1 = *reinterpret_cast<const float4*>(XH + off[1] + E + q8 * 4 + c * 32);
+            const float4 v0 = *reinterpret_cast<const float4*>(XH + off[0] + E + q8 * 4 + c * 4 * TPR);
+            const float4 v1 = *reinterpret_cast<const float4*>(XH + off[1] + E + q8 * 4 + c * 4 * TPR);
             s[c].x = v0.x + v1.x; s[c].y = v0.y + v1.y; s[c].z = v0.z + v1.z; s[c].w = v0.w + v1.w;
         }
         if (__any(m2 != 0ull)) {
@@ -315,13 +325,13 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
                 const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + c * 32);
+                    const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
                     s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
                 }
             }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 32) = s[c];
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
     };
 
     for (int it = 0; it < a.iters; ++it) {
@@ -365,18 +375,22 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
             {
                 const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
                 const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
-                constexpr int per = EV >> 3;
+                constexpr int per = EV / TPR;
 #pragma unroll
                 for (int j = q8 * per; j < (q8 + 1) * per; ++j)
                     XH[r8 * LDX + j] = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
                 int cy, cx;
                 scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
                 const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
-                constexpr int cper = C >> 3;
+                constexpr int cper = C / TPR;                                   // 8, 4 (float4s) or 2 (float2) channels per thread
+                if (cper >= 4) {
 #pragma unroll
-                for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4)
-                    *reinterpret_cast<float4*>(XH + r8 * LDX + EV + j) = *reinterpret_cast<const float4*>(gsrc + j);
-                for (int j = q8; j < a.mno; j += 8) {
+                    for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4)
+                        *reinterpret_cast<float4*>(XH + r8 * LDX + EV + j) = *reinterpret_cast<const float4*>(gsrc + j);
+                } else {
+                    *reinterpret_cast<float2*>(XH + r8 * LDX + EV + q8 * 2) = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
+                }
+                for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
                                                    a.nb_w, a.nb_h, a.G);
@@ -457,11 +471,13 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
         }
         __syncthreads();
         if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
-            float sc = red[tid] + red[TM + tid] + red[2 * TM + tid] + red[3 * TM + tid];
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
             a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
         }
         // ---- regression: Y += h_T W_r + b_r   (columns = (t, xy) flattened) ----
-        for (int nt = cb; nt < a.NTreg; nt += 4) {
+        for (int nt = cb; nt < a.NTreg; nt += NT) {
             f32x16 acc = zero16();
             mma1(acc, x_lane + E, a.Wreg + ((size_t)nt * GH) * 64 + lane, GH);
             const int cc = nt * 32 + (lane & 31);
@@ -485,19 +501,21 @@ __global__ __launch_bounds__(TM * 8, 2) void k_ioc(IocArgs a) {
 #endif
 }
 static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
-    const int EV = 16, H = a.H, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
-    size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + 4 * TM;
+    const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
+    size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + NT * TM;
     return f * sizeof(float) + TM + 64;
 }
 template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     allow_big_lds(k_ioc<H, 16, 32, TM>);
-    hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3(TM * 8), ioc_lds_bytes(a, TM), s, a);
+    hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64),
+                       ioc_lds_bytes(a, TM), s, a);
 }
 void launch_ioc(const IocArgs& a, hipStream_t s) {
-    // 32-row tiles (two workgroups per CU) whenever whole (scene,k) groups fit; variant=2 forces 64 rows (A/B)
+    // 32-row tiles (two workgroups per CU at H <= 128) whenever whole (scene,k) groups fit; variant=2 forces 64 rows (A/B)
     const bool small = (a.mno <= 32) && a.variant != 2;
-    if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
+    if (a.H == 256) launch_ioc_t<256, 32>(a, s);                  // mno = 64 at H = 256 exceeds the 160 KB LDS tile
+    else if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
     else { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
 }
 

@@ -78,8 +78,10 @@ class Dims:
             raise ValueError("mno must divide 64 (host pads max_num_obj up)")
         if self.H % 32 or self.L % 8 or self.C % 8 or self.E_v % 8:
             raise ValueError("H%32, L%8, C%8, E_v%8 required by the MFMA tiling")
-        if self.H not in (64, 128):
-            raise ValueError("H must be 64 or 128 in this round (instantiated recurrent tiles)")
+        if self.H not in (64, 128, 256):
+            raise ValueError("H must be 64, 128 or 256 (instantiated recurrent tiles)")
+        if self.H == 256 and self.mno > 32:
+            raise ValueError("H=256 needs mno <= 32 in this round (LDS tile)")
         if self.C != 32 or self.E_v != 16:
             raise ValueError("C=32, E_v=16 are the instantiated IOC widths in this round")
         if min(self.n_scenes, self.K, self.T_obs, self.T_pred, self.n_grids, self.iters) < 1:

@@ -85,11 +85,17 @@ def test_stagewise_parity_small(torch_cuda):
     dict(H=64, T_pred=7, K=3),                           # smaller hidden, odd horizon
     dict(iters=2, K=2),                                  # two refinement passes
     dict(grid_size=2, nb_w=0.6, nb_h=0.6, K=2),          # 2x2 social grid, wide window
+    dict(H=256, K=3, n_scenes=1, n_grids=1, T_pred=10),  # BASELINE configs[3] hidden width (mno <= 32 in this round)
+    dict(mno=8, n_scenes=5, K=3),                        # 4 groups per 32-row tile, R = 120 (ragged last tile)
+    dict(mno=1, n_scenes=3, K=2, n_absent=0),            # lone agents: social pooling sees nobody
+    dict(K=1, T_pred=1, n_scenes=1, n_grids=1),          # degenerate horizon / single draw
 ])
 def test_end_to_end_variants(torch_cuda, kw):
+    kw = dict(kw)
+    n_absent = kw.pop("n_absent", 3)
     d = small_dims(**kw)
     w = init_weights(d, 3)
-    past, fut, eps, grids, gos = make_case(d, seed=4)
+    past, fut, eps, grids, gos = make_case(d, seed=4, n_absent=min(n_absent, d.mno - 1))
     ref = oracle_forward(d, w, past, fut, eps, grids, gos)
     h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
