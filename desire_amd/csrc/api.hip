@@ -139,9 +139,10 @@ void fold_bn(desire_ctx* h, const std::string& p, std::vector<float>& scale, std
 
 int check_dims(const desire_dims& d) {
     if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
-    if (d.mno < 1 || d.mno > 64 || 64 % d.mno) return fail(DESIRE_ERR_ARG, "mno must divide 64");
+    if (d.mno < 1 || d.mno > 128 || (d.mno <= 32 ? (32 % d.mno) : (d.mno % 32)))
+        return fail(DESIRE_ERR_ARG, "mno must divide 32 or be 64, 96 or 128");
     if (d.H != 64 && d.H != 128 && d.H != 256) return fail(DESIRE_ERR_ARG, "H must be 64, 128 or 256");
-    if (d.H == 256 && d.mno > 32) return fail(DESIRE_ERR_ARG, "H=256 needs mno <= 32 in this round (64 rows x (E+2H) floats exceed the 160 KB LDS tile)");
+
     if (d.L % 8 || d.L < 8) return fail(DESIRE_ERR_ARG, "L must be a positive multiple of 8");
     if (d.C != 32 || d.E_v != 16) return fail(DESIRE_ERR_ARG, "C=32 and E_v=16 are the instantiated IOC widths in this round");
     if (d.n_scenes < 1 || d.K < 1 || d.T_obs < 1 || d.T_pred < 1 || d.n_grids < 1 || d.iters < 1 || d.Gh < 1 || d.Gw < 1)
@@ -424,6 +425,18 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
+    const bool cluster = d.mno > 64 || (d.mno == 64 && d.H == 256) || (a.variant == 4 && d.mno >= 64);
+    if (cluster) {
+        const size_t n_groups = (size_t)h->R / d.mno;
+        if (!h->ws.count("hex")) {
+            if (h->ws["hex"].alloc((size_t)2 * h->R * d.H * sizeof(float)) || h->ws["grp_cnt"].alloc(n_groups * sizeof(int)) ||
+                h->ws["ioc_err"].alloc(sizeof(int)))
+                return fail(DESIRE_ERR_HIP, "hipMalloc failed for the cluster exchange buffers");
+        }
+        HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
+        HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
+        a.hex = W(h, "hex"); a.grp_cnt = static_cast<int*>(h->ws["grp_cnt"].p); a.err = static_cast<int*>(h->ws["ioc_err"].p);
+    }
 #ifdef DESIRE_IOC_TIMING
     if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
     a.dbg = static_cast<long long*>(h->ws["dbg"].p);
@@ -441,6 +454,12 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     }
 #endif
     HIPCHK(hipGetLastError());
+    if (cluster) {
+        int err = 0;
+        HIPCHK(hipMemcpyAsync(&err, h->ws["ioc_err"].p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (err) return fail(DESIRE_ERR_HIP, "IOC cluster hand-off timed out (workgroups of a group were not co-resident)");
+    }
     return DESIRE_OK;
 }
 

@@ -83,6 +83,7 @@ struct IocArgs {
     const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed
     int variant;                                           // A/B switch, see launch_ioc
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
+    float* hex; int* grp_cnt; int* err;                    // cluster form: exchange buffer [2][R][H], group counters, error word
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 

@@ -511,12 +511,268 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64),
                        ioc_lds_bytes(a, TM), s, a);
 }
+void launch_ioc_cluster(const IocArgs& a, hipStream_t s);
 void launch_ioc(const IocArgs& a, hipStream_t s) {
+    // groups larger than one workgroup tile (mno > 64, or mno = 64 at H = 256) or variant=4: cluster form
+    if (a.mno > 64 || (a.mno == 64 && a.H == 256) || (a.variant == 4 && a.mno >= 64)) { launch_ioc_cluster(a, s); return; }
     // 32-row tiles (two workgroups per CU at H <= 128) whenever whole (scene,k) groups fit; variant=2 forces 64 rows (A/B)
     const bool small = (a.mno <= 32) && a.variant != 2;
     if (a.H == 256) launch_ioc_t<256, 32>(a, s);                  // mno = 64 at H = 256 exceeds the 160 KB LDS tile
     else if (a.H == 128) { if (small) launch_ioc_t<128, 32>(a, s); else launch_ioc_t<128, 64>(a, s); }
     else { if (small) launch_ioc_t<64, 32>(a, s); else launch_ioc_t<64, 64>(a, s); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IOC, cluster form: a (scene,k) group of mno = 32*tpg agents spans tpg 32-row tiles = tpg workgroups
+// that exchange their hidden-state tile once per step through global memory (the per-XCD L2s are not
+// coherent, so every hand-off is: plain stores -> s_waitcnt vmcnt(0) -> __syncthreads -> one lane
+// agent-scope release -> relaxed agent atomic add on the group's arrival counter; the consumers poll
+// that ONE word relaxed, then one agent-scope acquire, __syncthreads, plain loads).  The grid is
+// persistent (<= one workgroup per CU, a multiple of tpg) so all members of a group are co-resident by
+// construction; every spin is bounded (err word) and the counters are zeroed by a memset node per launch.
+// Exchange buffer Hex[2][R][H]: h_t goes to parity t&1; a tile can only reach the write of parity p again
+// after every group member has published the step in between, i.e. finished reading parity p.
+// Serves mno in {64, 96, 128} (and H = 256 with mno = 64, which does not fit one workgroup's LDS).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool group_wait(int* cnt, int target, int* err) {
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 40000000L) { atomicOr(err, 1); ok = false; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return ok;
+}
+__device__ __forceinline__ void group_publish(int* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl(IocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, MAXM = 128;
+    constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G8 = KX >> 3, GH = H >> 3, GX = E >> 3;
+    constexpr int NCH = H / (4 * TPR);
+    const int B = a.G * a.G;
+    const int tpg = a.mno / 32;                         // tiles (workgroups) per group
+    float* XH = smem;                                   // [TM][LDX]
+    float* AB = XH + TM * LDX;                          // [2][TM][LDB]
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B][2]
+    float* pg = reinterpret_cast<float*>(masks + TM * B * 2);  // [MAXM][2] positions of the whole group
+    float* pp = pg + MAXM * 2;                          // [TM][2] previous position of my rows
+    float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
+    float* red = wv + 3 * EV;                           // [NT][TM]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);  // [MAXM]
+
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int tile_pos = blockIdx.x % tpg;              // my tile inside its group
+    const int n_tiles = a.R / TM;
+
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const float* x_lane = XH + (lane & 31) * LDX + 4 * (lane >> 5);
+    float* my_x = XH + (4 * (lane >> 5)) * LDX + col;
+    const float* rh_lane = AB + (lane & 31) * LDB + 4 * (lane >> 5);
+    float* my_rh = AB + (4 * (lane >> 5)) * LDB + col;
+    int epoch = 0;                                      // publishes this workgroup has made so far in this launch
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * TM;
+        const int grow0 = row0 - tile_pos * TM;         // first row of the group
+        const int group = grow0 / a.mno;
+        int* cnt = a.grp_cnt + group;
+        const int scene = grow0 / (a.K * a.mno);
+        const float* grid = a.grids + (size_t)a.grid_of_scene[scene] * a.Gh * a.Gw * C;
+        const int my_slot = tile_pos * TM + r8;         // group-local index of my VALU row
+        int base = 0;                                   // counter value when this group started = 0 (fresh group)
+        __syncthreads();
+        for (int i = tid; i < a.mno; i += NTHR) vld[i] = a.valid[agent_of_row(grow0 + i, a.K, a.mno)];
+
+        for (int it = 0; it < a.iters; ++it) {
+            if (it > 0) group_wait(cnt, tpg * (base + it * (a.T + 1)), a.err);     // everybody's Y += dY has landed
+            for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+                const int ag = agent_of_row(row0 + r, a.K, a.mno);
+                *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
+                    *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
+            }
+            if (tid < TM) {
+                const int ag = agent_of_row(row0 + tid, a.K, a.mno);
+                pp[tid * 2] = a.p_last[(size_t)ag * 2];
+                pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            }
+            __syncthreads();
+            f32x16 h, sp = zero16();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = my_x[((i & 3) + 8 * (i >> 2)) * LDX + E];
+
+            for (int t = 0; t < a.T; ++t) {
+                // neighbours' h_{t-1}: published by their tiles at the end of step t-1
+                if (t > 0) group_wait(cnt, tpg * (base + it * (a.T + 1) + t), a.err);
+                for (int i = tid; i < a.mno; i += NTHR) {
+                    const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + i) * a.T + t) * 2);
+                    pg[i * 2] = y.x; pg[i * 2 + 1] = y.y;
+                }
+                for (int i = tid; i < TM * B * 2; i += NTHR) masks[i] = 0ull;
+                __syncthreads();
+                {
+                    const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
+                    const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                    constexpr int per = EV / TPR;
+#pragma unroll
+                    for (int j = q8 * per; j < (q8 + 1) * per; ++j)
+                        XH[r8 * LDX + j] = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                    int cy, cx;
+                    scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                    const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                    constexpr int cper = C / TPR;
+                    if (cper >= 4) {
+#pragma unroll
+                        for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4)
+                            *reinterpret_cast<float4*>(XH + r8 * LDX + EV + j) = *reinterpret_cast<const float4*>(gsrc + j);
+                    } else {
+                        *reinterpret_cast<float2*>(XH + r8 * LDX + EV + q8 * 2) = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
+                    }
+                    for (int j = q8; j < a.mno; j += TPR) {
+                        if (j == my_slot || !vld[j]) continue;
+                        const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G);
+                        if (b >= 0) atomicOr(&masks[(r8 * B + b) * 2 + (j >> 6)], 1ull << (j & 63));
+                    }
+                }
+                __syncthreads();
+                // pooled operand: local rows from LDS, other tiles' rows from the exchange buffer (Hx at t = 0)
+                const float* hex = a.hex + (size_t)((t + 1) & 1) * a.R * H;          // parity (t-1)&1
+                auto build = [&](int b) {
+                    float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+                    float4 s[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int wd = 0; wd < 2; ++wd) {
+                        unsigned long long m2 = masks[(r8 * B + b) * 2 + wd];
+                        while (m2) {
+                            const int j = wd * 64 + __ffsll((long long)m2) - 1;
+                            m2 &= m2 - 1;
+                            const float* src;
+                            if ((j >> 5) == tile_pos) src = XH + (j & 31) * LDX + E;
+                            else if (t == 0) src = a.Hx + (size_t)agent_of_row(grow0 + j, a.K, a.mno) * a.ldhx;
+                            else src = hex + (size_t)(grow0 + j) * H;
+#pragma unroll
+                            for (int c = 0; c < NCH; ++c) {
+                                const float4 v = *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
+                                s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
+                };
+                f32x16 soc = splat16(bso);
+                build(0);
+                __syncthreads();
+                for (int b = 0; b < B; ++b) {
+                    if (b + 1 < B) build(b + 1);
+                    mma1(soc, AB + (b & 1) * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5),
+                         a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+                __syncthreads();
+                f32x16 rh = splat16(bgr), u = splat16(bgu);
+                mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
+                mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
+                __syncthreads();
+                {
+                    f32x16 ac = splat16(bcc);
+                    mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
+                    mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
+                    float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)(row0 + 4 * (lane >> 5)) * H + col;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+                        sp[i] = fmaf(h[i], wsc, sp[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
+                        hout[(size_t)((i & 3) + 8 * (i >> 2)) * H] = h[i];
+                    }
+                }
+                if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
+                group_publish(cnt);                      // includes the end-of-step __syncthreads
+                ++epoch;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sp[i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+                if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
+            }
+            __syncthreads();
+            if (tid < TM && it == a.iters - 1) {
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+                a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+            }
+            for (int nt = cb; nt < a.NTreg; nt += NT) {
+                f32x16 acc = zero16();
+                mma1(acc, x_lane + E, a.Wreg + ((size_t)nt * GH) * 64 + lane, GH);
+                const int cc = nt * 32 + (lane & 31);
+                if (cc < 2 * a.T) {
+                    const float bb = a.b_reg[cc];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* y = a.Y + (size_t)(row0 + acc_row(i)) * 2 * a.T + cc;
+                        *y = *y + (acc[i] + bb);
+                    }
+                }
+            }
+            group_publish(cnt);                          // pass end: my rows of Y are final for this pass
+            ++epoch;
+        }
+        (void)epoch;
+    }
+}
+static size_t ioc_cl_lds_bytes(const IocArgs& a) {
+    const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G, TM = 32;
+    size_t f = (size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * 4 + 128 * 2 + TM * 2 + 3 * EV + NT * TM;
+    return f * sizeof(float) + 128 + 64;
+}
+template <int H>
+static void launch_ioc_cl_t(const IocArgs& a, hipStream_t s) {
+    allow_big_lds(k_ioc_cl<H, 16, 32>);
+    const int tpg = a.mno / 32, n_tiles = a.R / 32;
+    int grid = n_tiles < 256 ? n_tiles : 256;            // one workgroup per CU: all of them resident
+    grid -= grid % tpg;
+    hipLaunchKernelGGL((k_ioc_cl<H, 16, 32>), dim3(grid), dim3((H / 32) * 64), ioc_cl_lds_bytes(a), s, a);
+}
+void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
+    if (a.H == 256) launch_ioc_cl_t<256>(a, s);
+    else if (a.H == 128) launch_ioc_cl_t<128>(a, s);
+    else launch_ioc_cl_t<64>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------

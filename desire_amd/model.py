@@ -26,10 +26,11 @@ from .spec import Dims, init_weights
 
 
 def _next_divisor_of_64(n: int) -> int:
-    for m in (1, 2, 4, 8, 16, 32, 64):
+    """Pad max_num_obj up to a slot count the IOC tiling accepts: a divisor of 32, or 64 / 96 / 128."""
+    for m in (1, 2, 4, 8, 16, 32, 64, 96, 128):
         if m >= n:
             return m
-    raise ValueError("max_num_obj > 64 is not supported in this round (IOC tile = 64 rows)")
+    raise ValueError("max_num_obj > 128 is not supported in this round")
 
 
 def dims_from_args(args, n_scenes: int, posterior: bool = True) -> Dims:

@@ -30,7 +30,7 @@ class Dims:
     """Static sizes of one forward call.  Row index r = (scene*K + k)*mno + slot."""
 
     n_scenes: int = 1      # windows per call (DataLoader batch entries), each its own scene
-    mno: int = 32          # agent slots per window (max_num_obj), must divide 64
+    mno: int = 32          # agent slots per window (max_num_obj): divides 32, or 64 / 96 / 128
     K: int = 20            # samples per agent
     T_obs: int = 8
     T_pred: int = 40
@@ -74,14 +74,12 @@ class Dims:
     def validate(self) -> None:
         if self.S != 32:
             raise ValueError("CVAE stack closes only for S=32 (rnn_size=512), model/model.py:465-468")
-        if 64 % self.mno != 0:
-            raise ValueError("mno must divide 64 (host pads max_num_obj up)")
+        if not (1 <= self.mno <= 128) or (32 % self.mno if self.mno <= 32 else self.mno % 32):
+            raise ValueError("mno must divide 32 or be 64, 96 or 128 (host pads max_num_obj up)")
         if self.H % 32 or self.L % 8 or self.C % 8 or self.E_v % 8:
             raise ValueError("H%32, L%8, C%8, E_v%8 required by the MFMA tiling")
         if self.H not in (64, 128, 256):
             raise ValueError("H must be 64, 128 or 256 (instantiated recurrent tiles)")
-        if self.H == 256 and self.mno > 32:
-            raise ValueError("H=256 needs mno <= 32 in this round (LDS tile)")
         if self.C != 32 or self.E_v != 16:
             raise ValueError("C=32, E_v=16 are the instantiated IOC widths in this round")
         if min(self.n_scenes, self.K, self.T_obs, self.T_pred, self.n_grids, self.iters) < 1:

@@ -305,3 +305,29 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
     ref = O.ade_fde_k(Y.cpu().numpy(), O.normalise(to_oracle_layout(ft), d), d)
     assert np.abs(af.cpu().numpy() - ref).max() < 1e-5
     assert (af[:, 2] <= af[:, 0] + 1e-6).all() and (af[:, 3] <= af[:, 1] + 1e-6).all()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(mno=64, n_scenes=2, K=3, n_grids=1, T_pred=9),                  # 2 workgroups per group
+    dict(mno=128, n_scenes=1, K=2, n_grids=1, T_pred=6),                 # 4 workgroups per group, 128-bit masks
+    dict(mno=64, H=256, n_scenes=1, K=2, n_grids=1, T_pred=6),           # BASELINE configs[3] shape: H=256, 64 agents/scene
+    dict(mno=96, n_scenes=1, K=2, n_grids=1, T_pred=5, iters=2),         # 3 per group, two refinement passes
+])
+def test_ioc_cluster_form(torch_cuda, kw, monkeypatch):
+    """Groups larger than one workgroup tile: tpg workgroups exchange hidden states through global memory each
+    step (agent-scope release/acquire hand-off).  Checked against the oracle, and -- where the single-workgroup
+    64-row kernel exists -- bitwise against it (same summation order)."""
+    monkeypatch.setenv("DESIRE_IOC_VARIANT", "4")
+    d = small_dims(**kw)
+    w = init_weights(d, 13)
+    past, fut, eps, grids, gos = make_case(d, seed=14, n_absent=5, spread=0.3)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    assert (np.asarray(ref["Y"]) != 0).any()
+    _, Y2, score2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref["Y"]).max() < TOL_Y, np.abs(Y2 - ref["Y"]).max()
+    assert np.abs(score2 - ref["score"]).max() < 5e-3
+    if d.mno == 64 and d.H <= 128:
+        monkeypatch.setenv("DESIRE_IOC_VARIANT", "0")
+        _, Y3, score3 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+        np.testing.assert_array_equal(Y2, Y3)
+        np.testing.assert_array_equal(score2, score3)
