@@ -132,7 +132,69 @@ class DESIREModel(object):
         self._keep = (past, fut, eps_t)            # keep inputs alive until the stream has consumed them
         self.input_data, self.target_data = x_batch, y_batch
         self.final_output, self.final_states = Y, score
+        if posterior:                              # train-path scalars (model/model.py:339-376): cost = mean(recon + kld)
+            self._kld = torch.empty(d.A, device=self.device)
+            self._recon = torch.empty(d.A, device=self.device)
+            self._cost = torch.empty(2, device=self.device)
+            h.losses(fut.data_ptr(), Y.data_ptr(), self._kld.data_ptr(), self._recon.data_ptr(), self._cost.data_ptr(), stream)
+            self.cost = self._cost[0]              # 0-dim device tensor; float(model.cost) synchronises
+        else:
+            self.cost = None
         return Y, score
+
+    def forward_from_video(self, frames, starts: Sequence[int], posterior: bool = True, eps=None, seed: int = 0):
+        """Device-side batching: `frames` [F, max_num_obj, 3] is one preprocessed video
+        (DataLoader.data[i]); the windows starting at `starts` are cut and slot-assigned on the GPU with the
+        loader's exact semantics, then run through the hot path without touching the host again."""
+        torch = self.torch
+        n = len(starts)
+        h = self._handle(n, posterior)
+        d = h.dims
+        fr = torch.as_tensor(np.ascontiguousarray(np.asarray(frames), np.float32), device=self.device)
+        past = torch.empty((n, d.T_obs, d.mno, 3), device=self.device)
+        fut = torch.empty((n, d.T_pred, d.mno, 3), device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        h.build_windows(fr.data_ptr(), fr.shape[0], fr.shape[1], starts, past.data_ptr(), fut.data_ptr(), stream)
+        if eps is None:
+            g = torch.Generator(device=self.device).manual_seed(seed)
+            eps_t = torch.randn((d.R, d.L), generator=g, device=self.device, dtype=torch.float32)
+        else:
+            eps_t = torch.as_tensor(np.ascontiguousarray(eps, np.float32), device=self.device).reshape(d.R, d.L)
+        if self._grids is None:
+            self._grids = torch.zeros((d.n_grids, d.Gh, d.Gw, d.C), device=self.device)
+            self._grid_of_scene = np.zeros(n, np.int32)
+        gos = self._grid_of_scene if len(self._grid_of_scene) == n else np.resize(self._grid_of_scene, n)
+        h.set_scene_grids(self._grids.data_ptr(), gos)
+        Y = torch.empty((n, d.K, d.mno, d.T_pred, 2), device=self.device, dtype=torch.float32)
+        score = torch.empty((n, d.K, d.mno), device=self.device, dtype=torch.float32)
+        h.forward(past.data_ptr(), fut.data_ptr() if posterior else 0, eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
+        self._keep = (fr, past, fut, eps_t)
+        self.final_output, self.final_states = Y, score
+        return Y, score, past, fut
+
+    def evaluate(self, Y, fut_windows) -> np.ndarray:
+        """[A, 4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K), normalised units (N4 harness).
+        `fut_windows`: list of loader windows [T_pred, MNO, 3] or a device tensor [n, T_pred, mno, 3]."""
+        torch = self.torch
+        n = Y.shape[0]
+        h = self._handle(n, True)
+        d = h.dims
+        fut = fut_windows if torch.is_tensor(fut_windows) else self._pad_windows(fut_windows, d.mno)
+        out = torch.empty((d.A, 4), device=self.device)
+        h.ade_fde(Y.data_ptr(), fut.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out.cpu().numpy()
+
+    # ---- checkpoints (train.py:114,197-206 saves TF checkpoints; here: a named fp32 archive) -----------------
+    def save(self, path: str) -> None:
+        from .formats import save_weights
+        if self._weights is None:
+            raise ValueError("no weights yet: run forward() once or pass weights=")
+        save_weights(path, self._weights)
+
+    @classmethod
+    def restore(cls, args, path: str) -> "DESIREModel":
+        from .formats import load_weights
+        return cls(args, weights=load_weights(path))
 
     # ---- reference-shaped sampling API (model/model.py:613-688) ------------------------------------
     def sample(self, sess, traj, grid, dimensions, true_traj, num=10):

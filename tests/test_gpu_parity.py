@@ -185,6 +185,20 @@ def test_model_api_and_sample_layout(torch_cuda):
     Y, score = m.forward(x, y)
     assert tuple(Y.shape) == (2, 3, 32, 12, 2) and tuple(score.shape) == (2, 3, 32)
     assert bool(torch_cuda.isfinite(Y).all())
+    assert m.cost is not None and np.isfinite(float(m.cost))
+    ev = m.evaluate(Y, y)
+    assert ev.shape == (64, 4) and np.isfinite(ev).all() and (ev[:, 2] <= ev[:, 0] + 1e-6).all()
+    # device-side batching gives the same windows as the host path
+    frames = np.zeros((40, 30, 3)); frames[:20] = np.concatenate([x[0], y[0]]); frames[20:] = np.concatenate([x[1], y[1]])
+    Yv, _, pv, fv = m.forward_from_video(frames, [0, 20])
+    uniq0 = np.unique(frames[:20, :, 0]); has0 = 0.0 in uniq0
+    assert tuple(Yv.shape) == tuple(Y.shape) and bool(torch_cuda.isfinite(Yv).all())
+    import tempfile, os as _os
+    with tempfile.TemporaryDirectory() as td:
+        m.save(_os.path.join(td, "w.npz"))
+        m2 = DESIREModel.restore(args, _os.path.join(td, "w.npz"))
+        Y2, _ = m2.forward(x, y)
+        np.testing.assert_array_equal(Y2.cpu().numpy(), Y.cpu().numpy())
     out = m.sample(None, x[0], None, (1400.0, 1100.0), np.concatenate([x[0], y[0]]), num=10)
     assert out.shape == (18, 30, 3)
     np.testing.assert_array_equal(out[:8], x[0])
