@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=64, help="loader windows (scenes) per step per GPU")
+    ap.add_argument("--windows", type=int, default=128, help="loader windows (scenes) per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()

@@ -12,6 +12,7 @@
 // TF GRUCell: [r,u] = sigmoid([x,h] Wg + bg); c = tanh([x, r*h] Wc + bc); h' = u*h + (1-u)*c.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define RNN_WG 512         // 8 waves: wave = (column block cb = w&3, M-tile mt = w>>2), two per SIMD
 
@@ -129,7 +130,7 @@ void launch_encoder(const EncArgs& a, hipStream_t s) {
 // and kept in 48 accumulator-layout registers per wave; per step only the h-part contracts (K = H).
 // ------------------------------------------------------------------------------------------------
 template <int H, int TM>
-__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_decoder(DecArgs a) {
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM;
     float* hs = smem;                          // [64][LDH]  h / r*h as A operand
@@ -230,7 +231,9 @@ static void launch_decoder_t(const DecArgs& a, hipStream_t s) {
 }
 void launch_decoder(const DecArgs& a, hipStream_t s) {
     if (a.H == 256) launch_decoder_t<256, 32>(a, s);
-    else if (a.H == 128) launch_decoder_t<128, 64>(a, s);
+    else if (a.H == 128) {                              // 32-row tiles: 4 waves + 34 KB LDS -> two workgroups per CU
+        if (getenv("DESIRE_DEC_TM64")) launch_decoder_t<128, 64>(a, s); else launch_decoder_t<128, 32>(a, s);
+    }
     else launch_decoder_t<64, 64>(a, s);
 }
 
