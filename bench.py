@@ -15,7 +15,7 @@ across ranks with NO data-path collective; weak scaling (fixed windows per GPU).
 torch.cuda.synchronize() on both sides of exactly K steps, max over ranks, rank 0 prints one JSON
 line.  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
 hipEvents on the launch stream over the timed steps) and `cpu_baseline` (the numpy oracle timed on
-this host on a bounded sample: 4 windows = 2560 samples).
+this host on a bounded sample: 8 windows = 5120 samples).
 """
 import argparse
 import json
@@ -39,12 +39,27 @@ def ioc_flops_per_row(d):
     return d.iters * (T * (6.0 * H * (E + H) + 2.0 * B * H * H + 2 * H + 4 * d.E_v) + 2.0 * H * 2 * T)
 
 
+def committed_traffic(windows):
+    """HBM bytes per k_ioc launch from the committed rocprofv3 PMC passes (profiles/, collected from this very
+    command at 128 windows/step in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_final_bench_pmc_per_kernel.json")
+    if windows != 128 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        pmc = json.load(fh)
+    for name, c in pmc.items():
+        if name.startswith("void k_ioc<128") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def cpu_baseline(d_full, seed):
     """The CPU restatement (oracle, NOT TF1 -- the reference cannot run) on one window."""
     from oracle import desire_oracle as O                      # cpu_baseline leg: allowed importer
     from desire_amd.spec import init_weights
     from desire_amd.synth import make_case
-    d = d_full.replace(n_scenes=4, n_grids=1)
+    d = d_full.replace(n_scenes=8, n_grids=1)
     w = init_weights(d, seed)
     past, fut, eps, grids, gos = make_case(d, seed=seed + 1)
     tr = lambda x: np.ascontiguousarray(x.transpose(1, 0, 2, 3).reshape(x.shape[1], -1, 3))
@@ -57,7 +72,7 @@ def cpu_baseline(d_full, seed):
     O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
     dt = time.perf_counter() - t0
     return {"value": d.R / dt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
-            "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 4 windows = %d samples, "
+            "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 8 windows = %d samples, "
                       "%.1f s; CPU restatement, not TF1 (reference graph does not build)" % (d.R, dt)}
 
 
@@ -151,7 +166,9 @@ def main():
                        "flops_per_sample": flops_per_sample(d)},
             "roofline": {"bound": "mfma", "kernel": "k_ioc<128,16,32>", "achieved": ioc_tflops,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ioc_tflops / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": ioc_ms,
+                         "traffic": committed_traffic(a.windows), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_hbm_bytes_per_launch": d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4,
+                         "kernel_ms": ioc_ms,
                          "algorithmic_flops_per_launch": ioc_flops_per_row(d) * d.R,
                          "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / FP32_MFMA_PEAK_TFLOPS},
             "kernel_ms": kern_ms,
