@@ -396,3 +396,36 @@ def test_config3_per_gpu_shard_shape(torch_cuda):
     assert np.abs(h.read_buffer("Y0", (d3.R, d3.T_pred, 2)) - ref["Y0"]).max() < TOL_Y
     _, Yo, so = run_gpu(torch, d3, w, past[:1], fut[:1], e3, grids, gos[:1], Y_in=ref["Y0"])
     assert np.abs(Yo - ref["Y"]).max() < TOL_Y
+
+
+def test_abi_error_behaviour_on_device(torch_cuda):
+    """State and argument errors come back as codes + desire_last_error(), never as a crash."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    d = small_dims(n_scenes=1, K=1, T_pred=4)
+    h = _lib.Handle(d)
+    dev = torch.device("cuda")
+    z = torch.zeros(1 << 16, device=dev)
+    with pytest.raises(_lib.DesireError, match="not finalized"):
+        h.encode(z.data_ptr(), z.data_ptr())
+    w = init_weights(d, 0)
+    bad = dict(w); bad.pop("head/w")
+    with pytest.raises(_lib.DesireError, match="weight not set: head/w"):
+        h.set_weights(bad)
+    with pytest.raises(_lib.DesireError, match="expected"):
+        h.set_weights({"head/w": np.zeros(3, np.float32)})
+    with pytest.raises(_lib.DesireError, match="unknown weight"):
+        h.set_weights({"nope": np.zeros(3, np.float32)})
+    h.set_weights(w)
+    with pytest.raises(_lib.DesireError, match="needs dev_fut"):
+        h.encode(z.data_ptr(), 0)
+    with pytest.raises(_lib.DesireError, match="scene grids not set"):
+        h.ioc_refine(z.data_ptr(), z.data_ptr())
+    with pytest.raises(_lib.DesireError, match="out of range"):
+        h.set_scene_grids(z.data_ptr(), [3])
+    with pytest.raises(_lib.DesireError, match="unknown buffer"):
+        h.read_buffer("nope", (1,))
+    with pytest.raises(_lib.DesireError, match="expected"):
+        h.read_buffer("Hx", (1,))
+    with pytest.raises(ValueError):
+        _lib.Handle(small_dims(mno=24))
