@@ -71,9 +71,30 @@ def cpu_baseline(d_full, seed):
     t0 = time.perf_counter()
     O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
     dt = time.perf_counter() - t0
+    # the reference's own structure (model/model.py:211): one object at a time, batch dimension 1, for the
+    # sample-generation stages (the IOC stage needs the whole group and stays batched above)
+    d1 = d.replace(n_scenes=1, mno=1, iters=1)
+    n_obj = 16
+    t1 = time.perf_counter()
+    for a_ in range(n_obj):
+        e1 = eps.reshape(d.n_scenes, d.K, d.mno, d.L)[0, :, a_].reshape(d1.R, d.L)
+        pn = O.normalise(tr(past)[:, a_:a_ + 1], d1)
+        fn = O.normalise(tr(fut)[:, a_:a_ + 1], d1)
+        Hx = O.gru_encode(pn, w, "enc_x"); Hy = O.gru_encode(fn, w, "enc_y")
+        vin = O.relu(np.concatenate([Hx, Hy], -1) @ w["fc_c/w"] + w["fc_c/b"])
+        mu, ls = O.vae_encoder(vin, w, d.L)
+        z = O.rows_from_agents(mu, d1) + np.sqrt(np.exp(O.rows_from_agents(ls, d1))) * e1
+        xh = O.vae_decoder(z, w)
+        Hr = O.rows_from_agents(Hx, d1)
+        xz = O.softmax(O.relu(xh @ w["mask_fc/w"] + w["mask_fc/b"])) * Hr
+        O.decode(xz, Hr, O.rows_from_agents(pn[-1], d1), w, d1)
+    dt1 = (time.perf_counter() - t1) / n_obj
     return {"value": d.R / dt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
             "sample": "oracle/desire_oracle.py forward (numpy fp32, batched over the window) on 8 windows = %d samples, "
-                      "%.1f s; CPU restatement, not TF1 (reference graph does not build)" % (d.R, dt)}
+                      "%.1f s; CPU restatement, not TF1 (reference graph does not build)" % (d.R, dt),
+            "per_object_loop": {"value": d.K / dt1, "unit": "agent-trajectory-samples/s",
+                                "note": "sample-generation stages only, one object at a time like model/model.py:211 "
+                                        "(%d objects x K=%d, %.2f s each)" % (n_obj, d.K, dt1)}}
 
 
 def main():

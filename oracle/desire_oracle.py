@@ -137,7 +137,11 @@ def batch_norm(x, w, prefix, bn_mode, dt):
     (model/model.py:457-462,476-481).  'frozen' = inference phase (moving moments);
     'batch' = the reference's literal default phase=train (batch moments over N,H,W)."""
     gamma, beta = w[prefix + "/bn/gamma"].astype(dt), w[prefix + "/bn/beta"].astype(dt)
-    if bn_mode == "batch":
+    if bn_mode == "per_object":                          # the reference graph: one object per conv call, batch of 1
+        ax = tuple(range(1, x.ndim - 1))
+        mean = x.mean(axis=ax, keepdims=True, dtype=dt)
+        var = ((x - mean) ** 2).mean(axis=ax, keepdims=True, dtype=dt)
+    elif bn_mode == "batch":
         ax = tuple(range(x.ndim - 1))
         mean = x.mean(axis=ax, dtype=dt)
         var = ((x - mean) ** 2).mean(axis=ax, dtype=dt)  # tf.nn.moments: biased
@@ -346,6 +350,41 @@ def forward(past, fut, eps, grids, grid_of_scene, w, d, bn_mode="frozen", dt=np.
     out["Y"] = Y
     out["score"] = score
     return out
+
+
+def forward_ref_compat(input_data, target_data, eps, w, H=16, L=128, n_dec=7, dt=np.float32):
+    """The reference graph AS WRITTEN (model/model.py:116-311), for the parts that define arithmetic, at its own
+    dims: H = d_dim = 16, T = seq_length = 8 (H == 2T is REQUIRED by :286-289), 7 decoder steps (:280), ONE eps
+    draw per object (:262-263), raw-pixel inputs (:216-231), target = input shifted one frame, batch-norm in
+    train phase on a batch of one object (= moments over H,W of that object, :453,471), no output layer: each
+    decoder output [H] is re-read as T points (x,y) (:286-289).  CPU plumbing only (BASELINE configs[0]);
+    the HIP path implements the frozen spec of DESIGN.md section 2 instead.
+    input_data / target_data [MNO, T, 3] object-major as the placeholders (:91-105); eps [MNO, L].
+    Needs weights "temporal/w|b" and GRU/fc/CVAE weights sized for H (spec.init_weights(Dims-like)).
+    Returns rho [MNO,200], Hx, Hy, output_states [MNO, 7, T, 2], feature_pooling [MNO, 7, T, 200]."""
+    MNO, T, _ = input_data.shape
+    if H != 2 * T:
+        raise ValueError("the reference reinterprets each decoder output [H] as T (x,y) pairs: needs H == 2*T (model/model.py:286-289)")
+    rho = temporal_conv(input_data[None].astype(np.float32), w["temporal/w"], w["temporal/b"])[0, :, 0, :]   # O1
+    xin = input_data[:, :, 1:3].transpose(1, 0, 2).astype(dt)                 # [T, MNO, 2] raw pixels
+    yin = target_data[:, :, 1:3].transpose(1, 0, 2).astype(dt)
+    Hx = gru_encode(xin, w, "enc_x", dt)                                       # O2
+    Hy = gru_encode(yin, w, "enc_y", dt)                                       # O3
+    vae_in = relu(np.concatenate([Hx, Hy], -1) @ w["fc_c/w"].astype(dt) + w["fc_c/b"].astype(dt))   # O4
+    mu, lss = vae_encoder(vae_in, w, L, "per_object", dt)                      # O5
+    z = mu + np.sqrt(np.exp(lss)) * eps.astype(dt)                             # O6
+    xhat = vae_decoder(z, w, "per_object", dt)                                 # O7
+    beta = softmax(relu(xhat @ w["mask_fc/w"].astype(dt) + w["mask_fc/b"].astype(dt)))   # O8
+    Wg, bg, Wc, bc = _gru_w(w, "dec", dt)
+    x_in, h = beta * Hx, Hx
+    outs = []
+    for _ in range(n_dec):                                                     # O9: same input every step
+        h = gru_cell(x_in, h, Wg, bg, Wc, bc)
+        outs.append(h)
+    states = np.stack(outs, 1).reshape(MNO, n_dec, T, 2)                       # O10: [H] -> T x (x,y)
+    fp = np.concatenate([states[..., 0:1] * rho[:, None, None, :100],          # O11
+                         states[..., 1:2] * rho[:, None, None, 100:]], -1)
+    return {"rho": rho, "Hx": Hx, "Hy": Hy, "z": z, "xhat": xhat, "output_states": states, "feature_pooling": fp}
 
 
 # ------------------------------------------------------------------------------------------

@@ -139,3 +139,40 @@ def test_forward_shapes_and_batch_bn_mode_runs():
     c = O.forward(past, None, eps, grids, [0], w, dp)
     np.testing.assert_array_equal(c["z"], eps)
     assert 50e6 < flops_per_sample(Dims(mno=32, K=20)) < 56e6
+
+
+def test_ref_compat_literal_graph_plumbing(golden_dir):
+    """BASELINE configs[0]: the reference graph as written, on a real loader batch (CPU plumbing, no GPU):
+    H = d_dim = 16 = 2*T, 7 decoder steps, one eps per object, raw pixels, per-object train-phase BN."""
+    import os
+    from desire_amd.spec import weight_shapes
+    g = np.load(os.path.join(golden_dir, "loader_bookstore6_T8.npz"))
+    x, y = g["x"][0][0], g["y"][0][0]                       # [T=8, MNO=32, 3] loader layout (time-major)
+    inp, tgt = x.transpose(1, 0, 2), y.transpose(1, 0, 2)   # placeholders are object-major (model/model.py:91-105)
+    H, T, L = 16, 8, 128
+    rng = np.random.default_rng(0)
+    w = {}
+    def gru(p, n_in):
+        w[p + "/gates/kernel"] = (rng.standard_normal((n_in + H, 2 * H)) * 0.05).astype(np.float32)
+        w[p + "/gates/bias"] = np.ones(2 * H, np.float32)
+        w[p + "/candidate/kernel"] = (rng.standard_normal((n_in + H, H)) * 0.05).astype(np.float32)
+        w[p + "/candidate/bias"] = np.zeros(H, np.float32)
+    gru("enc_x", 2); gru("enc_y", 2); gru("dec", H)
+    big = init_weights(Dims(T_obs=T, T_pred=T), 1)
+    for k, v in big.items():
+        if k.startswith(("vae_enc", "vae_dec", "temporal")):
+            w[k] = v
+    w["fc_c/w"] = (rng.standard_normal((2 * H, 1024)) / np.sqrt(2 * H)).astype(np.float32); w["fc_c/b"] = np.zeros(1024, np.float32)
+    w["mask_fc/w"] = (rng.standard_normal((1024, H)) / 32).astype(np.float32); w["mask_fc/b"] = np.zeros(H, np.float32)
+    eps = rng.standard_normal((32, L)).astype(np.float32)
+    out = O.forward_ref_compat(inp, tgt, eps, w, H=H, L=L)
+    assert out["rho"].shape == (32, 200) and out["output_states"].shape == (32, 7, 8, 2)
+    assert out["feature_pooling"].shape == (32, 7, 8, 200) and np.isfinite(out["feature_pooling"]).all()
+    # O10/O11 are pure re-reads of the decoder outputs
+    k, t, obj = 3, 5, 9
+    assert out["feature_pooling"][obj, k, t, 150] == out["output_states"][obj, k, t, 1] * out["rho"][obj, 150]
+    # batch-of-one train-phase BN makes objects independent: running one object alone gives the same row
+    one = O.forward_ref_compat(inp[obj:obj + 1], tgt[obj:obj + 1], eps[obj:obj + 1], w, H=H, L=L)
+    np.testing.assert_allclose(one["output_states"][0], out["output_states"][obj], atol=1e-6)
+    with pytest.raises(ValueError):
+        O.forward_ref_compat(inp, tgt, eps, w, H=32, L=L)
