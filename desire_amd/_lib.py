@@ -19,6 +19,7 @@ EXPORTS = [
     "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
     "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
     "desire_temporal_conv", "desire_feature_pooling", "desire_build_windows", "desire_gaussian_sample", "desire_ade_fde",
+    "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
 ]
 
 
@@ -72,6 +73,10 @@ def load() -> C.CDLL:
     lib.desire_build_windows.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), i32, f32p, f32p, vp]
     lib.desire_gaussian_sample.argtypes = [vp, f32p, f32p, f32p, i32, vp]
     lib.desire_ade_fde.argtypes = [vp, f32p, f32p, f32p, vp]
+    lib.desire_set_training.argtypes = [vp, C.c_int]
+    lib.desire_backward.argtypes = [vp, f32p, f32p, f32p, vp]
+    lib.desire_get_grad.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
+    lib.desire_grad_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
@@ -166,6 +171,22 @@ class Handle:
 
     def ade_fde(self, yhat_ptr: int, fut_ptr: int, out_ptr: int, stream: int = 0) -> None:
         _chk(self.lib.desire_ade_fde(self._h, yhat_ptr, fut_ptr, out_ptr, stream or None))
+
+    def set_training(self, on: bool) -> None:
+        _chk(self.lib.desire_set_training(self._h, int(on)))
+
+    def backward(self, past_ptr: int, fut_ptr: int, eps_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_backward(self._h, past_ptr, fut_ptr, eps_ptr, stream or None))
+
+    def get_grad(self, name: str, shape: Tuple[int, ...], stream: int = 0) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        _chk(self.lib.desire_get_grad(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, stream or None))
+        return out
+
+    def grad_buffer(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib.desire_grad_buffer(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
 
     def set_profiling(self, on: bool) -> None:
         _chk(self.lib.desire_set_profiling(self._h, int(on)))

@@ -1,64 +1,17 @@
 // api.hip -- C ABI of libdesire_hip.so (include/desire_hip.h): handle, weight repacking into MFMA
 // B-fragment order, workspace, and the launch sequence of the hot path.  Host code only.
-#include "../../include/desire_hip.h"
-#include "kernels.h"
-
-#include <hip/hip_runtime.h>
+#include "ctx.h"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
-#include <map>
-#include <string>
-#include <vector>
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
-#define HIPCHK(x)                                                                                   \
-    do {                                                                                            \
-        hipError_t e_ = (x);                                                                        \
-        if (e_ != hipSuccess)                                                                       \
-            return fail(DESIRE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));            \
-    } while (0)
+int desire_fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* desire_last_error(void) { return g_err.c_str(); }
 extern "C" int desire_version(void) { return 1; }
-
-namespace {
-
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    int alloc(size_t b) {
-        bytes = b;
-        hipError_t e = hipMalloc(&p, b ? b : 4);
-        return e == hipSuccess ? 0 : -1;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
-    float* f() const { return static_cast<float*>(p); }
-};
-
-struct Prof { std::string name; hipEvent_t e0, e1; };
-
-}  // namespace
-
-struct desire_ctx {
-    desire_dims d;
-    int A, R, V, B, E;
-    std::map<std::string, std::vector<float>> host_w;       // raw weights as set
-    std::map<std::string, size_t> want;                      // name -> element count
-    std::map<std::string, DevBuf> dev;                       // raw / packed / folded device tensors
-    std::map<std::string, DevBuf> ws;                        // workspace
-    bool finalized = false;
-    const float* grids = nullptr;
-    bool grids_set = false;
-    bool profiling = false;
-    std::vector<Prof> prof;
-    std::vector<std::string> prof_name_store;
-};
-
-namespace {
 
 // Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
 std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at) {
@@ -74,16 +27,14 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
     return out;
 }
 
-int upload(desire_ctx* h, const std::string& name, const std::vector<float>& v) {
+int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v) {
     DevBuf& b = h->dev[name];
     b.release();
     if (b.alloc(v.size() * sizeof(float))) return -1;
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 
-const float* D(desire_ctx* h, const char* name) { return h->dev.at(name).f(); }
-const float4* D4(desire_ctx* h, const char* name) { return reinterpret_cast<const float4*>(h->dev.at(name).f()); }
-float* W(desire_ctx* h, const char* name) { return h->ws.at(name).f(); }
+namespace {
 
 void shapes(desire_ctx* h) {
     const desire_dims& d = h->d;
@@ -152,18 +103,6 @@ int check_dims(const desire_dims& d) {
     return 0;
 }
 
-struct Timer {
-    desire_ctx* h; hipStream_t s; bool on;
-    Timer(desire_ctx* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profiling) {
-        if (!on) return;
-        Prof p; p.name = name;
-        (void)hipEventCreate(&p.e0); (void)hipEventCreate(&p.e1);
-        (void)hipEventRecord(p.e0, s);
-        h->prof.push_back(p);
-    }
-    ~Timer() { if (on) (void)hipEventRecord(h->prof.back().e1, s); }
-};
-
 }  // namespace
 
 extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
@@ -229,10 +168,16 @@ extern "C" int desire_finalize_weights(desire_handle* h) {
     if (!h) return fail(DESIRE_ERR_ARG, "null handle");
     for (auto& kv : h->want)
         if (!h->host_w.count(kv.first)) return fail(DESIRE_ERR_STATE, "weight not set: " + kv.first);
+    if (int rc = desire_pack_all(h)) return rc;
+    h->finalized = true;
+    return DESIRE_OK;
+}
+
+int desire_pack_all(desire_ctx* h) {
     const desire_dims& d = h->d;
     const int H = d.H, L = d.L, V = h->V, E = h->E, B = h->B;
     auto& hw = h->host_w;
-    auto up = [&](const std::string& n, const std::vector<float>& v) { return upload(h, n, v); };
+    auto up = [&](const std::string& n, const std::vector<float>& v) { return desire_upload(h, n, v); };
     auto rowmajor = [](const std::vector<float>& w, int ldw, int k0) {
         return [&w, ldw, k0](int k, int n) { return w[(size_t)(k0 + k) * ldw + n]; };
     };
@@ -250,6 +195,13 @@ extern "C" int desire_finalize_weights(desire_handle* h) {
     bad |= up("dec/Whg", pack_b(H, 2 * H, rowmajor(hw["dec/gates/kernel"], 2 * H, H)));
     bad |= up("dec/Wxc", pack_b(H, H, rowmajor(hw["dec/candidate/kernel"], H, 0)));
     bad |= up("dec/Whc", pack_b(H, H, rowmajor(hw["dec/candidate/kernel"], H, H)));
+    {   // transposed blocks for the backward data-gradient contractions: B(k', n') = W[row0 + n'][k']
+        const auto& gk = hw["dec/gates/kernel"]; const auto& ck = hw["dec/candidate/kernel"];
+        bad |= up("dec/WgT_x", pack_b(2 * H, H, [&](int k, int n) { return gk[(size_t)n * 2 * H + k]; }));
+        bad |= up("dec/WgT_h", pack_b(2 * H, H, [&](int k, int n) { return gk[(size_t)(H + n) * 2 * H + k]; }));
+        bad |= up("dec/WcT_x", pack_b(H, H, [&](int k, int n) { return ck[(size_t)n * H + k]; }));
+        bad |= up("dec/WcT_h", pack_b(H, H, [&](int k, int n) { return ck[(size_t)(H + n) * H + k]; }));
+    }
     bad |= up("head/w", hw["head/w"]); bad |= up("head/b", hw["head/b"]);
     bad |= up("ioc/gb", hw["ioc/gates/bias"]); bad |= up("ioc/cb", hw["ioc/candidate/bias"]);
     bad |= up("ioc/Wg", pack_b(E + H, 2 * H, rowmajor(hw["ioc/gates/kernel"], 2 * H, 0)));
@@ -303,7 +255,6 @@ extern "C" int desire_finalize_weights(desire_handle* h) {
         bad |= up(n, hw[n]);
     if (bad) return fail(DESIRE_ERR_HIP, "weight upload failed");
     HIPCHK(hipDeviceSynchronize());
-    h->finalized = true;
     return DESIRE_OK;
 }
 
@@ -318,14 +269,14 @@ extern "C" int desire_set_scene_grids(desire_handle* h, const float* dev_grids, 
     return DESIRE_OK;
 }
 
-static int ready(desire_handle* h) {
+int desire_ready(desire_handle* h) {
     if (!h) return fail(DESIRE_ERR_ARG, "null handle");
     if (!h->finalized) return fail(DESIRE_ERR_STATE, "weights not finalized (desire_finalize_weights)");
     return 0;
 }
 
 extern "C" int desire_encode(desire_handle* h, const float* dev_past, const float* dev_fut, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     const desire_dims& d = h->d;
     if (!dev_past) return fail(DESIRE_ERR_ARG, "dev_past is null");
     if (d.posterior && !dev_fut) return fail(DESIRE_ERR_ARG, "dims.posterior=1 needs dev_fut");
@@ -369,7 +320,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
 }
 
 extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_Yhat, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     if (!dev_eps || !dev_Yhat) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -401,6 +352,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
     a.Y = W(h, "Y0"); a.hdump = nullptr;
+    if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
     HIPCHK(hipMemcpyAsync(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
@@ -408,7 +360,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
 }
 
 extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     if (!dev_Yhat || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
     if (!h->grids_set) return fail(DESIRE_ERR_STATE, "scene grids not set (desire_set_scene_grids)");
     const desire_dims& d = h->d;
@@ -518,7 +470,7 @@ extern "C" int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_
 }
 
 extern "C" int desire_scene_cnn(desire_handle* h, const float* dev_image, int32_t Hi, int32_t Wi, float* dev_grids, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     if (!dev_image || !dev_grids) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     if (Hi != 4 * d.Gh || Wi != 4 * d.Gw) return fail(DESIRE_ERR_ARG, "scene image must be [n_grids, 4*Gh, 4*Gw, 3]");
@@ -538,7 +490,7 @@ extern "C" int desire_scene_cnn(desire_handle* h, const float* dev_image, int32_
 
 extern "C" int desire_losses(desire_handle* h, const float* dev_fut, const float* dev_Yhat, float* dev_kld,
                              float* dev_recon, float* dev_cost, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     if (!dev_fut || !dev_Yhat || !dev_kld || !dev_recon || !dev_cost) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "losses need the posterior path (dims.posterior = 1)");
@@ -549,7 +501,7 @@ extern "C" int desire_losses(desire_handle* h, const float* dev_fut, const float
 }
 
 extern "C" int desire_temporal_conv(desire_handle* h, const float* dev_past, float* dev_rho, void* stream) {
-    if (int rc = ready(h)) return rc;
+    if (int rc = desire_ready(h)) return rc;
     if (!dev_past || !dev_rho) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     launch_temporal_conv(dev_past, D(h, "temporal/w"), D(h, "temporal/b"), dev_rho, d.n_scenes, d.T_obs, d.mno,

@@ -1,0 +1,78 @@
+// ctx.h -- the handle behind desire_handle* and the small host helpers shared by api.hip (inference ABI) and
+// train.hip (training ABI).  Host code only.
+#pragma once
+#include "../../include/desire_hip.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+int desire_fail(int code, const std::string& msg);            // sets the thread-local last-error text
+#define fail desire_fail
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(DESIRE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int alloc(size_t b) {
+        bytes = b;
+        hipError_t e = hipMalloc(&p, b ? b : 4);
+        return e == hipSuccess ? 0 : -1;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+struct Prof { std::string name; hipEvent_t e0, e1; };
+
+struct WSlot { size_t off; size_t n; };                       // a named tensor inside the flat training buffers
+
+struct desire_ctx {
+    desire_dims d;
+    int A, R, V, B, E;
+    std::map<std::string, std::vector<float>> host_w;       // raw weights as set
+    std::map<std::string, size_t> want;                      // name -> element count
+    std::map<std::string, DevBuf> dev;                       // raw / packed / folded device tensors
+    std::map<std::string, DevBuf> ws;                        // workspace
+    bool finalized = false;
+    const float* grids = nullptr;
+    bool grids_set = false;
+    bool profiling = false;
+    std::vector<Prof> prof;
+    std::vector<std::string> prof_name_store;
+    // ---- training (train.hip) ----
+    bool training = false;
+    std::map<std::string, WSlot> slots;                      // natural-layout offsets in Wflat / Gflat / Mflat / Vflat
+    size_t n_params = 0;
+    const float* last_eps = nullptr;                         // inputs of the last training-mode forward
+};
+
+struct Timer {
+    desire_ctx* h; hipStream_t s; bool on;
+    Timer(desire_ctx* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profiling) {
+        if (!on) return;
+        Prof p; p.name = name;
+        (void)hipEventCreate(&p.e0); (void)hipEventCreate(&p.e1);
+        (void)hipEventRecord(p.e0, s);
+        h->prof.push_back(p);
+    }
+    ~Timer() { if (on) (void)hipEventRecord(h->prof.back().e1, s); }
+};
+
+inline const float* D(desire_ctx* h, const char* name) { return h->dev.at(name).f(); }
+inline const float4* D4(desire_ctx* h, const char* name) { return reinterpret_cast<const float4*>(h->dev.at(name).f()); }
+inline float* W(desire_ctx* h, const char* name) { return h->ws.at(name).f(); }
+
+// Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
+std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at);
+int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v);
+int desire_ready(desire_handle* h);
+int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

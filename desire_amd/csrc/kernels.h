@@ -66,7 +66,8 @@ struct DecArgs {
     const float* b_g; const float* b_c;
     const float* w_head; const float* b_head;              // [H,2], [2]
     float* Y;                                              // [R, T, 2]
-    float* hdump;                                          // optional [R, T, H]
+    float* hdump;                                          // optional [R, T, H] hidden states h_t
+    float* sv_r; float* sv_u; float* sv_c;                 // optional [R, T, H] gate values (training mode)
 };
 void launch_decoder(const DecArgs& a, hipStream_t s);
 
@@ -104,3 +105,21 @@ void launch_build_windows(const float* frames, int F, int mno_in, const int32_t*
 void launch_gaussian_sample(const float* p, const float* nrm, float* out, int n, hipStream_t s);
 void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, int mno, int K, int T, float sx, float sy,
                     hipStream_t s);
+
+// ---- backward (kernels_bwd.hip) ----
+void launch_count_valid(const uint8_t* valid, int A, float* out, hipStream_t s);
+void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, const float* nvalid, float* dY, int n_scenes,
+                        int mno, int K, int T, float sx, float sy, hipStream_t s);
+struct DecBwdArgs {
+    const float* dY0;                                      // [R,T,2]
+    const float* sv_r; const float* sv_u; const float* sv_c; const float* sv_h;   // [R,T,H] from the training-mode forward
+    const float* Hx; int ldhx; const float* w_head;
+    const float4* WcT_h; const float4* WgT_h; const float4* WgT_x; const float4* WcT_x;   // transposed, packed
+    int R, K, mno, T, H;
+    float* dag; float* dac; float* rh; float* hprev;       // [R,T,2H], [R,T,H] x3: gate gradients, r*h_{t-1}, h_{t-1}
+    float* dxg; float* dxc; float* dxz; float* dHx_rows;   // [R,2H], [R,H], [R,H], [R,H]
+};
+void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
+struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial; };
+void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
+void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);

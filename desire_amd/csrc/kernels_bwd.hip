@@ -1,0 +1,245 @@
+// kernels_bwd.hip -- backward pass of the sample-generation module (the reference computes tf.gradients of its
+// cost, model/model.py:388, and never applies them; here the gradients exist and are applied).
+// Structure mirrors the forward: persistent reverse-time recurrences per 32-row tile with the data-gradient
+// contractions on the fp32 matrix pipe against TRANSPOSED weights (packed once per weight update), the gate
+// gradients written to HBM, and every weight gradient computed afterwards as one big A^T.G reduction over all
+// rows and steps (k_gemm_tn, slice partials + fixed-order reduce = deterministic).
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ f32x16 splat16b(float v) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = v;
+    return z;
+}
+__device__ __forceinline__ void mma1b(f32x16& acc, const float* a_lane, const float4* __restrict__ b_lane, int G) {
+    f32x16 t[1] = {acc};
+    mma_groups<1>(t, a_lane, 0, b_lane, G);
+    acc = t[0];
+}
+
+// ---- number of existing agents (id != 0 at the last observed frame), as float ------------------------------
+__global__ void k_count_valid(const uint8_t* __restrict__ valid, int A, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) s += valid[a] ? 1.f : 0.f;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = fmaxf(red[0], 1.f);
+}
+void launch_count_valid(const uint8_t* valid, int A, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(256), 0, s, valid, A, out);
+}
+
+// ---- d L_sgm / d Y0:  valid / (N K T) * (Y0 - gt) / ||Y0 - gt|| ------------------------------------------------
+__global__ void k_loss_grad_y(const float* __restrict__ Y, const float* __restrict__ fut, const uint8_t* __restrict__ valid,
+                              const float* __restrict__ nvalid, float* __restrict__ dY, int n_scenes, int mno, int K, int T,
+                              float sx, float sy) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long R = (long)n_scenes * K * mno;
+    if (i >= R * T) return;
+    const int t = i % T;
+    const long r = i / T;
+    const int slot = r % mno, sc = r / ((long)K * mno);
+    const int a = sc * mno + slot;
+    const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+    const float dx = Y[i * 2] - __fmul_rn(f[1], sx), dy = Y[i * 2 + 1] - __fmul_rn(f[2], sy);
+    const float nrm = sqrtf(dx * dx + dy * dy);
+    const float g = (valid[a] && nrm > 0.f) ? 1.0f / (nvalid[0] * (float)K * (float)T * nrm) : 0.f;
+    dY[i * 2] = g * dx;
+    dY[i * 2 + 1] = g * dy;
+}
+void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, const float* nvalid, float* dY, int n_scenes,
+                        int mno, int K, int T, float sx, float sy, hipStream_t s) {
+    const long n = (long)n_scenes * K * mno * T;
+    hipLaunchKernelGGL(k_loss_grad_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Y, fut, valid, nvalid, dY, n_scenes,
+                       mno, K, T, sx, sy);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decoder BPTT.  Tile = 32 rows, wave cb owns hidden columns [32cb, 32cb+32).  Per reverse step:
+//   dh_t   = dh_{t}(from t+1) + dY0_t Wo^T
+//   du = dh (h_{t-1} - c);  dc = dh (1-u);  dh_{t-1} = dh u
+//   da_c = dc (1-c^2);      d(r h) = da_c Wc_h^T            (MFMA, K = H)
+//   dr = d(rh) h_{t-1};     dh_{t-1} += d(rh) r
+//   da_r = dr r(1-r); da_u = du u(1-u);  dh_{t-1} += [da_r|da_u] Wg_h^T     (MFMA, K = 2H)
+// da_* and r*h_{t-1} go to HBM for the weight-gradient reductions; the constant-input sums dxg, dxc give dx_z.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decoder_bwd(DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
+    float* A1 = smem;                    // [32][LD1]   da_c
+    float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
+    float* dy = A2 + TM * LD2;           // [32][2]
+    float* wo = dy + TM * 2;             // [H][2]
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + (lane & 31);
+    for (int i = tid; i < 2 * H; i += NTHR) wo[i] = a.w_head[i];
+    const float* a1_lane = A1 + (lane & 31) * LD1 + 4 * (lane >> 5);
+    const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
+    float* my1 = A1 + (4 * (lane >> 5)) * LD1 + col;
+    float* my2 = A2 + (4 * (lane >> 5)) * LD2 + col;
+    f32x16 dh = zero16(), sxr = zero16(), sxu = zero16(), sxc = zero16();
+    int rowi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rowi[i] = min(row0 + acc_row(i), a.R - 1);
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        __syncthreads();                                   // previous step's A2 / dy consumers are done
+        if (tid < TM) {
+            const float2 v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
+            dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
+        }
+        __syncthreads();
+        f32x16 dhp, du, rr, hp, uu;
+        const float w0 = wo[col * 2], w1 = wo[col * 2 + 1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const size_t ix = ((size_t)rowi[i] * a.T + t) * H + col;
+            const float u = a.sv_u[ix], c = a.sv_c[ix], r = a.sv_r[ix];
+            const float hprev = (t > 0) ? a.sv_h[ix - H] : a.Hx[(size_t)agent_of_row(rowi[i], a.K, a.mno) * a.ldhx + col];
+            const float dht = dh[i] + dy[rl * 2] * w0 + dy[rl * 2 + 1] * w1;
+            du[i] = dht * (hprev - c);
+            const float dc = dht * (1.0f - u);
+            dhp[i] = dht * u;
+            const float dac = dc * (1.0f - c * c);
+            my1[((i & 3) + 8 * (i >> 2)) * LD1] = dac;
+            a.dac[ix] = dac;
+            a.rh[ix] = r * hprev;
+            a.hprev[ix] = hprev;
+            sxc[i] += dac;
+            rr[i] = r; hp[i] = hprev; uu[i] = u;
+        }
+        __syncthreads();
+        f32x16 drh = zero16();
+        mma1b(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float dr = drh[i] * hp[i];
+            dhp[i] += drh[i] * rr[i];
+            const float dar = dr * rr[i] * (1.0f - rr[i]);
+            const float dau = du[i] * uu[i] * (1.0f - uu[i]);
+            my2[((i & 3) + 8 * (i >> 2)) * LD2] = dar;
+            my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = dau;
+            const size_t ig = ((size_t)rowi[i] * a.T + t) * 2 * H + col;
+            a.dag[ig] = dar; a.dag[ig + H] = dau;
+            sxr[i] += dar; sxu[i] += dau;
+        }
+        __syncthreads();
+        f32x16 dhg = zero16();
+        mma1b(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + dhg[i];
+    }
+    __syncthreads();
+    // dh is now d L / d h_{-1} = the decoder's share of dHx (per row); constant-input sums -> dx_z
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (row0 + acc_row(i) < a.R) {
+            a.dHx_rows[(size_t)rowi[i] * H + col] = dh[i];
+            a.dxg[(size_t)rowi[i] * 2 * H + col] = sxr[i];
+            a.dxg[(size_t)rowi[i] * 2 * H + H + col] = sxu[i];
+            a.dxc[(size_t)rowi[i] * H + col] = sxc[i];
+        }
+        my2[((i & 3) + 8 * (i >> 2)) * LD2] = sxr[i];
+        my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = sxu[i];
+        my1[((i & 3) + 8 * (i >> 2)) * LD1] = sxc[i];
+    }
+    __syncthreads();
+    f32x16 dxz = zero16();
+    mma1b(dxz, a2_lane, a.WgT_x + ((size_t)cb * G2) * 64 + lane, G2);
+    mma1b(dxz, a1_lane, a.WcT_x + ((size_t)cb * GH) * 64 + lane, GH);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (row0 + acc_row(i) < a.R) a.dxz[(size_t)rowi[i] * H + col] = dxz[i];
+}
+void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
+    const int H = a.H;
+    const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 64 + 2 * H) * sizeof(float);
+    const dim3 grid((a.R + 31) / 32);
+    if (H == 256) { allow_big_lds(k_decoder_bwd<256>); hipLaunchKernelGGL(k_decoder_bwd<256>, grid, dim3(512), lds, s, a); }
+    else if (H == 128) hipLaunchKernelGGL(k_decoder_bwd<128>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_decoder_bwd<64>, grid, dim3(128), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradients:  out[Kd, N] (+)= sum_m A[m, Kd]^T G[m, N]   over M rows (up to R*T).
+// Workgroup = one 64x64 output block x one slice of M; the A and G chunks (64 rows) go through LDS, the contraction
+// index is m.  Slice partials are summed in slice order by k_reduce_slices (deterministic, no float atomics).
+// ------------------------------------------------------------------------------------------------------------------
+#define TN_MC 64
+#define TN_LD 68
+__global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[TN_MC * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Gs[TN_MC * TN_LD];
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int nbn = (a.N + 63) / 64;
+    const int bk = (blockIdx.x / nbn) * 64, bn = (blockIdx.x % nbn) * 64;
+    const int ti = w >> 1, tj = w & 1;
+    const long mper = ((a.M + a.nslices - 1) / a.nslices + TN_MC - 1) / TN_MC * TN_MC;
+    const long m_lo = (long)blockIdx.y * mper, m_hi = min(a.M, m_lo + mper);
+    f32x16 acc = zero16();
+    const int hi = lane >> 5, c = lane & 31;
+    for (long m0 = m_lo; m0 < m_hi; m0 += TN_MC) {
+        __syncthreads();
+        for (int i = tid; i < TN_MC * 64; i += 256) {
+            const int r = i >> 6, cc = i & 63;
+            const long m = m0 + r;
+            const bool ok = m < m_hi;
+            As[r * TN_LD + cc] = (ok && bk + cc < a.Kd) ? a.A[(size_t)m * a.lda + bk + cc] : 0.f;
+            Gs[r * TN_LD + cc] = (ok && bn + cc < a.N) ? a.G[(size_t)m * a.ldg + bn + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < TN_MC / 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 8 * g + 4 * hi + i;
+                acc = mfma32(As[m * TN_LD + ti * 32 + c], Gs[m * TN_LD + tj * 32 + c], acc);
+            }
+        }
+    }
+    float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = bk + ti * 32 + acc_row(i), n = bn + tj * 32 + c;
+        if (k < a.Kd && n < a.N) out[(size_t)k * a.N + n] = acc[i];
+    }
+}
+__global__ void k_reduce_slices(const float* __restrict__ partial, int nslices, int Kd, int N, float* __restrict__ out, int ldo,
+                                int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kd * N) return;
+    float s = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) s += partial[(size_t)sl * Kd * N + i];
+    float* o = out + (size_t)(i / N) * ldo + (i % N);
+    *o = accumulate ? (*o + s) : s;
+}
+void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s) {
+    const int nb = ((a.Kd + 63) / 64) * ((a.N + 63) / 64);
+    hipLaunchKernelGGL(k_gemm_tn, dim3(nb, a.nslices), dim3(256), 0, s, a);
+    const int n = a.Kd * a.N;
+    hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.nslices, a.Kd, a.N, out, ldo, accumulate);
+}
+
+// ---- column sums: out[N] (+)= sum_m G[m, N] ---------------------------------------------------------------------------
+__global__ void k_colsum(const float* __restrict__ G, int ldg, long M, int N, int nslices, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const long mper = (M + nslices - 1) / nslices;
+    const long lo = (long)blockIdx.y * mper, hi = min(M, lo + mper);
+    float s = 0.f;
+    if (n < N) for (long m = lo + q; m < hi; m += 4) s += G[(size_t)m * ldg + n];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && n < N) partial[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
+    hipLaunchKernelGGL(k_reduce_slices, dim3((N + 255) / 256), dim3(256), 0, s, partial, nslices, 1, N, out, N, accumulate);
+}

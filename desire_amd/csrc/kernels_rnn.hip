@@ -178,7 +178,17 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             mma1(rh, a_lane, a.Whg + ((size_t)cb * G) * 64 + lane, G);
             mma1(u, a_lane, a.Whg + ((size_t)(cb + NT) * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
+            for (int i = 0; i < 16; ++i) {
+                const float r = sigmoidf_(rh[i]);
+                rh[i] = r * h[i]; u[i] = sigmoidf_(u[i]);
+                if (a.sv_r) {                                   // training: keep the gates for BPTT
+                    const int rl = mt * 32 + acc_row(i);
+                    if (row0 + rl < a.R) {
+                        const size_t ix = ((size_t)(row0 + rl) * a.T + t) * H + col;
+                        a.sv_r[ix] = r; a.sv_u[ix] = u[i];
+                    }
+                }
+            }
         }
         __syncthreads();
         if (active) {
@@ -190,7 +200,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             f32x16 ac = xc;
             mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+            for (int i = 0; i < 16; ++i) {
+                const float c = tanhf_(ac[i]);
+                h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                if (a.sv_c) {
+                    const int rl = mt * 32 + acc_row(i);
+                    if (row0 + rl < a.R) a.sv_c[((size_t)(row0 + rl) * a.T + t) * H + col] = c;
+                }
+            }
         }
         __syncthreads();
         if (active) {

@@ -1,0 +1,119 @@
+// train.hip -- training half of the C ABI: training-mode buffers, backward orchestration, gradient access.
+// The reference computes tf.gradients(cost) and an Adam update but never runs them (model/model.py:388-403,
+// train.py:181); here they run.  Gradients live in ONE flat fp32 buffer in natural (TF) layouts, so a multi-GPU
+// caller all-reduces a single tensor (RCCL through torch.distributed) between desire_backward and desire_adam_step.
+#include "ctx.h"
+
+#include <cstring>
+
+namespace {
+
+int ensure(desire_ctx* h, const char* name, size_t bytes) {
+    if (h->ws.count(name) && h->ws[name].bytes >= bytes) return 0;
+    if (h->ws.count(name)) h->ws[name].release();
+    return h->ws[name].alloc(bytes);
+}
+
+float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slots.at(name).off; }
+
+// weight gradient block: out[Kd, N] = A^T G over M rows, written into a [.., ldo] matrix
+void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M, int Kd, int N, float* out, int ldo,
+        int accumulate, hipStream_t s) {
+    TnArgs a{};
+    a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N;
+    const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
+    long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
+    const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
+    while ((size_t)sl * Kd * N * sizeof(float) > h->ws["tn_partial"].bytes && sl > 1) sl /= 2;
+    a.nslices = (int)sl; a.partial = W(h, "tn_partial");
+    launch_gemm_tn(a, out, ldo, accumulate, s);
+}
+void colsum(desire_ctx* h, const float* Gm, int ldg, long M, int N, float* out, int accumulate, hipStream_t s) {
+    long sl = 256; const long maxsl = (M + 3) / 4; if (sl > maxsl) sl = maxsl; if (sl < 1) sl = 1;
+    launch_colsum(Gm, ldg, M, N, (int)sl, W(h, "tn_partial"), out, accumulate, s);
+}
+
+}  // namespace
+
+extern "C" int desire_set_training(desire_handle* h, int enable) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!enable) { h->training = false; return DESIRE_OK; }
+    const desire_dims& d = h->d;
+    if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
+    if (h->slots.empty()) {
+        size_t off = 0;
+        for (auto& kv : h->want) { h->slots[kv.first] = WSlot{off, kv.second}; off += (kv.second + 3) / 4 * 4; }
+        h->n_params = off;
+    }
+    const size_t R = h->R, T = d.T_pred, H = d.H, f = sizeof(float);
+    struct B { const char* n; size_t bytes; };
+    const B bufs[] = {
+        {"Gflat", h->n_params * f}, {"nvalid", 4 * f}, {"tn_partial", (size_t)96 << 20},
+        {"dec_sv_r", R * T * H * f}, {"dec_sv_u", R * T * H * f}, {"dec_sv_c", R * T * H * f}, {"dec_sv_h", R * T * H * f},
+        {"dY0", R * T * 2 * f}, {"dec_dag", R * T * 2 * H * f}, {"dec_dac", R * T * H * f}, {"dec_rh", R * T * H * f},
+        {"dec_hprev", R * T * H * f}, {"dec_dxg", R * 2 * H * f}, {"dec_dxc", R * H * f}, {"dxz", R * H * f},
+        {"dHx_rows", R * H * f},
+    };
+    for (const B& b : bufs)
+        if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
+    h->training = true;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_backward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "desire_set_training(h, 1) and a training-mode desire_forward come first");
+    if (!dev_past || !dev_fut || !dev_eps) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = d.H, T = d.T_pred;
+    const long R = h->R;
+    HIPCHK(hipMemsetAsync(W(h, "Gflat"), 0, h->n_params * sizeof(float), s));
+    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["valid"].p);
+    launch_count_valid(valid, h->A, W(h, "nvalid"), s);
+    // ---- sample-generation module ----
+    launch_loss_grad_y(W(h, "Y0"), dev_fut, valid, W(h, "nvalid"), W(h, "dY0"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
+    DecBwdArgs b{};
+    b.dY0 = W(h, "dY0"); b.sv_r = W(h, "dec_sv_r"); b.sv_u = W(h, "dec_sv_u"); b.sv_c = W(h, "dec_sv_c"); b.sv_h = W(h, "dec_sv_h");
+    b.Hx = W(h, "HxHy"); b.ldhx = 2 * H; b.w_head = D(h, "head/w");
+    b.WcT_h = D4(h, "dec/WcT_h"); b.WgT_h = D4(h, "dec/WgT_h"); b.WgT_x = D4(h, "dec/WgT_x"); b.WcT_x = D4(h, "dec/WcT_x");
+    b.R = (int)R; b.K = d.K; b.mno = d.mno; b.T = T; b.H = H;
+    b.dag = W(h, "dec_dag"); b.dac = W(h, "dec_dac"); b.rh = W(h, "dec_rh"); b.hprev = W(h, "dec_hprev");
+    b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = W(h, "dHx_rows");
+    { Timer t(h, s, "bwd_decoder"); launch_decoder_bwd(b, s); }
+    {
+        Timer t(h, s, "bwd_decoder_wgrad");
+        tn(h, W(h, "dec_sv_h"), H, W(h, "dY0"), 2, R * T, H, 2, G(h, "head/w"), 2, 0, s);
+        colsum(h, W(h, "dY0"), 2, R * T, 2, G(h, "head/b"), 0, s);
+        float* gk = G(h, "dec/gates/kernel");        // [(H+H), 2H]
+        tn(h, W(h, "xz"), H, W(h, "dec_dxg"), 2 * H, R, H, 2 * H, gk, 2 * H, 0, s);
+        tn(h, W(h, "dec_hprev"), H, W(h, "dec_dag"), 2 * H, R * T, H, 2 * H, gk + (size_t)H * 2 * H, 2 * H, 0, s);
+        colsum(h, W(h, "dec_dag"), 2 * H, R * T, 2 * H, G(h, "dec/gates/bias"), 0, s);
+        float* ck = G(h, "dec/candidate/kernel");    // [(H+H), H]
+        tn(h, W(h, "xz"), H, W(h, "dec_dxc"), H, R, H, H, ck, H, 0, s);
+        tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, R * T, H, H, ck + (size_t)H * H, H, 0, s);
+        colsum(h, W(h, "dec_dac"), H, R * T, H, G(h, "dec/candidate/bias"), 0, s);
+    }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
+    if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    auto it = h->slots.find(name);
+    if (it == h->slots.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
+    if (it->second.n != n) return fail(DESIRE_ERR_ARG, std::string(name) + ": expected " + std::to_string(it->second.n) + " values");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(host_out, W(h, "Gflat") + it->second.off, n * sizeof(float), hipMemcpyDeviceToHost));
+    return DESIRE_OK;
+}
+
+extern "C" int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n) {
+    if (!h || !dev_ptr || !n) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    *dev_ptr = W(h, "Gflat");
+    *n = h->n_params;
+    return DESIRE_OK;
+}

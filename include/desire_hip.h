@@ -133,6 +133,16 @@ int desire_gaussian_sample(desire_handle* h, const float* dev_params, const floa
 /* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K). */
 int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);
 
+/* ---- training (the reference builds tf.gradients(cost) + Adam and never runs them: model/model.py:388-403) ----
+ * desire_set_training(h,1) allocates the activation-save and gradient buffers; a desire_forward made afterwards keeps
+ * what backward needs.  desire_backward computes d(loss)/d(weight) for the loss of DESIGN.md section 8 into ONE flat
+ * fp32 device buffer (natural TF layouts; desire_grad_buffer exposes it so a multi-GPU caller can all-reduce it).
+ * Frozen batch-norm parameters are constants (no gradient). */
+int desire_set_training(desire_handle* h, int enable);
+int desire_backward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps, void* stream);
+int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
+int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n);
+
 /* Per-kernel GPU time measured with hipEvents on the launch stream (enabled by
  * desire_set_profiling(h,1); adds two event records per kernel, nothing else).  Entries accumulate
  * over calls; desire_get_profile synchronises on them, copies up to *count (in: capacity) entries
