@@ -253,6 +253,17 @@ int desire_pack_all(desire_ctx* h) {
     for (const char* n : {"scene_cnn/conv1/w", "scene_cnn/conv1/b", "scene_cnn/conv2/w", "scene_cnn/conv2/b",
                           "scene_cnn/conv3/w", "scene_cnn/conv3/b", "temporal/w", "temporal/b"})
         bad |= up(n, hw[n]);
+    {   // operands of the backward data-gradient passes (the forward kernels run with swapped roles)
+        const auto& wm = hw["mask_fc/w"]; const auto& wfc = hw["vae_enc/fc/w"]; const auto& wcc = hw["fc_c/w"];
+        bad |= up("mask/WT", pack_b(H, V, [&](int k, int n) { return wm[(size_t)n * H + k]; }));
+        bad |= up("vae_enc/fc/WT", pack_b(2 * L, 2048, [&](int k, int n) { return wfc[(size_t)n * 2 * L + k]; }));
+        bad |= up("fc_c/WT", pack_b(V, 2 * H, [&](int k, int n) { return wcc[(size_t)n * V + k]; }));
+        bad |= up("vae_dec/deconv1/WT", pack_b(2048, L, rowmajor(hw["vae_dec/deconv1/w"], L, 0)));
+        bad |= up("vae_dec/deconv3/Wbwd", pack_taps(hw["vae_dec/deconv3/w"], 32, 64, false));   // [tap][co=32][ci=64] as conv 32->64
+        bad |= up("vae_dec/deconv2/Wbwd", pack_taps(hw["vae_dec/deconv2/w"], 64, 128, false));  // [tap][co=64][ci=128] as conv 64->128
+        bad |= up("vae_enc/conv3/Wbwd", pack_taps(hw["vae_enc/conv3/w"], 128, 64, true));      // [tap][ci=64][co=128] as deconv 128->64
+        bad |= up("vae_enc/conv2/Wbwd", pack_taps(hw["vae_enc/conv2/w"], 64, 32, true));       // [tap][ci=32][co=64] as deconv 64->32
+    }
     if (bad) return fail(DESIRE_ERR_HIP, "weight upload failed");
     HIPCHK(hipDeviceSynchronize());
     return DESIRE_OK;
@@ -345,6 +356,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
+    if (h->training) m.sv_p = W(h, "mask_sv_p");
     { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
     DecArgs a{};
     a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");

@@ -128,6 +128,20 @@ __device__ __forceinline__ float sigmoidf_(float x) { return frcp_(1.0f + fexp_(
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * frcp_(1.0f + fexp_(2.0f * x)); }
 __device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : fexp_(x) - 1.0f; }
 
+// Epilogue of every conv-family kernel.  mode 0 (forward): act(acc*scale + shift), act = ELU (or sigmoid when
+// `sig`).  Backward data-gradient modes reuse the same kernels with the roles of the layers swapped and fold the
+// DESTINATION layer's activation derivative and frozen-BN scale into the store:
+//   1: acc * ELU'(y) * scale   (ELU'(y) = 1 if y > 0 else y + 1, y = saved post-activation)
+//   2: acc * (y > 0)           (ReLU')          3: acc (linear)          4: acc * y (1 - y) * scale  (sigmoid')
+__device__ __forceinline__ float conv_epilogue(float acc, float sc, float sh, int mode, bool sig, const float* yprev, size_t idx) {
+    if (mode == 0) return sig ? sigmoidf_(acc * sc + sh) : eluf_(acc * sc + sh);
+    if (mode == 3) return acc;
+    const float y = yprev[idx];
+    if (mode == 1) return acc * (y > 0.f ? 1.0f : y + 1.0f) * sc;
+    if (mode == 2) return y > 0.f ? acc : 0.f;
+    return acc * y * (1.0f - y) * sc;
+}
+
 // ---- integer paths: every float op is ONE IEEE fp32 operation (no contraction) ----------------
 // scene cell: cy = clamp(floor(y*Gh), 0, Gh-1), cx likewise (oracle: scene_cell)
 __device__ __forceinline__ void scene_cell_dev(float x, float y, int Gh, int Gw, int& cy, int& cx) {

@@ -13,7 +13,7 @@ inline void allow_big_lds(F* f) {
     }
 }
 
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_SCALE_SHIFT_ELU = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_SCALE_SHIFT_ELU = 2, EPI_NONE = 3, EPI_ELUGRAD = 4, EPI_SIGGRAD = 5 };
 
 // out[M, N] = epi(A[M, K] @ W[K, N]); W in packed fragment order [NT][G][64] float4.
 struct GemmArgs {
@@ -21,6 +21,7 @@ struct GemmArgs {
     const float4* Bp; int G; int NT;
     float* out; int ldo; int N;
     const float* p0; const float* p1; int chmod;
+    const float* aux;                              // [M, ldo] saved activation for the gradient epilogues
 };
 void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s);
 
@@ -30,6 +31,7 @@ void launch_reparam(const float* params, const float* eps, float* z, int R, int 
 struct MaskArgs {
     const float* xhat; int R; int V; int H; int K; int mno;
     const float4* Wp; const float* bias; const float* Hx; int ldhx; float* xz;
+    float* sv_p;                                   // optional [R,H]: relu(xhat W + b) kept for the backward softmax
 };
 void launch_mask(const MaskArgs& a, hipStream_t s);
 
@@ -38,6 +40,8 @@ struct ConvArgs {
     const float* in; float* out; int n;            // n = samples (agents or rows)
     const float4* Wp; const float* w_raw;          // packed taps / raw weights (VALU kernels)
     const float* scale; const float* shift;        // folded bias + frozen batch-norm
+    int mode; const float* yprev;                  // epilogue mode (common.h:conv_epilogue); saved activation of the
+                                                   // destination layer for the backward modes
 };
 void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
 void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
@@ -123,3 +127,11 @@ void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
 struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial; };
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
+void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
+                     int K, int mno, hipStream_t s);
+struct ConvWgradArgs { const float* S; int Cs; int Ps; const float* Lg; int Cl; int Pl; int stride; int pad; int n; float* partial; };
+void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s);
+void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s);
+void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
+                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s);
+void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s);

@@ -243,3 +243,210 @@ void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* p
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
     hipLaunchKernelGGL(k_reduce_slices, dim3((N + 255) / 256), dim3(256), 0, s, partial, nslices, 1, N, out, N, accumulate);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// mask fc backward (forward: q = xhat Wm + bm, p = relu(q), beta = softmax(p), xz = beta * Hx):
+//   dbeta = dxz * Hx;  dHx_rows += dxz * beta;  dp = beta * (dbeta - sum(beta dbeta));  dq = dp * (p > 0)
+// 4 threads per row, like the forward softmax.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ p, const float* __restrict__ dxz,
+                                                  const float* __restrict__ Hx, int ldhx, float* __restrict__ dq,
+                                                  float* __restrict__ dHx_rows, int R, int H, int K, int mno) {
+    const int r = blockIdx.x * 64 + (threadIdx.x >> 2), q4 = threadIdx.x & 3;
+    const int row = min(r, R - 1);
+    const int per = H >> 2;
+    const float* pr = p + (size_t)row * H + q4 * per;
+    const float* gx = dxz + (size_t)row * H + q4 * per;
+    const float* hx = Hx + (size_t)agent_of_row(row, K, mno) * ldhx + q4 * per;
+    float mx = -3.0e38f;
+    for (int c = 0; c < per; ++c) mx = fmaxf(mx, pr[c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float sum = 0.f;
+    for (int c = 0; c < per; ++c) sum += expf(pr[c] - mx);
+    sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+    float dot = 0.f;
+    for (int c = 0; c < per; ++c) { const float b = expf(pr[c] - mx) / sum; dot += b * gx[c] * hx[c]; }
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2);
+    if (r < R) {
+        for (int c = 0; c < per; ++c) {
+            const float b = expf(pr[c] - mx) / sum;
+            const float dbeta = gx[c] * hx[c];
+            dq[(size_t)row * H + q4 * per + c] = (pr[c] > 0.f) ? b * (dbeta - dot) : 0.f;
+            dHx_rows[(size_t)row * H + q4 * per + c] += gx[c] * b;
+        }
+    }
+}
+void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
+                     int K, int mno, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_bwd, dim3((R + 63) / 64), dim3(256), 0, s, p, dxz, Hx, ldhx, dq, dHx_rows, R, H, K, mno);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Convolution weight gradients (both directions of the CVAE stack).  With S the tensor on the SMALL pixel grid
+// [n, Ps, Ps, Cs] and Lg the one on the LARGE grid [n, Pl, Pl, Cl], related by q = stride*p + k - pad per tap k:
+//     dW[tap][cl][cs] = sum_{n, p} Lg[n, q(p, tap), cl] * S[n, p, cs]
+// (transposed conv: S = layer input, Lg = d(conv output), weights [tap][co][ci];  forward conv: S = d(conv output),
+//  Lg = layer input, weights [tap][ci][co] -- the same [tap][Cl][Cs] orientation.)
+// grid = (taps fastest so the 25 workgroups of a slice share its activations in L2, slices); workgroup = 4 waves,
+// wave w owns output tiles w, w+4 of the (Cl/32) x (Cs/32) tile grid; contraction chunks of 64 (n,p) pairs via LDS.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDL = a.Cl + 4, LDS_ = a.Cs + 4;
+    float* Ls = smem;                     // [64][LDL]
+    float* Ss = smem + 64 * LDL;          // [64][LDS_]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int tap = blockIdx.x, ky = tap / 5, kx = tap - ky * 5;
+    const int PP = a.Ps * a.Ps;
+    const long Mtot = (long)a.n * PP;
+    const long mper = ((Mtot + gridDim.y - 1) / gridDim.y + 63) / 64 * 64;
+    const long m_lo = (long)blockIdx.y * mper, m_hi = min(Mtot, m_lo + mper);
+    const int tjn = a.Cs / 32, ntiles = (a.Cl / 32) * tjn;
+    f32x16 acc[2] = {zero16(), zero16()};
+    const int hi = lane >> 5, c = lane & 31;
+    for (long m0 = m_lo; m0 < m_hi; m0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (a.Cs / 4); i += 256) {
+            const int r = i / (a.Cs / 4), c4 = i - r * (a.Cs / 4);
+            const long m = m0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi) v = *reinterpret_cast<const float4*>(a.S + (size_t)m * a.Cs + c4 * 4);
+            *reinterpret_cast<float4*>(Ss + r * LDS_ + c4 * 4) = v;
+        }
+        if (a.Cl >= 4) {
+            for (int i = tid; i < 64 * (a.Cl / 4); i += 256) {
+                const int r = i / (a.Cl / 4), c4 = i - r * (a.Cl / 4);
+                const long m = m0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < m_hi) {
+                    const long n = m / PP; const int p = (int)(m - n * PP);
+                    const int qy = a.stride * (p / a.Ps) + ky - a.pad, qx = a.stride * (p % a.Ps) + kx - a.pad;
+                    if (qy >= 0 && qy < a.Pl && qx >= 0 && qx < a.Pl)
+                        v = *reinterpret_cast<const float4*>(a.Lg + (((size_t)n * a.Pl + qy) * a.Pl + qx) * a.Cl + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(Ls + r * LDL + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tile = w + 4 * tt;
+            if (tile >= ntiles) continue;
+            const int ti = tile / tjn, tj = tile - ti * tjn;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 8 * g + 4 * hi + i;
+                    acc[tt] = mfma32(Ls[m * LDL + ti * 32 + c], Ss[m * LDS_ + tj * 32 + c], acc[tt]);
+                }
+        }
+    }
+    float* out = a.partial + ((size_t)blockIdx.y * 25 + tap) * a.Cl * a.Cs;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tile = w + 4 * tt;
+        if (tile >= ntiles) continue;
+        const int ti = tile / tjn, tj = tile - ti * tjn;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[(size_t)(ti * 32 + acc_row(i)) * a.Cs + tj * 32 + c] = acc[tt][i];
+    }
+}
+void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s) {
+    const size_t lds = 64 * (a.Cl + 4 + a.Cs + 4) * sizeof(float);
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(25, nslices), dim3(256), lds, s, a);
+    const int n = 25 * a.Cl * a.Cs;
+    hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0);
+}
+
+// the two single-channel ends of the stack (deconv4: Lg = d(xhat-conv) [n,32,32], S = d3 [n,16,16,32];
+// conv1: Lg = vae_in [n,32,32], S = d(conv1 output) [n,16,16,32]):  dW[tap][c] = sum_{n,p} Lg[n, 2p+k-1] * S[n,p,c]
+__global__ __launch_bounds__(256) void k_w1ch_grad(const float* __restrict__ Lg, const float* __restrict__ S, int n, float* __restrict__ partial) {
+    __shared__ float lg[32 * 32];
+    __shared__ float red[8][25 * 32 + 1];
+    const int tid = threadIdx.x, c = tid & 31, pg = tid >> 5;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float acc[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+    for (int smp = lo; smp < hi; ++smp) {
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) lg[i] = Lg[(size_t)smp * 1024 + i];
+        __syncthreads();
+        for (int p = pg; p < 256; p += 8) {
+            const float sv = S[((size_t)smp * 256 + p) * 32 + c];
+            const int py = p >> 4, px = p & 15;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int qy = 2 * py + ky - 1;
+                if (qy < 0 || qy >= 32) continue;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int qx = 2 * px + kx - 1;
+                    if (qx < 0 || qx >= 32) continue;
+                    acc[ky * 5 + kx] = fmaf(lg[qy * 32 + qx], sv, acc[ky * 5 + kx]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 25; ++k) red[pg][k * 32 + c] = acc[k];
+    __syncthreads();
+    for (int i = tid; i < 800; i += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += red[g][i];
+        partial[(size_t)blockIdx.x * 800 + i] = s;
+    }
+}
+void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_w1ch_grad, dim3(nslices), dim3(256), 0, s, Lg, S, n, partial);
+    hipLaunchKernelGGL(k_reduce_slices, dim3((800 + 255) / 256), dim3(256), 0, s, partial, nslices, 25, 32, out, 32, 0);
+}
+
+// ---- reparameterisation + KLD backward:  dparams[a] = (dmu | dlogsig2) ---------------------------------------------
+//   z = mu + sqrt(exp(ls)) eps   =>  dmu = sum_k dz ; dls = sum_k dz eps 0.5 sqrt(exp(ls))
+//   kld = -0.5 sum(1 + ls - mu^2 - exp(ls)), weight valid/N  =>  dmu += w mu ; dls += w (-0.5)(1 - exp(ls))
+__global__ void k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ eps, const float* __restrict__ params,
+                              const uint8_t* __restrict__ valid, const float* __restrict__ nvalid, float* __restrict__ dparams,
+                              int n_scenes, int mno, int K, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = n_scenes * mno;
+    if (i >= A * L) return;
+    const int a = i / L, l = i - a * L;
+    const int sc = a / mno, slot = a - sc * mno;
+    const float mu = params[(size_t)a * 2 * L + l], ls = params[(size_t)a * 2 * L + L + l];
+    const float sd = sqrtf(expf(ls));
+    float dmu = 0.f, dls = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        const float g = dz[r * L + l];
+        dmu += g;
+        dls += g * eps[r * L + l];
+    }
+    dls *= 0.5f * sd;
+    const float wv = valid[a] ? 1.0f / nvalid[0] : 0.f;
+    dparams[(size_t)a * 2 * L + l] = dmu + wv * mu;
+    dparams[(size_t)a * 2 * L + L + l] = dls + wv * (-0.5f) * (1.0f - expf(ls));
+}
+void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
+                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s) {
+    const int n = n_scenes * mno * L;
+    hipLaunchKernelGGL(k_reparam_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, eps, params, valid, nvalid, dparams, n_scenes, mno, K, L);
+}
+
+// ---- dHx[a] (+)= sum_k dHx_rows[(scene,k,slot)] --------------------------------------------------------------------------
+__global__ void k_rows_to_agents(const float* __restrict__ rows, float* __restrict__ out, int ldo, int n_scenes, int mno, int K, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_scenes * mno * H) return;
+    const int a = i / H, c = i - a * H;
+    const int sc = a / mno, slot = a - sc * mno;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += rows[(((size_t)sc * K + k) * mno + slot) * H + c];
+    out[(size_t)a * ldo + c] += s;
+}
+void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s) {
+    const int n = n_scenes * mno * H;
+    hipLaunchKernelGGL(k_rows_to_agents, dim3((n + 255) / 256), dim3(256), 0, s, rows, out, ldo, n_scenes, mno, K, H);
+}

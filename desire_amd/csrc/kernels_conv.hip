@@ -44,7 +44,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv1(ConvArgs a) {
                 acc = fmaf(in_s[iy * 32 + ix], w_s[(ky * 5 + kx) * 32 + co], acc);
             }
         }
-        a.out[((size_t)n * 256 + p) * 32 + co] = eluf_(acc * sc + sh);
+        { const size_t ix = ((size_t)n * 256 + p) * 32 + co; a.out[ix] = conv_epilogue(acc, sc, sh, a.mode, false, a.yprev, ix); }
     }
 }
 void launch_conv1(const ConvArgs& a, hipStream_t s) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv_gather(ConvArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int r = (mt0 + m) * 32 + acc_row(i);
             const int smp = s0 + r / PIX;
-            if (smp < a.n) a.out[((size_t)s0 * PIX + r) * CO + co] = eluf_(acc[m][i] * sc + sh);
+            if (smp < a.n) { const size_t ix = ((size_t)s0 * PIX + r) * CO + co; a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix); }
         }
 }
 void launch_conv2(const ConvArgs& a, hipStream_t s) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
         const int sp_px = i * 2 + hi;
         const int smp = s0 + (sp_px >> 6);
         if (smp < a.n)
-            a.out[((size_t)smp * 64 + (sp_px & 63)) * 64 + co] = eluf_(my[sp_px * 64 + co] * sc + sh);
+            { const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + co; a.out[ix] = conv_epilogue(my[sp_px * 64 + co], sc, sh, a.mode, false, a.yprev, ix); }
     }
 }
 void launch_deconv2(const ConvArgs& a, hipStream_t s) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
                     for (int i = 0; i < 16; ++i) {
                         const int q = m * 32 + acc_row(i);
                         const int oy = 2 * (q >> 3) + py, ox = 2 * (q & 7) + px;
-                        a.out[((size_t)smp * 256 + oy * 16 + ox) * 32 + c] = eluf_(acc[m][i] * sc + sh);
+                        { const size_t ix = ((size_t)smp * 256 + oy * 16 + ox) * 32 + c; a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix); }
                     }
             }
         }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv4(ConvArgs a) {
                 }
             }
         }
-        a.out[(size_t)n * 1024 + (2 * qy + py) * 32 + 2 * qx + px] = sigmoidf_(acc * sc + sh);
+        { const size_t ix = (size_t)n * 1024 + (2 * qy + py) * 32 + 2 * qx + px; a.out[ix] = conv_epilogue(acc, sc, sh, a.mode, true, a.yprev, ix); }
     }
 }
 void launch_deconv4(const ConvArgs& a, hipStream_t s) {

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(DS_WG) void k_gemm_rows(GemmArgs a) {
         if (col >= a.N) continue;
         float p0 = 0.f, p1 = 0.f;
         if (EPI == EPI_SCALE_SHIFT_ELU) { const int ch = col % a.chmod; p0 = a.p0[ch]; p1 = a.p1[ch]; }
-        else p0 = a.p0[col];
+        else if (EPI == EPI_ELUGRAD || EPI == EPI_SIGGRAD) p0 = a.p0[col % a.chmod];
+        else if (EPI != EPI_NONE) p0 = a.p0[col];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(DS_WG) void k_gemm_rows(GemmArgs a) {
                 float v = acc[j][m][i];
                 if (EPI == EPI_BIAS) v = v + p0;
                 else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + p0, 0.f);
-                else v = eluf_(v * p0 + p1);
+                else if (EPI == EPI_SCALE_SHIFT_ELU) v = eluf_(v * p0 + p1);
+                else if (EPI == EPI_ELUGRAD) { const float y = a.aux[(size_t)row * a.ldo + col]; v = v * (y > 0.f ? 1.0f : y + 1.0f) * p0; }
+                else if (EPI == EPI_SIGGRAD) { const float y = a.aux[(size_t)row * a.ldo + col]; v = v * y * (1.0f - y) * p0; }
                 a.out[(size_t)row * a.ldo + col] = v;
             }
     }
@@ -69,8 +72,12 @@ void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s) {
     dim3 grid((a.M + DS_TM - 1) / DS_TM, (a.NT + 4 * NTW - 1) / (4 * NTW));
     const size_t lds = DS_TM * LDA_C * sizeof(float);
     allow_big_lds(k_gemm_rows<EPI_BIAS, 4>); allow_big_lds(k_gemm_rows<EPI_BIAS_RELU, 4>);
-    allow_big_lds(k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>);
-    if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS, 4>), grid, dim3(DS_WG), lds, s, a);
+    allow_big_lds(k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>); allow_big_lds(k_gemm_rows<EPI_NONE, 4>);
+    allow_big_lds(k_gemm_rows<EPI_ELUGRAD, 4>); allow_big_lds(k_gemm_rows<EPI_SIGGRAD, 4>);
+    if (epi == EPI_NONE) hipLaunchKernelGGL((k_gemm_rows<EPI_NONE, 4>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_ELUGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_ELUGRAD, 4>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_SIGGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_SIGGRAD, 4>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS, 4>), grid, dim3(DS_WG), lds, s, a);
     else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS_RELU, 4>), grid, dim3(DS_WG), lds, s, a);
     else hipLaunchKernelGGL((k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>), grid, dim3(DS_WG), lds, s, a);
 }
@@ -139,7 +146,11 @@ __global__ __launch_bounds__(DS_WG) void k_mask(MaskArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) smem[(m * 32 + acc_row(i)) * LDT + col] = fmaxf(acc[j][m][i] + b, 0.f);
+            for (int i = 0; i < 16; ++i) {
+                const float pv = fmaxf(acc[j][m][i] + b, 0.f);
+                smem[(m * 32 + acc_row(i)) * LDT + col] = pv;
+                if (a.sv_p && row0 + m * 32 + acc_row(i) < a.R) a.sv_p[(size_t)(row0 + m * 32 + acc_row(i)) * a.H + col] = pv;
+            }
     }
     __syncthreads();
     // softmax over H per row: 4 threads per row

@@ -52,7 +52,11 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dec_sv_r", R * T * H * f}, {"dec_sv_u", R * T * H * f}, {"dec_sv_c", R * T * H * f}, {"dec_sv_h", R * T * H * f},
         {"dY0", R * T * 2 * f}, {"dec_dag", R * T * 2 * H * f}, {"dec_dac", R * T * H * f}, {"dec_rh", R * T * H * f},
         {"dec_hprev", R * T * H * f}, {"dec_dxg", R * 2 * H * f}, {"dec_dxc", R * H * f}, {"dxz", R * H * f},
-        {"dHx_rows", R * H * f},
+        {"dHx_rows", R * H * f}, {"mask_sv_p", R * H * f}, {"dq_mask", R * H * f},
+        {"dconv4", R * 1024 * f}, {"dconv3", R * 8192 * f}, {"dconv2", R * 4096 * f}, {"dconv1", R * 2048 * f},
+        {"dz", R * d.L * f}, {"dparams", (size_t)h->A * 2 * d.L * f}, {"dconvE3", (size_t)h->A * 2048 * f},
+        {"dconvE2", (size_t)h->A * 4096 * f}, {"dconvE1", (size_t)h->A * 8192 * f}, {"dq_c", (size_t)h->A * h->V * f},
+        {"dHxHy", (size_t)h->A * 2 * H * f},
     };
     for (const B& b : bufs)
         if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
@@ -93,6 +97,89 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         tn(h, W(h, "xz"), H, W(h, "dec_dxc"), H, R, H, H, ck, H, 0, s);
         tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, R * T, H, H, ck + (size_t)H * H, H, 0, s);
         colsum(h, W(h, "dec_dac"), H, R * T, H, G(h, "dec/candidate/bias"), 0, s);
+    }
+    // ---- mask fc ----
+    const int V = h->V, L = d.L, A = h->A;
+    {
+        Timer t(h, s, "bwd_mask");
+        launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), W(h, "HxHy"), 2 * H, W(h, "dq_mask"), W(h, "dHx_rows"), (int)R, H, d.K, d.mno, s);
+        colsum(h, W(h, "dq_mask"), H, R, H, G(h, "mask_fc/b"), 0, s);
+        tn(h, W(h, "xhat"), V, W(h, "dq_mask"), H, R, V, H, G(h, "mask_fc/w"), H, 0, s);
+        GemmArgs g{};
+        g.A = W(h, "dq_mask"); g.lda = H; g.M = (int)R; g.K = H; g.Bp = D4(h, "mask/WT"); g.G = H / 8; g.NT = V / 32;
+        g.out = W(h, "dconv4"); g.ldo = V; g.N = V; g.p0 = D(h, "vae_dec/deconv4/scale"); g.chmod = 1; g.aux = W(h, "xhat");
+        launch_gemm_rows(g, EPI_SIGGRAD, s);
+    }
+    // ---- CVAE decoder (each data gradient = the forward kernel of the mirrored layer with a gradient epilogue) ----
+    {
+        Timer t(h, s, "bwd_cvae_dec");
+        const int NSL = 40;
+        launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)R, 256, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
+        colsum(h, W(h, "dconv4"), 1, R * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
+        ConvArgs c{};
+        c.n = (int)R;
+        c.in = W(h, "dconv4"); c.out = W(h, "dconv3"); c.w_raw = D(h, "vae_dec/deconv4/raw");
+        c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = c.scale; c.mode = 1; c.yprev = W(h, "d3");
+        launch_conv1(c, s);
+        ConvWgradArgs wg{};
+        wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
+        wg.n = (int)R; wg.partial = W(h, "tn_partial");
+        launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
+        colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
+        c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, "vae_dec/deconv3/Wbwd");
+        c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
+        launch_conv2(c, s);
+        wg.S = W(h, "d1"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "dconv2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
+        launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv2/w"), s);
+        colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
+        c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, "vae_dec/deconv2/Wbwd");
+        c.scale = D(h, "vae_dec/deconv1/scale"); c.shift = c.scale; c.yprev = W(h, "d1");
+        launch_conv3(c, s);
+        tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, R, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
+        colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
+        GemmArgs g{};
+        g.A = W(h, "dconv1"); g.lda = 2048; g.M = (int)R; g.K = 2048; g.Bp = D4(h, "vae_dec/deconv1/WT"); g.G = 2048 / 8;
+        g.NT = (L + 31) / 32; g.out = W(h, "dz"); g.ldo = L; g.N = L;
+        launch_gemm_rows(g, EPI_NONE, s);
+    }
+    // ---- latent + CVAE encoder + fc_c ----
+    {
+        Timer t(h, s, "bwd_cvae_enc");
+        launch_reparam_bwd(W(h, "dz"), dev_eps, W(h, "params"), valid, W(h, "nvalid"), W(h, "dparams"), d.n_scenes, d.mno, d.K, L, s);
+        tn(h, W(h, "c3"), 2048, W(h, "dparams"), 2 * L, A, 2048, 2 * L, G(h, "vae_enc/fc/w"), 2 * L, 0, s);
+        colsum(h, W(h, "dparams"), 2 * L, A, 2 * L, G(h, "vae_enc/fc/b"), 0, s);
+        GemmArgs g{};
+        g.A = W(h, "dparams"); g.lda = 2 * L; g.M = A; g.K = 2 * L; g.Bp = D4(h, "vae_enc/fc/WT"); g.G = 2 * L / 8; g.NT = 64;
+        g.out = W(h, "dconvE3"); g.ldo = 2048; g.N = 2048; g.p0 = D(h, "vae_enc/conv3/scale"); g.chmod = 128; g.aux = W(h, "c3");
+        launch_gemm_rows(g, EPI_ELUGRAD, s);
+        const int NSL = 8;
+        ConvWgradArgs wg{};
+        wg.n = A; wg.partial = W(h, "tn_partial");
+        wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
+        launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv3/w"), s);
+        colsum(h, W(h, "dconvE3"), 128, (long)A * 16, 128, G(h, "vae_enc/conv3/b"), 0, s);
+        ConvArgs c{};
+        c.n = A; c.mode = 1;
+        c.in = W(h, "dconvE3"); c.out = W(h, "dconvE2"); c.Wp = D4(h, "vae_enc/conv3/Wbwd");
+        c.scale = D(h, "vae_enc/conv2/scale"); c.shift = c.scale; c.yprev = W(h, "c2");
+        launch_deconv2(c, s);
+        wg.S = W(h, "dconvE2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "c1"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
+        launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv2/w"), s);
+        colsum(h, W(h, "dconvE2"), 64, (long)A * 64, 64, G(h, "vae_enc/conv2/b"), 0, s);
+        c.in = W(h, "dconvE2"); c.out = W(h, "dconvE1"); c.Wp = D4(h, "vae_enc/conv2/Wbwd");
+        c.scale = D(h, "vae_enc/conv1/scale"); c.shift = c.scale; c.yprev = W(h, "c1");
+        launch_deconv3(c, s);
+        launch_w1ch_grad(W(h, "vae_in"), W(h, "dconvE1"), A, A < 64 ? A : 64, W(h, "tn_partial"), G(h, "vae_enc/conv1/w"), s);
+        colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
+        c.in = W(h, "dconvE1"); c.out = W(h, "dq_c"); c.w_raw = D(h, "vae_enc/conv1/raw"); c.mode = 2; c.yprev = W(h, "vae_in");
+        launch_deconv4(c, s);
+        tn(h, W(h, "HxHy"), 2 * H, W(h, "dq_c"), V, A, 2 * H, V, G(h, "fc_c/w"), V, 0, s);
+        colsum(h, W(h, "dq_c"), V, A, V, G(h, "fc_c/b"), 0, s);
+        g = GemmArgs{};
+        g.A = W(h, "dq_c"); g.lda = V; g.M = A; g.K = V; g.Bp = D4(h, "fc_c/WT"); g.G = V / 8; g.NT = 2 * H / 32;
+        g.out = W(h, "dHxHy"); g.ldo = 2 * H; g.N = 2 * H;
+        launch_gemm_rows(g, EPI_NONE, s);
+        launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
     }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
