@@ -190,6 +190,12 @@ int desire_pack_all(desire_ctx* h) {
         bad |= up(s + "/Whg", pack_b(H, 2 * H, rowmajor(hw[s + "/gates/kernel"], 2 * H, 2)));
         bad |= up(s + "/Whc", pack_b(H, H, rowmajor(hw[s + "/candidate/kernel"], H, 2)));
     }
+    for (const char* p : {"enc_x", "enc_y"}) {      // transposed h-blocks for the encoders' BPTT
+        const std::string s(p);
+        const auto& gk = hw[s + "/gates/kernel"]; const auto& ck = hw[s + "/candidate/kernel"];
+        bad |= up(s + "/WgT_h", pack_b(2 * H, H, [&](int k, int n) { return gk[(size_t)(2 + n) * 2 * H + k]; }));
+        bad |= up(s + "/WcT_h", pack_b(H, H, [&](int k, int n) { return ck[(size_t)(2 + n) * H + k]; }));
+    }
     bad |= up("dec/gb", hw["dec/gates/bias"]); bad |= up("dec/cb", hw["dec/candidate/bias"]);
     bad |= up("dec/Wxg", pack_b(H, 2 * H, rowmajor(hw["dec/gates/kernel"], 2 * H, 0)));
     bad |= up("dec/Whg", pack_b(H, 2 * H, rowmajor(hw["dec/gates/kernel"], 2 * H, H)));
@@ -299,12 +305,14 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
     e.out = W(h, "HxHy"); e.ldo = 2 * H; e.p_last = W(h, "p_last"); e.valid = static_cast<uint8_t*>(h->ws["valid"].p);
+    if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
     { Timer t(h, s, "encoder_x"); launch_encoder(e, s); }
     if (d.posterior) {
         e.frames = dev_fut; e.T = d.T_pred;
         e.wx_g = D(h, "enc_y/gk"); e.b_g = D(h, "enc_y/gb"); e.wx_c = D(h, "enc_y/ck"); e.b_c = D(h, "enc_y/cb");
         e.Whg = D4(h, "enc_y/Whg"); e.Whc = D4(h, "enc_y/Whc");
         e.out = W(h, "HxHy") + H; e.p_last = nullptr; e.valid = nullptr;
+        if (h->training) { e.sv_r = W(h, "ey_sv_r"); e.sv_u = W(h, "ey_sv_u"); e.sv_c = W(h, "ey_sv_c"); e.sv_h = W(h, "ey_sv_h"); e.sv_x = W(h, "ey_sv_x"); }
         { Timer t(h, s, "encoder_y"); launch_encoder(e, s); }
         GemmArgs g{};
         g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;

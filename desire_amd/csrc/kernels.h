@@ -60,6 +60,7 @@ struct EncArgs {
     float* out; int ldo;                                   // final state -> out[a*ldo + c]
     float* p_last;                                         // optional [A,2]: normalised last pos
     uint8_t* valid;                                        // optional [A]: id != 0 at last frame
+    float* sv_r; float* sv_u; float* sv_c; float* sv_h; float* sv_x;   // optional training saves [A,T,H] x4, [A,T,2]
 };
 void launch_encoder(const EncArgs& a, hipStream_t s);
 
@@ -121,7 +122,8 @@ struct DecBwdArgs {
     const float4* WcT_h; const float4* WgT_h; const float4* WgT_x; const float4* WcT_x;   // transposed, packed
     int R, K, mno, T, H;
     float* dag; float* dac; float* rh; float* hprev;       // [R,T,2H], [R,T,H] x3: gate gradients, r*h_{t-1}, h_{t-1}
-    float* dxg; float* dxc; float* dxz; float* dHx_rows;   // [R,2H], [R,H], [R,H], [R,H]
+    float* dxg; float* dxc; float* dxz; float* dHx_rows;   // [R,2H], [R,H], [R,H], [R,H]  (dxz == null: encoder use)
+    const float* dh_init; int ld_init;                     // optional gradient w.r.t. the FINAL state (encoders)
 };
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
 struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial; };

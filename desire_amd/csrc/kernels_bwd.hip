@@ -87,11 +87,16 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
     int rowi[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) rowi[i] = min(row0 + acc_row(i), a.R - 1);
+    if (a.dh_init) {                                       // encoders: the gradient arrives at the final state
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = a.dh_init[(size_t)rowi[i] * a.ld_init + col];
+    }
 
     for (int t = a.T - 1; t >= 0; --t) {
         __syncthreads();                                   // previous step's A2 / dy consumers are done
         if (tid < TM) {
-            const float2 v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
+            float2 v = make_float2(0.f, 0.f);
+            if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
             dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
         }
         __syncthreads();
@@ -102,7 +107,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
             const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
             const size_t ix = ((size_t)rowi[i] * a.T + t) * H + col;
             const float u = a.sv_u[ix], c = a.sv_c[ix], r = a.sv_r[ix];
-            const float hprev = (t > 0) ? a.sv_h[ix - H] : a.Hx[(size_t)agent_of_row(rowi[i], a.K, a.mno) * a.ldhx + col];
+            const float hprev = (t > 0) ? a.sv_h[ix - H]
+                                        : (a.Hx ? a.Hx[(size_t)agent_of_row(rowi[i], a.K, a.mno) * a.ldhx + col] : 0.f);
             const float dht = dh[i] + dy[rl * 2] * w0 + dy[rl * 2 + 1] * w1;
             du[i] = dht * (hprev - c);
             const float dc = dht * (1.0f - u);
@@ -138,6 +144,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
     }
     __syncthreads();
     // dh is now d L / d h_{-1} = the decoder's share of dHx (per row); constant-input sums -> dx_z
+    if (!a.dxz) return;                                    // encoders: inputs are data, nothing upstream
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (row0 + acc_row(i) < a.R) {

@@ -64,6 +64,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
             const float* f = a.frames + (((size_t)sc * a.T + t) * a.mno + slot) * 3;
             xs[tid * 2 + 0] = __fmul_rn(f[1], a.sx);
             xs[tid * 2 + 1] = __fmul_rn(f[2], a.sy);
+            if (a.sv_x && a0 + tid < A) { a.sv_x[((size_t)ag * a.T + t) * 2] = xs[tid * 2]; a.sv_x[((size_t)ag * a.T + t) * 2 + 1] = xs[tid * 2 + 1]; }
             if (t == a.T - 1 && a0 + tid < A) {
                 if (a.p_last) { a.p_last[(size_t)ag * 2] = xs[tid * 2]; a.p_last[(size_t)ag * 2 + 1] = xs[tid * 2 + 1]; }
                 if (a.valid) a.valid[ag] = (f[0] != 0.f) ? 1 : 0;
@@ -81,7 +82,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
             mma1(rh, a_lane, a.Whg + ((size_t)cb * G) * 64 + lane, G);
             mma1(u, a_lane, a.Whg + ((size_t)(cb + NT) * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { rh[i] = sigmoidf_(rh[i]) * h[i]; u[i] = sigmoidf_(u[i]); }
+            for (int i = 0; i < 16; ++i) {
+                const float r = sigmoidf_(rh[i]);
+                rh[i] = r * h[i]; u[i] = sigmoidf_(u[i]);
+                if (a.sv_r) {
+                    const int ag = a0 + mt * 32 + acc_row(i);
+                    if (ag < A) { const size_t ix = ((size_t)ag * a.T + t) * H + col; a.sv_r[ix] = r; a.sv_u[ix] = u[i]; }
+                }
+            }
         }
         __syncthreads();                                   // every wave done reading h_{t-1}
         if (active) {
@@ -98,7 +106,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
             }
             mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+            for (int i = 0; i < 16; ++i) {
+                const float c = tanhf_(ac[i]);
+                h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                if (a.sv_c) {
+                    const int ag = a0 + mt * 32 + acc_row(i);
+                    if (ag < A) { const size_t ix = ((size_t)ag * a.T + t) * H + col; a.sv_c[ix] = c; a.sv_h[ix] = h[i]; }
+                }
+            }
         }
         __syncthreads();                                   // every wave done reading r*h
         if (active) {

@@ -46,6 +46,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         h->n_params = off;
     }
     const size_t R = h->R, T = d.T_pred, H = d.H, f = sizeof(float);
+    const size_t Tm = d.T_pred > d.T_obs ? d.T_pred : d.T_obs;
     struct B { const char* n; size_t bytes; };
     const B bufs[] = {
         {"Gflat", h->n_params * f}, {"nvalid", 4 * f}, {"tn_partial", (size_t)96 << 20},
@@ -57,6 +58,12 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dz", R * d.L * f}, {"dparams", (size_t)h->A * 2 * d.L * f}, {"dconvE3", (size_t)h->A * 2048 * f},
         {"dconvE2", (size_t)h->A * 4096 * f}, {"dconvE1", (size_t)h->A * 8192 * f}, {"dq_c", (size_t)h->A * h->V * f},
         {"dHxHy", (size_t)h->A * 2 * H * f},
+        {"enc_dag", (size_t)h->A * Tm * 2 * H * f}, {"enc_dac", (size_t)h->A * Tm * H * f}, {"enc_rh", (size_t)h->A * Tm * H * f},
+        {"enc_hprev", (size_t)h->A * Tm * H * f},
+        {"ex_sv_r", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_u", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_c", (size_t)h->A * d.T_obs * H * f},
+        {"ex_sv_h", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_x", (size_t)h->A * d.T_obs * 2 * f},
+        {"ey_sv_r", (size_t)h->A * T * H * f}, {"ey_sv_u", (size_t)h->A * T * H * f}, {"ey_sv_c", (size_t)h->A * T * H * f},
+        {"ey_sv_h", (size_t)h->A * T * H * f}, {"ey_sv_x", (size_t)h->A * T * 2 * f},
     };
     for (const B& b : bufs)
         if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
@@ -181,6 +188,29 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_gemm_rows(g, EPI_NONE, s);
         launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
     }
+    // ---- encoders: BPTT from the final state (Hx / Hy), zero initial state ----
+    auto enc_bwd = [&](const std::string& p, const char* sv, int Te, int col0) {
+        DecBwdArgs e{};
+        e.sv_r = W(h, (std::string(sv) + "_sv_r").c_str()); e.sv_u = W(h, (std::string(sv) + "_sv_u").c_str());
+        e.sv_c = W(h, (std::string(sv) + "_sv_c").c_str()); e.sv_h = W(h, (std::string(sv) + "_sv_h").c_str());
+        e.w_head = D(h, "head/w");
+        e.WcT_h = D4(h, (p + "/WcT_h").c_str()); e.WgT_h = D4(h, (p + "/WgT_h").c_str());
+        e.R = A; e.K = 1; e.mno = d.mno; e.T = Te; e.H = H;
+        e.dag = W(h, "enc_dag"); e.dac = W(h, "enc_dac"); e.rh = W(h, "enc_rh"); e.hprev = W(h, "enc_hprev");
+        e.dh_init = W(h, "dHxHy") + col0; e.ld_init = 2 * H;
+        launch_decoder_bwd(e, s);
+        const float* xs = W(h, (std::string(sv) + "_sv_x").c_str());
+        float* gk = G(h, p + "/gates/kernel");           // [(2+H), 2H]
+        tn(h, xs, 2, W(h, "enc_dag"), 2 * H, (long)A * Te, 2, 2 * H, gk, 2 * H, 0, s);
+        tn(h, W(h, "enc_hprev"), H, W(h, "enc_dag"), 2 * H, (long)A * Te, H, 2 * H, gk + (size_t)2 * 2 * H, 2 * H, 0, s);
+        colsum(h, W(h, "enc_dag"), 2 * H, (long)A * Te, 2 * H, G(h, p + "/gates/bias"), 0, s);
+        float* ck = G(h, p + "/candidate/kernel");       // [(2+H), H]
+        tn(h, xs, 2, W(h, "enc_dac"), H, (long)A * Te, 2, H, ck, H, 0, s);
+        tn(h, W(h, "enc_rh"), H, W(h, "enc_dac"), H, (long)A * Te, H, H, ck + (size_t)2 * H, H, 0, s);
+        colsum(h, W(h, "enc_dac"), H, (long)A * Te, H, G(h, p + "/candidate/bias"), 0, s);
+    };
+    { Timer t(h, s, "bwd_encoder_y"); enc_bwd("enc_y", "ey", d.T_pred, H); }
+    { Timer t(h, s, "bwd_encoder_x"); enc_bwd("enc_x", "ex", d.T_obs, 0); }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

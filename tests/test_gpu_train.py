@@ -41,7 +41,8 @@ DONE = ["head/w", "head/b", "dec/gates/kernel", "dec/gates/bias", "dec/candidate
         "vae_dec/deconv4/w", "vae_dec/deconv4/b", "vae_dec/deconv3/w", "vae_dec/deconv3/b", "vae_dec/deconv2/w",
         "vae_dec/deconv2/b", "vae_dec/deconv1/w", "vae_dec/deconv1/b",
         "vae_enc/fc/w", "vae_enc/fc/b", "vae_enc/conv3/w", "vae_enc/conv3/b", "vae_enc/conv2/w", "vae_enc/conv2/b",
-        "vae_enc/conv1/w", "vae_enc/conv1/b", "fc_c/w", "fc_c/b"]
+        "vae_enc/conv1/w", "vae_enc/conv1/b", "fc_c/w", "fc_c/b",
+        "enc_y/gates/kernel", "enc_y/gates/bias", "enc_y/candidate/kernel", "enc_y/candidate/bias"]
 
 
 @pytest.mark.parametrize("name", DONE)
