@@ -212,6 +212,25 @@ int desire_pack_all(desire_ctx* h) {
     bad |= up("ioc/gb", hw["ioc/gates/bias"]); bad |= up("ioc/cb", hw["ioc/candidate/bias"]);
     bad |= up("ioc/Wg", pack_b(E + H, 2 * H, rowmajor(hw["ioc/gates/kernel"], 2 * H, 0)));
     bad |= up("ioc/Wc", pack_b(E + H, H, rowmajor(hw["ioc/candidate/kernel"], H, 0)));
+    {   // transposed blocks for the IOC BPTT: B(k', n') = W[row0 + n'][k']
+        const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
+        const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
+        const int xr = d.E_v + d.C;                      // first e_r row of the GRU kernels
+        const int T2 = 2 * d.T_pred, KR = (T2 + 7) / 8 * 8;
+        bad |= up("ioc/WgT_h", pack_b(2 * H, H, [&](int k, int n) { return gk[(size_t)(E + n) * 2 * H + k]; }));
+        bad |= up("ioc/WgT_er", pack_b(2 * H, H, [&](int k, int n) { return gk[(size_t)(xr + n) * 2 * H + k]; }));
+        bad |= up("ioc/WgT_ev", pack_b(2 * H, 32, [&](int k, int n) { return n < d.E_v ? gk[(size_t)n * 2 * H + k] : 0.f; }));
+        bad |= up("ioc/WcT_h", pack_b(H, H, [&](int k, int n) { return ck[(size_t)(E + n) * H + k]; }));
+        bad |= up("ioc/WcT_er", pack_b(H, H, [&](int k, int n) { return ck[(size_t)(xr + n) * H + k]; }));
+        bad |= up("ioc/WcT_ev", pack_b(H, 32, [&](int k, int n) { return n < d.E_v ? ck[(size_t)n * H + k] : 0.f; }));
+        bad |= up("ioc/WrT", pack_b(KR, H, [&](int k, int n) { return k < T2 ? wr[(size_t)n * T2 + k] : 0.f; }));
+        std::vector<float> all;
+        for (int b = 0; b < B; ++b) {
+            auto pk = pack_b(H, H, [&](int k, int n) { return ws[((size_t)b * H + n) * H + k]; });
+            all.insert(all.end(), pk.begin(), pk.end());
+        }
+        bad |= up("ioc/WsT", all);
+    }
     bad |= up("ioc/vel_w", hw["ioc/vel_fc/w"]); bad |= up("ioc/vel_b", hw["ioc/vel_fc/b"]);
     {
         std::vector<float> all;
@@ -413,7 +432,15 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
     a.dbg = static_cast<long long*>(h->ws["dbg"].p);
 #endif
+    if (h->training) {
+        if (cluster) return fail(DESIRE_ERR_STATE, "training supports groups of up to 32 agents per scene in this round (mno <= 32)");
+        a.sv_x = W(h, "ioc_sv_x"); a.sv_r = W(h, "ioc_sv_r"); a.sv_u = W(h, "ioc_sv_u"); a.sv_c = W(h, "ioc_sv_c"); a.sv_h = W(h, "ioc_sv_h");
+    }
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+    if (h->training) {
+        HIPCHK(hipMemcpyAsync(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(W(h, "score_sv"), dev_score, (size_t)h->R * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
 #ifdef DESIRE_IOC_TIMING
     {
         long long host[10];

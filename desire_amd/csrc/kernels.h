@@ -90,6 +90,7 @@ struct IocArgs {
     int variant;                                           // A/B switch, see launch_ioc
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
     float* hex; int* grp_cnt; int* err;                    // cluster form: exchange buffer [2][R][H], group counters, error word
+    float* sv_x; float* sv_r; float* sv_u; float* sv_c; float* sv_h;   // training saves: [R,T,E], [R,T,H] x4 (32-row form only)
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 
@@ -137,3 +138,17 @@ void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float
 void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
                         float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s);
 void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s);
+void launch_score_grad(const float* Y0, const float* fut, const float* score, const uint8_t* valid, const float* nvalid,
+                       float* dscore, float* dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s);
+struct IocBwdArgs {
+    const float* Y0; const float* p_last; const uint8_t* valid; const float* Hx; int ldhx;
+    const float* dYr; const float* dscore;
+    const float* sv_x; const float* sv_r; const float* sv_u; const float* sv_c; const float* sv_h;
+    const float* w_score;
+    int R, K, mno, T, H, G; float nb_w, nb_h;
+    const float4* WrT; const float4* WcT_h; const float4* WcT_er; const float4* WcT_ev;
+    const float4* WgT_h; const float4* WgT_er; const float4* WgT_ev; const float4* WsT;
+    float* dag; float* dac; float* rh; float* hprev; float* dpre_r; float* dpre_v; float* vel; float* pooled;
+    float* dHx_rows;
+};
+void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);

@@ -457,3 +457,262 @@ void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes,
     const int n = n_scenes * mno * H;
     hipLaunchKernelGGL(k_rows_to_agents, dim3((n + 255) / 256), dim3(256), 0, s, rows, out, ldo, n_scenes, mno, K, H);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// IOC loss gradients w.r.t. the scores:  CE(P, softmax_k(score)) with P = softmax_k(-max_t ||Y_gt - Y0_k||)
+//   dscore_k = valid / N * (softmax_k(score) - P_k);  dscoreT[r, t] = dscore[r] (broadcast used by the tn reductions)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_score_grad(const float* __restrict__ Y0, const float* __restrict__ fut, const float* __restrict__ score,
+                             const uint8_t* __restrict__ valid, const float* __restrict__ nvalid, float* __restrict__ dscore,
+                             float* __restrict__ dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_scenes * mno) return;
+    const int sc = a / mno, slot = a - sc * mno;
+    float m1 = -3.0e38f, m2 = -3.0e38f;
+    for (int k = 0; k < K; ++k) {                       // pass 1: maxima of the two logit sets
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        float dm = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+            const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+            dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
+        }
+        dscore[r] = dm;                                  // stash d_max
+        m1 = fmaxf(m1, -dm); m2 = fmaxf(m2, score[r]);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        s1 += expf(-dscore[r] - m1); s2 += expf(score[r] - m2);
+    }
+    const float wv = valid[a] ? 1.0f / nvalid[0] : 0.f;
+    for (int k = 0; k < K; ++k) {
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        const float g = wv * (expf(score[r] - m2) / s2 - expf(-dscore[r] - m1) / s1);
+        dscore[r] = g;
+        for (int t = 0; t < T; ++t) dscoreT[r * T + t] = g;
+    }
+}
+void launch_score_grad(const float* Y0, const float* fut, const float* score, const uint8_t* valid, const float* nvalid,
+                       float* dscore, float* dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s) {
+    const int A = n_scenes * mno;
+    hipLaunchKernelGGL(k_score_grad, dim3((A + 63) / 64), dim3(64), 0, s, Y0, fut, score, valid, nvalid, dscore, dscoreT,
+                       n_scenes, mno, K, T, sx, sy);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// IOC BPTT.  Tile = 32 rows = whole (scene,k) groups (mno <= 32), wave cb owns hidden columns [32cb, 32cb+32).
+// Reverse step t (forward: x = [e_v | e_s | e_r], e_r = relu(sum_b pool_b(h_{t-1}) W_b + b_s), GRU, score += h.w_s):
+//   dh_t += dscore w_s;  GRU cell backward as in k_decoder_bwd, plus
+//   de_r  = da_c Wc[e_r rows]^T + [da_r|da_u] Wg[e_r rows]^T ;  dpre_r = de_r (e_r > 0)
+//   de_v  likewise (16 columns, wave 0);                         dpre_v = de_v (e_v > 0)
+//   per bin b: dpool_b = dpre_r W_b^T (MFMA) -> LDS; every row j gathers sum_{i: j in bin b of i} dpool_b[i] into
+//   registers (observer bit-masks), which after the 16 bins is added to dh_{t-1}: the pooling transpose without atomics.
+//   pooled_b (rebuilt like the forward) is streamed to HBM for the social-fc weight gradient.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bwd(IocBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
+    constexpr int E = EV + C + H, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
+    const int B = a.G * a.G;
+    const int KR = (2 * a.T + 7) / 8 * 8, LDR = KR + 4;                   // regression-head operand width
+    float* A1 = smem;                         // [32][LD1]  da_c
+    float* A2 = A1 + TM * LD1;                // [32][LD2]  da_r | da_u
+    float* A3 = A2 + TM * LD2;                // [32][LD1]  dpre_r
+    float* DP = A3 + TM * LD1;                // [2][32][LD1] dpool_b
+    float* HP = DP + 2 * TM * LD1;            // [33][LD1]  h_{t-1} (+ zero row)
+    float* NB = HP + (TM + 1) * LD1;          // [32][LD1]  neighbour gradient
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(NB + TM * LD1);   // [32][B] neighbours of i in bin b
+    unsigned long long* obs = masks + TM * B;                                           // [32][B] observers of j in bin b
+    float* pc = reinterpret_cast<float*>(obs + TM * B);   // [32][2]
+    float* dsc = pc + TM * 2;                 // [32]
+    float* wsc = dsc + TM;                    // [H]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(wsc + H);   // [32]
+    float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
+
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
+    const float* a1_lane = A1 + (lane & 31) * LD1 + 4 * (lane >> 5);
+    const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
+    const float* a3_lane = A3 + (lane & 31) * LD1 + 4 * (lane >> 5);
+    const int rofs = (4 * (lane >> 5));       // + (i&3) + 8*(i>>2) = local row of accumulator element i
+    int rowi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rowi[i] = min(row0 + acc_row(i), a.R - 1);
+
+    for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
+    for (int i = tid; i < LD1; i += NTHR) HP[TM * LD1 + i] = 0.f;
+    if (tid < TM) {
+        const int row = min(row0 + tid, a.R - 1);
+        vld[tid] = a.valid[agent_of_row(row, a.K, a.mno)];
+        dsc[tid] = (row0 + tid < a.R) ? a.dscore[row] : 0.f;
+    }
+    for (int i = tid; i < TM * KR; i += NTHR) {
+        const int r = i / KR, c = i - r * KR;
+        DR[r * LDR + c] = (c < 2 * a.T && row0 + r < a.R) ? a.dYr[(size_t)(row0 + r) * 2 * a.T + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 dh = zero16();
+    mma1b(dh, DR + (lane & 31) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        __syncthreads();
+        // ---- P0: positions, cleared masks, h_{t-1} tile ----
+        if (tid < TM) {
+            const int row = min(row0 + tid, a.R - 1);
+            const float2 y = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t) * 2);
+            pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
+            float2 pv;
+            if (t > 0) pv = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t - 1) * 2);
+            else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
+            if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
+        }
+        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0ull;          // masks and obs are contiguous
+        for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+            const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+            const int row = min(row0 + r, a.R - 1);
+            const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
+                                       : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
+            *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+        }
+        __syncthreads();
+        // ---- P1: neighbour / observer masks ----
+        {
+            const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+            for (int j = q8; j < a.mno; j += TPR) {
+                if (j == my_slot || !vld[grp_base + j]) continue;
+                const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G);
+                if (b >= 0) {
+                    atomicOr(&masks[r8 * B + b], 1ull << j);
+                    atomicOr(&obs[(grp_base + j) * B + b], 1ull << my_slot);
+                }
+            }
+        }
+        // ---- GRU cell backward, part 1 ----
+        f32x16 dhp, du, rr, hp, uu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = rofs + (i & 3) + 8 * (i >> 2);
+            const size_t ix = ((size_t)rowi[i] * a.T + t) * H + col;
+            const float u = a.sv_u[ix], c = a.sv_c[ix], r = a.sv_r[ix];
+            const float hprev = HP[rl * LD1 + col];
+            const float dht = dh[i] + dsc[rl] * wsc[col];
+            du[i] = dht * (hprev - c);
+            const float dc = dht * (1.0f - u);
+            dhp[i] = dht * u;
+            const float dac = dc * (1.0f - c * c);
+            A1[rl * LD1 + col] = dac;
+            if (row0 + rl < a.R) { a.dac[ix] = dac; a.rh[ix] = r * hprev; a.hprev[ix] = hprev; }
+            rr[i] = r; hp[i] = hprev; uu[i] = u;
+        }
+        __syncthreads();
+        f32x16 drh = zero16(), der = zero16(), dev = zero16();
+        mma1b(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
+        mma1b(der, a1_lane, a.WcT_er + ((size_t)cb * GH) * 64 + lane, GH);
+        if (cb == 0) mma1b(dev, a1_lane, a.WcT_ev + lane, GH);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = rofs + (i & 3) + 8 * (i >> 2);
+            const float dr = drh[i] * hp[i];
+            dhp[i] += drh[i] * rr[i];
+            const float dar = dr * rr[i] * (1.0f - rr[i]);
+            const float dau = du[i] * uu[i] * (1.0f - uu[i]);
+            A2[rl * LD2 + col] = dar;
+            A2[rl * LD2 + H + col] = dau;
+            if (row0 + rl < a.R) { const size_t ig = ((size_t)rowi[i] * a.T + t) * 2 * H + col; a.dag[ig] = dar; a.dag[ig + H] = dau; }
+        }
+        __syncthreads();
+        {
+            f32x16 dhg = zero16();
+            mma1b(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
+            mma1b(der, a2_lane, a.WgT_er + ((size_t)cb * G2) * 64 + lane, G2);
+            if (cb == 0) mma1b(dev, a2_lane, a.WgT_ev + lane, G2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = rofs + (i & 3) + 8 * (i >> 2);
+                dhp[i] += dhg[i];
+                const size_t ixx = ((size_t)rowi[i] * a.T + t) * E;
+                const float er = a.sv_x[ixx + EV + C + col];
+                const float dpr = er > 0.f ? der[i] : 0.f;
+                A3[rl * LD1 + col] = dpr;
+                if (row0 + rl < a.R) {
+                    a.dpre_r[((size_t)rowi[i] * a.T + t) * H + col] = dpr;
+                    if (cb == 0 && (lane & 31) < EV) {
+                        const float ev = a.sv_x[ixx + (lane & 31)];
+                        a.dpre_v[((size_t)rowi[i] * a.T + t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- social pooling backward ----
+        float4 nb[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) nb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            {   // pooled_b[i] = sum_{j in bin b of i} h_{t-1}[j]  -> HBM (operand of the social-fc weight gradient)
+                float4 s[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned long long m2 = masks[r8 * B + b];
+                while (m2) {
+                    const int j = __ffsll((long long)m2) - 1;
+                    m2 &= m2 - 1;
+                    const float* src = HP + (grp_base + j) * LD1 + q8 * 4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
+                        s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                    }
+                }
+                if (row0 + r8 < a.R) {
+                    float* dst = a.pooled + (((size_t)my_row * a.T + t) * B + b) * H + q8 * 4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
+                }
+            }
+            f32x16 dpl = zero16();
+            mma1b(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+            float* dp = DP + (b & 1) * TM * LD1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
+            __syncthreads();
+            unsigned long long m2 = obs[r8 * B + b];
+            while (m2) {
+                const int i2 = __ffsll((long long)m2) - 1;
+                m2 &= m2 - 1;
+                const float* src = dp + (grp_base + i2) * LD1 + q8 * 4;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
+                    nb[c].x += v.x; nb[c].y += v.y; nb[c].z += v.z; nb[c].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(NB + r8 * LD1 + q8 * 4 + c * 4 * TPR) = nb[c];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (row0 + acc_row(i) < a.R) a.dHx_rows[(size_t)rowi[i] * H + col] += dh[i];
+}
+static size_t ioc_bwd_lds(const IocBwdArgs& a) {
+    const int H = a.H, LD1 = H + 4, LD2 = 2 * H + 4, B = a.G * a.G;
+    size_t f = (size_t)32 * LD1 * 3 + 32 * LD2 + 2 * 32 * LD1 + 33 * LD1 + (size_t)32 * B * 4 + 64 + 32 + H;
+    return f * sizeof(float) + 64;
+}
+void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s) {
+    const dim3 grid((a.R + 31) / 32);
+    const size_t lds = ioc_bwd_lds(a);
+    if (a.H == 256) { allow_big_lds(k_ioc_bwd<256, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<256, 16, 32>), grid, dim3(512), lds, s, a); }
+    else if (a.H == 128) { allow_big_lds(k_ioc_bwd<128, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<128, 16, 32>), grid, dim3(256), lds, s, a); }
+    else { allow_big_lds(k_ioc_bwd<64, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<64, 16, 32>), grid, dim3(128), lds, s, a); }
+}

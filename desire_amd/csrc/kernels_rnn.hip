@@ -288,8 +288,8 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 #else
 #define TICK(k)
 #endif
-template <int H, int EV, int C, int TM>
-__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, (H / 32) * (TM / 32) <= 2 ? 1 : 2) void k_ioc(IocArgs a) {
+template <int H, int EV, int C, int TM, bool TRAIN>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2 || (TRAIN && (H / 32) * (TM / 32) <= 4)) ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
@@ -458,6 +458,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, (H / 32) * (TM / 32) <= 
             }
             __syncthreads();
             TICK(6)
+            if (TRAIN) {                                                 // keep x_t = [e_v | e_s | e_r] for the weight gradients
+                for (int i = tid; i < TM * (E >> 2); i += NTHR) {
+                    const int r = i / (E >> 2), c4 = i - r * (E >> 2);
+                    if (row0 + r < a.R)
+                        *reinterpret_cast<float4*>(a.sv_x + ((size_t)(row0 + r) * a.T + t) * E + c4 * 4) =
+                            *reinterpret_cast<const float4*>(XH + r * LDX + c4 * 4);
+                }
+            }
             // ---- P4: gates over [x | h]; r*h goes to its own LDS tile so no "done reading h" barrier is needed ----
             f32x16 rh, u;
             if (active) {
@@ -465,11 +473,18 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, (H / 32) * (TM / 32) <= 
                 mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
                 mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
+                for (int i = 0; i < 16; ++i) {
+                    const float r = sigmoidf_(rh[i]);
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) a.sv_r[((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col] = r;
+                    rh[i] = r * h[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
+                for (int i = 0; i < 16; ++i) {
+                    u[i] = sigmoidf_(u[i]);
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) a.sv_u[((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col] = u[i];
+                }
             }
             __syncthreads();
             TICK(7)
@@ -480,8 +495,13 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, (H / 32) * (TM / 32) <= 
                 mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+                    const float c = tanhf_(ac[i]);
+                    h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
                     sp[i] = fmaf(h[i], wsc, sp[i]);
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) {
+                        const size_t ix = ((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col;
+                        a.sv_c[ix] = c; a.sv_h[ix] = h[i];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i)                               // h slot: last read by the gates, one barrier ago
@@ -542,9 +562,14 @@ static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
 }
 template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
-    allow_big_lds(k_ioc<H, 16, 32, TM>);
-    hipLaunchKernelGGL((k_ioc<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64),
-                       ioc_lds_bytes(a, TM), s, a);
+    const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * (TM / 32) * 64);
+    if (a.sv_h && TM == 32) {                                  // training-mode forward: keeps x_t, r, u, c, h per step
+        allow_big_lds(k_ioc<H, 16, 32, 32, true>);
+        hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+        return;
+    }
+    allow_big_lds(k_ioc<H, 16, 32, TM, false>);
+    hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, false>), grid, block, ioc_lds_bytes(a, TM), s, a);
 }
 void launch_ioc_cluster(const IocArgs& a, hipStream_t s);
 void launch_ioc(const IocArgs& a, hipStream_t s) {

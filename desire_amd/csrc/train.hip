@@ -40,6 +40,9 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (!enable) { h->training = false; return DESIRE_OK; }
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
+    if (d.mno > 32) return fail(DESIRE_ERR_STATE, "training supports mno <= 32 in this round");
+    if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
+    if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");
     if (h->slots.empty()) {
         size_t off = 0;
         for (auto& kv : h->want) { h->slots[kv.first] = WSlot{off, kv.second}; off += (kv.second + 3) / 4 * 4; }
@@ -58,6 +61,11 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dz", R * d.L * f}, {"dparams", (size_t)h->A * 2 * d.L * f}, {"dconvE3", (size_t)h->A * 2048 * f},
         {"dconvE2", (size_t)h->A * 4096 * f}, {"dconvE1", (size_t)h->A * 8192 * f}, {"dq_c", (size_t)h->A * h->V * f},
         {"dHxHy", (size_t)h->A * 2 * H * f},
+        {"ioc_sv_x", R * T * (size_t)h->E * f}, {"ioc_sv_r", R * T * H * f}, {"ioc_sv_u", R * T * H * f}, {"ioc_sv_c", R * T * H * f},
+        {"ioc_sv_h", R * T * H * f}, {"Y_ref", R * T * 2 * f}, {"score_sv", R * f}, {"dYr", R * T * 2 * f}, {"dscore", R * f},
+        {"dscoreT", R * T * f}, {"ioc_dag", R * T * 2 * H * f}, {"ioc_dac", R * T * H * f}, {"ioc_rh", R * T * H * f},
+        {"ioc_hprev", R * T * H * f}, {"ioc_dpre_r", R * T * H * f}, {"ioc_dpre_v", R * T * d.E_v * f}, {"ioc_vel", R * T * 2 * f},
+        {"ioc_pooled", R * T * (size_t)h->B * H * f},
         {"enc_dag", (size_t)h->A * Tm * 2 * H * f}, {"enc_dac", (size_t)h->A * Tm * H * f}, {"enc_rh", (size_t)h->A * Tm * H * f},
         {"enc_hprev", (size_t)h->A * Tm * H * f},
         {"ex_sv_r", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_u", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_c", (size_t)h->A * d.T_obs * H * f},
@@ -105,8 +113,45 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, R * T, H, H, ck + (size_t)H * H, H, 0, s);
         colsum(h, W(h, "dec_dac"), H, R * T, H, G(h, "dec/candidate/bias"), 0, s);
     }
-    // ---- mask fc ----
     const int V = h->V, L = d.L, A = h->A;
+    // ---- ranking / refinement module (trajectories detached: its only path into the rest is dHx) ----
+    {
+        Timer t(h, s, "bwd_ioc");
+        const int E = h->E, B = h->B;
+        launch_loss_grad_y(W(h, "Y_ref"), dev_fut, valid, W(h, "nvalid"), W(h, "dYr"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
+        launch_score_grad(W(h, "Y0"), dev_fut, W(h, "score_sv"), valid, W(h, "nvalid"), W(h, "dscore"), W(h, "dscoreT"), d.n_scenes,
+                          d.mno, d.K, T, d.sx, d.sy, s);
+        IocBwdArgs q{};
+        q.Y0 = W(h, "Y0"); q.p_last = W(h, "p_last"); q.valid = valid; q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
+        q.dYr = W(h, "dYr"); q.dscore = W(h, "dscore");
+        q.sv_x = W(h, "ioc_sv_x"); q.sv_r = W(h, "ioc_sv_r"); q.sv_u = W(h, "ioc_sv_u"); q.sv_c = W(h, "ioc_sv_c"); q.sv_h = W(h, "ioc_sv_h");
+        q.w_score = D(h, "ioc/score_w");
+        q.R = (int)R; q.K = d.K; q.mno = d.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
+        q.WrT = D4(h, "ioc/WrT"); q.WcT_h = D4(h, "ioc/WcT_h"); q.WcT_er = D4(h, "ioc/WcT_er"); q.WcT_ev = D4(h, "ioc/WcT_ev");
+        q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT");
+        q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
+        q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
+        q.dHx_rows = W(h, "dHx_rows");
+        launch_ioc_bwd(q, s);
+        const long RT = R * T;
+        tn(h, W(h, "ioc_sv_h") + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, 0, s);
+        colsum(h, W(h, "dYr"), 2 * T, R, 2 * T, G(h, "ioc/reg/b"), 0, s);
+        tn(h, W(h, "ioc_sv_h"), H, W(h, "dscoreT"), 1, RT, H, 1, G(h, "ioc/score/w"), 1, 0, s);
+        colsum(h, W(h, "dscoreT"), 1, RT, 1, G(h, "ioc/score/b"), 0, s);
+        float* gk = G(h, "ioc/gates/kernel");            // [(E+H), 2H]
+        tn(h, W(h, "ioc_sv_x"), E, W(h, "ioc_dag"), 2 * H, RT, E, 2 * H, gk, 2 * H, 0, s);
+        tn(h, W(h, "ioc_hprev"), H, W(h, "ioc_dag"), 2 * H, RT, H, 2 * H, gk + (size_t)E * 2 * H, 2 * H, 0, s);
+        colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), 0, s);
+        float* ck = G(h, "ioc/candidate/kernel");        // [(E+H), H]
+        tn(h, W(h, "ioc_sv_x"), E, W(h, "ioc_dac"), H, RT, E, H, ck, H, 0, s);
+        tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, 0, s);
+        colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), 0, s);
+        tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, 0, s);
+        colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), 0, s);
+        tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, 0, s);
+        colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), 0, s);
+    }
+    // ---- mask fc ----
     {
         Timer t(h, s, "bwd_mask");
         launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), W(h, "HxHy"), 2 * H, W(h, "dq_mask"), W(h, "dHx_rows"), (int)R, H, d.K, d.mno, s);
