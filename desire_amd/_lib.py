@@ -20,6 +20,7 @@ EXPORTS = [
     "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
     "desire_temporal_conv", "desire_feature_pooling", "desire_build_windows", "desire_gaussian_sample", "desire_ade_fde",
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
+    "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
 ]
 
 
@@ -77,6 +78,10 @@ def load() -> C.CDLL:
     lib.desire_backward.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_get_grad.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_grad_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.desire_train_loss.argtypes = [vp, f32p, C.POINTER(C.c_float), vp]
+    lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
+    lib.desire_clip_grads.argtypes = [vp, C.c_float, C.POINTER(C.c_float), vp]
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
@@ -187,6 +192,35 @@ class Handle:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.lib.desire_grad_buffer(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+    def grad_tensor(self):
+        """The flat gradient buffer as a zero-copy torch tensor (for torch.distributed.all_reduce over RCCL)."""
+        import torch
+        p, n = self.grad_buffer()
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (p, False), "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda")
+
+    def clip_grads(self, max_norm: float, want_norm: bool = False, stream: int = 0):
+        out = C.c_float(0.0)
+        _chk(self.lib.desire_clip_grads(self._h, C.c_float(max_norm), C.byref(out) if want_norm else None, stream or None))
+        return float(out.value) if want_norm else None
+
+    def train_loss(self, fut_ptr: int, stream: int = 0) -> Dict[str, float]:
+        out = (C.c_float * 5)()
+        _chk(self.lib.desire_train_loss(self._h, fut_ptr, out, stream or None))
+        r = dict(zip(("recon", "kld", "ce", "reg", "n_present"), (float(x) for x in out)))
+        r["loss"] = r["recon"] + r["kld"] + r["ce"] + r["reg"]
+        return r
+
+    def adam_step(self, lr: float = 0.005, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, stream: int = 0) -> None:
+        _chk(self.lib.desire_adam_step(self._h, C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), stream or None))
+
+    def get_weight(self, name: str, shape: Tuple[int, ...], stream: int = 0) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        _chk(self.lib.desire_get_weight(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, stream or None))
+        return out
 
     def set_profiling(self, on: bool) -> None:
         _chk(self.lib.desire_set_profiling(self._h, int(on)))

@@ -28,7 +28,10 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
 }
 
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v) {
+    if (h->pack_mode == 1) { h->captured[name] = v; return 0; }
     DevBuf& b = h->dev[name];
+    if (b.p && b.bytes == v.size() * sizeof(float))          // same shape: refresh in place (pointers stay valid)
+        return hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
     b.release();
     if (b.alloc(v.size() * sizeof(float))) return -1;
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
@@ -161,6 +164,7 @@ extern "C" int desire_set_weight(desire_handle* h, const char* name, const float
                                         " values, got " + std::to_string(n));
     h->host_w[name].assign(host_data, host_data + n);
     h->finalized = false;
+    h->training = false;            // the optimiser's master copy is rebuilt by the next desire_set_training(h, 1)
     return DESIRE_OK;
 }
 
@@ -290,7 +294,7 @@ int desire_pack_all(desire_ctx* h) {
         bad |= up("vae_enc/conv2/Wbwd", pack_taps(hw["vae_enc/conv2/w"], 64, 32, true));       // [tap][ci=32][co=64] as deconv 64->32
     }
     if (bad) return fail(DESIRE_ERR_HIP, "weight upload failed");
-    HIPCHK(hipDeviceSynchronize());
+    if (h->pack_mode == 0) HIPCHK(hipDeviceSynchronize());
     return DESIRE_OK;
 }
 

@@ -53,6 +53,10 @@ struct desire_ctx {
     std::map<std::string, WSlot> slots;                      // natural-layout offsets in Wflat / Gflat / Mflat / Vflat
     size_t n_params = 0;
     const float* last_eps = nullptr;                         // inputs of the last training-mode forward
+    int pack_mode = 0;                                       // 1: desire_upload captures instead of uploading (index pass)
+    std::map<std::string, std::vector<float>> captured;
+    int adam_t = 0;                                          // Adam step counter
+    int n_seg = 0;                                           // repack segments (train.hip)
 };
 
 struct Timer {

@@ -4,6 +4,7 @@
 // caller all-reduces a single tensor (RCCL through torch.distributed) between desire_backward and desire_adam_step.
 #include "ctx.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace {
@@ -31,6 +32,213 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
 void colsum(desire_ctx* h, const float* Gm, int ldg, long M, int N, float* out, int accumulate, hipStream_t s) {
     long sl = 256; const long maxsl = (M + 3) / 4; if (sl > maxsl) sl = maxsl; if (sl < 1) sl = 1;
     launch_colsum(Gm, ldg, M, N, (int)sl, W(h, "tn_partial"), out, accumulate, s);
+}
+
+// ---- optimiser state lives next to the gradients: Wflat (master weights), Mflat, Vflat, all in Gflat's layout ----
+__global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       size_t n, float lr_t, float b1, float b2, float eps) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// global-norm clipping (tf.clip_by_global_norm, model/model.py:390): g *= min(1, clip / ||g||), all on the device
+__global__ void k_sqsum(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void k_clip_scale(float* __restrict__ g, size_t n, const float* __restrict__ partial, int np, float clip, float* norm_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float norm = sqrtf(red[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    const float sc = norm > clip ? clip / norm : 1.f;
+    if (sc == 1.f) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= sc;
+}
+
+// every packed / raw device operand is a gather of the master weights: dst[i] = idx[i] ? Wflat[idx[i]-1] : 0
+struct Seg { float* dst; unsigned long long idx_off; unsigned long long n; };
+__global__ void k_repack(const Seg* __restrict__ segs, const uint32_t* __restrict__ idx, const float* __restrict__ w) {
+    const Seg sg = segs[blockIdx.y];
+    const uint32_t* ix = idx + sg.idx_off;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t j = ix[i];
+        sg.dst[i] = j ? w[j - 1] : 0.f;
+    }
+}
+
+// folded batch-norm shift follows the (trainable) conv bias: shift = beta + scale * (b - mean); scale is frozen
+__global__ void k_refold(const float* __restrict__ w, float* __restrict__ shift, const float* __restrict__ scale, size_t off_b,
+                         size_t off_beta, size_t off_mean, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) shift[c] = w[off_beta + c] + scale[c] * (w[off_b + c] - w[off_mean + c]);
+}
+
+// per-agent loss terms of DESIGN.md section 8: out[a] = {recon, kld, ce, reg} (0 for absent agents)
+__global__ void k_train_loss(const float* __restrict__ Y0, const float* __restrict__ Yr, const float* __restrict__ fut,
+                             const float* __restrict__ score, const float* __restrict__ params, const uint8_t* __restrict__ valid,
+                             float* __restrict__ out, int n_scenes, int mno, int K, int T, int L, float sx, float sy) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_scenes * mno) return;
+    const int sc = a / mno, slot = a - sc * mno;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid[a]) {
+        float m1 = -3.0e38f, m2 = -3.0e38f, e0s = 0.f, e1s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const size_t r = ((size_t)sc * K + k) * mno + slot;
+            float dm = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                const float gx = __fmul_rn(f[1], sx), gy = __fmul_rn(f[2], sy);
+                float dx = Y0[(r * T + t) * 2] - gx, dy = Y0[(r * T + t) * 2 + 1] - gy;
+                const float e0 = sqrtf(dx * dx + dy * dy);
+                dx = Yr[(r * T + t) * 2] - gx; dy = Yr[(r * T + t) * 2 + 1] - gy;
+                e0s += e0; e1s += sqrtf(dx * dx + dy * dy);
+                dm = fmaxf(dm, e0);
+            }
+            m1 = fmaxf(m1, -dm); m2 = fmaxf(m2, score[r]);
+        }
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const size_t r = ((size_t)sc * K + k) * mno + slot;
+            float dm = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+                dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
+            }
+            s1 += expf(-dm - m1); s2 += expf(score[r] - m2);
+        }
+        float ce = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const size_t r = ((size_t)sc * K + k) * mno + slot;
+            float dm = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+                dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
+            }
+            ce -= expf(-dm - m1) / s1 * (score[r] - m2 - logf(s2));
+        }
+        float kl = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float mu = params[(size_t)a * 2 * L + j], ls = params[(size_t)a * 2 * L + L + j];
+            kl += 1.f + ls - mu * mu - expf(ls);
+        }
+        o = make_float4(e0s / (K * T), -0.5f * kl, ce, e1s / (K * T));
+    }
+    reinterpret_cast<float4*>(out)[a] = o;
+}
+__global__ void k_sum_loss(const float* __restrict__ per_agent, const uint8_t* __restrict__ valid, int A, float* __restrict__ out) {
+    __shared__ float red[4][256];
+    float s[4] = {0.f, 0.f, 0.f, 0.f}; float nv = 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) {
+        for (int j = 0; j < 4; ++j) s[j] += per_agent[(size_t)a * 4 + j];
+        nv += valid[a] ? 1.f : 0.f;
+    }
+    __shared__ float rnv[256];
+    for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = s[j];
+    rnv[threadIdx.x] = nv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f}; float n = 0.f;
+        for (int i = 0; i < 256; ++i) { for (int j = 0; j < 4; ++j) t[j] += red[j][i]; n += rnv[i]; }
+        n = fmaxf(n, 1.f);
+        for (int j = 0; j < 4; ++j) out[j] = t[j] / n;
+        out[4] = n;
+    }
+}
+
+// Builds the gather maps: the packing code (desire_pack_all) is run a second time over weights whose VALUES are their
+// own 1-based flat indices (as bit patterns); whatever it would have uploaded is then the index map of that operand.
+// Each map is verified against the real device operand, so an operand that is not a pure gather cannot slip through.
+int build_repack_maps(desire_ctx* h) {
+    std::vector<float> flat(h->n_params, 0.f);
+    auto real = h->host_w;
+    for (auto& kv : h->slots) {
+        const auto& src = real.at(kv.first);
+        std::memcpy(flat.data() + kv.second.off, src.data(), kv.second.n * sizeof(float));
+        std::vector<float> coded(kv.second.n);
+        for (size_t i = 0; i < kv.second.n; ++i) {
+            const uint32_t u = (uint32_t)(kv.second.off + i + 1);
+            std::memcpy(&coded[i], &u, 4);
+        }
+        h->host_w[kv.first] = std::move(coded);
+    }
+    h->pack_mode = 1; h->captured.clear();
+    const int rc = desire_pack_all(h);
+    h->pack_mode = 0; h->host_w = std::move(real);
+    if (rc) return rc;
+    if (ensure(h, "Wflat", h->n_params * sizeof(float)) || ensure(h, "Mflat", h->n_params * sizeof(float)) ||
+        ensure(h, "Vflat", h->n_params * sizeof(float)))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the optimiser state");
+    HIPCHK(hipMemcpy(W(h, "Wflat"), flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(W(h, "Mflat"), 0, h->n_params * sizeof(float)));
+    HIPCHK(hipMemset(W(h, "Vflat"), 0, h->n_params * sizeof(float)));
+    std::vector<uint32_t> all_idx; std::vector<Seg> segs;
+    std::vector<float> devcopy;
+    for (auto& kv : h->captured) {
+        const std::string& name = kv.first; const auto& v = kv.second;
+        auto it = h->dev.find(name);
+        if (it == h->dev.end() || it->second.bytes != v.size() * sizeof(float))
+            return fail(DESIRE_ERR_STATE, "repack map: operand " + name + " changed shape");
+        devcopy.resize(v.size());
+        HIPCHK(hipMemcpy(devcopy.data(), it->second.p, it->second.bytes, hipMemcpyDeviceToHost));
+        bool gather = true;
+        std::vector<uint32_t> ix(v.size());
+        for (size_t i = 0; i < v.size() && gather; ++i) {
+            uint32_t u; std::memcpy(&u, &v[i], 4);
+            if (u > h->n_params) { gather = false; break; }
+            ix[i] = u;
+            const float want = u ? flat[u - 1] : 0.f;
+            if (std::memcmp(&want, &devcopy[i], 4) != 0) gather = false;
+        }
+        const bool folded = name.size() > 6 && (name.rfind("/scale") == name.size() - 6 || name.rfind("/shift") == name.size() - 6);
+        if (!gather) {
+            if (folded) continue;                              // handled by k_refold
+            return fail(DESIRE_ERR_STATE, "repack map: operand " + name + " is not a gather of the weights");
+        }
+        if (folded) continue;
+        segs.push_back(Seg{it->second.f(), (unsigned long long)all_idx.size(), (unsigned long long)v.size()});
+        all_idx.insert(all_idx.end(), ix.begin(), ix.end());
+        while (all_idx.size() % 4) all_idx.push_back(0);
+    }
+    h->captured.clear();
+    if (ensure(h, "repack_idx", all_idx.size() * sizeof(uint32_t)) || ensure(h, "repack_segs", segs.size() * sizeof(Seg)))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the repack maps");
+    HIPCHK(hipMemcpy(h->ws["repack_idx"].p, all_idx.data(), all_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->ws["repack_segs"].p, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    h->n_seg = (int)segs.size();
+    return DESIRE_OK;
+}
+
+int repack(desire_ctx* h, hipStream_t s) {
+    hipLaunchKernelGGL(k_repack, dim3(64, h->n_seg), dim3(256), 0, s, static_cast<const Seg*>(h->ws["repack_segs"].p),
+                       static_cast<const uint32_t*>(h->ws["repack_idx"].p), W(h, "Wflat"));
+    for (const char* n : {"vae_enc/conv1", "vae_enc/conv2", "vae_enc/conv3", "vae_dec/deconv1", "vae_dec/deconv2",
+                          "vae_dec/deconv3", "vae_dec/deconv4"}) {
+        const std::string p(n);
+        const int C = (int)h->slots.at(p + "/b").n;
+        hipLaunchKernelGGL(k_refold, dim3((C + 63) / 64), dim3(64), 0, s, W(h, "Wflat"), h->dev.at(p + "/shift").f(),
+                           h->dev.at(p + "/scale").f(), h->slots.at(p + "/b").off, h->slots.at(p + "/bn/beta").off,
+                           h->slots.at(p + "/bn/moving_mean").off, C);
+    }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
 }
 
 }  // namespace
@@ -75,6 +283,10 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     };
     for (const B& b : bufs)
         if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
+    if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss buffers");
+    if (int rc = build_repack_maps(h)) return rc;
+    h->adam_t = 0;
     h->training = true;
     return DESIRE_OK;
 }
@@ -277,5 +489,66 @@ extern "C" int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n) 
     if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
     *dev_ptr = W(h, "Gflat");
     *n = h->n_params;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_train_loss(desire_handle* h, const float* dev_fut, float* host_out5, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (!dev_fut || !host_out5) return fail(DESIRE_ERR_ARG, "null argument");
+    const desire_dims& d = h->d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["valid"].p);
+    hipLaunchKernelGGL(k_train_loss, dim3((h->A + 63) / 64), dim3(64), 0, s, W(h, "Y0"), W(h, "Y_ref"), dev_fut, W(h, "score_sv"),
+                       W(h, "params"), valid, W(h, "loss_pa"), d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy);
+    hipLaunchKernelGGL(k_sum_loss, dim3(1), dim3(256), 0, s, W(h, "loss_pa"), valid, h->A, W(h, "loss_out"));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(host_out5, W(h, "loss_out"), 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return DESIRE_OK;
+}
+
+extern "C" int desire_adam_step(desire_handle* h, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return fail(DESIRE_ERR_ARG, "bad Adam hyper-parameters");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int t = ++h->adam_t;
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t));
+    hipLaunchKernelGGL(k_adam, dim3(1024), dim3(256), 0, s, W(h, "Wflat"), W(h, "Gflat"), W(h, "Mflat"), W(h, "Vflat"), h->n_params,
+                       (float)lr_t, beta1, beta2, eps);
+    return repack(h, s);
+}
+
+extern "C" int desire_get_weight(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
+    if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
+    auto w = h->want.find(name);
+    if (w == h->want.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
+    if (w->second != n) return fail(DESIRE_ERR_ARG, std::string(name) + ": expected " + std::to_string(w->second) + " values");
+    if (h->training) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(host_out, W(h, "Wflat") + h->slots.at(name).off, n * sizeof(float), hipMemcpyDeviceToHost));
+        return DESIRE_OK;
+    }
+    auto it = h->host_w.find(name);
+    if (it == h->host_w.end()) return fail(DESIRE_ERR_STATE, std::string("weight not set: ") + name);
+    std::memcpy(host_out, it->second.data(), n * sizeof(float));
+    return DESIRE_OK;
+}
+
+extern "C" int desire_clip_grads(desire_handle* h, float max_norm, float* host_norm_out, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (!(max_norm > 0.f)) return fail(DESIRE_ERR_ARG, "max_norm must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* part = W(h, "tn_partial");
+    hipLaunchKernelGGL(k_sqsum, dim3(512), dim3(256), 0, s, W(h, "Gflat"), h->n_params, part);
+    hipLaunchKernelGGL(k_clip_scale, dim3(512), dim3(256), 0, s, W(h, "Gflat"), h->n_params, part, 512, max_norm, W(h, "loss_out") + 6);
+    HIPCHK(hipGetLastError());
+    if (host_norm_out) {
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(host_norm_out, W(h, "loss_out") + 6, sizeof(float), hipMemcpyDeviceToHost));
+    }
     return DESIRE_OK;
 }

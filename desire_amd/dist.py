@@ -40,3 +40,18 @@ def gather_results(local, n_windows: int, group=None):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0)
+
+
+def allreduce_mean_(flat, group=None):
+    """In-place mean of ONE flat gradient tensor over the data-parallel ranks (no-op when torch.distributed is not
+    initialised or world_size == 1).  Each rank's loss is a mean over ITS present agents, so this is the usual
+    data-parallel estimate of the global-batch gradient.  RCCL over xGMI on GPU tensors, gloo on CPU tensors."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    return flat

@@ -142,6 +142,39 @@ class DESIREModel(object):
             self.cost = None
         return Y, score
 
+    # ---- training (train.py:140-181 runs only `cost`; the Adam op of model/model.py:386-403 is never applied) ----
+    def train_step(self, x_batch: Sequence[np.ndarray], y_batch: Sequence[np.ndarray], eps: Optional[np.ndarray] = None,
+                   seed: int = 0, group=None) -> Dict[str, float]:
+        """One optimiser step on a batch of loader windows: forward (posterior path), backward, gradient mean over
+        the data-parallel ranks (RCCL all-reduce of ONE flat buffer when torch.distributed is initialised),
+        clip_by_global_norm(args.grad_clip), Adam(args.learning_rate).  Returns the loss terms of DESIGN.md section 8
+        evaluated BEFORE the update (what `sess.run([cost, train_op])` would have returned)."""
+        from .dist import allreduce_mean_
+        h = self._handle(len(x_batch), True)
+        if not getattr(h, "_training_on", False):
+            h.set_training(True)
+            h._training_on = True
+        self.forward(x_batch, y_batch, eps, seed)
+        past, fut, eps_t = self._keep
+        stream = self.torch.cuda.current_stream().cuda_stream
+        h.backward(past.data_ptr(), fut.data_ptr(), eps_t.data_ptr(), stream)
+        allreduce_mean_(h.grad_tensor(), group)
+        clip = float(getattr(self.args, "grad_clip", 0.0) or 0.0)
+        if clip > 0:
+            h.clip_grads(clip, stream=stream)
+        terms = h.train_loss(fut.data_ptr(), stream)
+        h.adam_step(self.learning_rate, stream=stream)
+        self._trained = h
+        return terms
+
+    def sync_weights(self) -> Dict[str, np.ndarray]:
+        """Pull the trained weights back from the device; other handles (batch sizes / prior path) are rebuilt lazily."""
+        h = getattr(self, "_trained", None)
+        if h is not None:
+            self._weights = {k: h.get_weight(k, np.shape(v)) for k, v in self._weights.items()}
+            self._handles = {k: v for k, v in self._handles.items() if v is h}
+        return self._weights
+
     def forward_from_video(self, frames, starts: Sequence[int], posterior: bool = True, eps=None, seed: int = 0):
         """Device-side batching: `frames` [F, max_num_obj, 3] is one preprocessed video
         (DataLoader.data[i]); the windows starting at `starts` are cut and slot-assigned on the GPU with the
@@ -189,7 +222,7 @@ class DESIREModel(object):
         from .formats import save_weights
         if self._weights is None:
             raise ValueError("no weights yet: run forward() once or pass weights=")
-        save_weights(path, self._weights)
+        save_weights(path, self.sync_weights())
 
     @classmethod
     def restore(cls, args, path: str) -> "DESIREModel":

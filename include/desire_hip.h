@@ -142,6 +142,17 @@ int desire_set_training(desire_handle* h, int enable);
 int desire_backward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps, void* stream);
 int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
 int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n);
+/* Loss terms of the last training-mode forward, means over present agents:
+ * host_out5 = {recon, kld, cross_entropy, regression, n_present};  loss = sum of the first four. */
+int desire_train_loss(desire_handle* h, const float* dev_fut, float* host_out5, void* stream);
+/* tf.clip_by_global_norm (model/model.py:390) on the flat gradient buffer, in place; host_norm_out (optional, may be
+ * NULL: then no synchronisation) receives the pre-clip norm. */
+int desire_clip_grads(desire_handle* h, float max_norm, float* host_norm_out, void* stream);
+/* One tf.train.AdamOptimizer update (model/model.py:394; lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) of the device master weights
+ * from the flat gradient buffer, followed by a device-side rebuild of every packed operand.  No host round trip. */
+int desire_adam_step(desire_handle* h, float lr, float beta1, float beta2, float eps, void* stream);
+/* Current value of a weight (the trained one in training mode), natural TF layout. */
+int desire_get_weight(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
 
 /* Per-kernel GPU time measured with hipEvents on the launch stream (enabled by
  * desire_set_profiling(h,1); adds two event records per kernel, nothing else).  Entries accumulate

@@ -64,3 +64,134 @@ def test_weight_gradient_matches_autograd(grads_case, name):
         assert np.abs(got).max() < 1e-6
         return
     assert rel_err(got, ref[name]) < 2e-4, (name, rel_err(got, ref[name]), np.abs(ref[name]).max())
+
+
+def _fresh(d, w):
+    import torch
+    from desire_amd import _lib
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    dev = torch.device("cuda")
+    past, fut, eps, grids, gos = make_case(d, seed=42, n_absent=4)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    ten = dict(past=t(past), fut=t(fut), eps=t(eps), grids=t(grids))
+    h.set_scene_grids(ten["grids"].data_ptr(), gos)
+    ten["Y"] = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    ten["score"] = torch.zeros((d.R,), device=dev)
+    return h, ten
+
+
+def _fwd(h, ten):
+    h.forward(ten["past"].data_ptr(), ten["fut"].data_ptr(), ten["eps"].data_ptr(), ten["Y"].data_ptr(), ten["score"].data_ptr())
+
+
+def _bwd(h, ten):
+    h.backward(ten["past"].data_ptr(), ten["fut"].data_ptr(), ten["eps"].data_ptr())
+
+
+def test_train_loss_matches_oracle(grads_case):
+    import torch
+    d, w, h, ref, vals = grads_case
+    past, fut, eps, grids, gos = make_case(d, seed=42, n_absent=4)
+    fut_t = torch.as_tensor(np.ascontiguousarray(fut), device="cuda")
+    got = h.train_loss(fut_t.data_ptr())
+    v = to_oracle_layout(past)[d.T_obs - 1, :, 0] != 0
+    n = max(v.sum(), 1)
+    for key in ("recon", "kld", "ce", "reg"):
+        want = float((vals[key] * v).sum() / n)
+        assert abs(got[key] - want) <= 2e-5 * max(1.0, abs(want)), (key, got[key], want)
+    assert got["n_present"] == n
+    assert abs(got["loss"] - float(vals["loss"])) < 1e-4 * max(1.0, abs(float(vals["loss"])))
+
+
+def test_adam_step_matches_tf_formula(grads_case):
+    from oracle import desire_torch as OT
+    d, w, _, _, _ = grads_case
+    h, ten = _fresh(d, w)
+    names = ["dec/gates/kernel", "ioc/social_fc/w", "vae_dec/deconv2/w", "vae_enc/conv1/b", "head/b", "enc_x/candidate/kernel"]
+    m = {k: np.zeros(w[k].shape) for k in names}
+    v = {k: np.zeros(w[k].shape) for k in names}
+    cur = {k: w[k].astype(np.float64) for k in names}
+    for step in (1, 2, 3):
+        _fwd(h, ten); _bwd(h, ten)
+        g = {k: h.get_grad(k, w[k].shape).astype(np.float64) for k in names}
+        h.adam_step(0.001)
+        for k in names:
+            cur[k], m[k], v[k] = OT.adam_step(cur[k], g[k], m[k], v[k], step, lr=0.001)
+            got = h.get_weight(k, w[k].shape)
+            assert np.abs(got - cur[k]).max() < 1e-6, (k, step)
+            cur[k] = got.astype(np.float64)        # follow the device weights so rounding does not accumulate
+    # frozen batch-norm statistics and the gradient-free auxiliaries never move
+    for k in ("vae_dec/deconv2/bn/gamma", "vae_enc/conv2/bn/moving_var", "scene_cnn/conv1/w", "temporal/w"):
+        assert np.array_equal(h.get_weight(k, w[k].shape), w[k])
+
+
+def test_device_repack_equals_host_pack(grads_case):
+    """After Adam the packed operands are rebuilt on the device; a fresh handle packing the same weights on the host
+    must produce the same forward."""
+    import torch
+    d, w, _, _, _ = grads_case
+    h, ten = _fresh(d, w)
+    for _ in range(2):
+        _fwd(h, ten); _bwd(h, ten); h.adam_step(0.01)
+    _fwd(h, ten)
+    torch.cuda.synchronize()
+    Y1, s1 = ten["Y"].cpu().numpy().copy(), ten["score"].cpu().numpy().copy()
+    w2 = {k: h.get_weight(k, v.shape) for k, v in w.items()}
+    assert any(not np.array_equal(w2[k], w[k]) for k in w)
+    h2, ten2 = _fresh(d, w2)
+    _fwd(h2, ten2)
+    torch.cuda.synchronize()
+    assert np.abs(ten2["Y"].cpu().numpy() - Y1).max() < 2e-6
+    assert np.abs(ten2["score"].cpu().numpy() - s1).max() < 2e-5
+    # and backward through the rebuilt transposed operands
+    _bwd(h, ten); _bwd(h2, ten2)
+    for k in ("dec/gates/kernel", "ioc/gates/kernel", "enc_x/gates/kernel", "vae_enc/conv2/w", "vae_dec/deconv3/w"):
+        a, b = h.get_grad(k, w[k].shape), h2.get_grad(k, w[k].shape)
+        assert rel_err(a, b) < 1e-4, k
+
+
+def test_clip_by_global_norm(grads_case):
+    d, w, _, _, _ = grads_case
+    h, ten = _fresh(d, w)
+    _fwd(h, ten); _bwd(h, ten)
+    g = h.grad_tensor()
+    n0 = float(g.double().norm())
+    got = h.clip_grads(n0 * 10, want_norm=True)
+    assert abs(got - n0) < 1e-4 * n0
+    assert abs(float(g.double().norm()) - n0) < 1e-6 * n0           # under the limit: untouched
+    h.clip_grads(n0 / 4)
+    assert abs(float(g.double().norm()) - n0 / 4) < 1e-4 * n0
+
+
+def test_loss_decreases_on_a_fixed_batch(grads_case):
+    d, w, _, _, _ = grads_case
+    h, ten = _fresh(d, w)
+    losses = []
+    for _ in range(40):
+        _fwd(h, ten); _bwd(h, ten)
+        losses.append(h.train_loss(ten["fut"].data_ptr())["loss"])
+        h.clip_grads(10.0)
+        h.adam_step(0.002)
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.7 * losses[0], losses[::8]
+
+
+def test_model_train_step_and_checkpoint(tmp_path):
+    from types import SimpleNamespace
+    from desire_amd.model import DESIREModel
+    args = SimpleNamespace(seq_length=6, pred_length=7, d_dim=64, rnn_size=512, latent_size=64, max_num_obj=8, learning_rate=0.0005,
+                           grad_clip=10.0, neighborhood_size=256, grid_size=4, num_samples=3, batch_size=2)
+    m = DESIREModel(args, seed=3)
+    rng = np.random.default_rng(0)
+    x = [np.concatenate([np.arange(1, 9, dtype=np.float32)[None, :, None].repeat(6, 0), rng.uniform(200, 1800, (6, 8, 2)).astype(np.float32)], -1) for _ in range(2)]
+    y = [np.concatenate([np.arange(1, 9, dtype=np.float32)[None, :, None].repeat(7, 0), rng.uniform(200, 1800, (7, 8, 2)).astype(np.float32)], -1) for _ in range(2)]
+    ls = [m.train_step(x, y, seed=1)["loss"] for _ in range(30)]
+    assert ls[-1] < ls[0], ls[::5]
+    p = str(tmp_path / "w.npz")
+    m.save(p)
+    m2 = DESIREModel.restore(args, p)
+    Ya, _ = m.forward(x, y, seed=1)
+    Yb, _ = m2.forward(x, y, seed=1)
+    assert float((Ya - Yb).abs().max()) < 2e-6
