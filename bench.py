@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--windows", type=int, default=128, help="loader windows (scenes) per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--train", action="store_true",
+                    help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
+                         "not the BASELINE metric -- the default run is")
     a = ap.parse_args()
 
     import torch
@@ -139,8 +142,18 @@ def main():
     score = torch.zeros((d.R,), device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    if a.train:
+        from desire_amd.dist import allreduce_mean_
+        h.set_training(True)
+        gflat = h.grad_tensor()
+
     def step():
         h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
+        if a.train:
+            h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), stream)
+            allreduce_mean_(gflat)
+            h.clip_grads(10.0, stream=stream)
+            h.adam_step(1e-4, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -173,7 +186,20 @@ def main():
     ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12
     whole_tflops = flops_per_sample(d) * d.R * a.steps / dt / 1e12
 
-    if rank == 0:
+    if rank == 0 and a.train:
+        samples = d.R * world * a.steps
+        fwd = sum(v for k, v in kern_ms.items() if not k.startswith("bwd_"))
+        bwd = sum(v for k, v in kern_ms.items() if k.startswith("bwd_"))
+        print(json.dumps({
+            "metric": "TRAINING agent-trajectory-samples/sec (K=20, T_pred=40; fwd+bwd+allreduce+clip+Adam+repack)",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU" % a.windows,
+                       "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
+            "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
+            "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))
+    elif rank == 0:
         samples = d.R * world * a.steps
         out = {
             "metric": "agent-trajectory-samples/sec (K=20, T_pred=40)",

@@ -227,9 +227,114 @@ __global__ void k_reduce_slices(const float* __restrict__ partial, int nslices, 
     float* o = out + (size_t)(i / N) * ldo + (i % N);
     *o = accumulate ? (*o + s) : s;
 }
+// Large blocks: (WK*64) x (WN*64) output tile per workgroup (WK*WN = 4 waves, each 2x2 32x32 tiles), 32-row chunks of
+// m double-buffered in LDS, next chunk's global float4 loads issued before the current chunk's 64 MFMAs per wave.  A
+// lane owns the column PAIR (2c, 2c+1) of its wave's 64-wide strip, so one ds_read_b64 per operand feeds two tiles
+// (the output index map absorbs the interleave).  Needs 16-byte aligned rows (lda, ldg, Kd, N multiples of 4).
+// CONV: the A operand is the im2col view of a convolution's large-grid tensor (ConvGather), column = tap*Cl + cl,
+// row m = (sample, small-grid pixel) -- the weight gradient of a (transposed) convolution as ONE [25*Cl] x [Cs] GEMM.
+struct ConvGather { int Cl, Pl, Ps, stride, pad; };
+template <int WK, int WN, bool CONV>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
+    constexpr int BK = WK * 64, BN = WN * 64, QA = BK / 4, QG = BN / 4, PA = 32 / (256 / QA), PG = 32 / (256 / QG);
+    __shared__ __attribute__((aligned(16))) float As[2][32 * BK];
+    __shared__ __attribute__((aligned(16))) float Gs[2][32 * BN];
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int nbn = (a.N + BN - 1) / BN;
+    const int bk = (blockIdx.x / nbn) * BK, bn = (blockIdx.x % nbn) * BN;
+    const int wk = w / WN, wn = w % WN;
+    const long mper = ((a.M + a.nslices - 1) / a.nslices + 31) / 32 * 32;
+    const long m_lo = (long)blockIdx.y * mper, m_hi = min(a.M, m_lo + mper);
+    const int hi = lane >> 5, c = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = zero16();
+    const int qa = tid % QA, ra0 = tid / QA, qg = tid % QG, rg0 = tid / QG;
+    const int kcol = bk + 4 * qa;
+    const bool ka = kcol < a.Kd, na = bn + 4 * qg < a.N;
+    int ky = 0, kx = 0, cl = 0;
+    if (CONV) { const int tap = kcol / cg.Cl; cl = kcol - tap * cg.Cl; ky = tap / 5; kx = tap - ky * 5; }
+    const int PP = cg.Ps * cg.Ps;
+    float4 ra[PA], rg[PG];
+    auto gload = [&](long m0) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const long m = m0 + ra0 + (256 / QA) * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi && ka) {
+                if (CONV) {
+                    const long n = m / PP; const int p = (int)(m - n * PP);
+                    const int py = p / cg.Ps, px = p - py * cg.Ps;
+                    const int qy = cg.stride * py + ky - cg.pad, qx = cg.stride * px + kx - cg.pad;
+                    if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
+                        v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
+                } else {
+                    v = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + kcol);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const long m = m0 + rg0 + (256 / QG) * j;
+            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)m * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) *reinterpret_cast<float4*>(&As[buf][(ra0 + (256 / QA) * j) * BK + 4 * qa]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < PG; ++j) *reinterpret_cast<float4*>(&Gs[buf][(rg0 + (256 / QG) * j) * BN + 4 * qg]) = rg[j];
+    };
+    if (m_lo < m_hi) { gload(m_lo); lstore(0); }
+    __syncthreads();
+    int buf = 0;
+    for (long m0 = m_lo; m0 < m_hi; m0 += 32) {
+        const bool more = m0 + 32 < m_hi;
+        if (more) gload(m0 + 32);
+        const float* ap = &As[buf][hi * BK + wk * 64 + 2 * c];
+        const float* gp = &Gs[buf][hi * BN + wn * 64 + 2 * c];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float2 av = *reinterpret_cast<const float2*>(ap + p * 2 * BK);
+            const float2 gv = *reinterpret_cast<const float2*>(gp + p * 2 * BN);
+            acc[0][0] = mfma32(av.x, gv.x, acc[0][0]);
+            acc[0][1] = mfma32(av.x, gv.y, acc[0][1]);
+            acc[1][0] = mfma32(av.y, gv.x, acc[1][0]);
+            acc[1][1] = mfma32(av.y, gv.y, acc[1][1]);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = bk + wk * 64 + 2 * acc_row(i) + u, n = bn + wn * 64 + 2 * c + v;
+                if (k < a.Kd && n < a.N) out[(size_t)k * a.N + n] = acc[u][v][i];
+            }
+}
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s) {
-    const int nb = ((a.Kd + 63) / 64) * ((a.N + 63) / 64);
-    hipLaunchKernelGGL(k_gemm_tn, dim3(nb, a.nslices), dim3(256), 0, s, a);
+    const bool big = a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
+                     !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);
+    if (big) {
+        if (a.N <= 64) {
+            const int nb = (a.Kd + 255) / 256;
+            hipLaunchKernelGGL((k_gemm_tn2<4, 1, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
+        } else {
+            const int nb = ((a.Kd + 127) / 128) * ((a.N + 127) / 128);
+            hipLaunchKernelGGL((k_gemm_tn2<2, 2, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
+        }
+    } else {
+        const int nb = ((a.Kd + 63) / 64) * ((a.N + 63) / 64);
+        hipLaunchKernelGGL(k_gemm_tn, dim3(nb, a.nslices), dim3(256), 0, s, a);
+    }
     const int n = a.Kd * a.N;
     hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.nslices, a.Kd, a.N, out, ldo, accumulate);
 }
@@ -246,8 +351,74 @@ __global__ void k_colsum(const float* __restrict__ G, int ldg, long M, int N, in
     __syncthreads();
     if (q == 0 && n < N) partial[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// float4 variant for N = 4 * VN with VN a power of two <= 256: thread owns one float4 column and every (256/VN)-th row,
+// four independent loads in flight; the workgroup covers all N columns, blockIdx.x = slice.
+__global__ __launch_bounds__(256) void k_colsum4(const float* __restrict__ G, int ldg, long M, int N, int nslices, float* __restrict__ partial) {
+    __shared__ float4 red[256];
+    const int VN = N >> 2, RP = 256 / VN;
+    const int cv = threadIdx.x % VN, ro = threadIdx.x / VN;
+    const long mper = (M + nslices - 1) / nslices;
+    const long lo = (long)blockIdx.x * mper, hi = min(M, lo + mper);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    const float* base = G + 4 * cv;
+    long m = lo + ro;
+    for (; m + 3 * RP < hi; m += 4 * RP) {
+        const float4 x0 = *reinterpret_cast<const float4*>(base + (size_t)m * ldg);
+        const float4 x1 = *reinterpret_cast<const float4*>(base + (size_t)(m + RP) * ldg);
+        const float4 x2 = *reinterpret_cast<const float4*>(base + (size_t)(m + 2 * RP) * ldg);
+        const float4 x3 = *reinterpret_cast<const float4*>(base + (size_t)(m + 3 * RP) * ldg);
+        s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+        s1.x += x1.x; s1.y += x1.y; s1.z += x1.z; s1.w += x1.w;
+        s2.x += x2.x; s2.y += x2.y; s2.z += x2.z; s2.w += x2.w;
+        s3.x += x3.x; s3.y += x3.y; s3.z += x3.z; s3.w += x3.w;
+    }
+    for (; m < hi; m += RP) {
+        const float4 x0 = *reinterpret_cast<const float4*>(base + (size_t)m * ldg);
+        s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+    }
+    s0.x = (s0.x + s1.x) + (s2.x + s3.x); s0.y = (s0.y + s1.y) + (s2.y + s3.y);
+    s0.z = (s0.z + s1.z) + (s2.z + s3.z); s0.w = (s0.w + s1.w) + (s2.w + s3.w);
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    if (ro == 0) {
+        float4 t = red[cv];
+        for (int j = 1; j < RP; ++j) { const float4 y = red[j * VN + cv]; t.x += y.x; t.y += y.y; t.z += y.z; t.w += y.w; }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * N + 4 * cv) = t;
+    }
+}
+__global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ G, long n4, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    const float4* g = reinterpret_cast<const float4*>(G);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long st = (long)gridDim.x * 256;
+    for (; i + st < n4; i += 2 * st) {
+        const float4 x = g[i], y = g[i + st];
+        s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+        s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
+    }
+    if (i < n4) { const float4 x = g[i]; s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w; }
+    red[threadIdx.x] = ((s0.x + s1.x) + (s0.y + s1.y)) + ((s0.z + s1.z) + (s0.w + s1.w));
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
+    if (N == 1 && ldg == 1 && !(M & 3) && !(reinterpret_cast<uintptr_t>(G) & 15) && M >= 4096) {
+        const int nb = 1024;
+        hipLaunchKernelGGL(k_sum_all, dim3(nb), dim3(256), 0, s, G, M / 4, partial);
+        hipLaunchKernelGGL(k_reduce_slices, dim3(1), dim3(256), 0, s, partial, nb, 1, 1, out, 1, accumulate);
+        return;
+    }
+    const int VN = N >> 2;
+    const bool vec = !(N & 3) && VN >= 1 && VN <= 256 && !(VN & (VN - 1)) && !(ldg & 3) && !(reinterpret_cast<uintptr_t>(G) & 15);
+    if (vec) {
+        long sl = M / 256; if (sl < 1) sl = 1; if (sl > 2048) sl = 2048;
+        nslices = (int)sl;
+        hipLaunchKernelGGL(k_colsum4, dim3(nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
+    } else {
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
+    }
     hipLaunchKernelGGL(k_reduce_slices, dim3((N + 255) / 256), dim3(256), 0, s, partial, nslices, 1, N, out, N, accumulate);
 }
 
@@ -360,6 +531,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     }
 }
 void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s) {
+    if (a.Cl % 4 == 0 && a.Cs % 64 == 0) {
+        TnArgs t{};
+        t.A = a.Lg; t.lda = 0; t.G = a.S; t.ldg = a.Cs; t.M = (long)a.n * a.Ps * a.Ps; t.Kd = 25 * a.Cl; t.N = a.Cs;
+        t.nslices = nslices; t.partial = a.partial;
+        const ConvGather cg{a.Cl, a.Pl, a.Ps, a.stride, a.pad};
+        if (a.Cs <= 64) hipLaunchKernelGGL((k_gemm_tn2<4, 1, true>), dim3((t.Kd + 255) / 256, nslices), dim3(256), 0, s, t, cg);
+        else hipLaunchKernelGGL((k_gemm_tn2<2, 2, true>), dim3(((t.Kd + 127) / 128) * ((t.N + 127) / 128), nslices), dim3(256), 0, s, t, cg);
+        const int n = 25 * a.Cl * a.Cs;
+        hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0);
+        return;
+    }
     const size_t lds = 64 * (a.Cl + 4 + a.Cs + 4) * sizeof(float);
     hipLaunchKernelGGL(k_conv_wgrad, dim3(25, nslices), dim3(256), lds, s, a);
     const int n = 25 * a.Cl * a.Cs;

@@ -377,8 +377,8 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     // ---- CVAE decoder (each data gradient = the forward kernel of the mirrored layer with a gradient epilogue) ----
     {
         Timer t(h, s, "bwd_cvae_dec");
-        const int NSL = 40;
-        launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)R, 256, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
+        const int NSL = 78;
+        launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)R, R < 2048 ? (int)R : 2048, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
         colsum(h, W(h, "dconv4"), 1, R * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
         ConvArgs c{};
         c.n = (int)R;
@@ -416,7 +416,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         g.A = W(h, "dparams"); g.lda = 2 * L; g.M = A; g.K = 2 * L; g.Bp = D4(h, "vae_enc/fc/WT"); g.G = 2 * L / 8; g.NT = 64;
         g.out = W(h, "dconvE3"); g.ldo = 2048; g.N = 2048; g.p0 = D(h, "vae_enc/conv3/scale"); g.chmod = 128; g.aux = W(h, "c3");
         launch_gemm_rows(g, EPI_ELUGRAD, s);
-        const int NSL = 8;
+        const int NSL = A >= 2048 ? 64 : (A >= 256 ? 16 : 4);
         ConvWgradArgs wg{};
         wg.n = A; wg.partial = W(h, "tn_partial");
         wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
@@ -515,6 +515,7 @@ extern "C" int desire_adam_step(desire_handle* h, float lr, float beta1, float b
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int t = ++h->adam_t;
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t));
+    Timer tm(h, s, "bwd_adam_repack");
     hipLaunchKernelGGL(k_adam, dim3(1024), dim3(256), 0, s, W(h, "Wflat"), W(h, "Gflat"), W(h, "Mflat"), W(h, "Vflat"), h->n_params,
                        (float)lr_t, beta1, beta2, eps);
     return repack(h, s);
