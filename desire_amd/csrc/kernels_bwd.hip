@@ -320,7 +320,97 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
                 if (k < a.Kd && n < a.N) out[(size_t)k * a.N + n] = acc[u][v][i];
             }
 }
+// same sum, 8 lanes per output striding the slices, then a fixed-order LDS combine (still deterministic)
+__global__ __launch_bounds__(256) void k_reduce_slices8(const float* __restrict__ partial, int nslices, int Kd, int N, float* __restrict__ out,
+                                                        int ldo, int accumulate) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (i < Kd * N) for (int sl = g; sl < nslices; sl += 8) s += partial[(size_t)sl * Kd * N + i];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < Kd * N) {
+        const float t = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+        float* o = out + (size_t)(i / N) * ldo + (i % N);
+        *o = accumulate ? (*o + t) : t;
+    }
+}
+static void reduce_slices(const float* partial, int nslices, int Kd, int N, float* out, int ldo, int accumulate, hipStream_t s) {
+    const int n = Kd * N;
+    if (nslices >= 32 && n <= (1 << 18))
+        hipLaunchKernelGGL(k_reduce_slices8, dim3((n + 31) / 32), dim3(256), 0, s, partial, nslices, Kd, N, out, ldo, accumulate);
+    else
+        hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, partial, nslices, Kd, N, out, ldo, accumulate);
+}
+
+// Skinny weight gradients (one side <= 4 wide: the 2-d output head, the scalar score head, the 2-d velocity input):
+//   out[k, j] = sum_m W[m, k] * Nn[m, j],  W wide (KW = 4*VW columns, VW a power of two <= 256), Nn narrow (NN <= 4).
+// HBM-bound streaming of W: thread owns one float4 column of W and every (256/VW)-th row.  transpose_out writes out[j, k].
+template <int NN>
+__global__ __launch_bounds__(256) void k_tn_skinny(const float* __restrict__ Wd, int ldw, int KW, const float* __restrict__ Nn, int ldn,
+                                                   long M, int nslices, float* __restrict__ partial) {
+    __shared__ float4 red[256];
+    const int VW = KW >> 2, RP = 256 / VW;
+    const int cv = threadIdx.x % VW, ro = threadIdx.x / VW;
+    const long mper = (M + nslices - 1) / nslices;
+    const long lo = (long)blockIdx.x * mper, hi = min(M, lo + mper);
+    float4 acc[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* base = Wd + 4 * cv;
+#pragma unroll 4
+    for (long m = lo + ro; m < hi; m += RP) {
+        const float4 x = *reinterpret_cast<const float4*>(base + (size_t)m * ldw);
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const float g = Nn[(size_t)m * ldn + j];
+            acc[j].x = fmaf(x.x, g, acc[j].x); acc[j].y = fmaf(x.y, g, acc[j].y);
+            acc[j].z = fmaf(x.z, g, acc[j].z); acc[j].w = fmaf(x.w, g, acc[j].w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        __syncthreads();
+        red[threadIdx.x] = acc[j];
+        __syncthreads();
+        if (ro == 0) {
+            float4 t = red[cv];
+            for (int q = 1; q < RP; ++q) { const float4 y = red[q * VW + cv]; t.x += y.x; t.y += y.y; t.z += y.z; t.w += y.w; }
+            float* o = partial + (size_t)blockIdx.x * KW * NN;      // [k][j]
+            o[(4 * cv + 0) * NN + j] = t.x; o[(4 * cv + 1) * NN + j] = t.y; o[(4 * cv + 2) * NN + j] = t.z; o[(4 * cv + 3) * NN + j] = t.w;
+        }
+    }
+}
+__global__ void k_reduce_slices_t(const float* __restrict__ partial, int nslices, int KW, int NN, float* __restrict__ out, int ldo, int accumulate) {
+    // partial [slice][k][j] -> out[j][k] (ld = ldo)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KW * NN) return;
+    float s = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) s += partial[(size_t)sl * KW * NN + i];
+    float* o = out + (size_t)(i % NN) * ldo + (i / NN);
+    *o = accumulate ? (*o + s) : s;
+}
+static bool skinny(const float* Wd, int ldw, int KW, const float* Nn, int ldn, int NN, long M, float* partial, float* out, int ldo,
+                   int accumulate, bool transpose_out, hipStream_t s) {
+    const int VW = KW >> 2;
+    if ((KW & 3) || VW < 1 || VW > 256 || (VW & (VW - 1)) || (ldw & 3) || (reinterpret_cast<uintptr_t>(Wd) & 15) || NN < 1 || NN > 4) return false;
+    long sl = M / 512; if (sl < 1) sl = 1; if (sl > 512) sl = 512;
+    const int ns = (int)sl;
+    switch (NN) {
+        case 1: hipLaunchKernelGGL(k_tn_skinny<1>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
+        case 2: hipLaunchKernelGGL(k_tn_skinny<2>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
+        case 3: hipLaunchKernelGGL(k_tn_skinny<3>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
+        default: hipLaunchKernelGGL(k_tn_skinny<4>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
+    }
+    if (transpose_out) hipLaunchKernelGGL(k_reduce_slices_t, dim3((KW * NN + 255) / 256), dim3(256), 0, s, partial, ns, KW, NN, out, ldo, accumulate);
+    else reduce_slices(partial, ns, KW, NN, out, ldo, accumulate, s);
+    return true;
+}
+
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s) {
+    if (a.N <= 4 && a.Kd >= 16 && skinny(a.A, a.lda, a.Kd, a.G, a.ldg, a.N, a.M, a.partial, out, ldo, accumulate, false, s)) return;
+    if (a.Kd <= 4 && a.N >= 16 && skinny(a.G, a.ldg, a.N, a.A, a.lda, a.Kd, a.M, a.partial, out, ldo, accumulate, true, s)) return;
     const bool big = a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
                      !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);
     if (big) {
@@ -335,8 +425,7 @@ void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStr
         const int nb = ((a.Kd + 63) / 64) * ((a.N + 63) / 64);
         hipLaunchKernelGGL(k_gemm_tn, dim3(nb, a.nslices), dim3(256), 0, s, a);
     }
-    const int n = a.Kd * a.N;
-    hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.nslices, a.Kd, a.N, out, ldo, accumulate);
+    reduce_slices(a.partial, a.nslices, a.Kd, a.N, out, ldo, accumulate, s);
 }
 
 // ---- column sums: out[N] (+)= sum_m G[m, N] ---------------------------------------------------------------------------
@@ -407,7 +496,7 @@ void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* p
     if (N == 1 && ldg == 1 && !(M & 3) && !(reinterpret_cast<uintptr_t>(G) & 15) && M >= 4096) {
         const int nb = 1024;
         hipLaunchKernelGGL(k_sum_all, dim3(nb), dim3(256), 0, s, G, M / 4, partial);
-        hipLaunchKernelGGL(k_reduce_slices, dim3(1), dim3(256), 0, s, partial, nb, 1, 1, out, 1, accumulate);
+        reduce_slices(partial, nb, 1, 1, out, 1, accumulate, s);
         return;
     }
     const int VN = N >> 2;
@@ -419,7 +508,7 @@ void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* p
     } else {
         hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nslices), dim3(256), 0, s, G, ldg, M, N, nslices, partial);
     }
-    hipLaunchKernelGGL(k_reduce_slices, dim3((N + 255) / 256), dim3(256), 0, s, partial, nslices, 1, N, out, N, accumulate);
+    reduce_slices(partial, nslices, 1, N, out, N, accumulate, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -534,18 +623,25 @@ void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStrea
     if (a.Cl % 4 == 0 && a.Cs % 64 == 0) {
         TnArgs t{};
         t.A = a.Lg; t.lda = 0; t.G = a.S; t.ldg = a.Cs; t.M = (long)a.n * a.Ps * a.Ps; t.Kd = 25 * a.Cl; t.N = a.Cs;
+        {
+            const int nb = a.Cs <= 64 ? (t.Kd + 255) / 256 : ((t.Kd + 127) / 128) * ((t.N + 127) / 128);
+            long sl = 1024 / nb; const long maxsl = (t.M + 255) / 256;
+            if (sl > maxsl) sl = maxsl; if (sl < 1) sl = 1;
+            while ((size_t)sl * t.Kd * t.N * sizeof(float) > ((size_t)96 << 20) && sl > 1) sl /= 2;
+            nslices = (int)sl;
+        }
         t.nslices = nslices; t.partial = a.partial;
         const ConvGather cg{a.Cl, a.Pl, a.Ps, a.stride, a.pad};
         if (a.Cs <= 64) hipLaunchKernelGGL((k_gemm_tn2<4, 1, true>), dim3((t.Kd + 255) / 256, nslices), dim3(256), 0, s, t, cg);
         else hipLaunchKernelGGL((k_gemm_tn2<2, 2, true>), dim3(((t.Kd + 127) / 128) * ((t.N + 127) / 128), nslices), dim3(256), 0, s, t, cg);
         const int n = 25 * a.Cl * a.Cs;
-        hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0);
+        reduce_slices(a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0, s);
         return;
     }
     const size_t lds = 64 * (a.Cl + 4 + a.Cs + 4) * sizeof(float);
     hipLaunchKernelGGL(k_conv_wgrad, dim3(25, nslices), dim3(256), lds, s, a);
     const int n = 25 * a.Cl * a.Cs;
-    hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0);
+    reduce_slices(a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0, s);
 }
 
 // the two single-channel ends of the stack (deconv4: Lg = d(xhat-conv) [n,32,32], S = d3 [n,16,16,32];
@@ -591,7 +687,7 @@ __global__ __launch_bounds__(256) void k_w1ch_grad(const float* __restrict__ Lg,
 }
 void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_w1ch_grad, dim3(nslices), dim3(256), 0, s, Lg, S, n, partial);
-    hipLaunchKernelGGL(k_reduce_slices, dim3((800 + 255) / 256), dim3(256), 0, s, partial, nslices, 25, 32, out, 32, 0);
+    reduce_slices(partial, nslices, 25, 32, out, 32, 0, s);
 }
 
 // ---- reparameterisation + KLD backward:  dparams[a] = (dmu | dlogsig2) ---------------------------------------------

@@ -433,7 +433,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         c.in = W(h, "dconvE2"); c.out = W(h, "dconvE1"); c.Wp = D4(h, "vae_enc/conv2/Wbwd");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = c.scale; c.yprev = W(h, "c1");
         launch_deconv3(c, s);
-        launch_w1ch_grad(W(h, "vae_in"), W(h, "dconvE1"), A, A < 64 ? A : 64, W(h, "tn_partial"), G(h, "vae_enc/conv1/w"), s);
+        launch_w1ch_grad(W(h, "vae_in"), W(h, "dconvE1"), A, A < 1024 ? A : 1024, W(h, "tn_partial"), G(h, "vae_enc/conv1/w"), s);
         colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
         c.in = W(h, "dconvE1"); c.out = W(h, "dq_c"); c.w_raw = D(h, "vae_enc/conv1/raw"); c.mode = 2; c.yprev = W(h, "vae_in");
         launch_deconv4(c, s);
