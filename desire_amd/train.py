@@ -1,0 +1,146 @@
+"""Training loop -- host-side mirror of the reference's train.py:24-207 on top of libdesire_hip.so.
+
+Kept from the reference: the argparse flags and defaults of train.py:28-88, the epoch loop with
+`lr = learning_rate * decay_rate ** epoch` (train.py:122-126), `reset_batch_pointer()` per epoch, the save cadence
+`(epoch * num_batches + batch) % save_every == 0 and > 0` (train.py:197-206), the per-batch log line
+(train.py:185-193) and `save/config.pkl` (train.py:100-101).
+
+Different on purpose: the reference fetches only `cost` (train.py:181, its Adam op is never run) one window at a
+time; here every batch is ONE forward + backward + clip + Adam step over all `batch_size` windows
+(`DESIREModel.train_step`), the loader window is `seq_length + pred_length` frames split into past / future (the
+reference has one length and feeds the window shifted by a frame as "target"), and checkpoints are named fp32 `.npz`
+files (formats.save_weights) instead of TF checkpoints.  With torch.distributed initialised every rank takes its block
+of the batch's windows and gradients are averaged with one flat all-reduce (dist.allreduce_mean_).
+
+    python -m desire_amd.train --data_dir data/ --batch_size 16 --max_num_obj 32 --d_dim 128 --num_epochs 1
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import sys
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="DESIRE training on MI355X (flags of the reference's train.py:28-88)")
+    p.add_argument("--rnn_size", type=int, default=512)
+    p.add_argument("--num_layers", type=int, default=1)
+    p.add_argument("--model", type=str, default="gru")
+    p.add_argument("--batch_size", type=int, default=10)
+    p.add_argument("--seq_length", type=int, default=8)
+    p.add_argument("--num_epochs", type=int, default=100)
+    p.add_argument("--save_every", type=int, default=400)
+    p.add_argument("--grad_clip", type=float, default=10.0)
+    p.add_argument("--learning_rate", type=float, default=0.005)
+    p.add_argument("--decay_rate", type=float, default=0.95)
+    p.add_argument("--keep_prob", type=float, default=0.8)
+    p.add_argument("--embedding_size", type=int, default=64)
+    p.add_argument("--neighborhood_size", type=int, default=32)
+    p.add_argument("--grid_size", type=int, default=4)
+    p.add_argument("--max_num_obj", type=int, default=60)
+    p.add_argument("--leave_dataset", type=int, default=5)
+    p.add_argument("--latent_size", type=int, default=128)
+    p.add_argument("--e_dim", type=int, default=256)
+    p.add_argument("--d_dim", type=int, default=16)
+    p.add_argument("--stride", type=int, default=1)
+    # ---- not in the reference ----
+    p.add_argument("--pred_length", type=int, default=None, help="future frames (default: seq_length)")
+    p.add_argument("--num_samples", type=int, default=20, help="K futures per agent")
+    p.add_argument("--data_dir", type=str, default="data/")
+    p.add_argument("--traj_bin", type=str, default=None, help="DSRTRJ1 container instead of CSV/cpkl")
+    p.add_argument("--save_dir", type=str, default="save")
+    p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimiser steps (0 = all epochs)")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--fix_id0", action="store_true", help="keep SDD track id 0 (the reference drops it)")
+    return p
+
+
+def lr_at_epoch(args, epoch: int) -> float:
+    """train.py:122-126."""
+    return float(args.learning_rate) * float(args.decay_rate) ** int(epoch)
+
+
+def should_save(epoch: int, batch: int, num_batches: int, save_every: int) -> bool:
+    """train.py:197-199."""
+    step = epoch * num_batches + batch
+    return step % save_every == 0 and step > 0
+
+
+def split_windows(xval: Sequence[np.ndarray], t_obs: int) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """Loader windows of seq_length + pred_length frames -> (past [T_obs, MNO, 3], future [T_pred, MNO, 3])."""
+    past = [np.asarray(x)[:t_obs] for x in xval]
+    fut = [np.asarray(x)[t_obs:] for x in xval]
+    return past, fut
+
+
+def train(args, data_loader=None, model=None, log: Callable[[str], None] = print) -> List[float]:
+    """Runs the loop; returns the per-step losses.  `data_loader` / `model` may be injected (tests)."""
+    from .data_loader import DataLoader
+    from .dist import shard_batch
+    from .model import DESIREModel
+    import torch.distributed as dist
+
+    if args.pred_length is None:
+        args.pred_length = args.seq_length
+    t_obs, t_pred = int(args.seq_length), int(args.pred_length)
+    if data_loader is None:
+        data_loader = DataLoader(args.batch_size, t_obs + t_pred, args.max_num_obj, args.leave_dataset, preprocess=False,
+                                 data_dir=args.data_dir, traj_bin=args.traj_bin, fix_id0=args.fix_id0)
+    if data_loader.seq_length != t_obs + t_pred:
+        raise ValueError("the loader window must be seq_length + pred_length frames")
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    if rank == 0:
+        os.makedirs(args.save_dir, exist_ok=True)
+        with open(os.path.join(args.save_dir, "config.pkl"), "wb") as fh:
+            pickle.dump(args, fh)
+    if model is None:
+        model = DESIREModel(args, seed=args.seed)
+    losses: List[float] = []
+    steps = 0
+    for epoch in range(args.num_epochs):
+        model.learning_rate = lr_at_epoch(args, epoch)
+        data_loader.reset_batch_pointer()
+        for batch in range(data_loader.num_batches):
+            start = time.time()
+            xval, _, _ = data_loader.next_batch()
+            past, fut = split_windows(shard_batch(xval, rank, world), t_obs)
+            terms = model.train_step(past, fut, seed=args.seed + steps * world + rank)
+            losses.append(terms["loss"])
+            steps += 1
+            if rank == 0:
+                log("{}/{} (epoch {}), train_loss = {:.3f}, time/batch = {:.3f}".format(
+                    epoch * data_loader.num_batches + batch, args.num_epochs * data_loader.num_batches, epoch,
+                    terms["loss"], time.time() - start))
+                sys.stdout.flush()
+            if rank == 0 and should_save(epoch, batch, data_loader.num_batches, args.save_every):
+                path = os.path.join(args.save_dir, "social_model-%d.npz" % (epoch * data_loader.num_batches + batch))
+                model.save(path)
+                log("model saved to {}".format(path))
+            if args.max_steps and steps >= args.max_steps:
+                return losses
+    return losses
+
+
+def main(argv=None) -> None:
+    args = build_parser().parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    try:
+        train(args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

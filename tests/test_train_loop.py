@@ -1,0 +1,75 @@
+"""Host-side training loop (desire_amd/train.py) against the reference's train.py:24-207 behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from desire_amd import train as T
+
+
+def test_parser_defaults_are_the_reference_flags():
+    a = T.build_parser().parse_args([])
+    # train.py:30-85
+    ref = dict(rnn_size=512, num_layers=1, model="gru", batch_size=10, seq_length=8, num_epochs=100, save_every=400,
+               grad_clip=10.0, learning_rate=0.005, decay_rate=0.95, keep_prob=0.8, embedding_size=64, neighborhood_size=32,
+               grid_size=4, max_num_obj=60, leave_dataset=5, latent_size=128, e_dim=256, d_dim=16, stride=1)
+    for k, v in ref.items():
+        assert getattr(a, k) == v, k
+
+
+def test_lr_decay_and_save_cadence():
+    a = T.build_parser().parse_args([])
+    assert T.lr_at_epoch(a, 0) == 0.005
+    assert abs(T.lr_at_epoch(a, 3) - 0.005 * 0.95 ** 3) < 1e-15              # train.py:122-126
+    nb = 58
+    saves = [(e, b) for e in range(20) for b in range(nb) if T.should_save(e, b, nb, 400)]
+    assert saves[0] == (6, 52) and all((e * nb + b) % 400 == 0 for e, b in saves)   # train.py:197-199, never at step 0
+    assert not T.should_save(0, 0, nb, 400)
+
+
+def test_split_windows():
+    x = [np.arange(5 * 3 * 3, dtype=np.float64).reshape(5, 3, 3)]
+    p, f = T.split_windows(x, 2)
+    assert p[0].shape == (2, 3, 3) and f[0].shape == (3, 3, 3)
+    np.testing.assert_array_equal(np.concatenate([p[0], f[0]]), x[0])
+
+
+def _synthetic_video(n_frames, mno, n_ids, rng):
+    """(frames, MNO, 3) array in the loader's preprocessed layout: smooth tracks, ids 1..n_ids in the first slots."""
+    t = np.arange(n_frames)[:, None]
+    x0, y0 = rng.uniform(300, 1100, n_ids), rng.uniform(300, 900, n_ids)
+    vx, vy = rng.normal(0, 3, n_ids), rng.normal(0, 3, n_ids)
+    arr = np.zeros((n_frames, mno, 3))
+    arr[:, :n_ids, 0] = np.arange(1, n_ids + 1)
+    arr[:, :n_ids, 1] = x0 + vx * t
+    arr[:, :n_ids, 2] = y0 + vy * t
+    return arr
+
+
+@pytest.mark.gpu
+def test_training_loop_runs_saves_and_learns(tmp_path):
+    from desire_amd.data_loader import DataLoader
+    from desire_amd.model import DESIREModel
+    rng = np.random.default_rng(0)
+    frames = [_synthetic_video(120, 8, 6, rng), _synthetic_video(90, 8, 5, rng)]
+    a = T.build_parser().parse_args(["--batch_size", "4", "--seq_length", "4", "--pred_length", "6", "--max_num_obj", "8",
+                                     "--d_dim", "64", "--latent_size", "64", "--num_samples", "3", "--num_epochs", "3",
+                                     "--save_every", "5", "--learning_rate", "0.0005", "--neighborhood_size", "256",
+                                     "--save_dir", str(tmp_path / "save")])
+    dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
+    assert dl.num_batches > 0
+    import random
+    random.seed(0)
+    lines = []
+    losses = T.train(a, data_loader=dl, log=lines.append)
+    assert len(losses) == a.num_epochs * dl.num_batches and np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
+    assert os.path.exists(tmp_path / "save" / "config.pkl")
+    saved = sorted((f for f in os.listdir(tmp_path / "save") if f.endswith(".npz")), key=lambda f: int(f.split("-")[1][:-4]))
+    assert saved and saved[0] == "social_model-5.npz"
+    assert any("train_loss" in l for l in lines) and any("model saved" in l for l in lines)
+    m2 = DESIREModel.restore(a, str(tmp_path / "save" / saved[-1]))
+    x, _, _ = dl.next_batch(random_update=False)
+    past, fut = T.split_windows(x, a.seq_length)
+    Y, s = m2.forward(past, fut, seed=0)
+    assert bool(np.isfinite(Y.cpu().numpy()).all())
