@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--windows", type=int, default=128, help="loader windows (scenes) per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bf16", action="store_true",
+                    help="bf16 matrix operands in the IOC kernel (BASELINE configs[2] arithmetic; NOT the headline fp32 line)")
+    ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]: 64)")
     ap.add_argument("--train", action="store_true",
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
@@ -129,7 +132,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    d = Dims(n_scenes=a.windows, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4,
+    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4,
              nb_w=0.15, nb_h=0.15, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
@@ -205,7 +208,7 @@ def main():
             "metric": "agent-trajectory-samples/sec (K=20, T_pred=40)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16 operands (IOC kernel), f32 accumulate/state; other kernels f32" if a.bf16 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SDD-like synthetic windows, 32 agent slots/window, K=20, "
                                    "T_obs=8/T_pred=40, H=128, L=128, fp32, posterior CVAE, IOC 1 refinement, "
                                    "social grid 4x4, scene grid 64x64x32; %d windows/step/GPU" % a.windows,

@@ -27,6 +27,27 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
     return out;
 }
 
+static uint16_t bf16_rne(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+std::vector<float> pack_b16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at) {
+    const int G = (K + 15) / 16, NT = (N + 31) / 32;
+    std::vector<uint16_t> o((size_t)NT * G * 64 * 8, 0);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int g = 0; g < G; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kmap(g, lane >> 5, e), n = nt * 32 + (lane & 31);
+                    if (k >= 0 && k < K && n < N) o[(((size_t)nt * G + g) * 64 + lane) * 8 + e] = bf16_rne(at(k, n));
+                }
+    std::vector<float> out(o.size() / 2);
+    std::memcpy(out.data(), o.data(), o.size() * 2);
+    return out;
+}
+
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v) {
     if (h->pack_mode == 1) { h->captured[name] = v; return 0; }
     DevBuf& b = h->dev[name];
@@ -102,6 +123,8 @@ int check_dims(const desire_dims& d) {
     if (d.n_scenes < 1 || d.K < 1 || d.T_obs < 1 || d.T_pred < 1 || d.n_grids < 1 || d.iters < 1 || d.Gh < 1 || d.Gw < 1)
         return fail(DESIRE_ERR_ARG, "sizes must be >= 1");
     if (d.grid_size < 1 || d.grid_size > 4) return fail(DESIRE_ERR_ARG, "grid_size 1..4 in this round (LDS budget)");
+    if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
+    if (d.bf16 && d.mno > 64) return fail(DESIRE_ERR_ARG, "bf16 operands: mno must divide 32 or be 64 in this round");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
     return 0;
 }
@@ -234,6 +257,23 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pk.begin(), pk.end());
         }
         bad |= up("ioc/WsT", all);
+    }
+    if (d.bf16) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
+        const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
+        const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
+        auto lin = [](int g, int hi, int e) { return 16 * g + 8 * hi + e; };
+        // chain order: k-slot (hi, e) of group g = 2*hb + g2 holds hidden 32*hb + rowmap(8*g2 + e, hi), the accumulator
+        // row a lane of the pooling MFMA owns (rowmap(r, hi) = (r&3) + 8*(r>>2) + 4*hi)
+        auto chain = [](int g, int hi, int e) { const int hb = g >> 1, r = 8 * (g & 1) + e; return 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi; };
+        bad |= up("ioc/Wg16", pack_b16(E + H, 2 * H, lin, [&](int k, int n) { return gk[(size_t)k * 2 * H + n]; }));
+        bad |= up("ioc/Wc16", pack_b16(E + H, H, lin, [&](int k, int n) { return ck[(size_t)k * H + n]; }));
+        bad |= up("ioc/Wreg16", pack_b16(H, 2 * d.T_pred, lin, [&](int k, int n) { return wr[(size_t)k * 2 * d.T_pred + n]; }));
+        std::vector<float> all;
+        for (int b = 0; b < B; ++b) {
+            auto pk = pack_b16(H, H, chain, [&](int k, int n) { return ws[((size_t)b * H + k) * H + n]; });
+            all.insert(all.end(), pk.begin(), pk.end());
+        }
+        bad |= up("ioc/Wsoc16", all);
     }
     bad |= up("ioc/vel_w", hw["ioc/vel_fc/w"]); bad |= up("ioc/vel_b", hw["ioc/vel_fc/b"]);
     {
@@ -440,6 +480,12 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         if (cluster) return fail(DESIRE_ERR_STATE, "training supports groups of up to 32 agents per scene in this round (mno <= 32)");
         a.sv_x = W(h, "ioc_sv_x"); a.sv_r = W(h, "ioc_sv_r"); a.sv_u = W(h, "ioc_sv_u"); a.sv_c = W(h, "ioc_sv_c"); a.sv_h = W(h, "ioc_sv_h");
     }
+    if (d.bf16) {
+        if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
+        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+        Timer t(h, s, "ioc");
+        launch_ioc_bf16(a, s);
+    } else
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
     if (h->training) {
         HIPCHK(hipMemcpyAsync(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -77,6 +77,9 @@ inline float* W(desire_ctx* h, const char* name) { return h->ws.at(name).f(); }
 
 // Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
 std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at);
+// bf16 fragment order (v_mfma_f32_32x32x16_bf16): out16[((nt*G + g)*64 + lane)*8 + e] = bf16(W(k = kmap(g, lane>>5, e), n = nt*32 + (lane&31))),
+// G = ceil(K/16); returned as floats holding two bf16 bit patterns each (so the float upload path carries it)
+std::vector<float> pack_b16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at);
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v);
 int desire_ready(desire_handle* h);
 int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

@@ -1,0 +1,378 @@
+// kernels_bf16.hip -- bf16-operand / fp32-accumulate forms of the recurrent hot kernels (BASELINE configs[2]).
+//
+// v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 matrix rate, so the fp32 kernels' structure (operands staged through
+// LDS by VALU phases between barriers) would leave the matrix pipe idle: this is a re-tiling, not a type swap.
+//   * recurrent state h, gate math and all accumulators stay fp32 in registers; only MFMA OPERANDS are bf16
+//   * social pooling never touches LDS or a barrier per bin: for bin b and a 32-row tile
+//         P_b^T [hidden, row i] = H^T [hidden, j] . M_b^T [j, i]            (MFMA 1: A = h^T from LDS, B = 0/1 bits)
+//     lands in registers with lane = row i and 4-row-aligned runs of the hidden index -- which IS the A-fragment
+//     layout (lane = row, 8 k per lane) of the next contraction up to a permutation of k, and the permutation is
+//     absorbed into how W_b is packed (chain order, pack_b16 in api.hip):
+//         e_r += P_b . W_b                                                  (MFMA 2: A = cvt(P_b^T regs), B = packed W_b)
+//     every wave redoes MFMA 1 for all hidden blocks (the pipe has the headroom); 4 barriers per step instead of ~36
+//   * the neighbour bits of (row, bin) expand to bf16 0/1 B fragments through a 16-entry LDS table (one nibble ->
+//     four bf16), conflict-free by construction
+// Layout reminders (see common.h): accumulator element i of a lane = row (i&3) + 8(i>>2) + 4(lane>>5), col lane&31.
+// A/B fragment of the bf16 MFMA: lane (c = lane&31, hi = lane>>5) holds 8 values for k-slot (hi, 0..7); A and B only
+// have to agree on which logical k a slot means, so any consistent k order is valid.
+#include "common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {            // v_cvt_pk_bf16_f32 (RNE): a -> low half
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ u16 bf16_of(float a) { return (u16)(pk_bf16(a, 0.f) & 0xffffu); }
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 splat16h(float v) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = v;
+    return z;
+}
+
+// acc[nb][m] += A_m[32 x 16G] . B_nb[16G x 32]: A fragments from LDS (bf16 row-major, ap[m] = row (lane&31) of M-tile m
+// + 8*(lane>>5) elements), B fragments from packed weights (bl[nb] already offset by +lane, uint4 units, stride 64 per
+// k-group).  Chunks of CH groups with the next chunk's B fragments in flight (two named register sets, fenced).
+#define CH16 4
+template <int MT, int NB>
+__device__ __forceinline__ void mma16_chunk(f32x16 (&acc)[NB][MT], const u16* const (&ap)[MT], int g, const uint4 (&b)[NB][CH16]) {
+#pragma unroll
+    for (int j = 0; j < CH16; ++j) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint4 a = *reinterpret_cast<const uint4*>(ap[m] + (g + j) * 16);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][m] = mfma16(a, b[nb][j], acc[nb][m]);
+        }
+    }
+}
+template <int NB>
+__device__ __forceinline__ void load_b16(uint4 (&b)[NB][CH16], const uint4* const (&bl)[NB], int g) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < CH16; ++j) b[nb][j] = bl[nb][(g + j) * 64];
+}
+template <int MT, int NB>
+__device__ __forceinline__ void mma16_groups(f32x16 (&acc)[NB][MT], const u16* const (&ap)[MT], const uint4* const (&bl)[NB], int G) {
+    const int nch = G / CH16;
+    int c = 0;
+    if (nch > 0) {
+        uint4 b0[NB][CH16], b1[NB][CH16];
+        load_b16<NB>(b0, bl, 0);
+#pragma clang loop unroll(disable)
+        for (; c + 2 <= nch; c += 2) {
+            load_b16<NB>(b1, bl, CH16 * (c + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mma16_chunk<MT, NB>(acc, ap, CH16 * c, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nch) load_b16<NB>(b0, bl, CH16 * (c + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            mma16_chunk<MT, NB>(acc, ap, CH16 * (c + 1), b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nch) { mma16_chunk<MT, NB>(acc, ap, CH16 * c, b0); ++c; }
+    }
+#pragma clang loop unroll(disable)
+    for (int g = CH16 * c; g < G; ++g) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint4 a = *reinterpret_cast<const uint4*>(ap[m] + g * 16);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][m] = mfma16(a, bl[nb][g * 64], acc[nb][m]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// IOC scoring / refinement, bf16 operands.  Workgroup = H/32 waves, tile = 32*MT rows = whole (scene,k) groups
+// (mno divides 32, or mno = 64 with MT = 2); wave cb owns hidden columns [32cb, 32cb+32) of every M-tile.
+// Weight pointers of IocArgs (Wg, Wc, Wsoc, Wreg) point at the bf16 packs ("ioc/*16" in api.hip).
+// ------------------------------------------------------------------------------------------------------------------
+template <int H, int EV, int C, int MT>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf16(IocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = H >> 5, TM = 32 * MT, E = EV + C + H, KX = E + H;
+    constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = TM + 8;          // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
+    const int B = a.G * a.G, LDM = B + 1;
+    u16* Xb = reinterpret_cast<u16*>(smem_raw);                       // [TM][LDXB]  e_v | e_s | e_r | h
+    u16* RHb = Xb + TM * LDXB;                                        // [TM][LDRB]  r * h
+    u16* Ht = RHb + TM * LDRB;                                        // [H][LDT]    h transposed (pooling operand)
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(Ht + H * LDT);   // [TM][B+1], bit = local row
+    uint2* lut = reinterpret_cast<uint2*>(masks + TM * LDM);          // [16] nibble -> 4 bf16 (0.0 / 1.0)
+    float* pc = reinterpret_cast<float*>(lut + 16);                   // [TM][2]
+    float* pp = pc + TM * 2;                                          // [TM][2]
+    float* wv = pp + TM * 2;                                          // [3][EV]
+    float* red = wv + 3 * EV;                                         // [NT][TM]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
+
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + c31;
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int my_scene = my_row / (a.K * a.mno);
+    const int grp_base = (r8 / a.mno) * a.mno;
+    const int my_slot = r8 - grp_base;
+    const bool wide = a.mno > 32;                                     // one group spans both M-tiles
+    const int JG = wide ? TM / 16 : 2;                                // 16-wide neighbour chunks per M-tile
+
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < 16) {
+        const unsigned lo = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        lut[tid] = make_uint2(lo, hi2);
+    }
+    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
+    const uint4* Wg = reinterpret_cast<const uint4*>(a.Wg);
+    const uint4* Wc = reinterpret_cast<const uint4*>(a.Wc);
+    const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
+    const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
+
+    const u16* xp[MT]; const u16* rp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        xp[m] = Xb + (m * 32 + c31) * LDXB + 8 * hi;
+        rp[m] = RHb + (m * 32 + c31) * LDRB + 8 * hi;
+    }
+    // h (fp32, accumulator layout) -> both bf16 images
+    auto publish_h = [&](const f32x16 (&h)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Xb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDXB + E + col] = bf16_of(h[m][i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint2*>(Ht + col * LDT + m * 32 + 8 * q + 4 * hi) =
+                    make_uint2(pk_bf16(h[m][4 * q], h[m][4 * q + 1]), pk_bf16(h[m][4 * q + 2], h[m][4 * q + 3]));
+        }
+    };
+
+    for (int it = 0; it < a.iters; ++it) {
+        f32x16 h[MT], sp[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            sp[m] = zero16();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = min(row0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi, a.R - 1);
+                h[m][i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
+            }
+        }
+        __syncthreads();                                  // previous iteration's readers of Xb / Ht are done
+        publish_h(h);
+        float2 ynext = make_float2(0.f, 0.f);
+        if (tid < TM) {
+            const int row = min(row0 + tid, a.R - 1);
+            const int ag = agent_of_row(row, a.K, a.mno);
+            pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)row * a.T) * 2);
+            pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
+        }
+        for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+        __syncthreads();
+
+        for (int t = 0; t < a.T; ++t) {
+            if (tid < TM && t + 1 < a.T)
+                ynext = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t + 1) * 2);
+            // ---- P1: e_v, e_s, neighbour bits (row threads) ----
+            {
+                const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+                const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                for (int j = 2 * q8; j < EV; j += 2 * TPR) {
+                    const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                    const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
+                    *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = pk_bf16(e0, e1);
+                }
+                int cy, cx;
+                scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                for (int j = 4 * q8; j < C; j += 4 * TPR) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
+                    *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(pk_bf16(g4.x, g4.y), pk_bf16(g4.z, g4.w));
+                }
+                for (int j = q8; j < a.mno; j += TPR) {
+                    if (j == my_slot || !vld[grp_base + j]) continue;
+                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G);
+                    if (b >= 0) atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j));
+                }
+            }
+            __syncthreads();
+            // ---- P2: social pooling chain -> e_r (no LDS traffic besides h^T fragments, no barriers) ----
+            {
+                f32x16 soc[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) soc[m] = splat16h(bso);
+                // this wave's n-tile of W_b (H/16 k-groups, chain order) lives in ONE register set that is refreshed in
+                // place: the fragments of bin b+1 are requested right after their last use in bin b, so every load is in
+                // flight for a whole bin of MFMAs
+                uint4 wb[2 * NT];
+                {
+                    const uint4* wsrc = Wsoc + ((size_t)cb * GH16) * 64 + lane;
+#pragma unroll
+                    for (int g = 0; g < 2 * NT; ++g) wb[g] = wsrc[g * 64];
+                }
+#pragma clang loop unroll(disable)
+                for (int b = 0; b < B; ++b) {
+                    const uint4* wnext = Wsoc + ((size_t)(min(b + 1, B - 1) * NT + cb) * GH16) * 64 + lane;
+                    uint4 mf[MT][2 * MT];                               // neighbour bits -> bf16 B fragments (16 neighbours each)
+                    int jb[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const unsigned long long m64 = masks[(m * 32 + c31) * LDM + b];
+                        jb[m] = wide ? 0 : m * 32;
+#pragma unroll
+                        for (int jg = 0; jg < 2 * MT; ++jg) {
+                            if (jg < JG) {
+                                const unsigned bits = (unsigned)(m64 >> (jb[m] + 16 * jg + 8 * hi)) & 0xffu;
+                                const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                                mf[m][jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int hb = 0; hb < NT; ++hb) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            f32x16 d1 = zero16();
+                            const u16* hp = Ht + (hb * 32 + c31) * LDT + jb[m] + 8 * hi;
+#pragma unroll
+                            for (int jg = 0; jg < 2 * MT; ++jg)
+                                if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[m][jg], d1);
+                            const uint4 p0 = make_uint4(pk_bf16(d1[0], d1[1]), pk_bf16(d1[2], d1[3]), pk_bf16(d1[4], d1[5]), pk_bf16(d1[6], d1[7]));
+                            const uint4 p1 = make_uint4(pk_bf16(d1[8], d1[9]), pk_bf16(d1[10], d1[11]), pk_bf16(d1[12], d1[13]), pk_bf16(d1[14], d1[15]));
+                            soc[m] = mfma16(p0, wb[2 * hb], soc[m]);
+                            soc[m] = mfma16(p1, wb[2 * hb + 1], soc[m]);
+                        }
+                        wb[2 * hb] = wnext[(2 * hb) * 64];
+                        wb[2 * hb + 1] = wnext[(2 * hb + 1) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        Xb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[m][i], 0.f));
+            }
+            __syncthreads();
+            // ---- P4: gates over [x | h] ----
+            f32x16 u[MT];
+            {
+                f32x16 g2[2][MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { g2[0][m] = splat16h(bgr); g2[1][m] = splat16h(bgu); }
+                const uint4* bl[2] = {Wg + ((size_t)cb * G16) * 64 + lane, Wg + ((size_t)(cb + NT) * G16) * 64 + lane};
+                mma16_groups<MT, 2>(g2, xp, bl, G16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float r = sigmoidf_(g2[0][m][i]);
+                        RHb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDRB + col] = bf16_of(r * h[m][i]);
+                        u[m][i] = sigmoidf_(g2[1][m][i]);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- P5: candidate over [x | r*h], blend, score; publish h_t ----
+            {
+                f32x16 ac[1][MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) ac[0][m] = splat16h(bcc);
+                const uint4* bx[1] = {Wc + ((size_t)cb * G16) * 64 + lane};
+                mma16_groups<MT, 1>(ac, xp, bx, GX16);
+                const uint4* bh[1] = {Wc + ((size_t)cb * G16 + GX16) * 64 + lane};
+                mma16_groups<MT, 1>(ac, rp, bh, GH16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float c = tanhf_(ac[0][m][i]);
+                        h[m][i] = u[m][i] * h[m][i] + (1.0f - u[m][i]) * c;
+                        sp[m][i] = fmaf(h[m][i], wsc, sp[m][i]);
+                    }
+                publish_h(h);                              // h slots of Xb / Ht were last read before the previous barrier
+            }
+            if (tid < TM) {
+                pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
+                pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
+            }
+            for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+            __syncthreads();
+        }
+        // ---- score ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sp[m][i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+                if (c31 == 0) red[cb * TM + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] = v;
+            }
+        __syncthreads();
+        if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+            a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+        }
+        // ---- regression: Y += h_T W_r + b_r ----
+        for (int nt = cb; nt < a.NTreg; nt += NT) {
+            f32x16 acc[1][MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[0][m] = zero16();
+            const u16* hp2[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) hp2[m] = xp[m] + E;
+            const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
+            mma16_groups<MT, 1>(acc, hp2, br, GH16);
+            const int cc = nt * 32 + c31;
+            if (cc < 2 * a.T) {
+                const float bb = a.b_reg[cc];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = row0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][m][i] + bb); }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t ioc16_lds(const IocArgs& a, int MT) {
+    const int H = a.H, TM = 32 * MT, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
+    size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2;
+    b += (size_t)TM * (B + 1) * 8 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 64;
+    return b;
+}
+template <int H, int MT>
+static void launch16(const IocArgs& a, hipStream_t s) {
+    const int TM = 32 * MT;
+    allow_big_lds(k_ioc_bf16<H, 16, 32, MT>);
+    hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, MT>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * 64), ioc16_lds(a, MT), s, a);
+}
+// mno must divide 32 (32-row tiles, two workgroups per CU) or be 64 (64-row tile); a.variant == 2 forces 64-row tiles (A/B:
+// measured 7.5 ms vs 4.0 ms for 81 920 rows at H = 128 -- the second M-tile's live state spills)
+void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
+    const bool two = a.mno > 32 || a.variant == 2;
+    if (a.H == 128) { if (two) launch16<128, 2>(a, s); else launch16<128, 1>(a, s); }
+    else if (a.H == 64) { if (two) launch16<64, 2>(a, s); else launch16<64, 1>(a, s); }
+    else { if (two) launch16<256, 2>(a, s); else launch16<256, 1>(a, s); }
+}

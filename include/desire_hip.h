@@ -44,6 +44,8 @@ typedef struct desire_dims {
     int32_t H, L, S, C, Gh, Gw, n_grids;
     int32_t grid_size, E_v, iters, posterior;
     float nb_w, nb_h, sx, sy;
+    int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
+                              for the recurrent IOC kernel (BASELINE configs[2]); inference only, mno <= 64 */
 } desire_dims;
 
 typedef struct desire_ctx desire_handle;

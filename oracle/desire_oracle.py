@@ -54,11 +54,21 @@ def softmax(x):
 #   c     = tanh([x, r*h] @ Wc + bc)          (reset applied BEFORE the candidate matmul)
 #   h'    = u*h + (1-u)*c                     (u gates the OLD state)
 # ------------------------------------------------------------------------------------------
-def gru_cell(x, h, Wg, bg, Wc, bc):
+def bf16_round(x):
+    """Round-to-nearest-even to bfloat16, returned as float32 (the operand quantiser of the bf16 kernels)."""
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def gru_cell(x, h, Wg, bg, Wc, bc, q=None):
+    """q: optional operand quantiser (bf16 kernels round matrix OPERANDS only; state and gate math stay fp32)."""
     H = h.shape[-1]
-    g = sigmoid(np.concatenate([x, h], -1) @ Wg + bg)
+    q = q or (lambda v: v)
+    g = sigmoid(np.concatenate([x, q(h)], -1) @ Wg + bg)
     r, u = g[..., :H], g[..., H:]
-    c = np.tanh(np.concatenate([x, r * h], -1) @ Wc + bc)
+    c = np.tanh(np.concatenate([x, q(r * h)], -1) @ Wc + bc)
     return (u * h + (1 - u) * c).astype(h.dtype)
 
 
@@ -282,14 +292,18 @@ def social_pool(pos_t, hprev, valid_rows, d, dt):
     return pooled.reshape(d.R, d.B * d.H).astype(dt), bins
 
 
-def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.float32):
+def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.float32, q=None):
     """One IOC scoring + regression pass (paper section 3.3; absent in the reference,
-    model/model.py:312-313).  Returns (score [R], dY [R,T_pred,2])."""
+    model/model.py:312-313).  Returns (score [R], dY [R,T_pred,2]).
+    q = bf16_round restates the bf16-operand kernel (kernels_bf16.hip): weights, x_t, h, r*h and the pooled sums are
+    rounded where they enter a matrix product; accumulation, state and gate math stay fp32."""
+    qq = q or (lambda v: v)
     Wg, bg, Wc, bc = _gru_w(w, "ioc", dt)
+    Wg, Wc = qq(Wg), qq(Wc)
     Wv, bv = w["ioc/vel_fc/w"].astype(dt), w["ioc/vel_fc/b"].astype(dt)
-    Ws, bs = w["ioc/social_fc/w"].astype(dt), w["ioc/social_fc/b"].astype(dt)
+    Ws, bs = qq(w["ioc/social_fc/w"].astype(dt)), w["ioc/social_fc/b"].astype(dt)
     wsc, bsc = w["ioc/score/w"].astype(dt), w["ioc/score/b"].astype(dt)
-    Wr, br = w["ioc/reg/w"].astype(dt), w["ioc/reg/b"].astype(dt)
+    Wr, br = qq(w["ioc/reg/w"].astype(dt)), w["ioc/reg/b"].astype(dt)
     scene_of_row = np.repeat(np.arange(d.n_scenes), d.K * d.mno)
     gidx = np.asarray(grid_of_scene)[scene_of_row]
     h = Hx_rows.astype(dt)
@@ -300,17 +314,17 @@ def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.f
         e_v = relu((cur - prev) @ Wv + bv)
         cy, cx = scene_cell(cur, d.Gh, d.Gw)
         e_s = grids[gidx, cy, cx].astype(dt)
-        pooled, _ = social_pool(cur, h, valid_rows, d, dt)
-        e_r = relu(pooled @ Ws + bs)
-        h = gru_cell(np.concatenate([e_v, e_s, e_r], -1), h, Wg, bg, Wc, bc)
+        pooled, _ = social_pool(cur, qq(h), valid_rows, d, dt)
+        e_r = relu(qq(pooled) @ Ws + bs)
+        h = gru_cell(qq(np.concatenate([e_v, e_s, e_r], -1)), h, Wg, bg, Wc, bc, q)
         score = score + (h @ wsc[:, 0] + bsc[0])
         prev = cur
-    dY = (h @ Wr + br).reshape(d.R, d.T_pred, 2)
+    dY = (qq(h) @ Wr + br).reshape(d.R, d.T_pred, 2)
     return score.astype(dt), dY.astype(dt)
 
 
 def forward(past, fut, eps, grids, grid_of_scene, w, d, bn_mode="frozen", dt=np.float32,
-            Y_override: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+            Y_override: Optional[np.ndarray] = None, ioc_q=None) -> Dict[str, np.ndarray]:
     """Whole hot path.  past [T_obs, A, 3], fut [T_pred, A, 3] (or None when d.posterior==0),
     eps [R, L] (row order r=(scene*K+k)*mno+slot), grids [n_grids, Gh, Gw, C],
     grid_of_scene [n_scenes] int.  Returns every intermediate the parity tests compare."""
@@ -345,7 +359,7 @@ def forward(past, fut, eps, grids, grid_of_scene, w, d, bn_mode="frozen", dt=np.
         Y = Y_override.astype(dt)
     score = np.zeros(d.R, dt)
     for _ in range(d.iters):
-        score, dY = ioc_pass(Y, Hx_rows, p_last_rows, valid_rows, grids, grid_of_scene, w, d, dt)
+        score, dY = ioc_pass(Y, Hx_rows, p_last_rows, valid_rows, grids, grid_of_scene, w, d, dt, q=ioc_q)
         Y = (Y + dY).astype(dt)
     out["Y"] = Y
     out["score"] = score
