@@ -274,6 +274,17 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pk.begin(), pk.end());
         }
         bad |= up("ioc/Wsoc16", all);
+        auto taps16 = [&](const std::vector<float>& wt, int CI, int CO) {       // transposed conv weights [tap][co][ci]
+            std::vector<float> out;
+            for (int tap = 0; tap < 25; ++tap) {
+                const float* base = wt.data() + (size_t)tap * CI * CO;
+                auto pk = pack_b16(CI, CO, lin, [&](int k, int n) { return base[(size_t)n * CI + k]; });
+                out.insert(out.end(), pk.begin(), pk.end());
+            }
+            return out;
+        };
+        bad |= up("vae_dec/deconv2/W16", taps16(hw["vae_dec/deconv2/w"], 128, 64));
+        bad |= up("vae_dec/deconv3/W16", taps16(hw["vae_dec/deconv3/w"], 64, 32));
     }
     bad |= up("ioc/vel_w", hw["ioc/vel_fc/w"]); bad |= up("ioc/vel_b", hw["ioc/vel_fc/b"]);
     {
@@ -417,10 +428,12 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.n = R;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
-    { Timer t(h, s, "deconv2"); launch_deconv2(c, s); }
+    if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
+    else { Timer t(h, s, "deconv2"); launch_deconv2(c, s); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
-    { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
+    if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
+    else { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
     c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
     c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
     { Timer t(h, s, "deconv4"); launch_deconv4(c, s); }

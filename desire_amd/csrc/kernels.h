@@ -93,7 +93,10 @@ struct IocArgs {
     float* sv_x; float* sv_r; float* sv_u; float* sv_c; float* sv_h;   // training saves: [R,T,E], [R,T,H] x4 (32-row form only)
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
-void launch_ioc_bf16(const IocArgs& a, hipStream_t s);    // kernels_bf16.hip; weight pointers = bf16 packs
+void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
+struct ConvArgs;
+void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s);
+void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);    // kernels_bf16.hip; weight pointers = bf16 packs
 
 void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
                           float nb_w, float nb_h, int G, hipStream_t s);

@@ -376,3 +376,159 @@ void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
     else if (a.H == 64) { if (two) launch16<64, 2>(a, s); else launch16<64, 1>(a, s); }
     else { if (two) launch16<256, 2>(a, s); else launch16<256, 1>(a, s); }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// CVAE decoder convolutions with bf16 operands (same tilings as kernels_conv.hip; activations stay fp32 in HBM and are
+// rounded on their way into fragments, accumulation and the BN/ELU epilogue are fp32).  a.Wp points at the bf16 packs.
+// ------------------------------------------------------------------------------------------------------------------
+// deconv2: [n,4,4,128] -> [n,8,8,64], 5x5 VALID stride 1, scatter form; wave = (co-half hf, sample pair sp), M-tile rows
+// = (sample, input pixel); A (K = 128) is 8 register fragments per lane; 8 MFMAs per tap, then the plain LDS scatter.
+__global__ __launch_bounds__(DS_WG) void k_deconv2_bf16(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float out_s16[];   // [4][64 px][64 co]
+    const int lane = lane_id(), w = wave_id();
+    const int hf = w & 1, sp = w >> 1;
+    const int s0 = blockIdx.x * 4 + sp * 2;
+    const int c = lane & 31, hi = lane >> 5;
+    float* my = out_s16 + (sp * 2) * 4096;
+    for (int i = 0; i < 64; ++i) my[(i * 2 + hi) * 64 + hf * 32 + c] = 0.f;
+    uint4 af[8];
+    {
+        const int row = lane & 31;
+        const int smp = min(s0 + (row >> 4), a.n - 1);
+        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 x0 = *reinterpret_cast<const float4*>(src + g * 16), x1 = *reinterpret_cast<const float4*>(src + g * 16 + 4);
+            af[g] = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
+        }
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    auto load_b = [&](uint4 (&b)[8], int tap) {
+        const uint4* bp = Wp + ((size_t)(tap * 2 + hf) * 8) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) b[g] = bp[g * 64];
+    };
+    auto do_tap = [&](const uint4 (&b)[8], int tap) {
+        const int ky = tap / 5, kx = tap - ky * 5;
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc = mfma16(af[g], b[g], acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            const int s = rr >> 4, p = rr & 15;
+            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+            float* dst = my + (s * 64 + o) * 64 + hf * 32 + c;
+            *dst = *dst + acc[i];
+        }
+    };
+    uint4 b0[8], b1[8];
+    load_b(b0, 0);
+#pragma clang loop unroll(disable)
+    for (int tap = 0; tap < 24; tap += 2) {
+        load_b(b1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        do_tap(b0, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(b0, tap + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        do_tap(b1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    do_tap(b0, 24);
+    const int co = hf * 32 + c;
+    const float sc = a.scale[co], sh = a.shift[co];
+    for (int i = 0; i < 64; ++i) {
+        const int sp_px = i * 2 + hi;
+        const int smp = s0 + (sp_px >> 6);
+        if (smp < a.n) {
+            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + co;
+            a.out[ix] = conv_epilogue(my[sp_px * 64 + co], sc, sh, a.mode, false, a.yprev, ix);
+        }
+    }
+}
+void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s) {
+    allow_big_lds(k_deconv2_bf16);
+    hipLaunchKernelGGL(k_deconv2_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+}
+
+// deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2, output-parity gather (see k_deconv3); one wave per sample,
+// the sample's input staged in LDS as bf16, K = 64 = 4 fragments per tap, next tap's B fragments in flight.
+__global__ __launch_bounds__(DS_WG) void k_deconv3_bf16(ConvArgs a) {
+    constexpr int LDP = 72;                                            // bf16 elements; 36 dwords = 4 mod 8
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_d3[];
+    u16* zero_row = reinterpret_cast<u16*>(smem_d3);
+    u16* in_s = zero_row + LDP;                                        // [4][64][LDP]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * 4;
+    for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
+    for (int i = tid; i < 4 * 64 * 8; i += DS_WG) {
+        const int pix = i >> 3, c8 = i & 7;
+        const int smp = s0 + (pix >> 6);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (smp < a.n) {
+            const float* src = a.in + ((size_t)s0 * 64 + pix) * 64 + c8 * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            v = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
+        }
+        *reinterpret_cast<uint4*>(in_s + pix * LDP + c8 * 8) = v;
+    }
+    __syncthreads();
+    const int smp = s0 + w;
+    const u16* mine = in_s + w * 64 * LDP;
+    const int c = lane & 31, hi = lane >> 5;
+    const float sc = a.scale[c], sh = a.shift[c];
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    int qy[2], qx[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int q = m * 32 + c; qy[m] = q >> 3; qx[m] = q & 7; }
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            f32x16 acc[2] = {zero16(), zero16()};
+            const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
+            auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
+            uint4 bc[4], bn[4];
+            {
+                const uint4* bp = Wp + ((size_t)tap_of(0) * 4) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bc[g] = bp[g * 64];
+            }
+#pragma clang loop unroll(disable)
+            for (int t = 0; t < ntap; ++t) {
+                const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
+                {
+                    const uint4* bp = Wp + ((size_t)tap_of(min(t + 1, ntap - 1)) * 4) * 64 + lane;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bn[g] = bp[g * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int iy = qy[m] + dy, ix = qx[m] + dx;
+                    const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                    const u16* ap = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 8 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[m] = mfma16(*reinterpret_cast<const uint4*>(ap + 16 * g), bc[g], acc[m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bc[g] = bn[g];
+            }
+            if (smp < a.n) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int q = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        const int oy = 2 * (q >> 3) + py, ox = 2 * (q & 7) + px;
+                        const size_t ix = ((size_t)smp * 256 + oy * 16 + ox) * 32 + c;
+                        a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix);
+                    }
+            }
+        }
+}
+void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (72 + 4 * 64 * 72) * sizeof(u16);
+    hipLaunchKernelGGL(k_deconv3_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+}

@@ -172,16 +172,20 @@ def vae_encoder(vae_in, w, L, bn_mode="frozen", dt=np.float32):
     return params[:, :L], params[:, L:]
 
 
-def vae_decoder(z, w, bn_mode="frozen", dt=np.float32, return_layers=False):
+def vae_decoder(z, w, bn_mode="frozen", dt=np.float32, return_layers=False, q=None):
     """model/model.py:453-469 (+ utils/convolutional_vae_util.py:27-135).  z [R, L] -> [R, 1024].
     All four deconvs sit inside defaults_scope(batch_normalize=True), so the last one is
-    BN -> sigmoid."""
+    BN -> sigmoid.  q = bf16_round restates the bf16-operand deconv2/deconv3 kernels (input activations and weights
+    rounded where they enter the contraction; accumulation and the BN/ELU epilogue in fp32)."""
     x = z.astype(dt).reshape(-1, 1, 1, z.shape[-1])
     layers = []
     for name, stride, pad, act in (("deconv1", 1, "VALID", elu), ("deconv2", 1, "VALID", elu),
                                    ("deconv3", 2, "SAME", elu), ("deconv4", 2, "SAME", sigmoid)):
         p = "vae_dec/" + name
-        x = conv2d_transpose(x, w[p + "/w"].astype(dt), stride, pad) + w[p + "/b"].astype(dt)
+        if q is not None and name in ("deconv2", "deconv3"):
+            x = conv2d_transpose(q(x), q(w[p + "/w"].astype(dt)), stride, pad) + w[p + "/b"].astype(dt)
+        else:
+            x = conv2d_transpose(x, w[p + "/w"].astype(dt), stride, pad) + w[p + "/b"].astype(dt)
         x = act(batch_norm(x, w, p, bn_mode, dt))
         layers.append(x)
     out = x.reshape(x.shape[0], -1)

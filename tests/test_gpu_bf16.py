@@ -73,3 +73,26 @@ def test_bf16_is_inference_only_and_validated(torch_cuda):
         _lib.Handle(small_dims(bf16=1, mno=128, n_scenes=1, K=1))
     with pytest.raises(_lib.DesireError):
         _lib.Handle(small_dims(bf16=2))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64)])
+def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw):
+    """deconv2 / deconv3 with bf16 operands: d2, d3 and xhat against the oracle's decoder with the same operand rounding
+    (fed with the kernel's own z so the comparison isolates these layers), and against plain fp32."""
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    d16 = d32.replace(bf16=1)
+    w = init_weights(d32, 5)
+    past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=2)
+    h, _, _ = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos)
+    z = h.read_buffer("z", (d32.R, d32.L))
+    xhat_q, layers_q = O.vae_decoder(z, w, return_layers=True, q=O.bf16_round)
+    xhat_f, layers_f = O.vae_decoder(z, w, return_layers=True)
+    for name, lq, lf, n in (("d2", layers_q[1], layers_f[1], 4096), ("d3", layers_q[2], layers_f[2], 8192), ("xhat", xhat_q, xhat_f, 1024)):
+        got = h.read_buffer(name, (d32.R, n))
+        eq = np.abs(got - lq.reshape(d32.R, n)).max()
+        ef = np.abs(got - lf.reshape(d32.R, n)).max()
+        scale = max(1.0, float(np.abs(lf).max()))
+        print("%s: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.2f)" % (name, eq, ef, np.abs(lf).max()))
+        assert eq < 2e-3 * scale, (name, eq)          # same rounding points: accumulation order + rare 1-ulp operand flips
+        assert ef < 3e-2 * scale, (name, ef)          # cost of bf16 operands over a K = 25*128 / 25*64 contraction
