@@ -283,6 +283,11 @@ int desire_pack_all(desire_ctx* h) {
             }
             return out;
         };
+        {
+            const auto& dg = hw["dec/gates/kernel"]; const auto& dc = hw["dec/candidate/kernel"];
+            bad |= up("dec/Whg16", pack_b16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }));
+            bad |= up("dec/Whc16", pack_b16(H, H, lin, [&](int k, int n) { return dc[(size_t)(H + k) * H + n]; }));
+        }
         bad |= up("vae_dec/deconv2/W16", taps16(hw["vae_dec/deconv2/w"], 128, 64));
         bad |= up("vae_dec/deconv3/W16", taps16(hw["vae_dec/deconv3/w"], 64, 32));
     }
@@ -449,6 +454,10 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
     a.Y = W(h, "Y0"); a.hdump = nullptr;
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
+    if (d.bf16) {
+        a.Whg = D4(h, "dec/Whg16"); a.Whc = D4(h, "dec/Whc16");
+        Timer t(h, s, "decoder"); launch_decoder_bf16(a, s);
+    } else
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
     HIPCHK(hipMemcpyAsync(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());

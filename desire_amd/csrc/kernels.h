@@ -75,6 +75,7 @@ struct DecArgs {
     float* sv_r; float* sv_u; float* sv_c;                 // optional [R, T, H] gate values (training mode)
 };
 void launch_decoder(const DecArgs& a, hipStream_t s);
+void launch_decoder_bf16(const DecArgs& a, hipStream_t s);    // kernels_bf16.hip; Whg / Whc = bf16 packs
 
 struct IocArgs {
     float* Y; float* score;                                // [R,T,2] in/out, [R]

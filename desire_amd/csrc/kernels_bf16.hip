@@ -532,3 +532,113 @@ void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (72 + 4 * 64 * 72) * sizeof(u16);
     hipLaunchKernelGGL(k_deconv3_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// GRU decoder + head with bf16 recurrent operands.  32-row tiles, wave cb = hidden columns [32cb, 32cb+32).
+// The constant-input half (x_z Wx, once per tile) stays on the exact fp32 pipe; per step only h Whg and (r*h) Whc run, as
+// 16 + 8 bf16 MFMAs per wave.  h lives in fp32 registers; LDS holds a bf16 image of h (next step's operand), a bf16
+// image of r*h, and an fp32 image of h for the 2-column head, which stays an fp32 VALU dot product (trajectory
+// coordinates come straight out of it).  Two barriers per step (the fp32 kernel needs four: it reuses one operand tile).
+// a.Whg / a.Whc point at the bf16 packs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decoder_bf16(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dec[];
+    constexpr int TM = 32, LDH = H + 4, LDB = H + 8, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
+    float* hs = reinterpret_cast<float*>(smem_dec);        // [32][LDH] fp32 h (head operand); x_z tile in the prologue
+    float* wo = hs + TM * LDH;                             // [H][2]
+    float* pl = wo + 2 * H;                                // [32][2]
+    u16* hb = reinterpret_cast<u16*>(pl + TM * 2);         // [32][LDB] bf16 h
+    u16* rb = hb + TM * LDB;                               // [32][LDB] bf16 r*h
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + c31;
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+        const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+        *reinterpret_cast<float4*>(hs + r * LDH + c4 * 4) =
+            *reinterpret_cast<const float4*>(a.xz + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4);
+    }
+    for (int i = tid; i < 2 * H; i += NTHR) wo[i] = a.w_head[i];
+    if (tid < TM) {
+        const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
+        pl[tid * 2] = a.p_last[(size_t)ag * 2]; pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+    }
+    __syncthreads();
+    f32x16 xr[1] = {splat16h(a.b_g[col])}, xu[1] = {splat16h(a.b_g[H + col])}, xc[1] = {splat16h(a.b_c[col])};
+    {
+        const float* x_lane = hs + c31 * LDH + 4 * hi;
+        mma_groups<1>(xr, x_lane, LDH, a.Wxg + ((size_t)cb * G) * 64 + lane, G);
+        mma_groups<1>(xu, x_lane, LDH, a.Wxg + ((size_t)(cb + NT) * G) * 64 + lane, G);
+        mma_groups<1>(xc, x_lane, LDH, a.Wxc + ((size_t)cb * G) * 64 + lane, G);
+    }
+    f32x16 h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = min(row0 + (i & 3) + 8 * (i >> 2) + 4 * hi, a.R - 1);
+        h[i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
+    }
+    __syncthreads();                                       // x_z tile consumed: hs becomes the fp32 h image
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hb[((i & 3) + 8 * (i >> 2) + 4 * hi) * LDB + col] = bf16_of(h[i]);
+    __syncthreads();
+    const uint4* Whg = reinterpret_cast<const uint4*>(a.Whg);
+    const uint4* Whc = reinterpret_cast<const uint4*>(a.Whc);
+    const u16* hp[1] = {hb + c31 * LDB + 8 * hi};
+    const u16* rp[1] = {rb + c31 * LDB + 8 * hi};
+    const uint4* bg[2] = {Whg + ((size_t)cb * GH16) * 64 + lane, Whg + ((size_t)(cb + NT) * GH16) * 64 + lane};
+    const uint4* bc[1] = {Whc + ((size_t)cb * GH16) * 64 + lane};
+    const float bh0 = a.b_head[0], bh1 = a.b_head[1];
+    const int hr = tid / TPR, hq = tid % TPR;
+    for (int t = 0; t < a.T; ++t) {
+        f32x16 g2[2][1] = {{xr[0]}, {xu[0]}};
+        mma16_groups<1, 2>(g2, hp, bg, GH16);
+        f32x16 u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float r = sigmoidf_(g2[0][0][i]);
+            rb[((i & 3) + 8 * (i >> 2) + 4 * hi) * LDB + col] = bf16_of(r * h[i]);
+            u[i] = sigmoidf_(g2[1][0][i]);
+        }
+        __syncthreads();
+        f32x16 ac[1][1] = {{xc[0]}};
+        mma16_groups<1, 1>(ac, rp, bc, GH16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float c = tanhf_(ac[0][0][i]);
+            h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            hb[rl * LDB + col] = bf16_of(h[i]);
+            hs[rl * LDH + col] = h[i];
+        }
+        __syncthreads();
+        {   // head: y = p_last + h W_o + b_o from the fp32 image; TPR threads per row
+            constexpr int per = H / TPR;
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = hq * per; c < (hq + 1) * per; ++c) {
+                const float hv = hs[hr * LDH + c];
+                s0 = fmaf(hv, wo[c * 2], s0);
+                s1 = fmaf(hv, wo[c * 2 + 1], s1);
+            }
+            s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
+            s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+            if (TPR >= 8) { s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4); }
+            if (TPR >= 16) { s0 += __shfl_xor(s0, 8); s1 += __shfl_xor(s1, 8); }
+            if (hq == 0 && row0 + hr < a.R)
+                *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + hr) * a.T + t) * 2) =
+                    make_float2(pl[hr * 2] + (s0 + bh0), pl[hr * 2 + 1] + (s1 + bh1));
+        }
+        // hs is rewritten only after the NEXT step's first barrier, which every head reader reaches first
+    }
+}
+template <int H>
+static void launch_dec16(const DecArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(32 * (H + 4) + 2 * H + 64) * sizeof(float) + (size_t)2 * 32 * (H + 8) * sizeof(u16);
+    allow_big_lds(k_decoder_bf16<H>);
+    hipLaunchKernelGGL((k_decoder_bf16<H>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+}
+void launch_decoder_bf16(const DecArgs& a, hipStream_t s) {
+    if (a.H == 256) launch_dec16<256>(a, s);
+    else if (a.H == 128) launch_dec16<128>(a, s);
+    else launch_dec16<64>(a, s);
+}

@@ -268,16 +268,22 @@ def rows_from_agents(x, d):
     return np.ascontiguousarray(x).reshape((d.R,) + x.shape[3:])
 
 
-def decode(xz, h0, p_last, w, d, dt=np.float32, return_hidden=False):
+def decode(xz, h0, p_last, w, d, dt=np.float32, return_hidden=False, q=None):
     """GRU decoder (model/model.py:279-285): the SAME input x_z at every step, initial state
     Hx, own weights (scope hidden_states).  Output head = the reference's commented-out linear
-    layer (:315-321) per step, added to the last observed position.  -> Yhat [R, T_pred, 2]."""
+    layer (:315-321) per step, added to the last observed position.  -> Yhat [R, T_pred, 2].
+    q = bf16_round restates k_decoder_bf16: only the RECURRENT operands (h, r*h and the h-rows of the kernels) are
+    rounded; the constant-input half and the head stay fp32."""
     Wg, bg, Wc, bc = _gru_w(w, "dec", dt)
+    if q is not None:
+        n_in = xz.shape[-1]
+        Wg = np.concatenate([Wg[:n_in], q(Wg[n_in:])], 0)
+        Wc = np.concatenate([Wc[:n_in], q(Wc[n_in:])], 0)
     Wo, bo = w["head/w"].astype(dt), w["head/b"].astype(dt)
     h = h0.astype(dt)
     ys, hs = [], []
     for _ in range(d.T_pred):
-        h = gru_cell(xz.astype(dt), h, Wg, bg, Wc, bc)
+        h = gru_cell(xz.astype(dt), h, Wg, bg, Wc, bc, q)
         ys.append(p_last.astype(dt) + (h @ Wo + bo))
         hs.append(h)
     Y = np.stack(ys, 1).astype(dt)

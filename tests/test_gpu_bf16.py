@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from desire_amd.spec import init_weights
-from tests.helpers import make_case, small_dims
+from tests.helpers import make_case, small_dims, to_oracle_layout
 from tests.test_gpu_parity import oracle_forward, run_gpu, torch_cuda  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -96,3 +96,25 @@ def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw):
         print("%s: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.2f)" % (name, eq, ef, np.abs(lf).max()))
         assert eq < 2e-3 * scale, (name, eq)          # same rounding points: accumulation order + rare 1-ulp operand flips
         assert ef < 3e-2 * scale, (name, ef)          # cost of bf16 operands over a K = 25*128 / 25*64 contraction
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3), dict(H=256, K=3, n_scenes=1, n_grids=1, T_pred=10),
+                                dict(T_pred=40, K=2)])
+def test_decoder_bf16_matches_rounding_oracle(torch_cuda, kw):
+    """k_decoder_bf16 on the kernel's own x_z / Hx against the oracle decoder with the same operand rounding."""
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 7)
+    past, fut, eps, grids, gos = make_case(d32, seed=8, n_absent=2)
+    h, _, _ = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos)
+    xz = h.read_buffer("xz", (d32.R, d32.H))
+    Hx = h.read_buffer("Hx", (d32.A, d32.H))
+    pn = O.normalise(to_oracle_layout(past), d32)
+    Hr, pl = O.rows_from_agents(Hx, d32), O.rows_from_agents(pn[d32.T_obs - 1], d32)
+    Yq = O.decode(xz, Hr, pl, w, d32, q=O.bf16_round)
+    Yf = O.decode(xz, Hr, pl, w, d32)
+    Y0 = h.read_buffer("Y0", (d32.R, d32.T_pred, 2))
+    eq, ef = np.abs(Y0 - Yq).max(), np.abs(Y0 - Yf).max()
+    print("Y0: vs rounding oracle %.2e, vs fp32 %.2e" % (eq, ef))
+    assert eq < 1e-3, eq          # normalised coordinates; same rounding points
+    assert ef < 5e-3, ef          # cost of bf16 recurrent operands on the decoded trajectory
