@@ -243,24 +243,35 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
                             }
                         }
                     }
+                    // software pipeline over the hidden blocks: MFMA 1 of block hb+1 is issued before block hb's
+                    // accumulators are converted and consumed, so the convert never waits on the matrix pipe
+                    auto chain = [&](int hb, int m) {
+                        f32x16 d1 = zero16();
+                        const u16* hp = Ht + (hb * 32 + c31) * LDT + jb[m] + 8 * hi;
+#pragma unroll
+                        for (int jg = 0; jg < 2 * MT; ++jg)
+                            if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[m][jg], d1);
+                        return d1;
+                    };
+                    f32x16 da[MT], dn[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) da[m] = chain(0, m);
 #pragma unroll
                     for (int hb = 0; hb < NT; ++hb) {
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
-                            f32x16 d1 = zero16();
-                            const u16* hp = Ht + (hb * 32 + c31) * LDT + jb[m] + 8 * hi;
-#pragma unroll
-                            for (int jg = 0; jg < 2 * MT; ++jg)
-                                if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[m][jg], d1);
+                            if (hb + 1 < NT) dn[m] = chain(hb + 1, m);
+                            const f32x16 d1 = da[m];
                             const uint4 p0 = make_uint4(pk_bf16(d1[0], d1[1]), pk_bf16(d1[2], d1[3]), pk_bf16(d1[4], d1[5]), pk_bf16(d1[6], d1[7]));
                             const uint4 p1 = make_uint4(pk_bf16(d1[8], d1[9]), pk_bf16(d1[10], d1[11]), pk_bf16(d1[12], d1[13]), pk_bf16(d1[14], d1[15]));
                             soc[m] = mfma16(p0, wb[2 * hb], soc[m]);
                             soc[m] = mfma16(p1, wb[2 * hb + 1], soc[m]);
+                            if (hb + 1 < NT) da[m] = dn[m];
                         }
                         wb[2 * hb] = wnext[(2 * hb) * 64];
                         wb[2 * hb + 1] = wnext[(2 * hb + 1) * 64];
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
