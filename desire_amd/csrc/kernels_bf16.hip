@@ -93,17 +93,18 @@ __device__ __forceinline__ void mma16_groups(f32x16 (&acc)[NB][MT], const u16* c
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// IOC scoring / refinement, bf16 operands.  Workgroup = H/32 waves, tile = 32*MT rows = whole (scene,k) groups
-// (mno divides 32, or mno = 64 with MT = 2); wave cb owns hidden columns [32cb, 32cb+32) of every M-tile.
-// Weight pointers of IocArgs (Wg, Wc, Wsoc, Wreg) point at the bf16 packs ("ioc/*16" in api.hip).
+// IOC scoring / refinement, bf16 operands.  Tile = 32*WM rows = whole (scene,k) groups (mno divides 32 with WM = 1, or
+// mno = 64 with WM = 2); workgroup = WM * H/32 waves, wave (mt, cb) owns rows [32mt, 32mt+32) x hidden columns
+// [32cb, 32cb+32).  Weight pointers of IocArgs (Wg, Wc, Wsoc, Wreg) point at the bf16 packs ("ioc/*16" in api.hip).
 // ------------------------------------------------------------------------------------------------------------------
-template <int H, int EV, int C, int MT>
-__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf16(IocArgs a) {
+template <int H, int EV, int C, int WM>
+__global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? 2 : 1) void k_ioc_bf16(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int NT = H >> 5, TM = 32 * MT, E = EV + C + H, KX = E + H;
+    constexpr int NT = H >> 5, TM = 32 * WM, E = EV + C + H, KX = E + H;
     constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = TM + 8;          // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
-    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int NTHR = NT * WM * 64, TPR = NTHR / TM;
     constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
+    constexpr int JGM = 2 * WM;                                       // most 16-neighbour chunks a row can have
     const int B = a.G * a.G, LDM = B + 1;
     u16* Xb = reinterpret_cast<u16*>(smem_raw);                       // [TM][LDXB]  e_v | e_s | e_r | h
     u16* RHb = Xb + TM * LDXB;                                        // [TM][LDRB]  r * h
@@ -116,7 +117,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
     float* red = wv + 3 * EV;                                         // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
 
-    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w % NT, mt = w / NT;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * TM;
     const int col = cb * 32 + c31;
@@ -125,8 +127,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
     const int my_scene = my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;
     const int my_slot = r8 - grp_base;
-    const bool wide = a.mno > 32;                                     // one group spans both M-tiles
-    const int JG = wide ? TM / 16 : 2;                                // 16-wide neighbour chunks per M-tile
+    const bool wide = a.mno > 32;                                     // one group spans both row blocks
+    const int JG = wide ? JGM : 2;                                    // 16-wide neighbour chunks of this wave's rows
+    const int jbase = wide ? 0 : mt * 32;                             // first local row its neighbours can have
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     if (tid < 16) {
@@ -142,35 +145,25 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
     const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
     const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
 
-    const u16* xp[MT]; const u16* rp[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        xp[m] = Xb + (m * 32 + c31) * LDXB + 8 * hi;
-        rp[m] = RHb + (m * 32 + c31) * LDRB + 8 * hi;
-    }
+    const u16* xp[1] = {Xb + (mt * 32 + c31) * LDXB + 8 * hi};
+    const u16* rp[1] = {RHb + (mt * 32 + c31) * LDRB + 8 * hi};
+    const int arow = mt * 32 + 4 * hi;                                // + (i&3) + 8(i>>2): local row of accumulator element i
     // h (fp32, accumulator layout) -> both bf16 images
-    auto publish_h = [&](const f32x16 (&h)[MT]) {
+    auto publish_h = [&](const f32x16& h) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int i = 0; i < 16; ++i) Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + E + col] = bf16_of(h[i]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) Xb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDXB + E + col] = bf16_of(h[m][i]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint2*>(Ht + col * LDT + m * 32 + 8 * q + 4 * hi) =
-                    make_uint2(pk_bf16(h[m][4 * q], h[m][4 * q + 1]), pk_bf16(h[m][4 * q + 2], h[m][4 * q + 3]));
-        }
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint2*>(Ht + col * LDT + arow + 8 * q) =
+                make_uint2(pk_bf16(h[4 * q], h[4 * q + 1]), pk_bf16(h[4 * q + 2], h[4 * q + 3]));
     };
 
     for (int it = 0; it < a.iters; ++it) {
-        f32x16 h[MT], sp[MT];
+        f32x16 h, sp = zero16();
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            sp[m] = zero16();
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = min(row0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi, a.R - 1);
-                h[m][i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(row0 + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
+            h[i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
         }
         __syncthreads();                                  // previous iteration's readers of Xb / Ht are done
         publish_h(h);
@@ -213,9 +206,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
             __syncthreads();
             // ---- P2: social pooling chain -> e_r (no LDS traffic besides h^T fragments, no barriers) ----
             {
-                f32x16 soc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) soc[m] = splat16h(bso);
+                f32x16 soc = splat16h(bso);
                 // this wave's n-tile of W_b (H/16 k-groups, chain order) lives in ONE register set that is refreshed in
                 // place: the fragments of bin b+1 are requested right after their last use in bin b, so every load is in
                 // flight for a whole bin of MFMAs
@@ -228,94 +219,72 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
 #pragma clang loop unroll(disable)
                 for (int b = 0; b < B; ++b) {
                     const uint4* wnext = Wsoc + ((size_t)(min(b + 1, B - 1) * NT + cb) * GH16) * 64 + lane;
-                    uint4 mf[MT][2 * MT];                               // neighbour bits -> bf16 B fragments (16 neighbours each)
-                    int jb[MT];
+                    uint4 mf[JGM];                                      // neighbour bits -> bf16 B fragments (16 neighbours each)
+                    const unsigned long long m64 = masks[(mt * 32 + c31) * LDM + b];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const unsigned long long m64 = masks[(m * 32 + c31) * LDM + b];
-                        jb[m] = wide ? 0 : m * 32;
-#pragma unroll
-                        for (int jg = 0; jg < 2 * MT; ++jg) {
-                            if (jg < JG) {
-                                const unsigned bits = (unsigned)(m64 >> (jb[m] + 16 * jg + 8 * hi)) & 0xffu;
-                                const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
-                                mf[m][jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                            }
+                    for (int jg = 0; jg < JGM; ++jg) {
+                        if (jg < JG) {
+                            const unsigned bits = (unsigned)(m64 >> (jbase + 16 * jg + 8 * hi)) & 0xffu;
+                            const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                            mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                         }
                     }
                     // software pipeline over the hidden blocks: MFMA 1 of block hb+1 is issued before block hb's
                     // accumulators are converted and consumed, so the convert never waits on the matrix pipe
-                    auto chain = [&](int hb, int m) {
+                    auto chain = [&](int hb) {
                         f32x16 d1 = zero16();
-                        const u16* hp = Ht + (hb * 32 + c31) * LDT + jb[m] + 8 * hi;
+                        const u16* hp = Ht + (hb * 32 + c31) * LDT + jbase + 8 * hi;
 #pragma unroll
-                        for (int jg = 0; jg < 2 * MT; ++jg)
-                            if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[m][jg], d1);
+                        for (int jg = 0; jg < JGM; ++jg)
+                            if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], d1);
                         return d1;
                     };
-                    f32x16 da[MT], dn[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) da[m] = chain(0, m);
+                    f32x16 da = chain(0), dn;
 #pragma unroll
                     for (int hb = 0; hb < NT; ++hb) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            if (hb + 1 < NT) dn[m] = chain(hb + 1, m);
-                            const f32x16 d1 = da[m];
-                            const uint4 p0 = make_uint4(pk_bf16(d1[0], d1[1]), pk_bf16(d1[2], d1[3]), pk_bf16(d1[4], d1[5]), pk_bf16(d1[6], d1[7]));
-                            const uint4 p1 = make_uint4(pk_bf16(d1[8], d1[9]), pk_bf16(d1[10], d1[11]), pk_bf16(d1[12], d1[13]), pk_bf16(d1[14], d1[15]));
-                            soc[m] = mfma16(p0, wb[2 * hb], soc[m]);
-                            soc[m] = mfma16(p1, wb[2 * hb + 1], soc[m]);
-                            if (hb + 1 < NT) da[m] = dn[m];
-                        }
+                        if (hb + 1 < NT) dn = chain(hb + 1);
+                        const uint4 p0 = make_uint4(pk_bf16(da[0], da[1]), pk_bf16(da[2], da[3]), pk_bf16(da[4], da[5]), pk_bf16(da[6], da[7]));
+                        const uint4 p1 = make_uint4(pk_bf16(da[8], da[9]), pk_bf16(da[10], da[11]), pk_bf16(da[12], da[13]), pk_bf16(da[14], da[15]));
+                        soc = mfma16(p0, wb[2 * hb], soc);
+                        soc = mfma16(p1, wb[2 * hb + 1], soc);
+                        if (hb + 1 < NT) da = dn;
                         wb[2 * hb] = wnext[(2 * hb) * 64];
                         wb[2 * hb + 1] = wnext[(2 * hb + 1) * 64];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        Xb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[m][i], 0.f));
+                for (int i = 0; i < 16; ++i)
+                    Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i], 0.f));
             }
             __syncthreads();
             // ---- P4: gates over [x | h] ----
-            f32x16 u[MT];
+            f32x16 u;
             {
-                f32x16 g2[2][MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) { g2[0][m] = splat16h(bgr); g2[1][m] = splat16h(bgu); }
+                f32x16 g2[2][1] = {{splat16h(bgr)}, {splat16h(bgu)}};
                 const uint4* bl[2] = {Wg + ((size_t)cb * G16) * 64 + lane, Wg + ((size_t)(cb + NT) * G16) * 64 + lane};
-                mma16_groups<MT, 2>(g2, xp, bl, G16);
+                mma16_groups<1, 2>(g2, xp, bl, G16);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float r = sigmoidf_(g2[0][m][i]);
-                        RHb[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDRB + col] = bf16_of(r * h[m][i]);
-                        u[m][i] = sigmoidf_(g2[1][m][i]);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const float r = sigmoidf_(g2[0][0][i]);
+                    RHb[(arow + (i & 3) + 8 * (i >> 2)) * LDRB + col] = bf16_of(r * h[i]);
+                    u[i] = sigmoidf_(g2[1][0][i]);
                 }
             }
             __syncthreads();
             // ---- P5: candidate over [x | r*h], blend, score; publish h_t ----
             {
-                f32x16 ac[1][MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) ac[0][m] = splat16h(bcc);
+                f32x16 ac[1][1] = {{splat16h(bcc)}};
                 const uint4* bx[1] = {Wc + ((size_t)cb * G16) * 64 + lane};
-                mma16_groups<MT, 1>(ac, xp, bx, GX16);
+                mma16_groups<1, 1>(ac, xp, bx, GX16);
                 const uint4* bh[1] = {Wc + ((size_t)cb * G16 + GX16) * 64 + lane};
-                mma16_groups<MT, 1>(ac, rp, bh, GH16);
+                mma16_groups<1, 1>(ac, rp, bh, GH16);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float c = tanhf_(ac[0][m][i]);
-                        h[m][i] = u[m][i] * h[m][i] + (1.0f - u[m][i]) * c;
-                        sp[m][i] = fmaf(h[m][i], wsc, sp[m][i]);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const float c = tanhf_(ac[0][0][i]);
+                    h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                    sp[i] = fmaf(h[i], wsc, sp[i]);
+                }
                 publish_h(h);                              // h slots of Xb / Ht were last read before the previous barrier
             }
             if (tid < TM) {
@@ -327,13 +296,11 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
         }
         // ---- score ----
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = sp[m][i];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-                if (c31 == 0) red[cb * TM + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] = v;
-            }
+        for (int i = 0; i < 16; ++i) {
+            float v = sp[i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+            if (c31 == 0) red[cb * TM + arow + (i & 3) + 8 * (i >> 2)] = v;
+        }
         __syncthreads();
         if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
             float sc = 0.f;
@@ -343,44 +310,38 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_ioc_bf
         }
         // ---- regression: Y += h_T W_r + b_r ----
         for (int nt = cb; nt < a.NTreg; nt += NT) {
-            f32x16 acc[1][MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[0][m] = zero16();
-            const u16* hp2[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) hp2[m] = xp[m] + E;
+            f32x16 acc[1][1] = {{zero16()}};
+            const u16* hp2[1] = {xp[0] + E};
             const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
-            mma16_groups<MT, 1>(acc, hp2, br, GH16);
+            mma16_groups<1, 1>(acc, hp2, br, GH16);
             const int cc = nt * 32 + c31;
             if (cc < 2 * a.T) {
                 const float bb = a.b_reg[cc];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = row0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                        if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][m][i] + bb); }
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + arow + (i & 3) + 8 * (i >> 2);
+                    if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][0][i] + bb); }
+                }
             }
         }
         __syncthreads();
     }
 }
 
-static size_t ioc16_lds(const IocArgs& a, int MT) {
-    const int H = a.H, TM = 32 * MT, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
+static size_t ioc16_lds(const IocArgs& a, int WM) {
+    const int H = a.H, TM = 32 * WM, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
     size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2;
     b += (size_t)TM * (B + 1) * 8 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 64;
     return b;
 }
-template <int H, int MT>
+template <int H, int WM>
 static void launch16(const IocArgs& a, hipStream_t s) {
-    const int TM = 32 * MT;
-    allow_big_lds(k_ioc_bf16<H, 16, 32, MT>);
-    hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, MT>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * 64), ioc16_lds(a, MT), s, a);
+    const int TM = 32 * WM;
+    allow_big_lds(k_ioc_bf16<H, 16, 32, WM>);
+    hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, WM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * WM * 64), ioc16_lds(a, WM), s, a);
 }
-// mno must divide 32 (32-row tiles, two workgroups per CU) or be 64 (64-row tile); a.variant == 2 forces 64-row tiles (A/B:
-// measured 7.5 ms vs 4.0 ms for 81 920 rows at H = 128 -- the second M-tile's live state spills)
+// mno must divide 32 (32-row tiles, two workgroups per CU at H <= 128) or be 64 (64-row tiles, twice the waves);
+// a.variant == 2 forces 64-row tiles (A/B)
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
     const bool two = a.mno > 32 || a.variant == 2;
     if (a.H == 128) { if (two) launch16<128, 2>(a, s); else launch16<128, 1>(a, s); }
