@@ -290,6 +290,10 @@ int desire_pack_all(desire_ctx* h) {
         }
         bad |= up("vae_dec/deconv2/W16", taps16(hw["vae_dec/deconv2/w"], 128, 64));
         bad |= up("vae_dec/deconv3/W16", taps16(hw["vae_dec/deconv3/w"], 64, 32));
+        {   // deconv4 as "tap products": A[m = tap][k = channel, chain order] = w4[tap][0][channel]
+            const auto& w4 = hw["vae_dec/deconv4/w"];
+            bad |= up("vae_dec/deconv4/W16", pack_b16(32, 32, chain, [&](int k, int n) { return n < 25 ? w4[(size_t)n * 32 + k] : 0.f; }));
+        }
     }
     bad |= up("ioc/vel_w", hw["ioc/vel_fc/w"]); bad |= up("ioc/vel_b", hw["ioc/vel_fc/b"]);
     {
@@ -437,11 +441,18 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
-    if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
-    else { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
-    c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
-    c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
-    { Timer t(h, s, "deconv4"); launch_deconv4(c, s); }
+    const bool fuse34 = d.bf16 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
+    if (fuse34) {
+        c.Wp = D4(h, "vae_dec/deconv3/W16"); c.w_raw = D(h, "vae_dec/deconv4/W16"); c.out = W(h, "xhat");
+        Timer t(h, s, "deconv34");
+        launch_deconv34_bf16(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), s);
+    } else {
+        if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
+        else { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
+        c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
+        c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
+        { Timer t(h, s, "deconv4"); launch_deconv4(c, s); }
+    }
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");

@@ -97,7 +97,8 @@ void launch_ioc(const IocArgs& a, hipStream_t s);
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
 struct ConvArgs;
 void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s);
-void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);    // kernels_bf16.hip; weight pointers = bf16 packs
+void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);
+void launch_deconv34_bf16(const ConvArgs& a, const float* sc4, const float* sh4, hipStream_t s);   // a.Wp = W3 pack, a.w_raw = W4 chain pack    // kernels_bf16.hip; weight pointers = bf16 packs
 
 void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
                           float nb_w, float nb_h, int G, hipStream_t s);

@@ -42,6 +42,9 @@ __device__ __forceinline__ f32x16 splat16h(float v) {
 // + 8*(lane>>5) elements), B fragments from packed weights (bl[nb] already offset by +lane, uint4 units, stride 64 per
 // k-group).  Chunks of CH groups with the next chunk's B fragments in flight (two named register sets, fenced).
 #define CH16 4
+#ifndef IOC16_OCC
+#define IOC16_OCC 2
+#endif
 template <int MT, int NB>
 __device__ __forceinline__ void mma16_chunk(f32x16 (&acc)[NB][MT], const u16* const (&ap)[MT], int g, const uint4 (&b)[NB][CH16]) {
 #pragma unroll
@@ -98,7 +101,7 @@ __device__ __forceinline__ void mma16_groups(f32x16 (&acc)[NB][MT], const u16* c
 // [32cb, 32cb+32).  Weight pointers of IocArgs (Wg, Wc, Wsoc, Wreg) point at the bf16 packs ("ioc/*16" in api.hip).
 // ------------------------------------------------------------------------------------------------------------------
 template <int H, int EV, int C, int WM>
-__global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? 2 : 1) void k_ioc_bf16(IocArgs a) {
+__global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OCC : 1) void k_ioc_bf16(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = H >> 5, TM = 32 * WM, E = EV + C + H, KX = E + H;
     constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = TM + 8;          // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
@@ -613,4 +616,122 @@ void launch_decoder_bf16(const DecArgs& a, hipStream_t s) {
     if (a.H == 256) launch_dec16<256>(a, s);
     else if (a.H == 128) launch_dec16<128>(a, s);
     else launch_dec16<64>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// deconv3 + deconv4 fused (bf16 operands): [n,8,8,64] -> [n,32,32] without ever writing the [n,16,16,32] activation.
+// deconv3 runs TRANSPOSED (A = packed W3 with lane = output channel, B = the gathered input pixel row from LDS), so its
+// accumulators come out with lane = pixel and registers = channels -- the B-fragment layout (up to the chain order of k)
+// of the next product.  deconv4 has ONE output channel, so it is done as "tap products first":
+//     T[tap, pixel] = sum_c W4[tap, c] * d3[pixel, c]            (2 MFMAs per 32 pixels, A = W4 packed in chain order)
+// and each of the 25 products of a pixel is then added to its output position o = 2i + k - 1 in an fp32 LDS image of the
+// sample (plain read-add-write, the two half-waves in turn: inside a half every lane holds the SAME tap, so the
+// addresses are distinct; deterministic).  One wave per sample.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG) void k_deconv34_bf16(ConvArgs a, const float* __restrict__ sc4p, const float* __restrict__ sh4p) {
+    constexpr int LDP = 72;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_d34[];
+    u16* zero_row = reinterpret_cast<u16*>(smem_d34);
+    u16* in_s = zero_row + LDP;                                        // [4][64][LDP]
+    float* xacc = reinterpret_cast<float*>(in_s + 4 * 64 * LDP);       // [4][1024]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * 4;
+    for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
+    for (int i = tid; i < 4 * 1024; i += DS_WG) xacc[i] = 0.f;
+    for (int i = tid; i < 4 * 64 * 8; i += DS_WG) {
+        const int pix = i >> 3, c8 = i & 7;
+        const int smp = s0 + (pix >> 6);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (smp < a.n) {
+            const float* src = a.in + ((size_t)s0 * 64 + pix) * 64 + c8 * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            v = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
+        }
+        *reinterpret_cast<uint4*>(in_s + pix * LDP + c8 * 8) = v;
+    }
+    __syncthreads();
+    const int smp = s0 + w;
+    const u16* mine = in_s + w * 64 * LDP;
+    float* xa = xacc + w * 1024;
+    const int c = lane & 31, hi = lane >> 5;
+    const uint4* W3 = reinterpret_cast<const uint4*>(a.Wp);
+    const uint4* W4 = reinterpret_cast<const uint4*>(a.w_raw);         // [2 k-groups][64] chain order, rows = taps
+    float sc3[16], sh3[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int co = (r & 3) + 8 * (r >> 2) + 4 * hi; sc3[r] = a.scale[co]; sh3[r] = a.shift[co]; }
+    const uint4 w4a = W4[lane], w4b = W4[64 + lane];
+    int qy[2], qx[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int q = m * 32 + c; qy[m] = q >> 3; qx[m] = q & 7; }
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            f32x16 acc[2] = {zero16(), zero16()};
+            const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
+            auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
+            uint4 bc[4], bn[4];
+            {
+                const uint4* bp = W3 + ((size_t)tap_of(0) * 4) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bc[g] = bp[g * 64];
+            }
+#pragma clang loop unroll(disable)
+            for (int t = 0; t < ntap; ++t) {
+                const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
+                {
+                    const uint4* bp = W3 + ((size_t)tap_of(min(t + 1, ntap - 1)) * 4) * 64 + lane;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bn[g] = bp[g * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int iy = qy[m] + dy, ix = qx[m] + dx;
+                    const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                    const u16* xp = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 8 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[m] = mfma16(bc[g], *reinterpret_cast<const uint4*>(xp + 16 * g), acc[m]);   // D[co][pixel]
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bc[g] = bn[g];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = eluf_(acc[m][r] * sc3[r] + sh3[r]);
+                const uint4 p0 = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
+                const uint4 p1 = make_uint4(pk_bf16(v[8], v[9]), pk_bf16(v[10], v[11]), pk_bf16(v[12], v[13]), pk_bf16(v[14], v[15]));
+                f32x16 tp = mfma16(w4a, p0, zero16());
+                tp = mfma16(w4b, p1, tp);                               // D[tap][pixel]
+                const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;    // this lane's pixel in the 16x16 grid
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (hi == half) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (tap < 25) {
+                                const int ky = tap / 5, kx = tap - ky * 5;
+                                const int Y = 2 * oy + ky - 1, X = 2 * ox + kx - 1;
+                                if (Y >= 0 && Y < 32 && X >= 0 && X < 32) xa[Y * 32 + X] += tp[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    if (smp < a.n) {
+        const float sc4 = sc4p[0], sh4 = sh4p[0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = i * 64 + lane;
+            a.out[(size_t)smp * 1024 + o] = sigmoidf_(xa[o] * sc4 + sh4);
+        }
+    }
+}
+void launch_deconv34_bf16(const ConvArgs& a, const float* sc4, const float* sh4, hipStream_t s) {
+    const size_t lds = (72 + 4 * 64 * 72) * sizeof(u16) + 4 * 1024 * sizeof(float);
+    hipLaunchKernelGGL(k_deconv34_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a, sc4, sh4);
 }

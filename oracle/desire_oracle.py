@@ -172,17 +172,18 @@ def vae_encoder(vae_in, w, L, bn_mode="frozen", dt=np.float32):
     return params[:, :L], params[:, L:]
 
 
-def vae_decoder(z, w, bn_mode="frozen", dt=np.float32, return_layers=False, q=None):
+def vae_decoder(z, w, bn_mode="frozen", dt=np.float32, return_layers=False, q=None, q_layers=("deconv2", "deconv3", "deconv4")):
     """model/model.py:453-469 (+ utils/convolutional_vae_util.py:27-135).  z [R, L] -> [R, 1024].
     All four deconvs sit inside defaults_scope(batch_normalize=True), so the last one is
-    BN -> sigmoid.  q = bf16_round restates the bf16-operand deconv2/deconv3 kernels (input activations and weights
-    rounded where they enter the contraction; accumulation and the BN/ELU epilogue in fp32)."""
+    BN -> sigmoid.  q = bf16_round restates the bf16-operand kernels (k_deconv2_bf16, k_deconv34_bf16): for the layers
+    in q_layers the input activations and the weights are rounded where they enter the contraction; accumulation and
+    the BN/ELU/sigmoid epilogues are fp32."""
     x = z.astype(dt).reshape(-1, 1, 1, z.shape[-1])
     layers = []
     for name, stride, pad, act in (("deconv1", 1, "VALID", elu), ("deconv2", 1, "VALID", elu),
                                    ("deconv3", 2, "SAME", elu), ("deconv4", 2, "SAME", sigmoid)):
         p = "vae_dec/" + name
-        if q is not None and name in ("deconv2", "deconv3"):
+        if q is not None and name in q_layers:
             x = conv2d_transpose(q(x), q(w[p + "/w"].astype(dt)), stride, pad) + w[p + "/b"].astype(dt)
         else:
             x = conv2d_transpose(x, w[p + "/w"].astype(dt), stride, pad) + w[p + "/b"].astype(dt)

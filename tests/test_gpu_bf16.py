@@ -76,19 +76,27 @@ def test_bf16_is_inference_only_and_validated(torch_cuda):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64)])
-def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw):
-    """deconv2 / deconv3 with bf16 operands: d2, d3 and xhat against the oracle's decoder with the same operand rounding
-    (fed with the kernel's own z so the comparison isolates these layers), and against plain fp32."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw, fused, monkeypatch):
+    """deconv2 / deconv3 (/ deconv4 when fused) with bf16 operands: d2, d3 and xhat against the oracle's decoder with the
+    same operand rounding (fed with the kernel's own z so the comparison isolates these layers), and against plain fp32.
+    Default = deconv3+deconv4 fused (d3 never exists); DESIRE_NO_FUSE34 keeps the separate kernels (fp32 deconv4)."""
     from oracle import desire_oracle as O
+    if not fused:
+        monkeypatch.setenv("DESIRE_NO_FUSE34", "1")
     d32 = small_dims(**kw)
     d16 = d32.replace(bf16=1)
     w = init_weights(d32, 5)
     past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=2)
     h, _, _ = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos)
     z = h.read_buffer("z", (d32.R, d32.L))
-    xhat_q, layers_q = O.vae_decoder(z, w, return_layers=True, q=O.bf16_round)
+    ql = ("deconv2", "deconv3", "deconv4") if fused else ("deconv2", "deconv3")
+    xhat_q, layers_q = O.vae_decoder(z, w, return_layers=True, q=O.bf16_round, q_layers=ql)
     xhat_f, layers_f = O.vae_decoder(z, w, return_layers=True)
-    for name, lq, lf, n in (("d2", layers_q[1], layers_f[1], 4096), ("d3", layers_q[2], layers_f[2], 8192), ("xhat", xhat_q, xhat_f, 1024)):
+    checks = [("d2", layers_q[1], layers_f[1], 4096), ("xhat", xhat_q, xhat_f, 1024)]
+    if not fused:
+        checks.insert(1, ("d3", layers_q[2], layers_f[2], 8192))
+    for name, lq, lf, n in checks:
         got = h.read_buffer(name, (d32.R, n))
         eq = np.abs(got - lq.reshape(d32.R, n)).max()
         ef = np.abs(got - lf.reshape(d32.R, n)).max()
