@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -39,17 +40,17 @@ def ioc_flops_per_row(d):
     return d.iters * (T * (6.0 * H * (E + H) + 2.0 * B * H * H + 2 * H + 4 * d.E_v) + 2.0 * H * 2 * T)
 
 
-def committed_traffic(windows):
+def committed_traffic(windows, bf16=False):
     """HBM bytes per k_ioc launch from the committed rocprofv3 PMC passes (profiles/, collected from this very
     command at 128 windows/step in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_final_bench_pmc_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01_bf16_bench_pmc_per_kernel.json" if bf16 else "r01_final_bench_pmc_per_kernel.json")
     if windows != 128 or not os.path.exists(path):
         return None
     with open(path) as fh:
         pmc = json.load(fh)
     for name, c in pmc.items():
-        if name.startswith("void k_ioc<128") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if (("k_ioc_bf16ILi128" in name) if bf16 else name.startswith("void k_ioc<128")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return None
 
@@ -189,6 +190,7 @@ def main():
     ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12
     whole_tflops = flops_per_sample(d) * d.R * a.steps / dt / 1e12
 
+    peak = BF16_MFMA_PEAK_TFLOPS if a.bf16 else FP32_MFMA_PEAK_TFLOPS
     if rank == 0 and a.train:
         samples = d.R * world * a.steps
         fwd = sum(v for k, v in kern_ms.items() if not k.startswith("bwd_"))
@@ -214,13 +216,13 @@ def main():
                                    "social grid 4x4, scene grid 64x64x32; %d windows/step/GPU" % a.windows,
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d" % world,
                        "flops_per_sample": flops_per_sample(d)},
-            "roofline": {"bound": "mfma", "kernel": "k_ioc<128,16,32>", "achieved": ioc_tflops,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ioc_tflops / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": committed_traffic(a.windows), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+            "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1>" if a.bf16 else "k_ioc<128,16,32>", "achieved": ioc_tflops,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ioc_tflops / peak,
+                         "traffic": committed_traffic(a.windows, a.bf16), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_hbm_bytes_per_launch": d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4,
                          "kernel_ms": ioc_ms,
                          "algorithmic_flops_per_launch": ioc_flops_per_row(d) * d.R,
-                         "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / FP32_MFMA_PEAK_TFLOPS},
+                         "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / peak},
             "kernel_ms": kern_ms,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -529,8 +529,11 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         long long host[10];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
-        const char* names[10] = {"P0 pos+clear", "P1 ev/es/masks", "build0+bar", "build(b+1)", "mma bin", "bin barrier",
-                                 "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
+        const char* n32[10] = {"P0 pos+clear", "P1 ev/es/masks", "build0+bar", "build(b+1)", "mma bin", "bin barrier",
+                               "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
+        const char* n16[10] = {"loop top", "P1 ev/es/masks", "barrier 1", "P2 pooling chain + e_r", "barrier 2", "P4 gates + r*h",
+                               "barrier 3", "P5 cand + publish", "barrier 4", ""};
+        const char** names = d.bf16 ? n16 : n32;
         long long tot = 0; for (int k = 0; k < 9; ++k) tot += host[k];
         for (int k = 0; k < 9; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
     }

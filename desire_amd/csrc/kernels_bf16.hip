@@ -100,8 +100,17 @@ __device__ __forceinline__ void mma16_groups(f32x16 (&acc)[NB][MT], const u16* c
 // mno = 64 with WM = 2); workgroup = WM * H/32 waves, wave (mt, cb) owns rows [32mt, 32mt+32) x hidden columns
 // [32cb, 32cb+32).  Weight pointers of IocArgs (Wg, Wc, Wsoc, Wreg) point at the bf16 packs ("ioc/*16" in api.hip).
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef DESIRE_IOC_TIMING
+#define TICK16(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICK16(k)
+#endif
 template <int H, int EV, int C, int WM>
 __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OCC : 1) void k_ioc_bf16(IocArgs a) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = H >> 5, TM = 32 * WM, E = EV + C + H, KX = E + H;
     constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = TM + 8;          // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
@@ -182,6 +191,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
         __syncthreads();
 
         for (int t = 0; t < a.T; ++t) {
+            TICK16(0)
             if (tid < TM && t + 1 < a.T)
                 ynext = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t + 1) * 2);
             // ---- P1: e_v, e_s, neighbour bits (row threads) ----
@@ -206,7 +216,9 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                     if (b >= 0) atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j));
                 }
             }
+            TICK16(1)
             __syncthreads();
+            TICK16(2)
             // ---- P2: social pooling chain -> e_r (no LDS traffic besides h^T fragments, no barriers) ----
             {
                 f32x16 soc = splat16h(bso);
@@ -260,7 +272,9 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 for (int i = 0; i < 16; ++i)
                     Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i], 0.f));
             }
+            TICK16(3)
             __syncthreads();
+            TICK16(4)
             // ---- P4: gates over [x | h] ----
             f32x16 u;
             {
@@ -274,7 +288,9 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                     u[i] = sigmoidf_(g2[1][0][i]);
                 }
             }
+            TICK16(5)
             __syncthreads();
+            TICK16(6)
             // ---- P5: candidate over [x | r*h], blend, score; publish h_t ----
             {
                 f32x16 ac[1][1] = {{splat16h(bcc)}};
@@ -295,7 +311,9 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
             }
             for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+            TICK16(7)
             __syncthreads();
+            TICK16(8)
         }
         // ---- score ----
 #pragma unroll
@@ -329,6 +347,10 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
         }
         __syncthreads();
     }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
+#endif
 }
 
 static size_t ioc16_lds(const IocArgs& a, int WM) {
