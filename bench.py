@@ -108,7 +108,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16", action="store_true",
                     help="bf16 matrix operands in the IOC kernel (BASELINE configs[2] arithmetic; NOT the headline fp32 line)")
-    ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]: 64)")
+    ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]/[3]: 64)")
+    ap.add_argument("--H", type=int, default=128, help="hidden width (configs[3]: 256)")
+    ap.add_argument("--K", type=int, default=20, help="samples per agent (configs[3]: 50)")
     ap.add_argument("--train", action="store_true",
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
@@ -133,7 +135,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4,
+    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=4,
              nb_w=0.15, nb_h=0.15, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)

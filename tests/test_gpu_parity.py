@@ -429,3 +429,37 @@ def test_abi_error_behaviour_on_device(torch_cuda):
         h.read_buffer("Hx", (1,))
     with pytest.raises(ValueError):
         _lib.Handle(small_dims(mno=24))
+
+
+def test_window_with_no_agents_and_duplicate_positions(torch_cuda):
+    """Edge inputs of the loader layout: one window whose slots are ALL empty (id 0 everywhere -- the loader emits such
+    windows when nothing is tracked), and a window where several agents stand on exactly the same spot (collisions: same
+    scene cell, centre social bin).  The path must stay finite and match the oracle; empty slots never act as neighbours."""
+    from oracle import desire_oracle as O
+    d = small_dims(n_scenes=3, K=2)
+    w = init_weights(d, 11)
+    past, fut, eps, grids, gos = make_case(d, seed=12, n_absent=2)
+    past[1] = 0.0
+    fut[1] = 0.0                                                    # window 1: nobody there
+    past[2, :, 1:6, 1:] = past[2, :, 0:1, 1:]
+    fut[2, :, 1:6, 1:] = fut[2, :, 0:1, 1:]                          # window 2: slots 1..5 walk exactly with slot 0
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    assert np.isfinite(Y).all() and np.isfinite(score).all()
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    assert np.abs(Y0 - ref["Y0"]).max() < TOL_Y
+    _, Y2, score2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref["Y"]).max() < TOL_Y
+    assert np.abs(score2 - ref["score"]).max() < 5e-3
+    # bins of the coincident agents: bit-exact against the oracle at the decoded positions
+    P = ref["Y0"].reshape(d.n_scenes * d.K, d.mno, d.T_pred, 2)[:, :, 0]
+    valid = np.repeat((past[:, d.T_obs - 1, :, 0] != 0)[:, None], d.K, 1).reshape(d.n_scenes * d.K, d.mno)
+    torch = torch_cuda
+    pos_t = torch.as_tensor(np.ascontiguousarray(P, np.float32), device="cuda")
+    val_t = torch.as_tensor(np.ascontiguousarray(valid).astype(np.uint8), device="cuda")
+    bins_t = torch.full((d.n_scenes * d.K, d.mno, d.mno), -7, dtype=torch.int32, device="cuda")
+    h.neighbor_bins(pos_t.data_ptr(), val_t.data_ptr(), bins_t.data_ptr(), d.n_scenes * d.K)
+    torch.cuda.synchronize()
+    got = bins_t.cpu().numpy()
+    np.testing.assert_array_equal(got, O.neighbor_bins(P.astype(np.float32), valid, d.nb_w, d.nb_h, d.grid_size))
+    assert (got[d.K * 1:d.K * 2] == -1).all()                       # the empty window has no neighbours at all
