@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]/[3]: 64)")
     ap.add_argument("--H", type=int, default=128, help="hidden width (configs[3]: 256)")
     ap.add_argument("--K", type=int, default=20, help="samples per agent (configs[3]: 50)")
+    ap.add_argument("--shard", choices=["scenes", "agents"], default="scenes",
+                    help="multi-GPU partitioning: 'scenes' (default; windows are independent, no data-path collective) or "
+                         "'agents' (the agents of EVERY scene block-sharded over the ranks: --mno slots per rank, hidden states "
+                         "all-gathered over RCCL once per IOC step -- SURVEY.md 8(e) E1's prescribed form)")
     ap.add_argument("--train", action="store_true",
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
@@ -153,7 +157,16 @@ def main():
         h.set_training(True)
         gflat = h.grad_tensor()
 
+    if a.shard == "agents":
+        from desire_amd.dist import ShardedIoc
+        sharded = ShardedIoc(h, rank, world)
+
     def step():
+        if a.shard == "agents":                    # per-agent stages locally, IOC with the neighbour all-gather per step
+            h.encode(past_t.data_ptr(), fut_t.data_ptr(), stream)
+            h.sample(eps_t.data_ptr(), Y.data_ptr(), stream)
+            sharded.run(Y, score)
+            return
         h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
         if a.train:
             h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), stream)
@@ -216,7 +229,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SDD-like synthetic windows, 32 agent slots/window, K=20, "
                                    "T_obs=8/T_pred=40, H=128, L=128, fp32, posterior CVAE, IOC 1 refinement, "
                                    "social grid 4x4, scene grid 64x64x32; %d windows/step/GPU" % a.windows,
-                       "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d" % world,
+                       "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": ("scene-sharded x%d" % world) if a.shard == "scenes" else
+                                      ("agent-sharded x%d: %d slots/rank of %d-agent scenes, RCCL all-gather of [R_loc, H] per IOC step" % (world, d.mno, d.mno * world)),
                        "flops_per_sample": flops_per_sample(d)},
             "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1>" if a.bf16 else "k_ioc<128,16,32>", "achieved": ioc_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": ioc_tflops / peak,

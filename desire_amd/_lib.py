@@ -21,6 +21,7 @@ EXPORTS = [
     "desire_temporal_conv", "desire_feature_pooling", "desire_build_windows", "desire_gaussian_sample", "desire_ade_fde",
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
+    "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish",
 ]
 
 
@@ -82,6 +83,9 @@ def load() -> C.CDLL:
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_clip_grads.argtypes = [vp, C.c_float, C.POINTER(C.c_float), vp]
+    lib.desire_device_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.desire_ioc_step.argtypes = [vp, i32, i32, i32, f32p, f32p, vp, f32p, f32p, f32p, vp]
+    lib.desire_ioc_finish.argtypes = [vp, f32p, f32p, f32p, f32p, vp]
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
@@ -192,6 +196,25 @@ class Handle:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.lib.desire_grad_buffer(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+    def device_tensor(self, name: str, dtype: str = "<f4"):
+        """A workspace tensor of the handle ("HxHy", "p_last", "valid", "Y0", ...) as a flat zero-copy torch tensor."""
+        import torch
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib.desire_device_buffer(self._h, name.encode(), C.byref(p), C.byref(n)))
+        cnt = int(n.value) // (1 if dtype == "|u1" else 4)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (cnt,), "typestr": dtype, "data": (int(p.value), False), "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda")
+
+    def ioc_step(self, t: int, rank: int, nranks: int, Yall_ptr: int, plast_all_ptr: int, valid_all_ptr: int, Hall_ptr: int,
+                 h_state_ptr: int, score_state_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_ioc_step(self._h, t, rank, nranks, Yall_ptr, plast_all_ptr, valid_all_ptr, Hall_ptr, h_state_ptr,
+                                      score_state_ptr, stream or None))
+
+    def ioc_finish(self, h_state_ptr: int, score_state_ptr: int, Y_ptr: int, score_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_ioc_finish(self._h, h_state_ptr, score_state_ptr, Y_ptr, score_ptr, stream or None))
 
     def grad_tensor(self):
         """The flat gradient buffer as a zero-copy torch tensor (for torch.distributed.all_reduce over RCCL)."""

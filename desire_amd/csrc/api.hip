@@ -584,6 +584,56 @@ extern "C" int desire_read_buffer(desire_handle* h, const char* name, float* hos
     return fail(DESIRE_ERR_ARG, "unknown buffer: " + nm);
 }
 
+extern "C" int desire_device_buffer(desire_handle* h, const char* name, void** dev_ptr, size_t* bytes) {
+    if (!h || !name || !dev_ptr || !bytes) return fail(DESIRE_ERR_ARG, "null argument");
+    auto it = h->ws.find(name);
+    if (it == h->ws.end()) return fail(DESIRE_ERR_ARG, std::string("unknown buffer: ") + name);
+    *dev_ptr = it->second.p; *bytes = it->second.bytes;
+    return DESIRE_OK;
+}
+
+// ---- agent-sharded IOC (one step per call; the caller all-gathers hidden states between steps) ----
+extern "C" int desire_ioc_step(desire_handle* h, int32_t t, int32_t rank, int32_t nranks, const float* dev_Yall,
+                               const float* dev_plast_all, const uint8_t* dev_valid_all, const float* dev_Hall,
+                               float* dev_h_state, float* dev_score_state, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    const desire_dims& d = h->d;
+    if (!dev_Yall || !dev_plast_all || !dev_valid_all || !dev_Hall || !dev_h_state || !dev_score_state) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!h->grids_set) return fail(DESIRE_ERR_STATE, "desire_set_scene_grids first");
+    if (t < 0 || t >= d.T_pred || nranks < 1 || rank < 0 || rank >= nranks) return fail(DESIRE_ERR_ARG, "bad step / rank");
+    if ((long)d.mno * nranks > 256) return fail(DESIRE_ERR_ARG, "agent-sharded IOC: at most 256 agents per scene over all ranks");
+    if (d.bf16) return fail(DESIRE_ERR_STATE, "agent-sharded IOC runs on fp32 operands");
+    IocStepArgs a{};
+    a.t = t; a.rank = rank; a.nranks = nranks; a.m_loc = d.mno; a.n_scenes = d.n_scenes; a.K = d.K; a.R = h->R;
+    a.H = d.H; a.T = d.T_pred; a.Gh = d.Gh; a.Gw = d.Gw; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;
+    a.Yall = dev_Yall; a.plast_all = dev_plast_all; a.valid_all = dev_valid_all; a.Hall = dev_Hall;
+    a.st_h = dev_h_state; a.st_h_out = dev_h_state; a.st_score = dev_score_state;
+    a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
+    a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b"); a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b");
+    a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb"); a.w_score = D(h, "ioc/score_w");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    { Timer tm(h, s, "ioc_step"); launch_ioc_step(a, s); }
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_ioc_finish(desire_handle* h, const float* dev_h_state, const float* dev_score_state, float* dev_Y,
+                                 float* dev_score, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    const desire_dims& d = h->d;
+    if (!dev_h_state || !dev_score_state || !dev_Y || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T2 = 2 * d.T_pred;
+    if (!h->ws.count("ioc_dY") && h->ws["ioc_dY"].alloc((size_t)h->R * T2 * sizeof(float))) return fail(DESIRE_ERR_HIP, "hipMalloc failed");
+    GemmArgs g{};
+    g.A = dev_h_state; g.lda = d.H; g.M = h->R; g.K = d.H; g.Bp = D4(h, "ioc/Wreg"); g.G = d.H / 8; g.NT = (T2 + 31) / 32;
+    g.out = W(h, "ioc_dY"); g.ldo = T2; g.N = T2; g.p0 = D(h, "ioc/reg_b");
+    launch_gemm_rows(g, EPI_BIAS, s);
+    launch_ioc_finish(dev_Y, W(h, "ioc_dY"), dev_score_state, D(h, "ioc/score_b"), dev_score, h->R, d.T_pred, s);
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
 extern "C" int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* dev_valid,
                                     int32_t* dev_bins, int32_t n_groups, void* stream) {
     if (!h || !dev_pos || !dev_valid || !dev_bins || n_groups < 0) return fail(DESIRE_ERR_ARG, "bad argument");

@@ -95,6 +95,18 @@ struct IocArgs {
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
+// agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
+struct IocStepArgs {
+    int t; int rank; int nranks; int m_loc; int n_scenes; int K; int R;       // R = local rows = n_scenes * K * m_loc
+    int H; int T; int Gh; int Gw; int G; float nb_w, nb_h;
+    const float* Yall; const float* plast_all; const uint8_t* valid_all; const float* Hall;
+    const float* st_h; float* st_h_out; float* st_score;
+    const float* grids; const int32_t* grid_of_scene;
+    const float* w_vel; const float* b_vel; const float4* Wsoc; const float* b_soc;
+    const float4* Wg; const float4* Wc; const float* b_g; const float* b_c; const float* w_score;
+};
+void launch_ioc_step(const IocStepArgs& a, hipStream_t s);
+void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const float* b_score, float* score, int R, int T, hipStream_t s);
 struct ConvArgs;
 void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s);
 void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);

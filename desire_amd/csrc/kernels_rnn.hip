@@ -836,6 +836,179 @@ void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// IOC, agent-sharded form (SURVEY.md 8(e) E1 / BASELINE north_star): the agents of every scene are block-sharded over G
+// ranks (rank g owns slots [g*m_loc, (g+1)*m_loc) of every scene).  Everything before the IOC is per-agent, so each rank
+// runs it on its own slots; the IOC couples agents through social pooling once per step, so ONE step is one launch of
+// k_ioc_step and the host all-gathers the hidden states in between (RCCL over xGMI; dist.ShardedIoc).  Positions of all
+// agents are gathered once (they are the decoder's output, fixed during a pass).
+//   Yall  [G][n_groups][m_loc][T][2]   all ranks' decoded positions      (gathered before the pass)
+//   Hall  [G][n_groups][m_loc][H]      all ranks' h_{t-1}                (gathered before every step)
+//   vall  [G][n_scenes][m_loc]         presence flags
+// Local state between launches: st_h [R_loc][H], st_score [R_loc].  Tile = 32 local rows (any mix of groups); the
+// pooled operand is built from Hall in global memory (L2), neighbours in ascending global slot order -- the same
+// summation order as the single-GPU kernels, so the result is bit-identical to them.
+// ------------------------------------------------------------------------------------------------
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_step(IocStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, MW = 4;                      // MW 64-bit mask words: up to 256 agents per scene
+    constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G8 = KX >> 3, GH = H >> 3, GX = E >> 3;
+    constexpr int NCH = H / (4 * TPR);
+    const int B = a.G * a.G;
+    float* XH = smem;                                   // [TM][LDX]
+    float* AB = XH + TM * LDX;                          // [2][TM][LDB]
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B][MW]
+    float* wv = reinterpret_cast<float*>(masks + TM * B * MW);    // [3][EV]
+    float* red = wv + 3 * EV;                           // [NT][TM]
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int row0 = blockIdx.x * TM;
+    const int mall = a.m_loc * a.nranks;
+    const int n_groups = a.R / a.m_loc;
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    for (int i = tid; i < TM * B * MW; i += NTHR) masks[i] = 0ull;
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+        const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+        *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
+            *reinterpret_cast<const float4*>(a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4);
+    }
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const float* x_lane = XH + (lane & 31) * LDX + 4 * (lane >> 5);
+    float* my_x = XH + (4 * (lane >> 5)) * LDX + col;
+    const float* rh_lane = AB + (lane & 31) * LDB + 4 * (lane >> 5);
+    float* my_rh = AB + (4 * (lane >> 5)) * LDB + col;
+    // my VALU row: local row -> (group, local slot) -> global slot
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int grp = my_row / a.m_loc, sl = my_row - grp * a.m_loc;
+    const int scene = grp / a.K;
+    const int my_gslot = a.rank * a.m_loc + sl;
+    auto pos_of = [&](int j, int t) {                    // position of global slot j of my group at step t (t = -1: last observed)
+        const int rk = j / a.m_loc, s = j - rk * a.m_loc;
+        if (t < 0) return *reinterpret_cast<const float2*>(a.plast_all + ((size_t)(rk * a.n_scenes + scene) * a.m_loc + s) * 2);
+        return *reinterpret_cast<const float2*>(a.Yall + ((((size_t)rk * n_groups + grp) * a.m_loc + s) * a.T + t) * 2);
+    };
+    __syncthreads();
+    f32x16 h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = my_x[((i & 3) + 8 * (i >> 2)) * LDX + E];
+    {
+        const float2 pcur = pos_of(my_gslot, a.t), pprev = pos_of(my_gslot, a.t - 1);
+        const float px = pcur.x, py = pcur.y;
+        const float vx = px - pprev.x, vy = py - pprev.y;
+        constexpr int per = EV / TPR;
+#pragma unroll
+        for (int j = q8 * per; j < (q8 + 1) * per; ++j)
+            XH[r8 * LDX + j] = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+        int cy, cx;
+        scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+        const float* gsrc = a.grids + (size_t)a.grid_of_scene[scene] * a.Gh * a.Gw * C + ((size_t)cy * a.Gw + cx) * C;
+        constexpr int cper = C / TPR;
+        if (cper >= 4) {
+#pragma unroll
+            for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4)
+                *reinterpret_cast<float4*>(XH + r8 * LDX + EV + j) = *reinterpret_cast<const float4*>(gsrc + j);
+        } else {
+            *reinterpret_cast<float2*>(XH + r8 * LDX + EV + q8 * 2) = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
+        }
+        for (int j = q8; j < mall; j += TPR) {
+            const int rk = j / a.m_loc, s = j - rk * a.m_loc;
+            if (j == my_gslot || !a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s]) continue;
+            const float2 pj = pos_of(j, a.t);
+            const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G);
+            if (b >= 0) atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63));
+        }
+    }
+    __syncthreads();
+    auto build = [&](int b) {
+        float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+        float4 s[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int wd = 0; wd < MW; ++wd) {
+            unsigned long long m2 = masks[(r8 * B + b) * MW + wd];
+            while (m2) {
+                const int j = wd * 64 + __ffsll((long long)m2) - 1;
+                m2 &= m2 - 1;
+                const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
+                const float* src = a.Hall + (((size_t)rk * n_groups + grp) * a.m_loc + sj) * H;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
+                    s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
+    };
+    f32x16 soc = splat16(bso);
+    build(0);
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        if (b + 1 < B) build(b + 1);
+        mma1(soc, AB + (b & 1) * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+    __syncthreads();
+    f32x16 rh = splat16(bgr), u = splat16(bgu);
+    mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
+    mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
+    __syncthreads();
+    f32x16 ac = splat16(bcc);
+    mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
+    mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+        const int row = row0 + acc_row(i);
+        if (row < a.R) a.st_h_out[(size_t)row * H + col] = h[i];
+        float v = h[i] * wsc;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+        if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
+    }
+    __syncthreads();
+    if (tid < TM && row0 + tid < a.R) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+        a.st_score[row0 + tid] = (a.t == 0 ? 0.f : a.st_score[row0 + tid]) + sc;
+    }
+}
+static size_t ioc_step_lds(const IocStepArgs& a) {
+    const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G, TM = 32;
+    return ((size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * 4 * 2 + 3 * EV + NT * TM) * sizeof(float) + 64;
+}
+void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
+    const dim3 grid((a.R + 31) / 32), block((a.H / 32) * 64);
+    const size_t lds = ioc_step_lds(a);
+    if (a.H == 256) { allow_big_lds(k_ioc_step<256, 16, 32>); hipLaunchKernelGGL((k_ioc_step<256, 16, 32>), grid, block, lds, s, a); }
+    else if (a.H == 128) { allow_big_lds(k_ioc_step<128, 16, 32>); hipLaunchKernelGGL((k_ioc_step<128, 16, 32>), grid, block, lds, s, a); }
+    else { allow_big_lds(k_ioc_step<64, 16, 32>); hipLaunchKernelGGL((k_ioc_step<64, 16, 32>), grid, block, lds, s, a); }
+}
+// end of a pass: Y += dY (dY [R, 2T] from the regression GEMM), score = accumulated + T * b_score
+__global__ void k_ioc_finish(float* __restrict__ Y, const float* __restrict__ dY, const float* __restrict__ st_score,
+                             const float* __restrict__ b_score, float* __restrict__ score, int R, int T2, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * T2) Y[i] = Y[i] + dY[i];
+    if (i < R) score[i] = st_score[i] + (float)T * b_score[0];
+}
+void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const float* b_score, float* score, int R, int T, hipStream_t s) {
+    const int n = R * 2 * T;
+    hipLaunchKernelGGL(k_ioc_finish, dim3((n + 255) / 256), dim3(256), 0, s, Y, dY, st_score, b_score, score, R, 2 * T, T);
+}
+
+// ------------------------------------------------------------------------------------------------
 // integer paths (standalone, for bit-exact tests)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_neighbor_bins(const float* __restrict__ pos, const uint8_t* __restrict__ valid,

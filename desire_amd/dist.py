@@ -55,3 +55,73 @@ def allreduce_mean_(flat, group=None):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / world)
     return flat
+
+
+# ---- agent-sharded IOC: the north_star's "RCCL all-gather only for the social-pooling neighbour exchange" -------------
+def all_gather_stack(t, group=None):
+    """[...] on every rank -> [world, ...] on every rank (rank-major), one all_gather_into_tensor (RCCL on GPU tensors,
+    gloo on CPU tensors); the identity stack when torch.distributed is not initialised."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t.unsqueeze(0).contiguous()
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    flat = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenated form: every backend takes it
+    dist.all_gather_into_tensor(flat, t, group=group)
+    return flat.view((world,) + tuple(t.shape))
+
+
+class ShardedIoc:
+    """IOC scoring / refinement when the AGENTS of every scene are block-sharded over the ranks (rank g owns slots
+    [g*m_loc, (g+1)*m_loc) of every scene; the handle is created with mno = m_loc).  Encoders, CVAE and decoder are
+    per-agent and run locally (Handle.encode / Handle.sample); here positions, last observed positions and presence
+    flags are gathered once per pass and the hidden states once per step -- T_pred all-gathers of [R_loc, H] fp32 per
+    pass, the only data-path collective of the whole framework.  `gather` defaults to all_gather_stack; tests inject a
+    stand-in to run several virtual ranks in one process.
+
+    Scene-sharding (dist.shard_windows) needs no collective at all and is what bench.py uses; this form exists for
+    scenes that must be split across GPUs."""
+
+    def __init__(self, handle, rank: int, nranks: int, gather=None, group=None):
+        self.h, self.rank, self.nranks = handle, int(rank), int(nranks)
+        self.gather = gather or (lambda t: all_gather_stack(t, group))
+
+    def local_state(self):
+        """(Hx rows [R_loc, H], p_last [A_loc, 2], valid [A_loc] uint8, Y0 [R_loc, T, 2]) views / copies on the device."""
+        d = self.h.dims
+        HxHy = self.h.device_tensor("HxHy")[: d.A * 2 * d.H].view(d.A, 2 * d.H)
+        Hx = HxHy[:, : d.H].reshape(d.n_scenes, 1, d.mno, d.H).expand(d.n_scenes, d.K, d.mno, d.H).reshape(d.R, d.H).contiguous()
+        p_last = self.h.device_tensor("p_last")[: d.A * 2].view(d.A, 2)
+        valid = self.h.device_tensor("valid", "|u1")[: d.A]
+        Y0 = self.h.device_tensor("Y0")[: d.R * d.T_pred * 2].view(d.R, d.T_pred, 2)
+        return Hx, p_last, valid, Y0
+
+    def prepare(self, Y_loc):
+        """Gathers what is fixed during a pass; returns the per-pass context."""
+        import torch
+        d = self.h.dims
+        Hx, p_last, valid, _ = self.local_state()
+        return {"plast_all": self.gather(p_last.contiguous()), "valid_all": self.gather(valid.contiguous()),
+                "Yall": self.gather(Y_loc.contiguous()), "hst": Hx.clone(),
+                "score": torch.zeros(d.R, device=Y_loc.device, dtype=torch.float32)}
+
+    def step(self, ctx, t: int, Hall, stream: int = 0):
+        self.h.ioc_step(t, self.rank, self.nranks, ctx["Yall"].data_ptr(), ctx["plast_all"].data_ptr(), ctx["valid_all"].data_ptr(),
+                        Hall.data_ptr(), ctx["hst"].data_ptr(), ctx["score"].data_ptr(), stream)
+
+    def finish(self, ctx, Y_loc, score_loc, stream: int = 0):
+        self.h.ioc_finish(ctx["hst"].data_ptr(), ctx["score"].data_ptr(), Y_loc.data_ptr(), score_loc.data_ptr(), stream)
+
+    def run(self, Y_loc, score_loc):
+        """Y_loc [R_loc, T, 2] (in: decoded, out: refined), score_loc [R_loc]; all d.iters passes."""
+        import torch
+        d = self.h.dims
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(d.iters):
+            ctx = self.prepare(Y_loc)
+            for t in range(d.T_pred):
+                Hall = self.gather(ctx["hst"])                      # the neighbour exchange
+                self.step(ctx, t, Hall, stream)
+            self.finish(ctx, Y_loc, score_loc, stream)
+        return Y_loc, score_loc

@@ -135,6 +135,26 @@ int desire_gaussian_sample(desire_handle* h, const float* dev_params, const floa
 /* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K). */
 int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);
 
+/* ---- agent-sharded IOC (BASELINE north_star / SURVEY.md 8(e) E1: "agents shard across the GPUs with an RCCL all-gather
+ * only for the social-pooling neighbour exchange").  The handle of rank g is created with mno = the slots it owns
+ * (m_loc); every scene then has nranks * m_loc agents.  Everything before the IOC is per-agent and runs unchanged
+ * (desire_encode / desire_sample); one IOC time step is one desire_ioc_step call, and the CALLER all-gathers the hidden
+ * states in between (desire_amd/dist.py: ShardedIoc does it with torch.distributed = RCCL).  Gathered layouts, rank-major:
+ *   Yall      [nranks][n_scenes*K][m_loc][T_pred][2]   decoded positions of every rank   (gathered once per pass)
+ *   plast_all [nranks][n_scenes][m_loc][2]             last observed positions           (gathered once)
+ *   valid_all [nranks][n_scenes][m_loc]                presence flags, uint8              (gathered once)
+ *   Hall      [nranks][n_scenes*K*m_loc][H]            h_{t-1} of every rank              (gathered before every step)
+ * dev_h_state [R_loc, H] (in: h_{t-1} of the local rows, out: h_t) and dev_score_state [R_loc] are the caller-held
+ * recurrent state; desire_ioc_finish applies the regression head (Y += dY) and writes the scores.
+ * desire_device_buffer exposes the handle's workspace tensors ("HxHy" [A,2H], "p_last" [A,2], "valid" [A] uint8,
+ * "Y0" [R,T,2]) so they can be gathered without a host round trip. */
+int desire_device_buffer(desire_handle* h, const char* name, void** dev_ptr, size_t* bytes);
+int desire_ioc_step(desire_handle* h, int32_t t, int32_t rank, int32_t nranks, const float* dev_Yall,
+                    const float* dev_plast_all, const uint8_t* dev_valid_all, const float* dev_Hall,
+                    float* dev_h_state, float* dev_score_state, void* stream);
+int desire_ioc_finish(desire_handle* h, const float* dev_h_state, const float* dev_score_state, float* dev_Y,
+                      float* dev_score, void* stream);
+
 /* ---- training (the reference builds tf.gradients(cost) + Adam and never runs them: model/model.py:388-403) ----
  * desire_set_training(h,1) allocates the activation-save and gradient buffers; a desire_forward made afterwards keeps
  * what backward needs.  desire_backward computes d(loss)/d(weight) for the loss of DESIGN.md section 8 into ONE flat

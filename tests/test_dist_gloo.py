@@ -120,3 +120,41 @@ def test_allreduce_mean_is_a_noop_without_a_process_group():
     from desire_amd.dist import allreduce_mean_
     t = torch.arange(4.0)
     assert allreduce_mean_(t) is t and torch.equal(t, torch.arange(4.0))
+
+
+# ---- the neighbour exchange of the agent-sharded IOC: rank-major stack of every rank's tensor ----
+def _stack_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from desire_amd.dist import all_gather_stack
+        h = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank          # "hidden states" of my 3 rows
+        v = torch.tensor([1, 0, 1], dtype=torch.uint8) * (rank + 1)                  # presence flags travel as uint8
+        q.put((rank, all_gather_stack(h).numpy(), all_gather_stack(v).numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_all_gather_stack_is_rank_major():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(6, dtype=np.float32).reshape(3, 2)
+    for rank, hs, vs in res:
+        np.testing.assert_array_equal(hs, np.stack([base, base + 100]))
+        np.testing.assert_array_equal(vs, np.stack([np.array([1, 0, 1], np.uint8), np.array([2, 0, 2], np.uint8)]))
+
+
+def test_all_gather_stack_without_process_group_is_the_identity_stack():
+    from desire_amd.dist import all_gather_stack
+    t = torch.arange(4.0).reshape(2, 2)
+    assert torch.equal(all_gather_stack(t), t[None])

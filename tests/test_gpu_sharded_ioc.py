@@ -1,0 +1,105 @@
+"""Agent-sharded IOC (k_ioc_step + dist.ShardedIoc): two / four VIRTUAL ranks in one process, each owning a block of the
+agent slots of every scene, with torch.stack standing in for the RCCL all-gather -- must reproduce the unsharded
+single-GPU result.  (The real collective is covered by the gloo test of all_gather_stack in tests/test_dist_gloo.py.)"""
+import numpy as np
+import pytest
+
+from desire_amd.spec import init_weights
+from tests.helpers import make_case, small_dims
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup_rank(torch, d_loc, w, past, fut, eps, grids, gos):
+    from desire_amd import _lib
+    h = _lib.Handle(d_loc)
+    h.set_weights(w)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    keep = dict(past=t(past), fut=t(fut), eps=t(eps), grids=t(grids))
+    h.set_scene_grids(keep["grids"].data_ptr(), gos)
+    h.encode(keep["past"].data_ptr(), keep["fut"].data_ptr())
+    keep["Ytmp"] = torch.zeros((d_loc.R, d_loc.T_pred, 2), device=dev)
+    h.sample(keep["eps"].data_ptr(), keep["Ytmp"].data_ptr())
+    return h, keep
+
+
+@pytest.mark.parametrize("kw,nranks", [(dict(), 2), (dict(), 4), (dict(mno=64, n_scenes=1, K=2, n_grids=1), 2),
+                                       (dict(H=64, T_pred=7, K=3), 2), (dict(iters=2, K=2), 2)])
+def test_virtual_ranks_reproduce_the_unsharded_ioc(kw, nranks):
+    import torch
+    from desire_amd import _lib
+    from desire_amd.dist import ShardedIoc
+    d = small_dims(**kw)
+    m_loc = d.mno // nranks
+    w = init_weights(d, 21)
+    past, fut, eps, grids, gos = make_case(d, seed=22, n_absent=3)
+    # unsharded reference run on the same GPU
+    hU, keepU = _setup_rank(torch, d, w, past, fut, eps, grids, gos)
+    Y0 = hU.read_buffer("Y0", (d.R, d.T_pred, 2))
+    YU = torch.as_tensor(Y0.copy(), device="cuda")
+    sU = torch.zeros(d.R, device="cuda")
+    hU.ioc_refine(YU.data_ptr(), sU.data_ptr())
+    torch.cuda.synchronize()
+    YU = YU.cpu().numpy().reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2)
+    sU = sU.cpu().numpy().reshape(d.n_scenes, d.K, d.mno)
+    # virtual ranks
+    d_loc = d.replace(mno=m_loc)
+    epsr = eps.reshape(d.n_scenes, d.K, d.mno, d.L)
+    ranks = []
+    for g in range(nranks):
+        sl = slice(g * m_loc, (g + 1) * m_loc)
+        h, keep = _setup_rank(torch, d_loc, w, past[:, :, sl], fut[:, :, sl], epsr[:, :, sl].reshape(-1, d.L), grids, gos)
+        ranks.append((h, keep))
+    torch.cuda.synchronize()
+    # the decoder is per-agent: local Y0 must equal the matching slots of the unsharded Y0 exactly
+    Y0r = Y0.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2)
+    for g, (h, _) in enumerate(ranks):
+        loc = h.read_buffer("Y0", (d_loc.R, d.T_pred, 2)).reshape(d.n_scenes, d.K, m_loc, d.T_pred, 2)
+        np.testing.assert_array_equal(loc, Y0r[:, :, g * m_loc:(g + 1) * m_loc])
+    shards = [ShardedIoc(h, g, nranks, gather=None) for g, (h, _) in enumerate(ranks)]
+    Ys = [s.local_state()[3].clone() for s in shards]
+    scores = [torch.zeros(d_loc.R, device="cuda") for _ in shards]
+    stack = lambda key, ctxs: torch.stack([c[key] for c in ctxs]).contiguous()
+    for _ in range(d.iters):
+        # lock-step emulation of ShardedIoc.run: every "collective" is a stack over the virtual ranks
+        loc = [s.local_state() for s in shards]
+        plast_all = torch.stack([l[1].contiguous() for l in loc]).contiguous()
+        valid_all = torch.stack([l[2].contiguous() for l in loc]).contiguous()
+        Yall = torch.stack(Ys).contiguous()
+        ctxs = [{"plast_all": plast_all, "valid_all": valid_all, "Yall": Yall, "hst": l[0].clone(),
+                 "score": torch.zeros(d_loc.R, device="cuda")} for l in loc]
+        for t in range(d.T_pred):
+            Hall = stack("hst", ctxs)
+            for s, c in zip(shards, ctxs):
+                s.step(c, t, Hall)
+        for s, c, Y, sc in zip(shards, ctxs, Ys, scores):
+            s.finish(c, Y, sc)
+    torch.cuda.synchronize()
+    for g in range(nranks):
+        Yg = Ys[g].cpu().numpy().reshape(d.n_scenes, d.K, m_loc, d.T_pred, 2)
+        sg = scores[g].cpu().numpy().reshape(d.n_scenes, d.K, m_loc)
+        ref_Y, ref_s = YU[:, :, g * m_loc:(g + 1) * m_loc], sU[:, :, g * m_loc:(g + 1) * m_loc]
+        if d.iters == 1:
+            assert np.abs(Yg - ref_Y).max() < 2e-6, (g, np.abs(Yg - ref_Y).max())
+            assert np.abs(sg - ref_s).max() < 2e-5
+        else:       # the second pass re-bins from refined positions: same caveat as everywhere (bin-edge flips)
+            assert np.abs(Yg - ref_Y).max() < 1e-3
+
+
+def test_sharded_ioc_single_rank_run_equals_ioc_refine():
+    """nranks = 1 through ShardedIoc.run (identity gather): the step-wise kernel against the persistent one."""
+    import torch
+    from desire_amd.dist import ShardedIoc
+    d = small_dims(K=3)
+    w = init_weights(d, 23)
+    past, fut, eps, grids, gos = make_case(d, seed=24, n_absent=2)
+    h, keep = _setup_rank(torch, d, w, past, fut, eps, grids, gos)
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    Ya = torch.as_tensor(Y0.copy(), device="cuda"); sa = torch.zeros(d.R, device="cuda")
+    h.ioc_refine(Ya.data_ptr(), sa.data_ptr())
+    Yb = torch.as_tensor(Y0.copy(), device="cuda"); sb = torch.zeros(d.R, device="cuda")
+    ShardedIoc(h, 0, 1).run(Yb, sb)
+    torch.cuda.synchronize()
+    assert float((Ya - Yb).abs().max()) < 2e-6
+    assert float((sa - sb).abs().max()) < 2e-5
