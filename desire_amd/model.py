@@ -10,7 +10,8 @@ Kept from the reference:
     (model/model.py:613-688).
 
 New (the reference has one seq_length, K hard-coded to 7, no IOC): args.pred_length, args.num_samples,
-args.ioc_iters, args.img_width/img_height, and forward() that returns all K refined samples + scores.
+args.ioc_iters, args.img_width/img_height, args.bf16 (bf16 matrix operands, inference only), and forward() that returns
+all K refined samples + scores.
 
 PyTorch is used for device memory and streams only.
 """
@@ -46,7 +47,8 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True) -> Dims:
         C=int(getattr(args, "scene_channels", 32)), Gh=int(getattr(args, "scene_grid", 64)),
         Gw=int(getattr(args, "scene_grid", 64)), n_grids=int(getattr(args, "n_grids", 1)),
         grid_size=int(getattr(args, "grid_size", 4)), E_v=16, iters=int(getattr(args, "ioc_iters", 1)),
-        posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img)
+        posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img,
+        bf16=int(bool(getattr(args, "bf16", False))))
 
 
 class DESIREModel(object):

@@ -73,3 +73,43 @@ def test_training_loop_runs_saves_and_learns(tmp_path):
     past, fut = T.split_windows(x, a.seq_length)
     Y, s = m2.forward(past, fut, seed=0)
     assert bool(np.isfinite(Y.cpu().numpy()).all())
+
+
+@pytest.mark.gpu
+def test_training_on_a_real_sdd_slice_improves_best_of_k_ade(tmp_path):
+    """End to end on real Stanford Drone Dataset frames (bookstore/video6, the 160 preprocessed frames kept as a loader
+    golden): reference-layout DataLoader -> desire_amd.train loop -> prior sampling -> ADE/FDE harness."""
+    import random
+    from desire_amd.data_loader import DataLoader
+    from desire_amd.model import DESIREModel
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loader_bookstore6_T8.npz"))
+    frames = [z["data0"]]                                            # [160, 32, 3] = [id, x_px, y_px], zero rows = absent
+    a = T.build_parser().parse_args(["--batch_size", "4", "--seq_length", "8", "--pred_length", "12", "--max_num_obj", "32",
+                                     "--d_dim", "64", "--latent_size", "64", "--num_samples", "5", "--num_epochs", "12",
+                                     "--save_every", "1000", "--learning_rate", "0.001", "--neighborhood_size", "200",
+                                     "--save_dir", str(tmp_path / "save")])
+    a.img_width, a.img_height = 1424.0, 1088.0                       # bookstore frame size (pixels -> normalised units)
+    dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
+    random.seed(1)
+    xval, _, _ = dl.next_batch(random_update=False)
+    past, fut = T.split_windows(xval, a.seq_length)
+    model = DESIREModel(a, seed=5)
+
+    pw = np.stack(past)                                              # [n, T_obs, 32, 3]
+    fw = np.stack(fut)
+    there = ((pw[:, -1, :, 0] != 0) & (fw[:, :, :, 0] != 0).all(1)).reshape(-1)   # tracked at the last observed frame and all future frames
+    assert there.sum() >= 8
+
+    def ade():
+        Y, _ = model.forward(past, None, seed=7)                     # prior sampling: no future given
+        return model.evaluate(Y, fut)[there].mean(0)                 # (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K)
+
+    before = ade()
+    dl.reset_batch_pointer()
+    losses = T.train(a, data_loader=dl, model=model, log=lambda s: None)
+    model.sync_weights()
+    after = ade()
+    print("loss %.3f -> %.3f; [ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K] (normalised units) before %s after %s"
+          % (losses[0], losses[-1], np.round(before, 4), np.round(after, 4)))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert after[0] < before[0] and after[2] < before[2]             # mean-of-K and best-of-K ADE both improve
