@@ -310,6 +310,54 @@ __global__ __launch_bounds__(DS_WG) void k_deconv4(ConvArgs a) {
         { const size_t ix = (size_t)n * 1024 + (2 * qy + py) * 32 + 2 * qx + px; a.out[ix] = conv_epilogue(acc, sc, sh, a.mode, true, a.yprev, ix); }
     }
 }
+// Forward form, "tap products first": deconv4 has ONE output channel, so every input pixel contributes 25 scalars
+//     T[tap] = sum_c d3[pixel, c] * w[tap, c]
+// to the outputs o = 2i + k - 1.  A lane owns a pixel (its 32 channels sit in registers, read once, coalesced from HBM),
+// the weights of a tap are wave-uniform (scalar loads), and the products are accumulated into an fp32 LDS image of the
+// sample with plain read-add-write: inside one instruction all lanes hold the SAME tap, so the addresses are distinct
+// (deterministic).  One wave per sample; HBM-bound (the gather form above is LDS-read-bound: 3x slower).
+__global__ __launch_bounds__(DS_WG) void k_deconv4_tp(ConvArgs a) {
+    __shared__ float xacc[4 * 1024];
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int smp = blockIdx.x * 4 + w;
+    for (int i = tid; i < 4 * 1024; i += DS_WG) xacc[i] = 0.f;
+    __syncthreads();
+    float* xa = xacc + w * 1024;
+    const float* __restrict__ wr = a.w_raw;                              // [25][32]
+    if (smp < a.n) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int p = j * 64 + lane, iy = p >> 4, ix = p & 15;
+            float4 x[8];
+            const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)smp * 256 + p) * 32);
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) x[c4] = src[c4];
+#pragma unroll 1
+            for (int ky = 0; ky < 5; ++ky) {
+                const int Y = 2 * iy + ky - 1;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const float* wt = wr + (ky * 5 + kx) * 32;           // wave-uniform
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        acc = fmaf(x[c4].x, wt[c4 * 4], acc); acc = fmaf(x[c4].y, wt[c4 * 4 + 1], acc);
+                        acc = fmaf(x[c4].z, wt[c4 * 4 + 2], acc); acc = fmaf(x[c4].w, wt[c4 * 4 + 3], acc);
+                    }
+                    const int X = 2 * ix + kx - 1;
+                    if (Y >= 0 && Y < 32 && X >= 0 && X < 32) xa[Y * 32 + X] += acc;
+                }
+            }
+        }
+        const float sc = a.scale[0], sh = a.shift[0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = i * 64 + lane;
+            a.out[(size_t)smp * 1024 + o] = sigmoidf_(xa[o] * sc + sh);
+        }
+    }
+}
 void launch_deconv4(const ConvArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_deconv4, dim3(a.n), dim3(DS_WG), 0, s, a);
+    if (a.mode == 0 && !getenv("DESIRE_DECONV4_GATHER")) hipLaunchKernelGGL(k_deconv4_tp, dim3((a.n + 3) / 4), dim3(DS_WG), 0, s, a);
+    else hipLaunchKernelGGL(k_deconv4, dim3(a.n), dim3(DS_WG), 0, s, a);
 }
