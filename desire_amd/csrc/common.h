@@ -46,11 +46,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const 
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-#ifdef DESIRE_EXP_A0   // experiment: one A read per chunk (wrong results) to expose the LDS-latency share
-            const float4 a = *reinterpret_cast<const float4*>(ap[m] + (g + (j & 0)) * 8);
-#else
             const float4 a = *reinterpret_cast<const float4*>(ap[m] + (g + j) * 8);
-#endif
             acc[m] = mfma32(a.x, b[j].x, acc[m]);
             acc[m] = mfma32(a.y, b[j].y, acc[m]);
             acc[m] = mfma32(a.z, b[j].z, acc[m]);
@@ -65,11 +61,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const 
 // therefore in flight for a whole 16*MT-MFMA chunk (>= 1024 cycles) before anything waits on it.
 __device__ __forceinline__ void load_b4(float4 (&b)[4], const float4* __restrict__ b_lane, int g) {
 #pragma unroll
-#ifdef DESIRE_EXP_B0   // experiment: every chunk re-reads the first 4 KB of the n-tile (L1-resident) -> wrong results
-    for (int j = 0; j < 4; ++j) b[j] = b_lane[((g & 0) + j) * 64];
-#else
     for (int j = 0; j < 4; ++j) b[j] = b_lane[(g + j) * 64];
-#endif
 }
 
 template <int MT>

@@ -151,11 +151,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     // is the only writer of its region (deterministic), and ds_add_f32 measured 1.4x SLOWER on the whole
     // kernel (LDS atomics retire at a fraction of the plain ds_read/ds_write rate).
     auto load_b = [&](float4 (&b)[16], int tap) {
-#ifdef DESIRE_EXP_B0
-        const float4* bp = a.Wp + ((size_t)((tap & 0) * 2 + hf) * 16) * 64 + lane;
-#else
         const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16) * 64 + lane;
-#endif
 #pragma unroll
         for (int g = 0; g < 16; ++g) b[g] = bp[g * 64];
     };
