@@ -133,10 +133,9 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     const int c = lane & 31, hi = lane >> 5;
     float* my = out_s + (sp * 2) * 4096;
     // zero this wave's region: 2 samples x 64 px x 32 co
-    for (int i = 0; i < 64; ++i) {
-        const int sp_px = i * 2 + hi;                                  // 0..127 = (s, px)
-        my[sp_px * 64 + hf * 32 + c] = 0.f;
-    }
+    // this wave's region = [2 samples x 64 px] x its 32 output channels; 8 lanes x float4 cover one row of it
+    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
     // A fragments: row = lane&31 -> (s = row>>4, p = row&15)
     float4 af[16];
     {
@@ -165,14 +164,20 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
             acc = mfma32(af[g].z, b[g].z, acc);
             acc = mfma32(af[g].w, b[g].w, acc);
         }
+        // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column:
+        // read all, then add and write all -- written as one dependent chain the compiler serialises 16 LDS round trips
+        float* dst[16]; float old[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rr = acc_row(i);
             const int s = rr >> 4, p = rr & 15;
             const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-            float* dst = my + (s * 64 + o) * 64 + hf * 32 + c;
-            *dst = *dst + acc[i];
+            dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) old[i] = *dst[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *dst[i] = old[i] + acc[i];
     };
     float4 b0[16], b1[16];
     load_b(b0, 0);
@@ -188,13 +193,20 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     do_tap(b0, 24);
-    const int co = hf * 32 + c;
-    const float sc = a.scale[co], sh = a.shift[co];
-    for (int i = 0; i < 64; ++i) {
-        const int sp_px = i * 2 + hi;
+    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
+    for (int i = 0; i < 16; ++i) {
+        const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
         const int smp = s0 + (sp_px >> 6);
-        if (smp < a.n)
-            { const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + co; a.out[ix] = conv_epilogue(my[sp_px * 64 + co], sc, sh, a.mode, false, a.yprev, ix); }
+        if (smp < a.n) {
+            const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
+            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
+            float4 o;
+            o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
+            o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
+            o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
+            o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+            *reinterpret_cast<float4*>(a.out + ix) = o;
+        }
     }
 }
 void launch_deconv2(const ConvArgs& a, hipStream_t s) {
