@@ -39,7 +39,9 @@ __device__ __forceinline__ f32x16 zero16() {
 // The K loop runs in chunks of 4 groups (16 MFMAs per M-tile) with the next chunk's B fragments
 // prefetched into registers while the current chunk computes; the loop is kept rolled so the
 // compiler cannot hoist a whole K extent of loads (38 groups at K=304 would need 300+ VGPRs).
-template <int MT>
+// SWAP = true contracts the same operands with their roles exchanged (A = the packed weights, B = the LDS rows): the
+// accumulators then hold the TRANSPOSED tile (lane = LDS row, registers = weight columns in runs of four).
+template <int MT, bool SWAP = false>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const (&ap)[MT], int g,
                                           const float4 (&b)[4]) {
 #pragma unroll
@@ -47,10 +49,17 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const float* const 
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const float4 a = *reinterpret_cast<const float4*>(ap[m] + (g + j) * 8);
-            acc[m] = mfma32(a.x, b[j].x, acc[m]);
-            acc[m] = mfma32(a.y, b[j].y, acc[m]);
-            acc[m] = mfma32(a.z, b[j].z, acc[m]);
-            acc[m] = mfma32(a.w, b[j].w, acc[m]);
+            if (SWAP) {
+                acc[m] = mfma32(b[j].x, a.x, acc[m]);
+                acc[m] = mfma32(b[j].y, a.y, acc[m]);
+                acc[m] = mfma32(b[j].z, a.z, acc[m]);
+                acc[m] = mfma32(b[j].w, a.w, acc[m]);
+            } else {
+                acc[m] = mfma32(a.x, b[j].x, acc[m]);
+                acc[m] = mfma32(a.y, b[j].y, acc[m]);
+                acc[m] = mfma32(a.z, b[j].z, acc[m]);
+                acc[m] = mfma32(a.w, b[j].w, acc[m]);
+            }
         }
     }
 }
@@ -64,7 +73,7 @@ __device__ __forceinline__ void load_b4(float4 (&b)[4], const float4* __restrict
     for (int j = 0; j < 4; ++j) b[j] = b_lane[(g + j) * 64];
 }
 
-template <int MT>
+template <int MT, bool SWAP = false>
 __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
                                                const float4* __restrict__ b_lane, int G) {
     const int nch = G >> 2;
@@ -76,14 +85,14 @@ __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* c
         for (; c + 2 <= nch; c += 2) {
             load_b4(b1, b_lane, 4 * c + 4);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<MT>(acc, ap, 4 * c, b0);
+            mma_chunk<MT, SWAP>(acc, ap, 4 * c, b0);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < nch) load_b4(b0, b_lane, 4 * c + 8);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<MT>(acc, ap, 4 * c + 4, b1);
+            mma_chunk<MT, SWAP>(acc, ap, 4 * c + 4, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (c < nch) { mma_chunk<MT>(acc, ap, 4 * c, b0); ++c; }
+        if (c < nch) { mma_chunk<MT, SWAP>(acc, ap, 4 * c, b0); ++c; }
     }
 #pragma clang loop unroll(disable)
     for (int g = 4 * c; g < G; ++g) {
@@ -91,10 +100,13 @@ __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* c
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const float4 a = *reinterpret_cast<const float4*>(ap[m] + g * 8);
-            acc[m] = mfma32(a.x, b.x, acc[m]);
-            acc[m] = mfma32(a.y, b.y, acc[m]);
-            acc[m] = mfma32(a.z, b.z, acc[m]);
-            acc[m] = mfma32(a.w, b.w, acc[m]);
+            if (SWAP) {
+                acc[m] = mfma32(b.x, a.x, acc[m]); acc[m] = mfma32(b.y, a.y, acc[m]);
+                acc[m] = mfma32(b.z, a.z, acc[m]); acc[m] = mfma32(b.w, a.w, acc[m]);
+            } else {
+                acc[m] = mfma32(a.x, b.x, acc[m]); acc[m] = mfma32(a.y, b.y, acc[m]);
+                acc[m] = mfma32(a.z, b.z, acc[m]); acc[m] = mfma32(a.w, b.w, acc[m]);
+            }
         }
     }
 }

@@ -239,7 +239,14 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
     const int smp = s0 + w;
     const float* mine = in_s + w * 64 * LDP;
     const int c = lane & 31, hi = lane >> 5;
-    const float sc = a.scale[c], sh = a.shift[c];
+    // transposed contraction (weights as the A operand): the accumulators hold D[co][pixel] with lane = pixel and the 16
+    // registers = output channels in runs of four, so the epilogue stores float4 (4x fewer store instructions)
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
+        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
+    }
     int qy[2], qx[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
@@ -256,17 +263,24 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
                         const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
                         ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 4 * hi;
                     }
-                    mma_groups_ptr<2>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
+                    mma_groups_ptr<2, true>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
                 }
             if (smp < a.n) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
+                    const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int q = m * 32 + acc_row(i);
-                        const int oy = 2 * (q >> 3) + py, ox = 2 * (q & 7) + px;
-                        { const size_t ix = ((size_t)smp * 256 + oy * 16 + ox) * 32 + c; a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix); }
+                    for (int q = 0; q < 4; ++q) {
+                        const size_t ix = base + 8 * q;
+                        float4 o;
+                        o.x = conv_epilogue(acc[m][4 * q], sc[q].x, sh[q].x, a.mode, false, a.yprev, ix);
+                        o.y = conv_epilogue(acc[m][4 * q + 1], sc[q].y, sh[q].y, a.mode, false, a.yprev, ix + 1);
+                        o.z = conv_epilogue(acc[m][4 * q + 2], sc[q].z, sh[q].z, a.mode, false, a.yprev, ix + 2);
+                        o.w = conv_epilogue(acc[m][4 * q + 3], sc[q].w, sh[q].w, a.mode, false, a.yprev, ix + 3);
+                        *reinterpret_cast<float4*>(a.out + ix) = o;
                     }
+                }
             }
         }
 }
