@@ -175,7 +175,9 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
     __syncthreads();
     const float* x_lane = xs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
     const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
+    const float* r_lane = xs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);     // r*h operand: the x_z tile's space after the prologue
     float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;
+    float* my_rh = xs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;
     f32x16 xr, xu, xc, h;
     if (active) {
         xr = splat16(a.b_g[col]); xu = splat16(a.b_g[H + col]); xc = splat16(a.b_c[col]);
@@ -185,7 +187,10 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
 #pragma unroll
         for (int i = 0; i < 16; ++i) h[i] = my_h[((i & 3) + 8 * (i >> 2)) * LDH];
     }
+    __syncthreads();                                   // every wave is done with the x_z tile: its space now carries r*h
     const float bh0 = a.b_head[0], bh1 = a.b_head[1];
+    // two barriers per step: h and r*h live in separate tiles, so the gates read h while nobody writes it, the candidate
+    // reads r*h while nobody writes it, and h_t is published (for the head and the next step) after the first barrier
     for (int t = 0; t < a.T; ++t) {
         f32x16 rh, u;
         if (active) {
@@ -204,16 +209,13 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
                     }
                 }
             }
-        }
-        __syncthreads();
-        if (active) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = rh[i];
+            for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDH] = rh[i];
         }
         __syncthreads();
         if (active) {
             f32x16 ac = xc;
-            mma1(ac, a_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
+            mma1(ac, r_lane, a.Whc + ((size_t)cb * G) * 64 + lane, G);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float c = tanhf_(ac[i]);
@@ -223,9 +225,6 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
                     if (row0 + rl < a.R) a.sv_c[((size_t)(row0 + rl) * a.T + t) * H + col] = c;
                 }
             }
-        }
-        __syncthreads();
-        if (active) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
@@ -252,7 +251,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
                 *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + r) * a.T + t) * 2) = y;
             }
         }
-        // next step's first barrier (after the gate contraction) orders these reads before the r*h write
+        // the head's reads of h_t are ordered before the next rewrite of the h tile by the next step's first barrier
     }
 }
 template <int H, int TM>
