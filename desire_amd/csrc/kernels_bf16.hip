@@ -449,10 +449,8 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2_bf16(ConvArgs a) {
             const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
             const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
             float4 o;
-            o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
-            o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
-            o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
-            o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+            o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);      // inference only: BN + ELU
+            o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
             *reinterpret_cast<float4*>(a.out + ix) = o;
         }
     }
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3_bf16(ConvArgs a) {
                         const int q = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
                         const int oy = 2 * (q >> 3) + py, ox = 2 * (q & 7) + px;
                         const size_t ix = ((size_t)smp * 256 + oy * 16 + ox) * 32 + c;
-                        a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix);
+                        a.out[ix] = eluf_(acc[m][i] * sc + sh);
                     }
             }
         }

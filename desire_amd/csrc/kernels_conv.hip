@@ -125,6 +125,7 @@ void launch_conv3(const ConvArgs& a, hipStream_t s) {
 // Workgroup = 4 samples; wave = (co-half hf = w&1, sample pair sp = w>>1).
 // M-tile rows = (sample s in {0,1}, input pixel p in 0..15); A (K=128) lives in 64 VGPRs.
 // ------------------------------------------------------------------------------------------------
+template <bool FWD>
 __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float out_s[];     // [4][64 px][64 co]
     const int lane = lane_id(), w = wave_id();
@@ -201,17 +202,23 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
             const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
             const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
             float4 o;
-            o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
-            o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
-            o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
-            o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+            if (FWD) {                                                 // forward: BN + ELU, nothing else in the loop
+                o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);
+                o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
+            } else {
+                o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
+                o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
+                o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
+                o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+            }
             *reinterpret_cast<float4*>(a.out + ix) = o;
         }
     }
 }
 void launch_deconv2(const ConvArgs& a, hipStream_t s) {
-    allow_big_lds(k_deconv2);
-    hipLaunchKernelGGL(k_deconv2, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+    allow_big_lds(k_deconv2<true>); allow_big_lds(k_deconv2<false>);
+    if (a.mode == 0) hipLaunchKernelGGL(k_deconv2<true>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+    else hipLaunchKernelGGL(k_deconv2<false>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -220,6 +227,7 @@ void launch_deconv2(const ConvArgs& a, hipStream_t s) {
 // input shift d = (p + 1 - k)/2, i = q + d for o = 2q + p.  One wave per sample, MT = 2 covers the
 // 64 outputs of a class.
 // ------------------------------------------------------------------------------------------------
+template <bool FWD>
 __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
     constexpr int LDP = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -274,10 +282,15 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const size_t ix = base + 8 * q;
                         float4 o;
-                        o.x = conv_epilogue(acc[m][4 * q], sc[q].x, sh[q].x, a.mode, false, a.yprev, ix);
-                        o.y = conv_epilogue(acc[m][4 * q + 1], sc[q].y, sh[q].y, a.mode, false, a.yprev, ix + 1);
-                        o.z = conv_epilogue(acc[m][4 * q + 2], sc[q].z, sh[q].z, a.mode, false, a.yprev, ix + 2);
-                        o.w = conv_epilogue(acc[m][4 * q + 3], sc[q].w, sh[q].w, a.mode, false, a.yprev, ix + 3);
+                        if (FWD) {
+                            o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
+                            o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
+                        } else {
+                            o.x = conv_epilogue(acc[m][4 * q], sc[q].x, sh[q].x, a.mode, false, a.yprev, ix);
+                            o.y = conv_epilogue(acc[m][4 * q + 1], sc[q].y, sh[q].y, a.mode, false, a.yprev, ix + 1);
+                            o.z = conv_epilogue(acc[m][4 * q + 2], sc[q].z, sh[q].z, a.mode, false, a.yprev, ix + 2);
+                            o.w = conv_epilogue(acc[m][4 * q + 3], sc[q].w, sh[q].w, a.mode, false, a.yprev, ix + 3);
+                        }
                         *reinterpret_cast<float4*>(a.out + ix) = o;
                     }
                 }
@@ -286,8 +299,9 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
 }
 void launch_deconv3(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (68 + 4 * 64 * 68) * sizeof(float);
-    allow_big_lds(k_deconv3);
-    hipLaunchKernelGGL(k_deconv3, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+    allow_big_lds(k_deconv3<true>); allow_big_lds(k_deconv3<false>);
+    if (a.mode == 0) hipLaunchKernelGGL(k_deconv3<true>, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+    else hipLaunchKernelGGL(k_deconv3<false>, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

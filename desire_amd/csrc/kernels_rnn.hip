@@ -144,7 +144,7 @@ void launch_encoder(const EncArgs& a, hipStream_t s) {
 // Decoder: tile = 64 rows; constant input x_z => its contribution (and the biases) is computed once
 // and kept in 48 accumulator-layout registers per wave; per step only the h-part contracts (K = H).
 // ------------------------------------------------------------------------------------------------
-template <int H, int TM>
+template <int H, int TM, bool SAVE>       // SAVE: training-mode forward (gates / candidate / hidden states kept for BPTT)
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             for (int i = 0; i < 16; ++i) {
                 const float r = sigmoidf_(rh[i]);
                 rh[i] = r * h[i]; u[i] = sigmoidf_(u[i]);
-                if (a.sv_r) {                                   // training: keep the gates for BPTT
+                if (SAVE && a.sv_r) {                           // training: keep the gates for BPTT
                     const int rl = mt * 32 + acc_row(i);
                     if (row0 + rl < a.R) {
                         const size_t ix = ((size_t)(row0 + rl) * a.T + t) * H + col;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             for (int i = 0; i < 16; ++i) {
                 const float c = tanhf_(ac[i]);
                 h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
-                if (a.sv_c) {
+                if (SAVE && a.sv_c) {
                     const int rl = mt * 32 + acc_row(i);
                     if (row0 + rl < a.R) a.sv_c[((size_t)(row0 + rl) * a.T + t) * H + col] = c;
                 }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             for (int i = 0; i < 16; ++i) {
                 my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
                 const int rl = mt * 32 + acc_row(i);
-                if (a.hdump && row0 + rl < a.R) a.hdump[((size_t)(row0 + rl) * a.T + t) * H + col] = h[i];
+                if (SAVE && a.hdump && row0 + rl < a.R) a.hdump[((size_t)(row0 + rl) * a.T + t) * H + col] = h[i];
             }
         }
         __syncthreads();
@@ -257,8 +257,13 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
 template <int H, int TM>
 static void launch_decoder_t(const DecArgs& a, hipStream_t s) {
     const size_t lds = (2 * TM * (H + 4) + 2 * H + TM * 2) * sizeof(float);
-    allow_big_lds(k_decoder<H, TM>);
-    hipLaunchKernelGGL((k_decoder<H, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64), lds, s, a);
+    if (a.sv_r || a.sv_c || a.hdump) {
+        allow_big_lds(k_decoder<H, TM, true>);
+        hipLaunchKernelGGL((k_decoder<H, TM, true>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64), lds, s, a);
+    } else {
+        allow_big_lds(k_decoder<H, TM, false>);
+        hipLaunchKernelGGL((k_decoder<H, TM, false>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64), lds, s, a);
+    }
 }
 void launch_decoder(const DecArgs& a, hipStream_t s) {
     if (a.H == 256) launch_decoder_t<256, 32>(a, s);
