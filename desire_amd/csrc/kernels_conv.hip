@@ -227,16 +227,17 @@ void launch_deconv2(const ConvArgs& a, hipStream_t s) {
 // input shift d = (p + 1 - k)/2, i = q + d for o = 2q + p.  One wave per sample, MT = 2 covers the
 // 64 outputs of a class.
 // ------------------------------------------------------------------------------------------------
-template <bool FWD>
-__global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
+// NS = samples (= waves) per workgroup (4; NS = 2 -- four small workgroups per CU instead of two -- measured 15 % slower).
+template <bool FWD, int NS>
+__global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
     constexpr int LDP = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* zero_row = smem;
-    float* in_s = smem + LDP;                                          // [4][64][LDP]
+    float* in_s = smem + LDP;                                          // [NS][64][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int s0 = blockIdx.x * 4;
-    for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
-    for (int i = tid; i < 4 * 64 * 16; i += DS_WG) {
+    const int s0 = blockIdx.x * NS;
+    for (int i = tid; i < LDP; i += NS * 64) zero_row[i] = 0.f;
+    for (int i = tid; i < NS * 64 * 16; i += NS * 64) {
         const int pix = i >> 4, c4 = i & 15;
         const int smp = s0 + (pix >> 6);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -298,10 +299,16 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3(ConvArgs a) {
         }
 }
 void launch_deconv3(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (68 + 4 * 64 * 68) * sizeof(float);
-    allow_big_lds(k_deconv3<true>); allow_big_lds(k_deconv3<false>);
-    if (a.mode == 0) hipLaunchKernelGGL(k_deconv3<true>, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
-    else hipLaunchKernelGGL(k_deconv3<false>, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+    static const int ns = getenv("DESIRE_DECONV3_NS2") ? 2 : 4;       // A/B: four 2-wave workgroups per CU measured 15 % slower
+    const size_t lds = (68 + (size_t)ns * 64 * 68) * sizeof(float);
+    allow_big_lds(k_deconv3<true, 4>); allow_big_lds(k_deconv3<false, 4>);
+    if (ns == 4) {
+        if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_deconv3<false, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
+    } else {
+        if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 2>), dim3((a.n + 1) / 2), dim3(128), lds, s, a);
+        else hipLaunchKernelGGL((k_deconv3<false, 2>), dim3((a.n + 1) / 2), dim3(128), lds, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
