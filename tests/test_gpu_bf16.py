@@ -126,3 +126,4 @@ def test_decoder_bf16_matches_rounding_oracle(torch_cuda, kw):
     print("Y0: vs rounding oracle %.2e, vs fp32 %.2e" % (eq, ef))
     assert eq < 1e-3, eq          # normalised coordinates; same rounding points
     assert ef < 5e-3, ef          # cost of bf16 recurrent operands on the decoded trajectory
+
