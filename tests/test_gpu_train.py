@@ -195,3 +195,44 @@ def test_model_train_step_and_checkpoint(tmp_path):
     Ya, _ = m.forward(x, y, seed=1)
     Yb, _ = m2.forward(x, y, seed=1)
     assert float((Ya - Yb).abs().max()) < 2e-6
+
+
+def test_full_size_gradient_is_the_mean_of_its_halves():
+    """BASELINE configs[1] shapes at 64 windows (40 960 rows: activation indices pass 2^31 elements): with every agent
+    present the loss is a plain mean over windows, so the gradient of the whole batch must equal the mean of the gradients
+    of its two halves -- a size-independent check of the backward path at the size the bench runs."""
+    import torch
+    from desire_amd import _lib
+    from desire_amd.spec import Dims
+    from desire_amd.synth import make_case as mk
+    n = 64
+    d = Dims(n_scenes=n, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4, nb_w=0.15, nb_h=0.15,
+             sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
+    w = init_weights(d, 0)
+    past, fut, eps, grids, gos = mk(d, seed=1, n_absent=0)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    grids_t = t(grids)
+
+    def grad_of(lo, hi):
+        dd = d.replace(n_scenes=hi - lo)
+        h = _lib.Handle(dd)
+        h.set_weights(w)
+        h.set_training(True)
+        rows = slice(lo * d.K * d.mno, hi * d.K * d.mno)
+        p, f, e = t(past[lo:hi]), t(fut[lo:hi]), t(eps[rows])
+        h.set_scene_grids(grids_t.data_ptr(), gos[lo:hi])
+        Y = torch.zeros((dd.R, d.T_pred, 2), device=dev); sc = torch.zeros((dd.R,), device=dev)
+        h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+        h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+        torch.cuda.synchronize()
+        g = h.grad_tensor().clone()
+        del h
+        return g
+
+    g_all = grad_of(0, n)
+    g_half = 0.5 * (grad_of(0, n // 2) + grad_of(n // 2, n))
+    assert bool(torch.isfinite(g_all).all())
+    scale = float(g_all.abs().max())
+    err = float((g_all - g_half).abs().max())
+    assert scale > 0 and err < 2e-4 * scale, (err, scale)
