@@ -129,7 +129,11 @@ __device__ __forceinline__ void mma_groups(f32x16 (&acc)[MT], const float* a_lan
 __device__ __forceinline__ float fexp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float frcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return frcp_(1.0f + fexp_(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * frcp_(1.0f + fexp_(2.0f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return fmaf(-2.0f, frcp_(1.0f + fexp_(2.0f * x)), 1.0f); }
+// GRU blend h' = u h + (1 - u) c with the contraction spelled out: left to -ffp-contract the compiler fuses SOME unrolled
+// elements and not others, which makes a row's result depend on the accumulator register it happens to sit in (1 ulp) --
+// and tiles / shards must be bit-identical whatever row a sample lands in
+__device__ __forceinline__ float gru_blend(float u, float h, float c) { return fmaf(u, h, (1.0f - u) * c); }
 __device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : fexp_(x) - 1.0f; }
 
 // Epilogue of every conv-family kernel.  mode 0 (forward): act(acc*scale + shift), act = ELU (or sigmoid when

@@ -301,7 +301,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float c = tanhf_(ac[0][0][i]);
-                    h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                    h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                 }
                 publish_h(h);                              // h slots of Xb / Ht were last read before the previous barrier
@@ -614,7 +614,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float c = tanhf_(ac[0][0][i]);
-            h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+            h[i] = gru_blend(u[i], h[i], c);
             const int rl = (i & 3) + 8 * (i >> 2) + 4 * hi;
             hb[rl * LDB + col] = bf16_of(h[i]);
             hs[rl * LDH + col] = h[i];

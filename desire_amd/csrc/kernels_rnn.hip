@@ -108,7 +108,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float c = tanhf_(ac[i]);
-                h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                h[i] = gru_blend(u[i], h[i], c);
                 if (a.sv_c) {
                     const int ag = a0 + mt * 32 + acc_row(i);
                     if (ag < A) { const size_t ix = ((size_t)ag * a.T + t) * H + col; a.sv_c[ix] = c; a.sv_h[ix] = h[i]; }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float c = tanhf_(ac[i]);
-                h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                h[i] = gru_blend(u[i], h[i], c);
                 if (SAVE && a.sv_c) {
                     const int rl = mt * 32 + acc_row(i);
                     if (row0 + rl < a.R) a.sv_c[((size_t)(row0 + rl) * a.T + t) * H + col] = c;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float c = tanhf_(ac[i]);
-                    h[i] = u[i] * h[i] + (1.0f - u[i]) * c;
+                    h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                     if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) {
                         const size_t ix = ((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)(row0 + 4 * (lane >> 5)) * H + col;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+                        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i]));
                         sp[i] = fmaf(h[i], wsc, sp[i]);
                     }
 #pragma unroll
@@ -974,7 +974,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        h[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf_(ac[i]);
+        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i]));
         const int row = row0 + acc_row(i);
         if (row < a.R) a.st_h_out[(size_t)row * H + col] = h[i];
         float v = h[i] * wsc;

@@ -463,3 +463,23 @@ def test_window_with_no_agents_and_duplicate_positions(torch_cuda):
     got = bins_t.cpu().numpy()
     np.testing.assert_array_equal(got, O.neighbor_bins(P.astype(np.float32), valid, d.nb_w, d.nb_h, d.grid_size))
     assert (got[d.K * 1:d.K * 2] == -1).all()                       # the empty window has no neighbours at all
+
+
+@pytest.mark.parametrize("kw", [dict(H=64, T_pred=7, K=3, mno=16), dict(H=64, T_pred=7, K=3), dict(K=3, mno=8, n_scenes=5), dict(H=256, K=3, T_pred=5)])
+def test_outputs_do_not_depend_on_where_a_window_sits_in_the_batch(torch_cuda, kw):
+    """Reversing the order of the windows must reverse the outputs BIT-EXACTLY: a sample's arithmetic may not depend on
+    the tile row / accumulator register it lands in (what scene-sharding over GPUs and the sharded-IOC equality rely on;
+    an implicit fp contraction that the compiler applied to some unrolled elements only once broke this by 1 ulp)."""
+    d = small_dims(**kw)
+    w = init_weights(d, 31)
+    past, fut, eps, grids, gos = make_case(d, seed=32, n_absent=2)
+    h, Y, s = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    rows = d.K * d.mno
+    e2 = eps.reshape(d.n_scenes, rows, d.L)[::-1].reshape(d.R, d.L).copy()
+    h2, Y2, s2 = run_gpu(torch_cuda, d, w, past[::-1].copy(), fut[::-1].copy(), e2, grids, np.asarray(gos)[::-1].copy())
+    Y02 = h2.read_buffer("Y0", (d.R, d.T_pred, 2))
+    back = lambda x: x.reshape((d.n_scenes, rows) + x.shape[1:])[::-1].reshape(x.shape)
+    np.testing.assert_array_equal(back(Y02), Y0)
+    np.testing.assert_array_equal(back(Y2), Y)
+    np.testing.assert_array_equal(back(s2), s)
