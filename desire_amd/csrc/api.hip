@@ -288,6 +288,11 @@ int desire_pack_all(desire_ctx* h) {
             bad |= up("dec/Whg16", pack_b16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }));
             bad |= up("dec/Whc16", pack_b16(H, H, lin, [&](int k, int n) { return dc[(size_t)(H + k) * H + n]; }));
         }
+        {
+            const auto& w1 = hw["vae_dec/deconv1/w"]; const auto& wm = hw["mask_fc/w"];
+            bad |= up("vae_dec/deconv1/W16", pack_b16(L, 2048, lin, [&](int k, int n) { return w1[(size_t)n * L + k]; }));
+            bad |= up("mask/W16", pack_b16(V, H, lin, [&](int k, int n) { return wm[(size_t)k * H + n]; }));
+        }
         bad |= up("vae_dec/deconv2/W16", taps16(hw["vae_dec/deconv2/w"], 128, 64));
         bad |= up("vae_dec/deconv3/W16", taps16(hw["vae_dec/deconv3/w"], 64, 32));
         {   // deconv4 as "tap products": A[m = tap][k = channel, chain order] = w4[tap][0][channel]
@@ -432,7 +437,8 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
-    { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
+    if (d.bf16 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
+    else { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
     ConvArgs c{};
     c.n = R;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
@@ -457,7 +463,8 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
     if (h->training) m.sv_p = W(h, "mask_sv_p");
-    { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
+    if (d.bf16) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
+    else { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
     DecArgs a{};
     a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");
     a.R = R; a.K = d.K; a.mno = d.mno; a.H = H; a.T = d.T_pred;

@@ -768,3 +768,126 @@ void launch_deconv34_bf16(const ConvArgs& a, const float* sc4, const float* sh4,
     const size_t lds = (72 + 4 * 64 * 72) * sizeof(u16) + 4 * 1024 * sizeof(float);
     hipLaunchKernelGGL(k_deconv34_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a, sc4, sh4);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-tiled GEMMs with bf16 operands for the two dense layers that see every (agent, k) row: deconv1
+// ([R, L] x [L, 2048], BN + ELU) and the mask fc ([R, 1024] x [1024, H], ReLU -> softmax -> * Hx).  64-row tiles, the
+// fp32 activations are rounded on their way into a bf16 LDS image; accumulation and epilogues fp32.
+// ------------------------------------------------------------------------------------------------------------------
+#define KC16 512
+#define LDA16 (KC16 + 8)          // bf16 elements: 260 dwords = 4 mod 8
+__device__ __forceinline__ void stage16(u16* dst, const float* __restrict__ src, int lds_ld, int ld, int row0, int M, int k0, int kc, int tid) {
+    const int q = kc >> 3;                                             // 8-element chunks per row
+    for (int i = tid; i < 64 * q; i += DS_WG) {
+        const int r = i / q, c8 = i - r * q;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + r < M) {
+            const float* p = src + (size_t)(row0 + r) * ld + k0 + c8 * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
+            v = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
+        }
+        *reinterpret_cast<uint4*>(dst + r * lds_ld + c8 * 8) = v;
+    }
+}
+
+// deconv1: out[row, col] = elu((z W)[row, col] * scale[col % 128] + shift[col % 128]); K = L <= 512 in one chunk.
+// grid = (row tiles, column blocks of 16 n-tiles); wave w takes n-tiles w, w+4, w+8, w+12 of its block.
+__global__ __launch_bounds__(DS_WG) void k_deconv1_bf16(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g16[];
+    u16* As = reinterpret_cast<u16*>(smem_g16);                        // [64][K + 8]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * 64, ld = a.K + 8, G16 = a.K >> 4;
+    stage16(As, a.A, ld, a.lda, row0, a.M, 0, a.K, tid);
+    __syncthreads();
+    const uint4* Bp = reinterpret_cast<const uint4*>(a.Bp);
+    const u16* ap[2] = {As + c31 * ld + 8 * hi, As + (32 + c31) * ld + 8 * hi};
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const int nt = (blockIdx.y * 4 + j) * 4 + w;
+        if (nt >= a.NT) continue;
+        f32x16 acc[1][2] = {{zero16(), zero16()}};
+        const uint4* bl[1] = {Bp + ((size_t)nt * G16) * 64 + lane};
+        mma16_groups<2, 1>(acc, ap, bl, G16);
+        const int col = nt * 32 + c31;
+        const float sc = a.p0[col % a.chmod], sh = a.p1[col % a.chmod];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                if (row < a.M) a.out[(size_t)row * a.ldo + col] = eluf_(acc[0][m][i] * sc + sh);
+            }
+    }
+}
+void launch_deconv1_bf16(const GemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)64 * (a.K + 8) * sizeof(u16);
+    hipLaunchKernelGGL(k_deconv1_bf16, dim3((a.M + 63) / 64, (a.NT + 15) / 16), dim3(DS_WG), lds, s, a);
+}
+
+// mask fc: x_z[r, :] = softmax(relu(xhat[r, :] Wm + bm)) * Hx[agent(r), :]; K = V = 1024 in two chunks, H <= 256.
+__global__ __launch_bounds__(DS_WG) void k_mask_bf16(MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m16[];
+    u16* As = reinterpret_cast<u16*>(smem_m16);                        // [64][LDA16]; reused as the fp32 softmax tile
+    float* tile = reinterpret_cast<float*>(smem_m16);
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * 64;
+    const int NT = a.H >> 5, G16 = a.V >> 4;
+    f32x16 acc[2][1][2] = {{{zero16(), zero16()}}, {{zero16(), zero16()}}};
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    const u16* ap[2] = {As + c31 * LDA16 + 8 * hi, As + (32 + c31) * LDA16 + 8 * hi};
+    for (int k0 = 0; k0 < a.V; k0 += KC16) {
+        stage16(As, a.xhat, LDA16, a.V, row0, a.R, k0, KC16, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nt = w + 4 * j;
+            if (nt < NT) {
+                const uint4* bl[1] = {Wp + ((size_t)nt * G16 + (k0 >> 4)) * 64 + lane};
+                mma16_groups<2, 1>(acc[j], ap, bl, KC16 >> 4);
+            }
+        }
+        __syncthreads();
+    }
+    const int LDT = a.H + 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nt = w + 4 * j;
+        if (nt >= NT) continue;
+        const int col = nt * 32 + c31;
+        const float b = a.bias[col];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDT + col] = fmaxf(acc[j][0][m][i] + b, 0.f);
+    }
+    __syncthreads();
+    const int r = tid >> 2, q4 = tid & 3;
+    const int row = row0 + r;
+    const int per = a.H >> 2;
+    float mx = -3.0e38f;
+    for (int c = 0; c < per; ++c) mx = fmaxf(mx, tile[r * LDT + q4 * per + c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float sum = 0.f;
+    for (int c = 0; c < per; ++c) {
+        const float e = expf(tile[r * LDT + q4 * per + c] - mx);
+        tile[r * LDT + q4 * per + c] = e;
+        sum += e;
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (row < a.R) {
+        const int ag = agent_of_row(row, a.K, a.mno);
+        for (int c = 0; c < per; ++c) {
+            const int col = q4 * per + c;
+            a.xz[(size_t)row * a.H + col] = (tile[r * LDT + col] / sum) * a.Hx[(size_t)ag * a.ldhx + col];
+        }
+    }
+}
+void launch_mask_bf16(const MaskArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)64 * LDA16 * sizeof(u16);               // 66.6 KB >= the [64][H+4] fp32 softmax tile
+    allow_big_lds(k_mask_bf16);
+    hipLaunchKernelGGL(k_mask_bf16, dim3((a.R + 63) / 64), dim3(DS_WG), lds, s, a);
+}

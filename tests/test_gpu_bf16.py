@@ -90,10 +90,10 @@ def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw, fused, mo
     past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=2)
     h, _, _ = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos)
     z = h.read_buffer("z", (d32.R, d32.L))
-    ql = ("deconv2", "deconv3", "deconv4") if fused else ("deconv2", "deconv3")
+    ql = ("deconv1", "deconv2", "deconv3", "deconv4") if fused else ("deconv1", "deconv2", "deconv3")
     xhat_q, layers_q = O.vae_decoder(z, w, return_layers=True, q=O.bf16_round, q_layers=ql)
     xhat_f, layers_f = O.vae_decoder(z, w, return_layers=True)
-    checks = [("d2", layers_q[1], layers_f[1], 4096), ("xhat", xhat_q, xhat_f, 1024)]
+    checks = [("d1", layers_q[0], layers_f[0], 2048), ("d2", layers_q[1], layers_f[1], 4096), ("xhat", xhat_q, xhat_f, 1024)]
     if not fused:
         checks.insert(1, ("d3", layers_q[2], layers_f[2], 8192))
     for name, lq, lf, n in checks:
@@ -104,6 +104,15 @@ def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw, fused, mo
         print("%s: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.2f)" % (name, eq, ef, np.abs(lf).max()))
         assert eq < 2e-3 * scale, (name, eq)          # same rounding points: accumulation order + rare 1-ulp operand flips
         assert ef < 3e-2 * scale, (name, ef)          # cost of bf16 operands over a K = 25*128 / 25*64 contraction
+    # mask fc (bf16 operands) on the kernel's own xhat / Hx
+    xhat = h.read_buffer("xhat", (d32.R, 1024))
+    Hr = O.rows_from_agents(h.read_buffer("Hx", (d32.A, d32.H)), d32)
+    q = O.bf16_round
+    xz_q = O.softmax(O.relu(q(xhat) @ q(w["mask_fc/w"]) + w["mask_fc/b"])) * Hr
+    xz_f = O.softmax(O.relu(xhat @ w["mask_fc/w"] + w["mask_fc/b"])) * Hr
+    xz = h.read_buffer("xz", (d32.R, d32.H))
+    print("xz: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.3f)" % (np.abs(xz - xz_q).max(), np.abs(xz - xz_f).max(), np.abs(xz_f).max()))
+    assert np.abs(xz - xz_q).max() < 2e-5 and np.abs(xz - xz_f).max() < 2e-4
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3), dict(H=256, K=3, n_scenes=1, n_grids=1, T_pred=10),
