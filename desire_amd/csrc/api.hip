@@ -293,6 +293,19 @@ int desire_pack_all(desire_ctx* h) {
             bad |= up("vae_dec/deconv1/W16", pack_b16(L, 2048, lin, [&](int k, int n) { return w1[(size_t)n * L + k]; }));
             bad |= up("mask/W16", pack_b16(V, H, lin, [&](int k, int n) { return wm[(size_t)k * H + n]; }));
         }
+        {   // forward conv weights [tap][ci][co]
+            auto fwd16 = [&](const std::vector<float>& wt, int CI, int CO) {
+                std::vector<float> out;
+                for (int tap = 0; tap < 25; ++tap) {
+                    const float* base = wt.data() + (size_t)tap * CI * CO;
+                    auto pk = pack_b16(CI, CO, lin, [&](int k, int n) { return base[(size_t)k * CO + n]; });
+                    out.insert(out.end(), pk.begin(), pk.end());
+                }
+                return out;
+            };
+            bad |= up("vae_enc/conv2/W16", fwd16(hw["vae_enc/conv2/w"], 32, 64));
+            bad |= up("vae_enc/conv3/W16", fwd16(hw["vae_enc/conv3/w"], 64, 128));
+        }
         bad |= up("vae_dec/deconv2/W16", taps16(hw["vae_dec/deconv2/w"], 128, 64));
         bad |= up("vae_dec/deconv3/W16", taps16(hw["vae_dec/deconv3/w"], 64, 32));
         {   // deconv4 as "tap products": A[m = tap][k = channel, chain order] = w4[tap][0][channel]
@@ -413,10 +426,12 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         { Timer t(h, s, "conv1"); launch_conv1(c, s); }
         c.in = W(h, "c1"); c.out = W(h, "c2"); c.Wp = D4(h, "vae_enc/conv2/W");
         c.scale = D(h, "vae_enc/conv2/scale"); c.shift = D(h, "vae_enc/conv2/shift");
-        { Timer t(h, s, "conv2"); launch_conv2(c, s); }
+        if (d.bf16) { c.Wp = D4(h, "vae_enc/conv2/W16"); Timer t(h, s, "conv2"); launch_conv2_bf16(c, s); }
+        else { Timer t(h, s, "conv2"); launch_conv2(c, s); }
         c.in = W(h, "c2"); c.out = W(h, "c3"); c.Wp = D4(h, "vae_enc/conv3/W");
         c.scale = D(h, "vae_enc/conv3/scale"); c.shift = D(h, "vae_enc/conv3/shift");
-        { Timer t(h, s, "conv3"); launch_conv3(c, s); }
+        if (d.bf16) { c.Wp = D4(h, "vae_enc/conv3/W16"); Timer t(h, s, "conv3"); launch_conv3_bf16(c, s); }
+        else { Timer t(h, s, "conv3"); launch_conv3(c, s); }
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = A; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
         g.NT = (2 * d.L + 31) / 32; g.out = W(h, "params"); g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");

@@ -109,6 +109,8 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s);
 void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const float* b_score, float* score, int R, int T, hipStream_t s);
 struct ConvArgs;
 void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s);
+void launch_conv2_bf16(const ConvArgs& a, hipStream_t s);
+void launch_conv3_bf16(const ConvArgs& a, hipStream_t s);
 void launch_deconv1_bf16(const GemmArgs& a, hipStream_t s);     // a.Bp = bf16 pack [L, 2048]
 void launch_mask_bf16(const MaskArgs& a, hipStream_t s);        // a.Wp = bf16 pack [1024, H]
 void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);

@@ -891,3 +891,77 @@ void launch_mask_bf16(const MaskArgs& a, hipStream_t s) {
     allow_big_lds(k_mask_bf16);
     hipLaunchKernelGGL(k_mask_bf16, dim3((a.R + 63) / 64), dim3(DS_WG), lds, s, a);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// CVAE encoder convolutions conv2 / conv3 with bf16 operands (per AGENT; same gather tiling as k_conv_gather: the input
+// image of SPW samples in LDS as bf16, rows = output pixels, taps gathered; G16 = CI/16 fragments per tap).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CI, int IW, int OW, int STRIDE, int PAD, int CO>
+__global__ __launch_bounds__(DS_WG) void k_conv_gather_bf16(ConvArgs a) {
+    constexpr int PIX = OW * OW, SPW = 64 / PIX, LDP = CI + 8, NT = CO / 32, G16 = CI / 16;
+    constexpr int MT = (NT == 4) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cg[];
+    u16* zero_row = reinterpret_cast<u16*>(smem_cg);                   // LDP zeros
+    u16* in_s = zero_row + LDP;                                        // [SPW][IW*IW][LDP]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int s0 = blockIdx.x * SPW;
+    for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
+    constexpr int Q = CI / 8;
+    for (int i = tid; i < SPW * IW * IW * Q; i += DS_WG) {
+        const int pix = i / Q, c8 = i - pix * Q;
+        const int smp = s0 + pix / (IW * IW);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (smp < a.n) {
+            const float* p = a.in + ((size_t)s0 * IW * IW + pix) * CI + c8 * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
+            v = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
+        }
+        *reinterpret_cast<uint4*>(in_s + pix * LDP + c8 * 8) = v;
+    }
+    __syncthreads();
+    const int nt = (NT == 4) ? w : (w & 1);
+    const int mt0 = (NT == 4) ? 0 : (w >> 1);
+    f32x16 acc[1][MT];
+    int oy[MT], ox[MT], sm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc[0][m] = zero16();
+        const int r = (mt0 + m) * 32 + c31;
+        sm[m] = r / PIX;
+        const int q = r - sm[m] * PIX;
+        oy[m] = q / OW;
+        ox[m] = q - oy[m] * OW;
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) {
+            const u16* ap[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
+                const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
+                ap[m] = (ok ? in_s + ((sm[m] * IW + iy) * IW + ix) * LDP : zero_row) + 8 * hi;
+            }
+            const uint4* bl[1] = {Wp + ((size_t)((ky * 5 + kx) * NT + nt) * G16) * 64 + lane};
+            mma16_groups<MT, 1>(acc, ap, bl, G16);
+        }
+    const int co = nt * 32 + c31;
+    const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (mt0 + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+            const int smp = s0 + r / PIX;
+            if (smp < a.n) a.out[((size_t)s0 * PIX + r) * CO + co] = eluf_(acc[0][m][i] * sc + sh);
+        }
+}
+void launch_conv2_bf16(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(40 + 256 * 40) * sizeof(u16);
+    hipLaunchKernelGGL((k_conv_gather_bf16<32, 16, 8, 2, 1, 64>), dim3(a.n), dim3(DS_WG), lds, s, a);
+}
+void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(72 + 4 * 64 * 72) * sizeof(u16);
+    hipLaunchKernelGGL((k_conv_gather_bf16<64, 8, 4, 1, 0, 128>), dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
+}

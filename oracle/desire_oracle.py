@@ -160,15 +160,23 @@ def batch_norm(x, w, prefix, bn_mode, dt):
     return ((x - mean) * (gamma / np.sqrt(var + dt(BN_EPS))) + beta).astype(dt)
 
 
-def vae_encoder(vae_in, w, L, bn_mode="frozen", dt=np.float32):
-    """model/model.py:471-492.  vae_in [A, 1024] -> (z_mean, z_log_sigma_sq) each [A, L]."""
+def vae_encoder(vae_in, w, L, bn_mode="frozen", dt=np.float32, q=None, return_layers=False):
+    """model/model.py:471-492.  vae_in [A, 1024] -> (z_mean, z_log_sigma_sq) each [A, L].
+    q = bf16_round restates k_conv_gather_bf16: conv2 / conv3 round their input activations and weights."""
     x = vae_in.astype(dt).reshape(-1, 32, 32, 1)
+    layers = []
     for name, stride, pad in (("conv1", 2, "SAME"), ("conv2", 2, "SAME"), ("conv3", 1, "VALID")):
         p = "vae_enc/" + name
-        x = conv2d(x, w[p + "/w"].astype(dt), stride, pad) + w[p + "/b"].astype(dt)
+        if q is not None and name != "conv1":
+            x = conv2d(q(x), q(w[p + "/w"].astype(dt)), stride, pad) + w[p + "/b"].astype(dt)
+        else:
+            x = conv2d(x, w[p + "/w"].astype(dt), stride, pad) + w[p + "/b"].astype(dt)
         x = elu(batch_norm(x, w, p, bn_mode, dt))
+        layers.append(x)
     flat = x.reshape(x.shape[0], -1)                      # [A, 4*4*128] NHWC flatten
     params = flat @ w["vae_enc/fc/w"].astype(dt) + w["vae_enc/fc/b"].astype(dt)
+    if return_layers:
+        return params[:, :L], params[:, L:], layers
     return params[:, :L], params[:, L:]
 
 

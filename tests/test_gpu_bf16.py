@@ -160,3 +160,23 @@ def test_bf16_path_is_window_independent_and_deterministic(torch_cuda):
         _, Yh, sh = run_gpu(torch_cuda, dd, w, past[lo:hi], fut[lo:hi], eps[lo * rows:hi * rows], grids, gos[lo:hi])
         np.testing.assert_array_equal(Yh, Y[lo * rows:hi * rows])
         np.testing.assert_array_equal(sh, s[lo * rows:hi * rows])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64)])
+def test_cvae_encoder_bf16_convs_match_rounding_oracle(torch_cuda, kw):
+    """conv2 / conv3 of the CVAE encoder with bf16 operands, on the kernel's own vae_in."""
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 9)
+    past, fut, eps, grids, gos = make_case(d32, seed=10, n_absent=2)
+    h, _, _ = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos)
+    vin = h.read_buffer("vae_in", (d32.A, 1024))
+    mu_q, ls_q, lq = O.vae_encoder(vin, w, d32.L, q=O.bf16_round, return_layers=True)
+    mu_f, ls_f, lf = O.vae_encoder(vin, w, d32.L, return_layers=True)
+    for name, a_q, a_f, n in (("c2", lq[1], lf[1], 4096), ("c3", lq[2], lf[2], 2048), ("z_mean", mu_q, mu_f, d32.L),
+                              ("z_log_sigma_sq", ls_q, ls_f, d32.L)):
+        got = h.read_buffer(name, (d32.A, n))
+        eq, ef = np.abs(got - a_q.reshape(d32.A, n)).max(), np.abs(got - a_f.reshape(d32.A, n)).max()
+        scale = max(1.0, float(np.abs(a_f).max()))
+        print("%s: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.2f)" % (name, eq, ef, np.abs(a_f).max()))
+        assert eq < 2e-3 * scale and ef < 3e-2 * scale, (name, eq, ef)
