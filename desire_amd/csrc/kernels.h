@@ -63,6 +63,7 @@ struct EncArgs {
     float* sv_r; float* sv_u; float* sv_c; float* sv_h; float* sv_x;   // optional training saves [A,T,H] x4, [A,T,2]
 };
 void launch_encoder(const EncArgs& a, hipStream_t s);
+void launch_encoder_bf16(const EncArgs& a, hipStream_t s);    // kernels_bf16.hip; Whg / Whc = bf16 packs
 
 struct DecArgs {
     const float* xz; const float* Hx; int ldhx; const float* p_last;

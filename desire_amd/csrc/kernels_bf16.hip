@@ -965,3 +965,94 @@ void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(72 + 4 * 64 * 72) * sizeof(u16);
     hipLaunchKernelGGL((k_conv_gather_bf16<64, 8, 4, 1, 0, 128>), dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// GRU encoders with bf16 recurrent operands (per AGENT, latency-bound: T sequential steps on A/32 tiles).  The 2-wide
+// input contribution stays fp32 VALU (explicit fma chain like k_encoder); h and r*h are bf16 LDS images, h itself stays
+// fp32 in registers; two barriers per step.  a.Whg / a.Whc point at the bf16 packs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__((H / 32) * 64) void k_encoder_bf16(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_e16[];
+    constexpr int TM = 32, LDB = H + 8, NT = H >> 5, GH16 = H >> 4, NTHR = NT * 64;
+    u16* hb = reinterpret_cast<u16*>(smem_e16);            // [32][LDB] bf16 h
+    u16* rb = hb + TM * LDB;                               // [32][LDB] bf16 r*h
+    float* xs = reinterpret_cast<float*>(rb + TM * LDB);   // [2][32][2] normalised input, double-buffered over t
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int A = a.n_scenes * a.mno;
+    const int a0 = blockIdx.x * TM;
+    const int col = cb * 32 + c31;
+    const float wr0 = a.wx_g[col], wr1 = a.wx_g[2 * H + col], wu0 = a.wx_g[H + col], wu1 = a.wx_g[2 * H + H + col];
+    const float wc0 = a.wx_c[col], wc1 = a.wx_c[H + col];
+    const float br = a.b_g[col], bu = a.b_g[H + col], bc = a.b_c[col];
+    f32x16 h = zero16();
+    for (int i = tid; i < TM * LDB / 2; i += NTHR) reinterpret_cast<unsigned*>(hb)[i] = 0u;
+    const uint4* Whg = reinterpret_cast<const uint4*>(a.Whg);
+    const uint4* Whc = reinterpret_cast<const uint4*>(a.Whc);
+    const u16* hp[1] = {hb + c31 * LDB + 8 * hi};
+    const u16* rp[1] = {rb + c31 * LDB + 8 * hi};
+    const uint4* bg[2] = {Whg + ((size_t)cb * GH16) * 64 + lane, Whg + ((size_t)(cb + NT) * GH16) * 64 + lane};
+    const uint4* bcp[1] = {Whc + ((size_t)cb * GH16) * 64 + lane};
+    auto load_x = [&](int t) {
+        if (tid < TM) {
+            const int ag = min(a0 + tid, A - 1);
+            const int sc = ag / a.mno, slot = ag - sc * a.mno;
+            const float* f = a.frames + (((size_t)sc * a.T + t) * a.mno + slot) * 3;
+            float* x = xs + (t & 1) * TM * 2;
+            x[tid * 2] = __fmul_rn(f[1], a.sx); x[tid * 2 + 1] = __fmul_rn(f[2], a.sy);
+            if (t == a.T - 1 && a0 + tid < A) {
+                if (a.p_last) { a.p_last[(size_t)ag * 2] = x[tid * 2]; a.p_last[(size_t)ag * 2 + 1] = x[tid * 2 + 1]; }
+                if (a.valid) a.valid[ag] = (f[0] != 0.f) ? 1 : 0;
+            }
+        }
+    };
+    load_x(0);
+    __syncthreads();
+    for (int t = 0; t < a.T; ++t) {
+        const float* x = xs + (t & 1) * TM * 2;
+        if (t + 1 < a.T) load_x(t + 1);                    // other buffer: read after the next barrier pair
+        f32x16 g2[2][1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            g2[0][0][i] = fmaf(x[row * 2 + 1], wr1, fmaf(x[row * 2], wr0, br));
+            g2[1][0][i] = fmaf(x[row * 2 + 1], wu1, fmaf(x[row * 2], wu0, bu));
+        }
+        mma16_groups<1, 2>(g2, hp, bg, GH16);
+        f32x16 u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float r = sigmoidf_(g2[0][0][i]);
+            rb[((i & 3) + 8 * (i >> 2) + 4 * hi) * LDB + col] = bf16_of(r * h[i]);
+            u[i] = sigmoidf_(g2[1][0][i]);
+        }
+        __syncthreads();
+        f32x16 ac[1][1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            ac[0][0][i] = fmaf(x[row * 2 + 1], wc1, fmaf(x[row * 2], wc0, bc));
+        }
+        mma16_groups<1, 1>(ac, rp, bcp, GH16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            h[i] = gru_blend(u[i], h[i], tanhf_(ac[0][0][i]));
+            hb[((i & 3) + 8 * (i >> 2) + 4 * hi) * LDB + col] = bf16_of(h[i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ag = a0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+        if (ag < A) a.out[(size_t)ag * a.ldo + col] = h[i];
+    }
+}
+void launch_encoder_bf16(const EncArgs& a, hipStream_t s) {
+    const int A = a.n_scenes * a.mno;
+    const dim3 grid((A + 31) / 32);
+    const size_t lds = (size_t)2 * 32 * (a.H + 8) * sizeof(u16) + 2 * 32 * 2 * sizeof(float);
+    if (a.H == 256) hipLaunchKernelGGL(k_encoder_bf16<256>, grid, dim3(512), lds, s, a);
+    else if (a.H == 128) hipLaunchKernelGGL(k_encoder_bf16<128>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_encoder_bf16<64>, grid, dim3(128), lds, s, a);
+}

@@ -77,13 +77,19 @@ def _gru_w(w, prefix, dt):
             w[prefix + "/candidate/kernel"].astype(dt), w[prefix + "/candidate/bias"].astype(dt))
 
 
-def gru_encode(seq, w, prefix, dt=np.float32):
+def gru_encode(seq, w, prefix, dt=np.float32, q=None):
     """static_rnn over the sequence from a zero state -> final state
-    (model/model.py:152-167,233-241).  seq [T, A, n_in]."""
+    (model/model.py:152-167,233-241).  seq [T, A, n_in].
+    q = bf16_round restates k_encoder_bf16: the recurrent operands (h, r*h, the h-rows of the kernels) are rounded, the
+    2-wide input contribution stays fp32."""
     Wg, bg, Wc, bc = _gru_w(w, prefix, dt)
+    if q is not None:
+        n_in = seq.shape[-1]
+        Wg = np.concatenate([Wg[:n_in], q(Wg[n_in:])], 0)
+        Wc = np.concatenate([Wc[:n_in], q(Wc[n_in:])], 0)
     h = np.zeros((seq.shape[1], Wc.shape[1]), dt)
     for t in range(seq.shape[0]):
-        h = gru_cell(seq[t].astype(dt), h, Wg, bg, Wc, bc)
+        h = gru_cell(seq[t].astype(dt), h, Wg, bg, Wc, bc, q)
     return h
 
 

@@ -180,3 +180,20 @@ def test_cvae_encoder_bf16_convs_match_rounding_oracle(torch_cuda, kw):
         scale = max(1.0, float(np.abs(a_f).max()))
         print("%s: vs rounding oracle %.2e, vs fp32 %.2e (|x|max %.2f)" % (name, eq, ef, np.abs(a_f).max()))
         assert eq < 2e-3 * scale and ef < 3e-2 * scale, (name, eq, ef)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3), dict(H=256, K=2, n_scenes=1, n_grids=1, T_pred=10),
+                                dict(T_pred=40, K=2)])
+def test_encoders_bf16_match_rounding_oracle(torch_cuda, kw):
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 13)
+    past, fut, eps, grids, gos = make_case(d32, seed=14, n_absent=2)
+    h, _, _ = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos)
+    pn, fn = O.normalise(to_oracle_layout(past), d32), O.normalise(to_oracle_layout(fut), d32)
+    for name, seq, pfx in (("Hx", pn, "enc_x"), ("Hy", fn, "enc_y")):
+        got = h.read_buffer(name, (d32.A, d32.H))
+        eq = np.abs(got - O.gru_encode(seq, w, pfx, q=O.bf16_round)).max()
+        ef = np.abs(got - O.gru_encode(seq, w, pfx)).max()
+        print("%s: vs rounding oracle %.2e, vs fp32 %.2e" % (name, eq, ef))
+        assert eq < 1e-3 and ef < 1e-2, (name, eq, ef)
