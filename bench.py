@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]/[3]: 64)")
     ap.add_argument("--H", type=int, default=128, help="hidden width (configs[3]: 256)")
     ap.add_argument("--K", type=int, default=20, help="samples per agent (configs[3]: 50)")
+    ap.add_argument("--grid", type=int, default=4, help="social grid side: 4 = the reference's flag (16 bins), 6 = the paper's 36 bins")
     ap.add_argument("--shard", choices=["scenes", "agents"], default="scenes",
                     help="multi-GPU partitioning: 'scenes' (default; windows are independent, no data-path collective) or "
                          "'agents' (the agents of EVERY scene block-sharded over the ranks: --mno slots per rank, hidden states "
@@ -140,7 +141,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=4,
+    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
              nb_w=0.15, nb_h=0.15, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)

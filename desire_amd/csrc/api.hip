@@ -122,7 +122,8 @@ int check_dims(const desire_dims& d) {
     if (d.C != 32 || d.E_v != 16) return fail(DESIRE_ERR_ARG, "C=32 and E_v=16 are the instantiated IOC widths in this round");
     if (d.n_scenes < 1 || d.K < 1 || d.T_obs < 1 || d.T_pred < 1 || d.n_grids < 1 || d.iters < 1 || d.Gh < 1 || d.Gw < 1)
         return fail(DESIRE_ERR_ARG, "sizes must be >= 1");
-    if (d.grid_size < 1 || d.grid_size > 4) return fail(DESIRE_ERR_ARG, "grid_size 1..4 in this round (LDS budget)");
+    if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
+    if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
     if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
     if (d.bf16 && d.mno > 64) return fail(DESIRE_ERR_ARG, "bf16 operands: mno must divide 32 or be 64 in this round");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");

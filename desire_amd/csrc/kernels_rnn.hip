@@ -287,6 +287,12 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 // TM = rows per workgroup (32 or 64; must hold whole (scene,k) groups: TM % mno == 0), 8 threads per
 // row.  TM=32 runs 4 waves and ~77 KB of LDS so that TWO workgroups share a CU: their barrier/VALU
 // phases interleave with each other's MFMA phases.
+// neighbour bit-masks: 32 bits are enough when the tile holds 32 rows (mno <= 32), which keeps a 36-bin tile under half
+// the LDS of a CU (two workgroups per CU); 64-row tiles use 64 bits
+template <int TM> struct MaskT { typedef unsigned long long type; };
+template <> struct MaskT<32> { typedef unsigned type; };
+__device__ __forceinline__ int ffs_(unsigned m) { return __ffs((int)m); }
+__device__ __forceinline__ int ffs_(unsigned long long m) { return __ffsll((long long)m); }
 #ifdef DESIRE_IOC_TIMING
 #define TICK(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
 #else
@@ -307,7 +313,8 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     float* XH = smem;                                   // [TM+1][LDX] [e_v | e_s | e_r | h]; row TM stays zero
     float* AB = XH + (TM + 1) * LDX;                    // [2][TM][LDB] pooled operand, double buffered;
                                                         //   buffer 0 doubles as the r*h operand of the candidate
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B]
+    typedef typename MaskT<TM>::type mask_t;
+    mask_t* masks = reinterpret_cast<mask_t*>(AB + 2 * TM * LDB);   // [TM][B]
     float* pc = reinterpret_cast<float*>(masks + TM * B);      // [TM][2] current position
     float* pp = pc + TM * 2;                            // [TM][2] previous position
     float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
@@ -343,11 +350,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     constexpr int NS = 2;
     auto build = [&](int b) {
         float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
-        unsigned long long m2 = masks[r8 * B + b];
+        mask_t m2 = masks[r8 * B + b];
         int off[NS];
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            off[sl] = m2 ? (grp_base + __ffsll((long long)m2) - 1) * LDX : TM * LDX;
+            off[sl] = m2 ? (grp_base + ffs_(m2) - 1) * LDX : TM * LDX;
             m2 &= m2 - 1;
         }
         float4 s[NCH];
@@ -357,9 +364,9 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             const float4 v1 = *reinterpret_cast<const float4*>(XH + off[1] + E + q8 * 4 + c * 4 * TPR);
             s[c].x = v0.x + v1.x; s[c].y = v0.y + v1.y; s[c].z = v0.z + v1.z; s[c].w = v0.w + v1.w;
         }
-        if (__any(m2 != 0ull)) {
+        if (__any(m2 != 0)) {
             while (m2) {
-                const int j = __ffsll((long long)m2) - 1;
+                const int j = ffs_(m2) - 1;
                 m2 &= m2 - 1;
                 const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
 #pragma unroll
@@ -399,7 +406,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T) * 2);
             pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
         }
-        for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
+        for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
         __syncthreads();
         const float* rh_lane = AB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5);     // r*h operand (AB buffer 0)
         float* my_rh = AB + (mt * 32 + 4 * (lane >> 5)) * LDB + col;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
                                                    a.nb_w, a.nb_h, a.G);
-                    if (b >= 0) atomicOr(&masks[r8 * B + b], 1ull << j);
+                    if (b >= 0) atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
                 }
             }
             __syncthreads();
@@ -516,7 +523,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
                 pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
             }
-            for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0ull;
+            for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
             __syncthreads();
             TICK(8)
         }
@@ -561,7 +568,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 }
 static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
     const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
-    size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * 2 + TM * 4 + 3 * EV + NT * TM;
+    size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * (TM == 32 ? 1 : 2) + TM * 4 + 3 * EV + NT * TM;
     return f * sizeof(float) + TM + 64;
 }
 template <int H, int TM>

@@ -252,6 +252,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (d.mno > 32) return fail(DESIRE_ERR_STATE, "training supports mno <= 32 in this round");
     if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");
+    if (d.grid_size > 4) return fail(DESIRE_ERR_STATE, "training supports grid_size <= 4 (LDS budget of the IOC backward tile)");
     if (h->slots.empty()) {
         size_t off = 0;
         for (auto& kv : h->want) { h->slots[kv.first] = WSlot{off, kv.second}; off += (kv.second + 3) / 4 * 4; }

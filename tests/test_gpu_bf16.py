@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
     dict(mno=8, n_scenes=5, K=3),
     dict(mno=1, n_scenes=3, K=2, n_absent=0),
     dict(T_pred=40, K=2),
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),          # 36 bins
 ])
 def test_ioc_bf16_matches_rounding_oracle(torch_cuda, kw):
     from oracle import desire_oracle as O

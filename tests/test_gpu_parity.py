@@ -89,6 +89,9 @@ def test_stagewise_parity_small(torch_cuda):
     dict(mno=8, n_scenes=5, K=3),                        # 4 groups per 32-row tile, R = 120 (ragged last tile)
     dict(mno=1, n_scenes=3, K=2, n_absent=0),            # lone agents: social pooling sees nobody
     dict(K=1, T_pred=1, n_scenes=1, n_grids=1),          # degenerate horizon / single draw
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),          # 36 social bins (the paper's count)
+    dict(grid_size=5, nb_w=0.4, nb_h=0.4, K=2, mno=64, n_scenes=1, n_grids=1),   # 25 bins, cluster-free 64-row tile
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2, H=64, mno=16, n_scenes=3),
 ])
 def test_end_to_end_variants(torch_cuda, kw):
     kw = dict(kw)
