@@ -21,7 +21,7 @@ EXPORTS = [
     "desire_temporal_conv", "desire_feature_pooling", "desire_build_windows", "desire_gaussian_sample", "desire_ade_fde",
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
-    "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish",
+    "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
 ]
 
 
@@ -29,12 +29,13 @@ class DesireDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_scenes", "mno", "K", "T_obs", "T_pred", "H", "L", "S", "C", "Gh", "Gw", "n_grids",
                  "grid_size", "E_v", "iters", "posterior")] + \
-               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bf16", C.c_int32)]
+               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bf16", C.c_int32)]
 
     @classmethod
     def from_dims(cls, d: Dims) -> "DesireDims":
         return cls(d.n_scenes, d.mno, d.K, d.T_obs, d.T_pred, d.H, d.L, d.S, d.C, d.Gh, d.Gw, d.n_grids,
-                   d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy, int(getattr(d, "bf16", 0)))
+                   d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy, int(getattr(d, "bin_mode", 0)),
+                   int(getattr(d, "bf16", 0)))
 
 
 class DesireError(RuntimeError):
@@ -83,6 +84,7 @@ def load() -> C.CDLL:
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_clip_grads.argtypes = [vp, C.c_float, C.POINTER(C.c_float), vp]
+    lib.desire_get_bin_table.argtypes = [vp, C.POINTER(C.c_float)]
     lib.desire_device_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_ioc_step.argtypes = [vp, i32, i32, i32, f32p, f32p, vp, f32p, f32p, f32p, vp]
     lib.desire_ioc_finish.argtypes = [vp, f32p, f32p, f32p, f32p, vp]
@@ -196,6 +198,11 @@ class Handle:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.lib.desire_grad_buffer(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+    def bin_table(self) -> np.ndarray:
+        out = np.zeros(20, np.float32)
+        _chk(self.lib.desire_get_bin_table(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def device_tensor(self, name: str, dtype: str = "<f4"):
         """A workspace tensor of the handle ("HxHy", "p_last", "valid", "Y0", ...) as a flat zero-copy torch tensor."""

@@ -125,6 +125,9 @@ int check_dims(const desire_dims& d) {
     if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
     if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
     if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
+    if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
+    if (d.bin_mode == 1 && (d.grid_size < 3 || !(d.nb_h > 0.f) || !(d.nb_w > d.nb_h)))
+        return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
     if (d.bf16 && d.mno > 64) return fail(DESIRE_ERR_ARG, "bf16 operands: mno must divide 32 or be 64 in this round");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
     return 0;
@@ -166,7 +169,28 @@ extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
         if (h->ws[w.n].alloc(w.bytes)) { desire_destroy(h); return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n); }
         (void)hipMemset(h->ws[w.n].p, 0, w.bytes);
     }
+    if (d.bin_mode == 1) {
+        // log-polar social bins: G rings with geometric radii between r_min = nb_h and r_max = nb_w, G equal sectors
+        std::vector<float> tab(20, 0.f);
+        const int G = d.grid_size;
+        for (int k = 0; k < G; ++k) {
+            const float t = (float)((double)d.nb_h * std::pow((double)d.nb_w / (double)d.nb_h, (double)(k + 1) / G));
+            tab[k] = t * t;
+            tab[8 + 2 * k] = (float)std::cos(2.0 * M_PI * k / G);
+            tab[9 + 2 * k] = (float)std::sin(2.0 * M_PI * k / G);
+        }
+        h->bin_tab_host = tab;
+        if (h->ws["bin_tab"].alloc(20 * f)) { desire_destroy(h); return fail(DESIRE_ERR_HIP, "hipMalloc failed for bin_tab"); }
+        if (hipMemcpy(h->ws["bin_tab"].p, tab.data(), 20 * f, hipMemcpyHostToDevice) != hipSuccess) { desire_destroy(h); return fail(DESIRE_ERR_HIP, "bin table upload failed"); }
+    }
     *out = h;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_get_bin_table(desire_handle* h, float* host_out20) {
+    if (!h || !host_out20) return fail(DESIRE_ERR_ARG, "null argument");
+    if (h->d.bin_mode != 1) return fail(DESIRE_ERR_STATE, "the rectangular grid has no table (dims.bin_mode = 0)");
+    std::memcpy(host_out20, h->bin_tab_host.data(), 20 * sizeof(float));
     return DESIRE_OK;
 }
 
@@ -518,6 +542,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.R = h->R; a.K = d.K; a.mno = d.mno; a.H = d.H; a.T = d.T_pred; a.iters = d.iters;
     a.C = d.C; a.Gh = d.Gh; a.Gw = d.Gw; a.E_v = d.E_v; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;
     a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
+    a.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
     a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b");
     a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b");
     a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
@@ -642,6 +667,7 @@ extern "C" int desire_ioc_step(desire_handle* h, int32_t t, int32_t rank, int32_
     a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
     a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b"); a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b");
     a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb"); a.w_score = D(h, "ioc/score_w");
+    a.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     { Timer tm(h, s, "ioc_step"); launch_ioc_step(a, s); }
     HIPCHK(hipGetLastError());
@@ -670,7 +696,7 @@ extern "C" int desire_neighbor_bins(desire_handle* h, const float* dev_pos, cons
     if (!h || !dev_pos || !dev_valid || !dev_bins || n_groups < 0) return fail(DESIRE_ERR_ARG, "bad argument");
     if (n_groups == 0) return DESIRE_OK;
     launch_neighbor_bins(dev_pos, dev_valid, dev_bins, n_groups, h->d.mno, h->d.nb_w, h->d.nb_h, h->d.grid_size,
-                         static_cast<hipStream_t>(stream));
+                         h->d.bin_mode == 1 ? W(h, "bin_tab") : nullptr, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

@@ -163,8 +163,33 @@ __device__ __forceinline__ void scene_cell_dev(float x, float y, int Gh, int Gw,
 
 // neighbour bin of `other` (xj,yj) seen from centre (xi,yi); -1 when outside the window
 // (oracle: neighbor_bins; lineage: Social-LSTM getGridMask, the reference's missing grid.py)
+// tab != nullptr selects the LOG-POLAR layout (the paper's): G rings x G sectors around the centre.  tab[0..G-1] =
+// squared ring radii (ascending, the last one = r_max^2), tab[8 + 2k], tab[9 + 2k] = (cos, sin) of sector boundary k.
+// ring = #{k : d^2 >= tab[k]} (outside when ring == G); sector = first k with cross(dir_k, v) >= 0 and
+// cross(dir_{k+1}, v) < 0, else 0.  Comparisons and single IEEE operations only: bit-exact against the oracle.
 __device__ __forceinline__ int neighbor_bin_dev(float xi, float yi, float xj, float yj,
-                                                float nb_w, float nb_h, int G) {
+                                                float nb_w, float nb_h, int G, const float* __restrict__ tab = nullptr) {
+#pragma clang fp contract(off)      // d2 and the cross products are sums of products: they must NOT become fmas (bit-exactness)
+    if (tab) {
+        // plain operators under contract(off): the __f*_rn intrinsics inline library IR that may still carry the
+        // `contract` flag, and mul + mul + add is exactly the shape the backend would fuse
+        const float dx = xj - xi, dy = yj - yi;
+        const float dxx = dx * dx, dyy = dy * dy;
+        const float d2 = dxx + dyy;
+        int ring = 0;
+        for (int k = 0; k < G; ++k) ring += (d2 >= tab[k]) ? 1 : 0;
+        if (ring >= G) return -1;
+        int sector = 0;
+        bool found = false;
+        for (int k = 0; k < G; ++k) {
+            const int k1 = (k + 1 == G) ? 0 : k + 1;
+            const float a0 = tab[8 + 2 * k] * dy, b0 = tab[9 + 2 * k] * dx;
+            const float a1 = tab[8 + 2 * k1] * dy, b1 = tab[9 + 2 * k1] * dx;
+            const float c0 = a0 - b0, c1 = a1 - b1;
+            if (!found && c0 >= 0.f && c1 < 0.f) { sector = k; found = true; }
+        }
+        return ring * G + sector;
+    }
     const float hw = __fdiv_rn(nb_w, 2.0f), hh = __fdiv_rn(nb_h, 2.0f);
     const float lx = __fsub_rn(xi, hw), hx = __fadd_rn(xi, hw);
     const float ly = __fsub_rn(yi, hh), hy = __fadd_rn(yi, hh);

@@ -93,6 +93,7 @@ struct IocArgs {
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
     float* hex; int* grp_cnt; int* err;                    // cluster form: exchange buffer [2][R][H], group counters, error word
     float* sv_x; float* sv_r; float* sv_u; float* sv_c; float* sv_h;   // training saves: [R,T,E], [R,T,H] x4 (32-row form only)
+    const float* bin_tab;                                  // log-polar bin table (common.h:neighbor_bin_dev) or nullptr = rectangular grid
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
@@ -105,6 +106,7 @@ struct IocStepArgs {
     const float* grids; const int32_t* grid_of_scene;
     const float* w_vel; const float* b_vel; const float4* Wsoc; const float* b_soc;
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c; const float* w_score;
+    const float* bin_tab;
 };
 void launch_ioc_step(const IocStepArgs& a, hipStream_t s);
 void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const float* b_score, float* score, int R, int T, hipStream_t s);
@@ -118,7 +120,7 @@ void launch_deconv3_bf16(const ConvArgs& a, hipStream_t s);
 void launch_deconv34_bf16(const ConvArgs& a, const float* sc4, const float* sh4, hipStream_t s);   // a.Wp = W3 pack, a.w_raw = W4 chain pack    // kernels_bf16.hip; weight pointers = bf16 packs
 
 void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
-                          float nb_w, float nb_h, int G, hipStream_t s);
+                          float nb_w, float nb_h, int G, const float* bin_tab, hipStream_t s);
 void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw, hipStream_t s);
 
 // ---- cold rows (kernels_aux.hip) ----
@@ -173,5 +175,6 @@ struct IocBwdArgs {
     const float4* WgT_h; const float4* WgT_er; const float4* WgT_ev; const float4* WsT;
     float* dag; float* dac; float* rh; float* hprev; float* dpre_r; float* dpre_v; float* vel; float* pooled;
     float* dHx_rows;
+    const float* bin_tab;
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);

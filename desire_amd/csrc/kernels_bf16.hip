@@ -212,7 +212,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 }
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
-                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G);
+                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                     if (b >= 0) atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j));
                 }
             }

@@ -864,7 +864,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
             const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
             for (int j = q8; j < a.mno; j += TPR) {
                 if (j == my_slot || !vld[grp_base + j]) continue;
-                const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G);
+                const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                 if (b >= 0) {
                     atomicOr(&masks[r8 * B + b], 1ull << j);
                     atomicOr(&obs[(grp_base + j) * B + b], 1ull << my_slot);

@@ -439,7 +439,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
-                                                   a.nb_w, a.nb_h, a.G);
+                                                   a.nb_w, a.nb_h, a.G, a.bin_tab);
                     if (b >= 0) atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
                 }
             }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     }
                     for (int j = q8; j < a.mno; j += TPR) {
                         if (j == my_slot || !vld[j]) continue;
-                        const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G);
+                        const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                         if (b >= 0) atomicOr(&masks[(r8 * B + b) * 2 + (j >> 6)], 1ull << (j & 63));
                     }
                 }
@@ -928,7 +928,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
             const int rk = j / a.m_loc, s = j - rk * a.m_loc;
             if (j == my_gslot || !a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s]) continue;
             const float2 pj = pos_of(j, a.t);
-            const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G);
+            const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G, a.bin_tab);
             if (b >= 0) atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63));
         }
     }
@@ -1023,7 +1023,8 @@ void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const f
 // integer paths (standalone, for bit-exact tests)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_neighbor_bins(const float* __restrict__ pos, const uint8_t* __restrict__ valid,
-                                int32_t* __restrict__ bins, int n_groups, int mno, float nb_w, float nb_h, int G) {
+                                int32_t* __restrict__ bins, int n_groups, int mno, float nb_w, float nb_h, int G,
+                                const float* __restrict__ bin_tab) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_groups * mno * mno) return;
     const int g = idx / (mno * mno), ij = idx - g * mno * mno;
@@ -1031,14 +1032,14 @@ __global__ void k_neighbor_bins(const float* __restrict__ pos, const uint8_t* __
     int b = -1;
     if (i != j && valid[g * mno + j]) {
         const float* p = pos + (size_t)g * mno * 2;
-        b = neighbor_bin_dev(p[i * 2], p[i * 2 + 1], p[j * 2], p[j * 2 + 1], nb_w, nb_h, G);
+        b = neighbor_bin_dev(p[i * 2], p[i * 2 + 1], p[j * 2], p[j * 2 + 1], nb_w, nb_h, G, bin_tab);
     }
     bins[idx] = b;
 }
 void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins, int n_groups, int mno,
-                          float nb_w, float nb_h, int G, hipStream_t s) {
+                          float nb_w, float nb_h, int G, const float* bin_tab, hipStream_t s) {
     const int n = n_groups * mno * mno;
-    hipLaunchKernelGGL(k_neighbor_bins, dim3((n + 255) / 256), dim3(256), 0, s, pos, valid, bins, n_groups, mno, nb_w, nb_h, G);
+    hipLaunchKernelGGL(k_neighbor_bins, dim3((n + 255) / 256), dim3(256), 0, s, pos, valid, bins, n_groups, mno, nb_w, nb_h, G, bin_tab);
 }
 
 __global__ void k_scene_cells(const float* __restrict__ pos, int32_t* __restrict__ cells, int n, int Gh, int Gw) {

@@ -346,6 +346,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
         q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
         q.dHx_rows = W(h, "dHx_rows");
+        q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
         launch_ioc_bwd(q, s);
         const long RT = R * T;
         tn(h, W(h, "ioc_sv_h") + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, 0, s);

@@ -44,6 +44,9 @@ typedef struct desire_dims {
     int32_t H, L, S, C, Gh, Gw, n_grids;
     int32_t grid_size, E_v, iters, posterior;
     float nb_w, nb_h, sx, sy;
+    int32_t bin_mode;      /* social pooling layout: 0 = rectangular grid_size x grid_size window of nb_w x nb_h (Social-LSTM /
+                              the reference's flags, train.py:68-72); 1 = log-polar (the paper's): grid_size rings with
+                              geometric radii between nb_h (inner radius) and nb_w (outer radius) x grid_size sectors */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only, mno <= 64 */
 } desire_dims;
@@ -97,6 +100,9 @@ int desire_read_buffer(desire_handle* h, const char* name, float* host_out, size
 /* Integer paths, exposed for bit-exact tests (the same device functions the IOC kernel uses).
  * dev_pos [n_groups, mno, 2] normalised; dev_valid [n_groups, mno] uint8;
  * dev_bins [n_groups, mno, mno] int32 out (-1 = not pooled). */
+/* The log-polar bin table of a bin_mode = 1 handle: out[0..grid_size-1] squared ring radii, out[8+2k], out[9+2k] = (cos, sin)
+ * of sector boundary k -- the exact fp32 constants the kernels compare against (the oracle takes them as input). */
+int desire_get_bin_table(desire_handle* h, float* host_out20);
 int desire_neighbor_bins(desire_handle* h, const float* dev_pos, const uint8_t* dev_valid,
                          int32_t* dev_bins, int32_t n_groups, void* stream);
 /* dev_pos [n, 2] -> dev_cells [n, 2] = (cy, cx). */

@@ -221,13 +221,58 @@ def scene_cell(pos, Gh, Gw):
     return cy, cx
 
 
-def neighbor_bins(pos, valid, nb_w, nb_h, G):
-    """Social-LSTM style rectangular neighbourhood grid (lineage of the reference's missing
+def logpolar_table(r_min, r_max, G):
+    """The constants of the log-polar layout: [0..G-1] squared ring radii (geometric between r_min and r_max), [8+2k],
+    [9+2k] = (cos, sin) of sector boundary k.  The HIP library builds the same table with the C library's pow/cos/sin;
+    parity tests feed the oracle the library's table (desire_get_bin_table) so that a last-bit difference between two
+    libm's cannot move a bin edge."""
+    tab = np.zeros(20, np.float32)
+    for k in range(G):
+        t = np.float32(float(r_min) * (float(r_max) / float(r_min)) ** ((k + 1) / G))
+        tab[k] = t * t
+        tab[8 + 2 * k] = np.float32(np.cos(2.0 * np.pi * k / G))
+        tab[9 + 2 * k] = np.float32(np.sin(2.0 * np.pi * k / G))
+    return tab
+
+
+def neighbor_bins_logpolar(pos, valid, G, tab):
+    """Log-polar social bins (the paper's layout): for centre i and other j, v = p_j - p_i, d2 = vx*vx + vy*vy (each a
+    single fp32 operation); ring = #{k < G : d2 >= tab[k]}, dropped when ring == G (beyond r_max), when j == i or
+    !valid[j]; sector = first k with cross(dir_k, v) >= 0 and cross(dir_{k+1}, v) < 0, cross(d, v) = d.x*v.y - d.y*v.x,
+    else 0; bin = ring*G + sector.  Comparisons and single IEEE operations only."""
+    p = pos.astype(np.float32)
+    tab = np.asarray(tab, np.float32)
+    xi, yi = p[..., :, None, 0], p[..., :, None, 1]
+    xj, yj = p[..., None, :, 0], p[..., None, :, 1]
+    dx, dy = (xj - xi).astype(np.float32), (yj - yi).astype(np.float32)
+    d2 = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32)
+    ring = np.zeros(d2.shape, np.int32)
+    for k in range(G):
+        ring += (d2 >= tab[k]).astype(np.int32)
+    sector = np.zeros(d2.shape, np.int32)
+    found = np.zeros(d2.shape, bool)
+    for k in range(G):
+        k1 = 0 if k + 1 == G else k + 1
+        c0 = ((tab[8 + 2 * k] * dy).astype(np.float32) - (tab[9 + 2 * k] * dx).astype(np.float32)).astype(np.float32)
+        c1 = ((tab[8 + 2 * k1] * dy).astype(np.float32) - (tab[9 + 2 * k1] * dx).astype(np.float32)).astype(np.float32)
+        hit = (~found) & (c0 >= 0) & (c1 < 0)
+        sector = np.where(hit, k, sector)
+        found |= hit
+    M = p.shape[-2]
+    inside = (ring < G) & ~np.eye(M, dtype=bool) & valid[..., None, :].astype(bool)
+    return np.where(inside, ring * G + sector, -1).astype(np.int32)
+
+
+def neighbor_bins(pos, valid, nb_w, nb_h, G, tab=None):
+    """tab given: log-polar layout (neighbor_bins_logpolar).  Otherwise:
+    Social-LSTM style rectangular neighbourhood grid (lineage of the reference's missing
     grid.getSequenceGridMask, train.py:21,156-157; flags train.py:68-72).
     pos [..., M, 2] fp32, valid [..., M] bool -> bins [..., M, M] int32 (-1 = not pooled).
     For centre i and other j:  low = p_i - nb/2 ; high = p_i + nb/2 ;
     j is dropped if j==i, !valid[j], x_j >= high_x, x_j < low_x, y_j >= high_y, y_j < low_y;
     cell_x = min(int(floor(((x_j - low_x)/nb_w) * G)), G-1), same for y; bin = cell_x + cell_y*G."""
+    if tab is not None:
+        return neighbor_bins_logpolar(pos, valid, G, tab)
     p = pos.astype(np.float32)
     f = np.float32
     hw, hh = f(nb_w) / f(2), f(nb_h) / f(2)
@@ -305,19 +350,19 @@ def decode(xz, h0, p_last, w, d, dt=np.float32, return_hidden=False, q=None):
     return (Y, np.stack(hs, 1)) if return_hidden else Y
 
 
-def social_pool(pos_t, hprev, valid_rows, d, dt):
+def social_pool(pos_t, hprev, valid_rows, d, dt, bin_tab=None):
     """pos_t [R,2], hprev [R,H], valid_rows [R] -> pooled [R, B*H] (bin-major)."""
     G = d.grid_size
     P = pos_t.reshape(d.n_scenes * d.K, d.mno, 2)
     Hh = hprev.reshape(d.n_scenes * d.K, d.mno, d.H)
     V = valid_rows.reshape(d.n_scenes * d.K, d.mno)
-    bins = neighbor_bins(P, V, d.nb_w, d.nb_h, G)                      # [SK, M, M]
+    bins = neighbor_bins(P, V, d.nb_w, d.nb_h, G, bin_tab)             # [SK, M, M]
     onehot = (bins[..., None] == np.arange(d.B)).astype(dt)             # [SK, M, M, B]
     pooled = np.einsum("gijb,gjh->gibh", onehot, Hh.astype(dt))
     return pooled.reshape(d.R, d.B * d.H).astype(dt), bins
 
 
-def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.float32, q=None):
+def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.float32, q=None, bin_tab=None):
     """One IOC scoring + regression pass (paper section 3.3; absent in the reference,
     model/model.py:312-313).  Returns (score [R], dY [R,T_pred,2]).
     q = bf16_round restates the bf16-operand kernel (kernels_bf16.hip): weights, x_t, h, r*h and the pooled sums are
@@ -339,7 +384,7 @@ def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.f
         e_v = relu((cur - prev) @ Wv + bv)
         cy, cx = scene_cell(cur, d.Gh, d.Gw)
         e_s = grids[gidx, cy, cx].astype(dt)
-        pooled, _ = social_pool(cur, qq(h), valid_rows, d, dt)
+        pooled, _ = social_pool(cur, qq(h), valid_rows, d, dt, bin_tab)
         e_r = relu(qq(pooled) @ Ws + bs)
         h = gru_cell(qq(np.concatenate([e_v, e_s, e_r], -1)), h, Wg, bg, Wc, bc, q)
         score = score + (h @ wsc[:, 0] + bsc[0])
@@ -349,7 +394,7 @@ def ioc_pass(Y, Hx_rows, p_last, valid_rows, grids, grid_of_scene, w, d, dt=np.f
 
 
 def forward(past, fut, eps, grids, grid_of_scene, w, d, bn_mode="frozen", dt=np.float32,
-            Y_override: Optional[np.ndarray] = None, ioc_q=None) -> Dict[str, np.ndarray]:
+            Y_override: Optional[np.ndarray] = None, ioc_q=None, bin_tab=None) -> Dict[str, np.ndarray]:
     """Whole hot path.  past [T_obs, A, 3], fut [T_pred, A, 3] (or None when d.posterior==0),
     eps [R, L] (row order r=(scene*K+k)*mno+slot), grids [n_grids, Gh, Gw, C],
     grid_of_scene [n_scenes] int.  Returns every intermediate the parity tests compare."""
@@ -384,7 +429,9 @@ def forward(past, fut, eps, grids, grid_of_scene, w, d, bn_mode="frozen", dt=np.
         Y = Y_override.astype(dt)
     score = np.zeros(d.R, dt)
     for _ in range(d.iters):
-        score, dY = ioc_pass(Y, Hx_rows, p_last_rows, valid_rows, grids, grid_of_scene, w, d, dt, q=ioc_q)
+        if bin_tab is None and getattr(d, "bin_mode", 0) == 1:
+            bin_tab = logpolar_table(d.nb_h, d.nb_w, d.grid_size)
+        score, dY = ioc_pass(Y, Hx_rows, p_last_rows, valid_rows, grids, grid_of_scene, w, d, dt, q=ioc_q, bin_tab=bin_tab)
         Y = (Y + dY).astype(dt)
     out["Y"] = Y
     out["score"] = score

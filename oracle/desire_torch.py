@@ -87,7 +87,7 @@ def rows_from_agents(x, d):
     return x.expand((d.n_scenes, d.K, d.mno) + tuple(x.shape[3:])).reshape((d.R,) + tuple(x.shape[3:]))
 
 
-def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor], d, fixed=None):
+def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor], d, fixed=None, bin_tab=None):
     """past/fut in the oracle layout [T, A, 3]; returns dict with every forward tensor + the loss terms.
     `fixed` = {"Yd": ..., "dmax": ...} pins the stop-gradient quantities (for finite-difference checks)."""
     pn = _t(O.normalise(past, d, np.float64))
@@ -136,7 +136,7 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
         cy, cx = O.scene_cell(cur.numpy().astype(np.float32), d.Gh, d.Gw)
         e_s = gr[gidx, cy, cx]
         P = cur.numpy().astype(np.float32).reshape(d.n_scenes * d.K, d.mno, 2)
-        bins = O.neighbor_bins(P, valid_rows.reshape(d.n_scenes * d.K, d.mno), d.nb_w, d.nb_h, d.grid_size)
+        bins = O.neighbor_bins(P, valid_rows.reshape(d.n_scenes * d.K, d.mno), d.nb_w, d.nb_h, d.grid_size, bin_tab)
         onehot = _t((bins[..., None] == np.arange(d.B)).astype(np.float64))     # [g, i, j, b]
         pooled = torch.einsum("gijb,gjh->gibh", onehot, h.reshape(d.n_scenes * d.K, d.mno, d.H)).reshape(d.R, d.B * d.H)
         e_r = torch.relu(pooled @ w["ioc/social_fc/w"] + w["ioc/social_fc/b"])

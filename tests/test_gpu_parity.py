@@ -486,3 +486,55 @@ def test_outputs_do_not_depend_on_where_a_window_sits_in_the_batch(torch_cuda, k
     np.testing.assert_array_equal(back(Y02), Y0)
     np.testing.assert_array_equal(back(Y2), Y)
     np.testing.assert_array_equal(back(s2), s)
+
+
+@pytest.mark.parametrize("G", [3, 4, 6])
+def test_logpolar_bins_bit_exact(torch_cuda, G):
+    """dims.bin_mode = 1: rings x sectors around every agent, bit-exact against the oracle fed with the library's own
+    table; random points plus adversarial ones on ring radii, on sector boundaries, coincident, and beyond r_max."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    from oracle import desire_oracle as O
+    d = small_dims(mno=32, grid_size=G, bin_mode=1, nb_w=0.4, nb_h=0.05)
+    h = _lib.Handle(d)
+    tab = h.bin_table()
+    np.testing.assert_allclose(tab, O.logpolar_table(d.nb_h, d.nb_w, G), rtol=2e-7, atol=1e-12)
+    rng = np.random.default_rng(3)
+    n_groups = 129
+    pos = rng.uniform(0.0, 1.0, (n_groups, d.mno, 2)).astype(np.float32)
+    radii = np.sqrt(tab[:G].astype(np.float64))
+    for k in range(G):                                              # exactly on every ring radius, along every boundary direction
+        pos[0, 1 + k] = pos[0, 0] + np.float32(radii[k]) * np.float32([tab[8 + 2 * k], tab[9 + 2 * k]])
+        pos[1, 1 + k] = pos[1, 0] + np.float32(0.1) * np.float32([tab[8 + 2 * k], tab[9 + 2 * k]])
+    pos[2, 1] = pos[2, 0]                                            # coincident
+    pos[2, 2] = pos[2, 0] + np.float32([0.5, 0.0])                   # beyond r_max
+    valid = rng.random((n_groups, d.mno)) > 0.15
+    pos_t = torch.as_tensor(pos, device="cuda")
+    val_t = torch.as_tensor(valid.astype(np.uint8), device="cuda")
+    bins_t = torch.full((n_groups, d.mno, d.mno), -7, dtype=torch.int32, device="cuda")
+    h.neighbor_bins(pos_t.data_ptr(), val_t.data_ptr(), bins_t.data_ptr(), n_groups)
+    torch.cuda.synchronize()
+    ref = O.neighbor_bins(pos, valid, d.nb_w, d.nb_h, G, tab)
+    np.testing.assert_array_equal(bins_t.cpu().numpy(), ref)
+    assert ref.max() == G * G - 1 and (ref >= 0).mean() > 0.1        # the case exercises every ring and sector
+
+
+@pytest.mark.parametrize("kw", [dict(grid_size=6, K=2), dict(grid_size=4, K=3, mno=16, n_scenes=3), dict(grid_size=3, K=2, mno=64, n_scenes=1, n_grids=1),
+                                dict(grid_size=6, K=2, bf16=1)])
+def test_ioc_with_logpolar_pooling(torch_cuda, kw):
+    """The IOC stage with the paper's log-polar social pooling (all IOC kernel forms: 32-row, 64-row / cluster, bf16)."""
+    from oracle import desire_oracle as O
+    kw = dict(kw)
+    bf16 = kw.pop("bf16", 0)
+    d = small_dims(bin_mode=1, nb_w=0.45, nb_h=0.04, **kw)
+    w = init_weights(d, 17)
+    past, fut, eps, grids, gos = make_case(d, seed=18, n_absent=2)
+    from desire_amd import _lib
+    tab = _lib.Handle(d).bin_table()
+    ref0 = oracle_forward(d, w, past, fut, eps, grids, gos, bin_tab=tab)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos, bin_tab=tab, Y_override=ref0["Y0"], ioc_q=O.bf16_round if bf16 else None)
+    _, Y, score = run_gpu(torch_cuda, d.replace(bf16=bf16), w, past, fut, eps, grids, gos, Y_in=ref0["Y0"])
+    scale = max(1.0, float(np.abs(ref["Y"] - ref0["Y0"]).max()))
+    tol = 5e-3 * scale if bf16 else TOL_Y
+    assert np.abs(Y - ref["Y"]).max() < tol, np.abs(Y - ref["Y"]).max()
+    assert np.abs(score - ref["score"]).max() < (2e-2 if bf16 else 5e-3) * max(1.0, float(np.abs(ref["score"]).max()))

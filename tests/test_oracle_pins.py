@@ -176,3 +176,30 @@ def test_ref_compat_literal_graph_plumbing(golden_dir):
     np.testing.assert_allclose(one["output_states"][0], out["output_states"][obj], atol=1e-6)
     with pytest.raises(ValueError):
         O.forward_ref_compat(inp, tgt, eps, w, H=32, L=L)
+
+
+def test_logpolar_bins_known_answers():
+    """Hand-checked cases of the log-polar layout (G = 4 rings x 4 sectors, r_min = 0.125, r_max = 0.5: ring radii
+    0.125*4^(k/4)... -> thresholds 0.1768, 0.25, 0.3536, 0.5).  Sector boundaries at 0, 90, 180, 270 degrees."""
+    from oracle import desire_oracle as O
+    G = 4
+    tab = O.logpolar_table(0.125, 0.5, G)
+    np.testing.assert_allclose(np.sqrt(tab[:4]), [0.125 * 4 ** 0.25, 0.25, 0.125 * 4 ** 0.75, 0.5], rtol=1e-6)
+    c = np.float32([0.5, 0.5])
+    pts = np.float32([[0.5, 0.5],          # the centre itself
+                      [0.6, 0.55],         # d = 0.112 -> ring 0, first quadrant -> sector 0      -> bin 0
+                      [0.5, 0.7],          # d = 0.2   -> ring 1, on the +y axis: cross(dir_1, v) = 0 >= 0, sector 1 -> bin 5
+                      [0.2, 0.5],          # d = 0.3   -> ring 2, on the -x axis -> sector 2     -> bin 10
+                      [0.5, 0.05],         # d = 0.45  -> ring 3, on the -y axis -> sector 3     -> bin 15
+                      [0.9, 0.9],          # d = 0.566 >= r_max -> outside
+                      [0.75, 0.5],         # d = 0.25 exactly on the ring-1/2 threshold (d2 >= t) -> ring 2, +x axis -> sector 0 -> bin 8
+                      [0.45, 0.45]])       # d = 0.0707 < r_min -> ring 0 (the inner disc belongs to ring 0), third quadrant -> sector 2 -> bin 2
+    pts[0] = c
+    valid = np.ones(len(pts), bool)
+    bins = O.neighbor_bins_logpolar(pts, valid, G, tab)[0]          # seen from agent 0 (the centre)
+    assert bins.tolist() == [-1, 0, 5, 10, 15, -1, 8, 2]
+    valid[3] = False
+    assert O.neighbor_bins_logpolar(pts, valid, G, tab)[0][3] == -1  # absent agents are never pooled
+    # coincident agents: v = 0 -> ring 0, no sector test succeeds -> sector 0
+    two = np.float32([[0.3, 0.3], [0.3, 0.3]])
+    assert O.neighbor_bins_logpolar(two, np.ones(2, bool), G, tab).tolist() == [[-1, 0], [0, -1]]
