@@ -166,9 +166,9 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     return out
 
 
-def loss_and_grads(past, fut, eps, grids, grid_of_scene, w_np: Dict[str, np.ndarray], d):
+def loss_and_grads(past, fut, eps, grids, grid_of_scene, w_np: Dict[str, np.ndarray], d, bin_tab=None):
     w = leaf_weights(w_np)
-    out = forward_loss(past, fut, eps, grids, grid_of_scene, w, d)
+    out = forward_loss(past, fut, eps, grids, grid_of_scene, w, d, bin_tab=bin_tab)
     out["loss"].backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in w.items()}
     vals = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}

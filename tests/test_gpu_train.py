@@ -236,3 +236,35 @@ def test_full_size_gradient_is_the_mean_of_its_halves():
     scale = float(g_all.abs().max())
     err = float((g_all - g_half).abs().max())
     assert scale > 0 and err < 2e-4 * scale, (err, scale)
+
+
+def test_gradients_with_logpolar_pooling():
+    """Backward through the log-polar social layout (dims.bin_mode = 1): the pooling transpose only sees the bins through
+    the neighbour / observer masks, so the IOC and encoder gradients must still match autograd."""
+    import torch
+    from desire_amd import _lib
+    from oracle import desire_torch as OT
+    d = small_dims(n_scenes=2, mno=16, K=3, T_obs=5, T_pred=6, n_grids=1, bin_mode=1, nb_w=0.45, nb_h=0.04)
+    w = init_weights(d, 51)
+    for k in w:
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    past, fut, eps, grids, gos = make_case(d, seed=52, n_absent=2)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    tab = h.bin_table()
+    _, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d, bin_tab=tab)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(g.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev); sc = torch.zeros((d.R,), device=dev)
+    h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+    h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+    torch.cuda.synchronize()
+    for name in ("ioc/social_fc/w", "ioc/gates/kernel", "ioc/candidate/kernel", "ioc/reg/w", "ioc/score/w", "enc_x/gates/kernel", "dec/gates/kernel"):
+        got = h.get_grad(name, w[name].shape)
+        assert rel_err(got, ref[name]) < 2e-4, (name, rel_err(got, ref[name]))
