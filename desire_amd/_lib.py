@@ -29,13 +29,13 @@ class DesireDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_scenes", "mno", "K", "T_obs", "T_pred", "H", "L", "S", "C", "Gh", "Gw", "n_grids",
                  "grid_size", "E_v", "iters", "posterior")] + \
-               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bf16", C.c_int32)]
+               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bn_mode", C.c_int32), ("bf16", C.c_int32)]
 
     @classmethod
     def from_dims(cls, d: Dims) -> "DesireDims":
         return cls(d.n_scenes, d.mno, d.K, d.T_obs, d.T_pred, d.H, d.L, d.S, d.C, d.Gh, d.Gw, d.n_grids,
                    d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy, int(getattr(d, "bin_mode", 0)),
-                   int(getattr(d, "bf16", 0)))
+                   int(getattr(d, "bn_mode", 0)), int(getattr(d, "bf16", 0)))
 
 
 class DesireError(RuntimeError):

@@ -125,6 +125,8 @@ int check_dims(const desire_dims& d) {
     if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
     if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
     if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
+    if (d.bn_mode != 0 && d.bn_mode != 1) return fail(DESIRE_ERR_ARG, "bn_mode must be 0 (frozen statistics) or 1 (per-object statistics)");
+    if (d.bn_mode == 1 && d.bf16) return fail(DESIRE_ERR_ARG, "per-object batch-norm runs on fp32 operands (bf16 = 0)");
     if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
     if (d.bin_mode == 1 && (d.grid_size < 3 || !(d.nb_h > 0.f) || !(d.nb_w > d.nb_h)))
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
@@ -368,6 +370,7 @@ int desire_pack_all(desire_ctx* h) {
                           "vae_dec/deconv3", "vae_dec/deconv4"}) {
         fold_bn(h, n, sc, sh);
         bad |= up(std::string(n) + "/scale", sc); bad |= up(std::string(n) + "/shift", sh);
+        if (d.bn_mode == 1) { bad |= up(std::string(n) + "/gamma", hw[std::string(n) + "/bn/gamma"]); bad |= up(std::string(n) + "/beta", hw[std::string(n) + "/bn/beta"]); }
     }
     bad |= up("vae_enc/conv1/raw", hw["vae_enc/conv1/w"]);
     bad |= up("vae_dec/deconv4/raw", hw["vae_dec/deconv4/w"]);
@@ -456,15 +459,20 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         c.n = A;
         c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
-        { Timer t(h, s, "conv1"); launch_conv1(c, s); }
+        const bool pobn = d.bn_mode == 1;                 // per-object BN: linear conv epilogue, then k_instnorm_act per layer
+        auto norm = [&](const char* layer, float* x, int n, int P, int C, int sig) {
+            launch_instnorm_act(x, n, P, C, D(h, (std::string(layer) + "/gamma").c_str()), D(h, (std::string(layer) + "/beta").c_str()), sig, s);
+        };
+        if (pobn) c.mode = 3;
+        { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), A, 256, 32, 0); }
         c.in = W(h, "c1"); c.out = W(h, "c2"); c.Wp = D4(h, "vae_enc/conv2/W");
         c.scale = D(h, "vae_enc/conv2/scale"); c.shift = D(h, "vae_enc/conv2/shift");
         if (d.bf16) { c.Wp = D4(h, "vae_enc/conv2/W16"); Timer t(h, s, "conv2"); launch_conv2_bf16(c, s); }
-        else { Timer t(h, s, "conv2"); launch_conv2(c, s); }
+        else { Timer t(h, s, "conv2"); launch_conv2(c, s); if (pobn) norm("vae_enc/conv2", W(h, "c2"), A, 64, 64, 0); }
         c.in = W(h, "c2"); c.out = W(h, "c3"); c.Wp = D4(h, "vae_enc/conv3/W");
         c.scale = D(h, "vae_enc/conv3/scale"); c.shift = D(h, "vae_enc/conv3/shift");
         if (d.bf16) { c.Wp = D4(h, "vae_enc/conv3/W16"); Timer t(h, s, "conv3"); launch_conv3_bf16(c, s); }
-        else { Timer t(h, s, "conv3"); launch_conv3(c, s); }
+        else { Timer t(h, s, "conv3"); launch_conv3(c, s); if (pobn) norm("vae_enc/conv3", W(h, "c3"), A, 16, 128, 0); }
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = A; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
         g.NT = (2 * d.L + 31) / 32; g.out = W(h, "params"); g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
@@ -486,13 +494,20 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
     if (d.bf16 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
+    else if (d.bn_mode == 1) {
+        Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_NONE, s);
+        launch_instnorm_act(W(h, "d1"), R, 16, 128, D(h, "vae_dec/deconv1/gamma"), D(h, "vae_dec/deconv1/beta"), 0, s);
+    }
     else { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
     ConvArgs c{};
     c.n = R;
+    const bool pobn = d.bn_mode == 1;
+    if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
-    else { Timer t(h, s, "deconv2"); launch_deconv2(c, s); }
+    else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
+           if (pobn) launch_instnorm_act(W(h, "d2"), R, 64, 64, D(h, "vae_dec/deconv2/gamma"), D(h, "vae_dec/deconv2/beta"), 0, s); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
     const bool fuse34 = d.bf16 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
@@ -502,10 +517,12 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         launch_deconv34_bf16(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), s);
     } else {
         if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
-        else { Timer t(h, s, "deconv3"); launch_deconv3(c, s); }
+        else { Timer t(h, s, "deconv3"); launch_deconv3(c, s);
+               if (pobn) launch_instnorm_act(W(h, "d3"), R, 256, 32, D(h, "vae_dec/deconv3/gamma"), D(h, "vae_dec/deconv3/beta"), 0, s); }
         c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
         c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
-        { Timer t(h, s, "deconv4"); launch_deconv4(c, s); }
+        { Timer t(h, s, "deconv4"); launch_deconv4(c, s);
+          if (pobn) launch_instnorm_act(W(h, "xhat"), R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), D(h, "vae_dec/deconv4/beta"), 1, s); }
     }
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;

@@ -249,6 +249,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
     if (d.bf16) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0)");
+    if (d.bn_mode) return fail(DESIRE_ERR_STATE, "training runs with frozen batch-norm statistics (dims.bn_mode = 0)");
     if (d.mno > 32) return fail(DESIRE_ERR_STATE, "training supports mno <= 32 in this round");
     if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");

@@ -50,6 +50,7 @@ class Dims:
     sx: float = 1.0        # pixel -> normalised scale, x
     sy: float = 1.0        # pixel -> normalised scale, y
     bin_mode: int = 0      # social bins: 0 rectangular window nb_w x nb_h; 1 log-polar (rings nb_h .. nb_w x sectors)
+    bn_mode: int = 0       # CVAE batch-norm: 0 frozen moving statistics; 1 per-object statistics (the reference's batch of one)
     bf16: int = 0          # 1: bf16 MFMA operands (fp32 accumulate / state) in the IOC kernel; inference only
 
     @property

@@ -47,6 +47,10 @@ typedef struct desire_dims {
     int32_t bin_mode;      /* social pooling layout: 0 = rectangular grid_size x grid_size window of nb_w x nb_h (Social-LSTM /
                               the reference's flags, train.py:68-72); 1 = log-polar (the paper's): grid_size rings with
                               geometric radii between nb_h (inner radius) and nb_w (outer radius) x grid_size sectors */
+    int32_t bn_mode;       /* batch normalisation of the CVAE conv stacks: 0 = frozen moving statistics folded into the kernels
+                              (default); 1 = "per-object": the reference's literal graph -- phase=train on a batch of one
+                              object (model/model.py:453-462,471-481), i.e. per-sample per-channel moments over the layer's
+                              pixels.  fp32 operands, inference only. */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only, mno <= 64 */
 } desire_dims;

@@ -538,3 +538,43 @@ def test_ioc_with_logpolar_pooling(torch_cuda, kw):
     tol = 5e-3 * scale if bf16 else TOL_Y
     assert np.abs(Y - ref["Y"]).max() < tol, np.abs(Y - ref["Y"]).max()
     assert np.abs(score - ref["score"]).max() < (2e-2 if bf16 else 5e-3) * max(1.0, float(np.abs(ref["score"]).max()))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(posterior=0)])
+def test_per_object_batch_norm_mode(torch_cuda, kw):
+    """dims.bn_mode = 1: the reference's literal batch-norm (phase=train on a batch of ONE object, model/model.py:453-462,
+    471-481) = per-sample, per-channel moments over each conv layer's pixels -- stagewise against the oracle's
+    bn_mode="per_object"."""
+    d = small_dims(bn_mode=1, **kw)
+    w = init_weights(d, 41)
+    rng = np.random.default_rng(5)
+    for k in list(w):                                    # non-trivial affine parameters (fresh init: gamma = 1, beta = 0)
+        if k.endswith("/bn/gamma"):
+            w[k] = (1.0 + 0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        if k.endswith("/bn/beta"):
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    past, fut, eps, grids, gos = make_case(d, seed=42, n_absent=2)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos, bn_mode="per_object")
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    A, R = d.A, d.R
+    shapes = {"z": (R, d.L), "d1": (R, 2048), "d2": (R, 4096), "d3": (R, 8192), "xhat": (R, 1024), "xz": (R, d.H), "Y0": (R, d.T_pred, 2)}
+    if d.posterior:
+        shapes.update({"z_mean": (A, d.L), "z_log_sigma_sq": (A, d.L)})
+    report = {name: float(np.abs(h.read_buffer(name, shp) - ref[name].reshape(shp)).max()) for name, shp in shapes.items()}
+    print("per-object BN, max abs err per stage:", report)
+    for name, err in report.items():
+        assert err < (TOL_Y if name == "Y0" else 5e-4), (name, err, report)
+    # and it is a different function from the frozen-statistics default
+    ref_frozen = oracle_forward(d.replace(bn_mode=0), w, past, fut, eps, grids, gos)
+    assert np.abs(ref_frozen["xhat"] - ref["xhat"]).max() > 1e-2
+
+
+def test_per_object_batch_norm_is_fp32_inference_only(torch_cuda):
+    from desire_amd import _lib
+    with pytest.raises(_lib.DesireError):
+        _lib.Handle(small_dims(bn_mode=1, bf16=1))
+    d = small_dims(bn_mode=1)
+    h = _lib.Handle(d)
+    h.set_weights(init_weights(d, 0))
+    with pytest.raises(_lib.DesireError):
+        h.set_training(True)
