@@ -15,7 +15,7 @@ across ranks with NO data-path collective; weak scaling (fixed windows per GPU).
 torch.cuda.synchronize() on both sides of exactly K steps, max over ranks, rank 0 prints one JSON
 line.  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
 hipEvents on the launch stream over the timed steps) and `cpu_baseline` (the numpy oracle timed on
-this host on a bounded sample: 8 windows = 5120 samples).
+this host on a bounded sample: 8 windows = 5120 samples).  Default: 512 windows per step per GPU.
 """
 import argparse
 import json
@@ -42,10 +42,12 @@ def ioc_flops_per_row(d):
 
 def committed_traffic(windows, bf16=False):
     """HBM bytes per k_ioc launch from the committed rocprofv3 PMC passes (profiles/, collected from this very
-    command at 128 windows/step in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
+    command at the same windows/step in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_bf16_bench_pmc_per_kernel.json" if bf16 else "r01_final_bench_pmc_per_kernel.json")
-    if windows != 128 or not os.path.exists(path):
+    name = {(128, False): "r01_final_bench_pmc_per_kernel.json", (128, True): "r01_bf16_bench_pmc_per_kernel.json",
+            (512, False): "r01_final_bench_w512_pmc_per_kernel.json"}.get((windows, bool(bf16)))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if path is None or not os.path.exists(path):
         return None
     with open(path) as fh:
         pmc = json.load(fh)
@@ -104,7 +106,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=128, help="loader windows (scenes) per step per GPU")
+    ap.add_argument("--windows", type=int, default=512, help="loader windows (scenes) per step per GPU (128 = the size the per-kernel tables "
+                                                             "in profiles/README.md were taken at; throughput saturates around 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16", action="store_true",
