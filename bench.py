@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=512, help="loader windows (scenes) per step per GPU (128 = the size the per-kernel tables "
+    ap.add_argument("--windows", type=int, default=None, help="loader windows (scenes) per step per GPU (128 = the size the per-kernel tables "
                                                              "in profiles/README.md were taken at; throughput saturates around 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -124,6 +124,10 @@ def main():
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
     a = ap.parse_args()
+    if a.windows is None:
+        # inference saturates around 512 windows; a training step keeps ~0.5 GB of activations per window (27 GB of it the
+        # pooled operand at 128 windows), so it stays at the size its profile was taken at
+        a.windows = 128 if (a.train or a.bf16 or a.shard == "agents") else 512
 
     import torch
     import torch.distributed as dist
