@@ -120,6 +120,9 @@ def main():
                     help="multi-GPU partitioning: 'scenes' (default; windows are independent, no data-path collective) or "
                          "'agents' (the agents of EVERY scene block-sharded over the ranks: --mno slots per rank, hidden states "
                          "all-gathered over RCCL once per IOC step -- SURVEY.md 8(e) E1's prescribed form)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
+                         "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")
     ap.add_argument("--train", action="store_true",
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
@@ -183,6 +186,29 @@ def main():
             h.clip_grads(10.0, stream=stream)
             h.adam_step(1e-4, stream=stream)
 
+    if a.graph:
+        if world != 1 or a.shard == "agents":
+            raise SystemExit("--graph: single-GPU, scene-sharded runs only")
+        side = torch.cuda.Stream()
+        gstream = side.cuda_stream
+
+        def body(st):                                # everything except Adam (its step size changes per call)
+            h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), st)
+            if a.train:
+                h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), st)
+                h.clip_grads(10.0, stream=st)
+        torch.cuda.synchronize()
+        body(gstream)                                # warm-up outside capture (lazy allocations)
+        side.synchronize()
+        h.graph_begin(gstream)
+        body(gstream)
+        gid = h.graph_end(gstream)
+
+        def step():                                  # noqa: F811
+            h.graph_launch(gid, gstream)
+            if a.train:
+                h.adam_step(1e-4, stream=gstream)
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -192,7 +218,8 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    h.set_profiling(True)
+    if not a.graph:                                  # per-kernel hipEvents are host-side records: not part of a replayed graph
+        h.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -210,8 +237,8 @@ def main():
     for name, ms in prof:
         per_kernel.setdefault(name, []).append(ms)
     kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
-    ioc_ms = kern_ms.get("ioc", float("nan"))
-    ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12
+    ioc_ms = kern_ms.get("ioc")
+    ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12 if ioc_ms else None
     whole_tflops = flops_per_sample(d) * d.R * a.steps / dt / 1e12
 
     peak = BF16_MFMA_PEAK_TFLOPS if a.bf16 else FP32_MFMA_PEAK_TFLOPS
@@ -224,7 +251,7 @@ def main():
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU" % a.windows,
+            "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU%s" % (a.windows, "; launch sequence replayed from a hipGraph" if a.graph else ""),
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
             "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
             "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))
@@ -242,7 +269,7 @@ def main():
                                       ("agent-sharded x%d: %d slots/rank of %d-agent scenes, RCCL all-gather of [R_loc, H] per IOC step" % (world, d.mno, d.mno * world)),
                        "flops_per_sample": flops_per_sample(d)},
             "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1>" if a.bf16 else "k_ioc<128,16,32>", "achieved": ioc_tflops,
-                         "peak": peak, "unit": "TFLOP/s", "frac": ioc_tflops / peak,
+                         "peak": peak, "unit": "TFLOP/s", "frac": (ioc_tflops / peak) if ioc_tflops else None,
                          "traffic": committed_traffic(a.windows, a.bf16), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_hbm_bytes_per_launch": d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4,
                          "kernel_ms": ioc_ms,

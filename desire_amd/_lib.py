@@ -22,6 +22,7 @@ EXPORTS = [
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
+    "desire_graph_begin", "desire_graph_end", "desire_graph_launch",
 ]
 
 
@@ -85,6 +86,9 @@ def load() -> C.CDLL:
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_clip_grads.argtypes = [vp, C.c_float, C.POINTER(C.c_float), vp]
     lib.desire_get_bin_table.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.desire_graph_begin.argtypes = [vp, vp]
+    lib.desire_graph_end.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    lib.desire_graph_launch.argtypes = [vp, i32, vp]
     lib.desire_device_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_ioc_step.argtypes = [vp, i32, i32, i32, f32p, f32p, vp, f32p, f32p, f32p, vp]
     lib.desire_ioc_finish.argtypes = [vp, f32p, f32p, f32p, f32p, vp]
@@ -198,6 +202,17 @@ class Handle:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.lib.desire_grad_buffer(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+    def graph_begin(self, stream: int) -> None:
+        _chk(self.lib.desire_graph_begin(self._h, stream))
+
+    def graph_end(self, stream: int) -> int:
+        gid = C.c_int32(-1)
+        _chk(self.lib.desire_graph_end(self._h, stream, C.byref(gid)))
+        return int(gid.value)
+
+    def graph_launch(self, graph_id: int, stream: int) -> None:
+        _chk(self.lib.desire_graph_launch(self._h, graph_id, stream))
 
     def bin_table(self) -> np.ndarray:
         out = np.zeros(20, np.float32)

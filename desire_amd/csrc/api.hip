@@ -201,6 +201,7 @@ extern "C" int desire_destroy(desire_handle* h) {
     for (auto& kv : h->dev) kv.second.release();
     for (auto& kv : h->ws) kv.second.release();
     for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (void* g : h->graphs) if (g) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g));
     delete h;
     return DESIRE_OK;
 }
@@ -542,7 +543,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         Timer t(h, s, "decoder"); launch_decoder_bf16(a, s);
     } else
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
-    HIPCHK(hipMemcpyAsync(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_copy_f32(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2, s);
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }
@@ -594,8 +595,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     } else
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
     if (h->training) {
-        HIPCHK(hipMemcpyAsync(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(W(h, "score_sv"), dev_score, (size_t)h->R * sizeof(float), hipMemcpyDeviceToDevice, s));
+        launch_copy_f32(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2, s);
+        launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
     }
 #ifdef DESIRE_IOC_TIMING
     {
@@ -655,6 +656,39 @@ extern "C" int desire_read_buffer(desire_handle* h, const char* name, float* hos
             return DESIRE_OK;
         }
     return fail(DESIRE_ERR_ARG, "unknown buffer: " + nm);
+}
+
+// ---- hipGraph capture of any sequence of desire_* calls made on `stream` (launch-bound shapes: small batches, the
+// training step's ~100 launches, the agent-sharded IOC loop).  Everything the library enqueues is stream-ordered and
+// pointer-stable, so a captured sequence can be replayed as long as the caller keeps the same device buffers.
+// Not capturable: calls that synchronise or copy to the host (desire_train_loss, desire_read_buffer, desire_get_*, the
+// cluster-form IOC's error read-back) and desire_adam_step (its bias-corrected step size is a per-call kernel argument).
+extern "C" int desire_graph_begin(desire_handle* h, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!stream) return fail(DESIRE_ERR_ARG, "graph capture needs an explicit (non-default) stream");
+    if (h->profiling) return fail(DESIRE_ERR_STATE, "switch profiling off before capturing (event records are not part of the graph)");
+    HIPCHK(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+    return DESIRE_OK;
+}
+
+extern "C" int desire_graph_end(desire_handle* h, void* stream, int32_t* graph_id) {
+    if (!h || !stream || !graph_id) return fail(DESIRE_ERR_ARG, "null argument");
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(DESIRE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    h->graphs.push_back(ex);
+    *graph_id = (int32_t)h->graphs.size() - 1;
+    return DESIRE_OK;
+}
+
+extern "C" int desire_graph_launch(desire_handle* h, int32_t graph_id, void* stream) {
+    if (!h) return fail(DESIRE_ERR_ARG, "null handle");
+    if (graph_id < 0 || graph_id >= (int32_t)h->graphs.size() || !h->graphs[graph_id]) return fail(DESIRE_ERR_ARG, "unknown graph id");
+    HIPCHK(hipGraphLaunch(static_cast<hipGraphExec_t>(h->graphs[graph_id]), static_cast<hipStream_t>(stream)));
+    return DESIRE_OK;
 }
 
 extern "C" int desire_device_buffer(desire_handle* h, const char* name, void** dev_ptr, size_t* bytes) {

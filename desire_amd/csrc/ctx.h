@@ -43,6 +43,7 @@ struct desire_ctx {
     std::map<std::string, DevBuf> dev;                       // raw / packed / folded device tensors
     std::map<std::string, DevBuf> ws;                        // workspace
     bool finalized = false;
+    std::vector<void*> graphs;                               // instantiated hipGraphExec_t of desire_graph_end
     std::vector<float> bin_tab_host;                         // log-polar bin table (20 floats) when dims.bin_mode == 1
     const float* grids = nullptr;
     bool grids_set = false;

@@ -124,6 +124,8 @@ void launch_neighbor_bins(const float* pos, const uint8_t* valid, int32_t* bins,
 void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw, hipStream_t s);
 
 // ---- cold rows (kernels_aux.hip) ----
+void launch_fill_f32(float* dst, size_t n, float v, hipStream_t s);
+void launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s);
 void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
                         int Co, int stride, int relu, hipStream_t s);

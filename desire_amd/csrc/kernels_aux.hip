@@ -297,3 +297,21 @@ __global__ __launch_bounds__(256) void k_instnorm_act(float* __restrict__ x, int
 void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s) {
     hipLaunchKernelGGL(k_instnorm_act, dim3(n), dim3(256), 0, s, x, n, P, C, gamma, beta, sig);
 }
+
+
+// Stream-ordered fill / copy as KERNELS: the hot sequences stay kernel-only, which keeps them capturable into a hipGraph
+// (memset / memcpy nodes of a captured stream were observed to run out of order on repeated launches of the same exec).
+__global__ void k_fill_f32(float* __restrict__ dst, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+__global__ void k_copy_f32(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_fill_f32(float* dst, size_t n, float v, hipStream_t s) {
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)(nb < 2048 ? (nb ? nb : 1) : 2048)), dim3(256), 0, s, dst, n, v);
+}
+void launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_copy_f32, dim3((unsigned)(nb < 2048 ? (nb ? nb : 1) : 2048)), dim3(256), 0, s, dst, src, n);
+}

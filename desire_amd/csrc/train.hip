@@ -302,7 +302,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = d.H, T = d.T_pred;
     const long R = h->R;
-    HIPCHK(hipMemsetAsync(W(h, "Gflat"), 0, h->n_params * sizeof(float), s));
+    launch_fill_f32(W(h, "Gflat"), h->n_params, 0.f, s);
     const uint8_t* valid = static_cast<const uint8_t*>(h->ws["valid"].p);
     launch_count_valid(valid, h->A, W(h, "nvalid"), s);
     // ---- sample-generation module ----

@@ -145,6 +145,15 @@ int desire_gaussian_sample(desire_handle* h, const float* dev_params, const floa
 /* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K). */
 int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);
 
+/* ---- hipGraph capture: desire_graph_begin(h, stream); any stream-ordered desire_* calls on that stream (desire_forward,
+ * desire_backward, desire_clip_grads, desire_ioc_step ...) ; desire_graph_end -> graph id; desire_graph_launch replays them with
+ * the SAME device pointers.  For launch-bound shapes (small batches, the training step, the agent-sharded IOC loop).  Calls
+ * that synchronise or read back to the host, and desire_adam_step (per-call step size), cannot be captured.  `stream` must be an
+ * explicit non-default stream. */
+int desire_graph_begin(desire_handle* h, void* stream);
+int desire_graph_end(desire_handle* h, void* stream, int32_t* graph_id);
+int desire_graph_launch(desire_handle* h, int32_t graph_id, void* stream);
+
 /* ---- agent-sharded IOC (BASELINE north_star / SURVEY.md 8(e) E1: "agents shard across the GPUs with an RCCL all-gather
  * only for the social-pooling neighbour exchange").  The handle of rank g is created with mno = the slots it owns
  * (m_loc); every scene then has nranks * m_loc agents.  Everything before the IOC is per-agent and runs unchanged
