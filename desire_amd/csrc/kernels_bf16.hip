@@ -128,6 +128,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
     float* wv = pp + TM * 2;                                          // [3][EV]
     float* red = wv + 3 * EV;                                         // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                  // [2] bins that hold a neighbour anywhere in the tile
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
@@ -188,6 +189,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
         }
         for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+        if (tid < 2) occ[tid] = 0;
         __syncthreads();
 
         for (int t = 0; t < a.T; ++t) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j));
+                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
                 }
             }
             TICK16(1)
@@ -225,15 +227,20 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 // this wave's n-tile of W_b (H/16 k-groups, chain order) lives in ONE register set that is refreshed in
                 // place: the fragments of bin b+1 are requested right after their last use in bin b, so every load is in
                 // flight for a whole bin of MFMAs
+                // Only bins that hold a neighbour somewhere in the tile are visited (an empty bin contributes exact zeros).
+                unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+                om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
                 uint4 wb[2 * NT];
-                {
-                    const uint4* wsrc = Wsoc + ((size_t)cb * GH16) * 64 + lane;
+                if (om) {
+                    const uint4* wsrc = Wsoc + ((size_t)((__ffsll((long long)om) - 1) * NT + cb) * GH16) * 64 + lane;
 #pragma unroll
                     for (int g = 0; g < 2 * NT; ++g) wb[g] = wsrc[g * 64];
                 }
 #pragma clang loop unroll(disable)
-                for (int b = 0; b < B; ++b) {
-                    const uint4* wnext = Wsoc + ((size_t)(min(b + 1, B - 1) * NT + cb) * GH16) * 64 + lane;
+                while (om) {
+                    const int b = __ffsll((long long)om) - 1;
+                    om &= om - 1;
+                    const uint4* wnext = Wsoc + ((size_t)((om ? __ffsll((long long)om) - 1 : b) * NT + cb) * GH16) * 64 + lane;
                     uint4 mf[JGM];                                      // neighbour bits -> bf16 B fragments (16 neighbours each)
                     const unsigned long long m64 = masks[(mt * 32 + c31) * LDM + b];
 #pragma unroll
@@ -311,6 +318,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
             }
             for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+            if (tid < 2) occ[tid] = 0;
             TICK16(7)
             __syncthreads();
             TICK16(8)

@@ -807,6 +807,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
     float* dsc = pc + TM * 2;                 // [32]
     float* wsc = dsc + TM;                    // [H]
     unsigned char* vld = reinterpret_cast<unsigned char*>(wsc + H);   // [32]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);            // [2] bins that hold a neighbour anywhere in the tile
     float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
 
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
@@ -851,6 +852,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
             if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
         }
         for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0ull;          // masks and obs are contiguous
+        if (tid < 2) occ[tid] = 0;
         for (int i = tid; i < TM * (H >> 2); i += NTHR) {
             const int r = i / (H >> 2), c4 = i - r * (H >> 2);
             const int row = min(row0 + r, a.R - 1);
@@ -868,6 +870,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
                 if (b >= 0) {
                     atomicOr(&masks[r8 * B + b], 1ull << j);
                     atomicOr(&obs[(grp_base + j) * B + b], 1ull << my_slot);
+                    atomicOr(&occ[b >> 5], 1u << (b & 31));
                 }
             }
         }
@@ -932,7 +935,12 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
         float4 nb[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) nb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // bins without a neighbour anywhere in the tile have dpool_b gathered by nobody: only their (zero) pooled rows are written
+        unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+        om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+        int buf = 0;
         for (int b = 0; b < B; ++b) {
+            const bool live = (om >> b) & 1ull;
             {   // pooled_b[i] = sum_{j in bin b of i} h_{t-1}[j]  -> HBM (operand of the social-fc weight gradient)
                 float4 s[NCH];
 #pragma unroll
@@ -954,9 +962,11 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
                     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
                 }
             }
+            if (!live) continue;
             f32x16 dpl = zero16();
             mma1b(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
-            float* dp = DP + (b & 1) * TM * LD1;
+            float* dp = DP + buf * TM * LD1;
+            buf ^= 1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
             __syncthreads();

@@ -320,6 +320,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
     float* red = wv + 3 * EV;                           // [NT][TM] score reduction
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);  // [TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                 // [2] bins that hold a neighbour anywhere in the tile
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
@@ -348,8 +349,8 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     // one selects the all-zero row TM, so the 4*NS LDS reads are independent and issue back to back; the
     // (rare) overflow is finished by a wave-uniform loop.  Summation order = ascending slot: deterministic.
     constexpr int NS = 2;
-    auto build = [&](int b) {
-        float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+    auto build = [&](int b, int buf) {
+        float* ab = AB + buf * TM * LDB + r8 * LDB;
         mask_t m2 = masks[r8 * B + b];
         int off[NS];
 #pragma unroll
@@ -407,6 +408,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
         }
         for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
+        if (tid < 2) occ[tid] = 0;
         __syncthreads();
         const float* rh_lane = AB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5);     // r*h operand (AB buffer 0)
         float* my_rh = AB + (mt * 32 + 4 * (lane >> 5)) * LDB + col;
@@ -440,27 +442,35 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
                                                    a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
+                    if (b >= 0) { atomicOr(&masks[r8 * B + b], (mask_t)1 << j); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
                 }
             }
             __syncthreads();
             TICK(1)
-            // ---- P2/P3: social pooling -> e_r.  build(b+1) and the contraction of bin b sit between the same
-            //      two barriers, so waves that finish building early start their MFMAs while others still build
+            // ---- P2/P3: social pooling -> e_r, over the bins that hold a neighbour somewhere in this tile only
+            //      (an empty bin's pooled operand is all zeros: skipping it drops exact-zero products, and on real
+            //      tracks most of the window is empty).  build(next) and the contraction of the current bin sit between
+            //      the same two barriers, so waves that finish building early start their MFMAs while others build
             {
                 f32x16 soc = splat16(bso);
-                build(0);
+                unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+                om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                int buf = 0;
+                if (om) build(ffs_(om) - 1, 0);
                 __syncthreads();
                 TICK(2)
-                for (int b = 0; b < B; ++b) {
-                    if (b + 1 < B) build(b + 1);
+                while (om) {
+                    const int b = ffs_(om) - 1;
+                    om &= om - 1;
+                    if (om) build(ffs_(om) - 1, buf ^ 1);
                     TICK(3)
                     if (active)
-                        mma1(soc, AB + (b & 1) * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
+                        mma1(soc, AB + buf * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
                              a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
                     TICK(4)
                     __syncthreads();
                     TICK(5)
+                    buf ^= 1;
                 }
                 if (active) {
 #pragma unroll
@@ -524,6 +534,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
             }
             for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
+            if (tid < 2) occ[tid] = 0;
             __syncthreads();
             TICK(8)
         }
@@ -646,6 +657,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
     float* wv = pp + TM * 2;                            // [2][E_v] + [E_v]
     float* red = wv + 3 * EV;                           // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);  // [MAXM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + MAXM);               // [2] bins that hold a neighbour anywhere in the tile
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w;
@@ -700,6 +712,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     pg[i * 2] = y.x; pg[i * 2 + 1] = y.y;
                 }
                 for (int i = tid; i < TM * B * 2; i += NTHR) masks[i] = 0ull;
+                if (tid < 2) occ[tid] = 0;
                 __syncthreads();
                 {
                     const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
@@ -722,14 +735,14 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     for (int j = q8; j < a.mno; j += TPR) {
                         if (j == my_slot || !vld[j]) continue;
                         const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                        if (b >= 0) atomicOr(&masks[(r8 * B + b) * 2 + (j >> 6)], 1ull << (j & 63));
+                        if (b >= 0) { atomicOr(&masks[(r8 * B + b) * 2 + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
                     }
                 }
                 __syncthreads();
                 // pooled operand: local rows from LDS, other tiles' rows from the exchange buffer (Hx at t = 0)
                 const float* hex = a.hex + (size_t)((t + 1) & 1) * a.R * H;          // parity (t-1)&1
-                auto build = [&](int b) {
-                    float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+                auto build = [&](int b, int buf) {
+                    float* ab = AB + buf * TM * LDB + r8 * LDB;
                     float4 s[NCH];
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -753,13 +766,19 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
                 };
                 f32x16 soc = splat16(bso);
-                build(0);
+                unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+                om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                int buf = 0;
+                if (om) build(ffs_(om) - 1, 0);
                 __syncthreads();
-                for (int b = 0; b < B; ++b) {
-                    if (b + 1 < B) build(b + 1);
-                    mma1(soc, AB + (b & 1) * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5),
+                while (om) {                                              // occupied bins only (see k_ioc)
+                    const int b = ffs_(om) - 1;
+                    om &= om - 1;
+                    if (om) build(ffs_(om) - 1, buf ^ 1);
+                    mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5),
                          a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
                     __syncthreads();
+                    buf ^= 1;
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
@@ -873,6 +892,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(AB + 2 * TM * LDB);   // [TM][B][MW]
     float* wv = reinterpret_cast<float*>(masks + TM * B * MW);    // [3][EV]
     float* red = wv + 3 * EV;                           // [NT][TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(red + NT * TM);   // [2] bins that hold a neighbour anywhere in the tile
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid / TPR, q8 = tid % TPR;
@@ -881,6 +901,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     const int n_groups = a.R / a.m_loc;
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     for (int i = tid; i < TM * B * MW; i += NTHR) masks[i] = 0ull;
+    if (tid < 2) occ[tid] = 0;
     for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
         *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
@@ -929,12 +950,12 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
             if (j == my_gslot || !a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s]) continue;
             const float2 pj = pos_of(j, a.t);
             const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G, a.bin_tab);
-            if (b >= 0) atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63));
+            if (b >= 0) { atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
         }
     }
     __syncthreads();
-    auto build = [&](int b) {
-        float* ab = AB + (b & 1) * TM * LDB + r8 * LDB;
+    auto build = [&](int b, int buf) {
+        float* ab = AB + buf * TM * LDB + r8 * LDB;
         float4 s[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -956,12 +977,18 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
     };
     f32x16 soc = splat16(bso);
-    build(0);
+    unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+    om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+    int buf = 0;
+    if (om) build(ffs_(om) - 1, 0);
     __syncthreads();
-    for (int b = 0; b < B; ++b) {
-        if (b + 1 < B) build(b + 1);
-        mma1(soc, AB + (b & 1) * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+    while (om) {                                                          // occupied bins only (see k_ioc)
+        const int b = ffs_(om) - 1;
+        om &= om - 1;
+        if (om) build(ffs_(om) - 1, buf ^ 1);
+        mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
         __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);

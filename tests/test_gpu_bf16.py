@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
     dict(mno=1, n_scenes=3, K=2, n_absent=0),
     dict(T_pred=40, K=2),
     dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),          # 36 bins
+    dict(nb_w=0.04, nb_h=0.04, K=2),                     # sparse windows: empty bins skipped per tile
+    dict(grid_size=6, nb_w=0.08, nb_h=0.08, K=2, mno=64, n_scenes=1, n_grids=1),
 ])
 def test_ioc_bf16_matches_rounding_oracle(torch_cuda, kw):
     from oracle import desire_oracle as O

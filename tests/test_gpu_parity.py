@@ -92,6 +92,9 @@ def test_stagewise_parity_small(torch_cuda):
     dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),          # 36 social bins (the paper's count)
     dict(grid_size=5, nb_w=0.4, nb_h=0.4, K=2, mno=64, n_scenes=1, n_grids=1),   # 25 bins, cluster-free 64-row tile
     dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2, H=64, mno=16, n_scenes=3),
+    dict(nb_w=0.04, nb_h=0.04, K=2),                     # sparse windows: most bins empty in a tile -> skipped, some tiles skip all
+    dict(grid_size=6, nb_w=0.08, nb_h=0.08, K=2),        # sparse, 36 bins (occupancy word 1 in use)
+    dict(nb_w=0.05, nb_h=0.05, K=2, mno=64, n_scenes=1, n_grids=1),   # sparse, 64-row tile
 ])
 def test_end_to_end_variants(torch_cuda, kw):
     kw = dict(kw)
@@ -329,6 +332,7 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
     dict(mno=128, n_scenes=1, K=2, n_grids=1, T_pred=6),                 # 4 workgroups per group, 128-bit masks
     dict(mno=64, H=256, n_scenes=1, K=2, n_grids=1, T_pred=6),           # BASELINE configs[3] shape: H=256, 64 agents/scene
     dict(mno=96, n_scenes=1, K=2, n_grids=1, T_pred=5, iters=2),         # 3 per group, two refinement passes
+    dict(mno=64, n_scenes=2, K=3, n_grids=1, T_pred=9, nb_w=0.04, nb_h=0.04),   # sparse windows: empty bins skipped per tile
 ])
 def test_ioc_cluster_form(torch_cuda, kw, monkeypatch):
     """Groups larger than one workgroup tile: tpg workgroups exchange hidden states through global memory each

@@ -25,7 +25,8 @@ def _setup_rank(torch, d_loc, w, past, fut, eps, grids, gos):
 
 
 @pytest.mark.parametrize("kw,nranks", [(dict(), 2), (dict(), 4), (dict(mno=64, n_scenes=1, K=2, n_grids=1), 2),
-                                       (dict(H=64, T_pred=7, K=3), 2), (dict(iters=2, K=2), 2)])
+                                       (dict(H=64, T_pred=7, K=3), 2), (dict(iters=2, K=2), 2),
+                                       (dict(nb_w=0.04, nb_h=0.04, K=2), 2)])
 def test_virtual_ranks_reproduce_the_unsharded_ioc(kw, nranks):
     import torch
     from desire_amd import _lib

@@ -238,13 +238,16 @@ def test_full_size_gradient_is_the_mean_of_its_halves():
     assert scale > 0 and err < 2e-4 * scale, (err, scale)
 
 
-def test_gradients_with_logpolar_pooling():
-    """Backward through the log-polar social layout (dims.bin_mode = 1): the pooling transpose only sees the bins through
-    the neighbour / observer masks, so the IOC and encoder gradients must still match autograd."""
+@pytest.mark.parametrize("kw", [dict(bin_mode=1, nb_w=0.45, nb_h=0.04),        # log-polar rings x sectors
+                                dict(nb_w=0.05, nb_h=0.05, mno=32)])           # sparse rectangular windows: empty bins skipped
+def test_gradients_with_logpolar_or_sparse_pooling(kw):
+    """Backward through the log-polar social layout (dims.bin_mode = 1) and through windows so small that most bins of a
+    tile hold nobody (forward and backward skip those bins): the pooling transpose only sees the bins through the
+    neighbour / observer masks, so the IOC and encoder gradients must still match autograd."""
     import torch
     from desire_amd import _lib
     from oracle import desire_torch as OT
-    d = small_dims(n_scenes=2, mno=16, K=3, T_obs=5, T_pred=6, n_grids=1, bin_mode=1, nb_w=0.45, nb_h=0.04)
+    d = small_dims(**{**dict(n_scenes=2, mno=16, K=3, T_obs=5, T_pred=6, n_grids=1), **kw})
     w = init_weights(d, 51)
     for k in w:
         if k.startswith("vae_dec/") and k.endswith("/w"):
@@ -255,7 +258,7 @@ def test_gradients_with_logpolar_pooling():
     h = _lib.Handle(d)
     h.set_weights(w)
     h.set_training(True)
-    tab = h.bin_table()
+    tab = h.bin_table() if d.bin_mode == 1 else None
     _, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d, bin_tab=tab)
     dev = torch.device("cuda")
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
