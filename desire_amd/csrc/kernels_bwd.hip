@@ -788,21 +788,23 @@ void launch_score_grad(const float* Y0, const float* fut, const float* score, co
 //   registers (observer bit-masks), which after the 16 bins is added to dh_{t-1}: the pooling transpose without atomics.
 //   pooled_b (rebuilt like the forward) is streamed to HBM for the social-fc weight gradient.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef IOC_BWD_OCC
+#define IOC_BWD_OCC 2
+#endif
 template <int H, int EV, int C>
-__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bwd(IocBwdArgs a) {
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) void k_ioc_bwd(IocBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
     constexpr int E = EV + C + H, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
     const int B = a.G * a.G;
     const int KR = (2 * a.T + 7) / 8 * 8, LDR = KR + 4;                   // regression-head operand width
-    float* A1 = smem;                         // [32][LD1]  da_c
-    float* A2 = A1 + TM * LD1;                // [32][LD2]  da_r | da_u
-    float* A3 = A2 + TM * LD2;                // [32][LD1]  dpre_r
-    float* DP = A3 + TM * LD1;                // [2][32][LD1] dpool_b
-    float* HP = DP + 2 * TM * LD1;            // [33][LD1]  h_{t-1} (+ zero row)
-    float* NB = HP + (TM + 1) * LD1;          // [32][LD1]  neighbour gradient
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(NB + TM * LD1);   // [32][B] neighbours of i in bin b
-    unsigned long long* obs = masks + TM * B;                                           // [32][B] observers of j in bin b
+    // LDS (72 KB at H = 128, so two workgroups share a CU): three operand tiles, each reused once its MFMAs are done
+    float* A1 = smem;                         // [32][LD1]  da_c;  then h_{t-1} (pooled rebuild);  then the neighbour gradient
+    float* A2 = A1 + TM * LD1;                // [32][LD2]  da_r | da_u;  then dpool_b, double buffered
+    float* A3 = A2 + 2 * TM * LD1;            // [32][LD1]  dpre_r  (2 LD1 > LD2: the two dpool tiles are the larger tenant)
+    float* DP = A2, *HP = A1, *NB = A1;
+    unsigned* masks = reinterpret_cast<unsigned*>(A3 + TM * LD1);     // [32][B] neighbours of i in bin b (bit = slot)
+    unsigned* obs = masks + TM * B;                                   // [32][B] observers of j in bin b
     float* pc = reinterpret_cast<float*>(obs + TM * B);   // [32][2]
     float* dsc = pc + TM * 2;                 // [32]
     float* wsc = dsc + TM;                    // [H]
@@ -820,12 +822,17 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
     const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
     const float* a3_lane = A3 + (lane & 31) * LD1 + 4 * (lane >> 5);
     const int rofs = (4 * (lane >> 5));       // + (i&3) + 8*(i>>2) = local row of accumulator element i
-    int rowi[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rowi[i] = min(row0 + acc_row(i), a.R - 1);
+    auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
+    // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
+    const int nloc = min(TM, a.R - row0);
+    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nloc - 1) * a.T + t); };   // (local row, t) index
+    const size_t tb = (size_t)row0 * a.T;
+    const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
+    const float* svx = a.sv_x + tb * E;
+    float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
+    float* o_dpr = a.dpre_r + tb * H; float* o_dpv = a.dpre_v + tb * EV;
 
     for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
-    for (int i = tid; i < LD1; i += NTHR) HP[TM * LD1 + i] = 0.f;
     if (tid < TM) {
         const int row = min(row0 + tid, a.R - 1);
         vld[tid] = a.valid[agent_of_row(row, a.K, a.mno)];
@@ -851,15 +858,18 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
             else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
             if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
         }
-        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0ull;          // masks and obs are contiguous
+        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0u;            // masks and obs are contiguous
         if (tid < 2) occ[tid] = 0;
-        for (int i = tid; i < TM * (H >> 2); i += NTHR) {
-            const int r = i / (H >> 2), c4 = i - r * (H >> 2);
-            const int row = min(row0 + r, a.R - 1);
-            const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
-                                       : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
-            *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
-        }
+        auto load_hprev = [&]() {                                              // h_{t-1} tile -> A1's space
+            for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+                const int row = min(row0 + r, a.R - 1);
+                const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
+                                           : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
+                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+            }
+        };
+        load_hprev();                                    // part 1 reads each element, then overwrites it with da_c
         __syncthreads();
         // ---- P1: neighbour / observer masks ----
         {
@@ -868,28 +878,32 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
                 if (j == my_slot || !vld[grp_base + j]) continue;
                 const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                 if (b >= 0) {
-                    atomicOr(&masks[r8 * B + b], 1ull << j);
-                    atomicOr(&obs[(grp_base + j) * B + b], 1ull << my_slot);
+                    atomicOr(&masks[r8 * B + b], 1u << j);
+                    atomicOr(&obs[(grp_base + j) * B + b], 1u << my_slot);
                     atomicOr(&occ[b >> 5], 1u << (b & 31));
                 }
             }
         }
         // ---- GRU cell backward, part 1 ----
-        f32x16 dhp, du, rr, hp, uu;
+        f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rl = rofs + (i & 3) + 8 * (i >> 2);
-            const size_t ix = ((size_t)rowi[i] * a.T + t) * H + col;
-            const float u = a.sv_u[ix], c = a.sv_c[ix], r = a.sv_r[ix];
-            const float hprev = HP[rl * LD1 + col];
+            const unsigned ix = tl(i, t) * H + col;
+            const float u = svu[ix], c = svc[ix], r = svr[ix];
+            const float hprev = A1[rl * LD1 + col];
             const float dht = dh[i] + dsc[rl] * wsc[col];
-            du[i] = dht * (hprev - c);
+            const float dau = dht * (hprev - c) * u * (1.0f - u);
             const float dc = dht * (1.0f - u);
             dhp[i] = dht * u;
             const float dac = dc * (1.0f - c * c);
             A1[rl * LD1 + col] = dac;
-            if (row0 + rl < a.R) { a.dac[ix] = dac; a.rh[ix] = r * hprev; a.hprev[ix] = hprev; }
-            rr[i] = r; hp[i] = hprev; uu[i] = u;
+            A2[rl * LD2 + H + col] = dau;             // (the dpool tiles that share A2 were last read before the step's barrier)
+            if (row0 + rl < a.R) {
+                o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
+                o_dag[tl(i, t) * 2 * H + H + col] = dau;
+            }
+            rr[i] = r; hp[i] = hprev;
         }
         __syncthreads();
         f32x16 drh = zero16(), der = zero16(), dev = zero16();
@@ -902,12 +916,12 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
             const float dr = drh[i] * hp[i];
             dhp[i] += drh[i] * rr[i];
             const float dar = dr * rr[i] * (1.0f - rr[i]);
-            const float dau = du[i] * uu[i] * (1.0f - uu[i]);
             A2[rl * LD2 + col] = dar;
-            A2[rl * LD2 + H + col] = dau;
-            if (row0 + rl < a.R) { const size_t ig = ((size_t)rowi[i] * a.T + t) * 2 * H + col; a.dag[ig] = dar; a.dag[ig + H] = dau; }
+            if (row0 + rl < a.R) o_dag[tl(i, t) * 2 * H + col] = dar;
         }
         __syncthreads();
+        // da_c is consumed: its tile now takes h_{t-1} for the pooled rebuild (visible after the next barrier)
+        load_hprev();
         {
             f32x16 dhg = zero16();
             mma1b(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
@@ -917,15 +931,15 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
             for (int i = 0; i < 16; ++i) {
                 const int rl = rofs + (i & 3) + 8 * (i >> 2);
                 dhp[i] += dhg[i];
-                const size_t ixx = ((size_t)rowi[i] * a.T + t) * E;
-                const float er = a.sv_x[ixx + EV + C + col];
+                const unsigned ixx = tl(i, t) * E;
+                const float er = svx[ixx + EV + C + col];
                 const float dpr = er > 0.f ? der[i] : 0.f;
                 A3[rl * LD1 + col] = dpr;
                 if (row0 + rl < a.R) {
-                    a.dpre_r[((size_t)rowi[i] * a.T + t) * H + col] = dpr;
+                    o_dpr[tl(i, t) * H + col] = dpr;
                     if (cb == 0 && (lane & 31) < EV) {
-                        const float ev = a.sv_x[ixx + (lane & 31)];
-                        a.dpre_v[((size_t)rowi[i] * a.T + t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
+                        const float ev = svx[ixx + (lane & 31)];
+                        o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
                     }
                 }
             }
@@ -945,9 +959,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
                 float4 s[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                unsigned long long m2 = masks[r8 * B + b];
+                unsigned m2 = masks[r8 * B + b];
                 while (m2) {
-                    const int j = __ffsll((long long)m2) - 1;
+                    const int j = __ffs((int)m2) - 1;
                     m2 &= m2 - 1;
                     const float* src = HP + (grp_base + j) * LD1 + q8 * 4;
 #pragma unroll
@@ -970,9 +984,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
 #pragma unroll
             for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
             __syncthreads();
-            unsigned long long m2 = obs[r8 * B + b];
+            unsigned m2 = obs[r8 * B + b];
             while (m2) {
-                const int i2 = __ffsll((long long)m2) - 1;
+                const int i2 = __ffs((int)m2) - 1;
                 m2 &= m2 - 1;
                 const float* src = dp + (grp_base + i2) * LD1 + q8 * 4;
 #pragma unroll
@@ -990,11 +1004,11 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_bw
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        if (row0 + acc_row(i) < a.R) a.dHx_rows[(size_t)rowi[i] * H + col] += dh[i];
+        if (row0 + acc_row(i) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
 }
 static size_t ioc_bwd_lds(const IocBwdArgs& a) {
     const int H = a.H, LD1 = H + 4, LD2 = 2 * H + 4, B = a.G * a.G;
-    size_t f = (size_t)32 * LD1 * 3 + 32 * LD2 + 2 * 32 * LD1 + 33 * LD1 + (size_t)32 * B * 4 + 64 + 32 + H;
+    size_t f = (size_t)32 * LD1 * 4 + (size_t)32 * B * 2 + 64 + 32 + H;
     return f * sizeof(float) + 64;
 }
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s) {

@@ -299,7 +299,7 @@ __device__ __forceinline__ int ffs_(unsigned long long m) { return __ffsll((long
 #define TICK(k)
 #endif
 template <int H, int EV, int C, int TM, bool TRAIN>
-__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2 || (TRAIN && (H / 32) * (TM / 32) <= 4)) ? 1 : 2) void k_ioc(IocArgs a) {
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2) ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
@@ -342,6 +342,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     const float* x_lane = XH + (mt * 32 + (lane & 31)) * LDX + 4 * (lane >> 5);
     float* my_x = XH + (mt * 32 + 4 * (lane >> 5)) * LDX + col;        // + acc-row * LDX (+ column base)
     const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
+    // training-mode saves: (uniform tile base) + (32-bit offset inside the tile) keeps the addresses out of the VGPR budget
+    const size_t sv_tb = TRAIN ? (size_t)row0 * a.T * H : 0;
+    float* sv_r_t = TRAIN ? a.sv_r + sv_tb : nullptr; float* sv_u_t = TRAIN ? a.sv_u + sv_tb : nullptr;
+    float* sv_c_t = TRAIN ? a.sv_c + sv_tb : nullptr; float* sv_h_t = TRAIN ? a.sv_h + sv_tb : nullptr;
+    auto sv_off = [&](int i, int t) { return (unsigned)(((mt * 32 + 4 * (lane >> 5) + (i & 3) + 8 * (i >> 2)) * a.T + t) * H + col); };
 
     // pooled operand of bin b: ab[r8][:] = sum_{j in mask} h_{t-1}[group row j][:].  Thread q8 owns the
     // float4 chunks q8, q8+8, ... so the 8 lanes of a row touch 128 contiguous bytes (no bank conflicts).
@@ -496,7 +501,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float r = sigmoidf_(rh[i]);
-                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) a.sv_r[((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col] = r;
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) sv_r_t[sv_off(i, t)] = r;
                     rh[i] = r * h[i];
                 }
 #pragma unroll
@@ -504,7 +509,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     u[i] = sigmoidf_(u[i]);
-                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) a.sv_u[((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col] = u[i];
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) sv_u_t[sv_off(i, t)] = u[i];
                 }
             }
             __syncthreads();
@@ -519,10 +524,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     const float c = tanhf_(ac[i]);
                     h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
-                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) {
-                        const size_t ix = ((size_t)(row0 + mt * 32 + acc_row(i)) * a.T + t) * H + col;
-                        a.sv_c[ix] = c; a.sv_h[ix] = h[i];
-                    }
+                    if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) { sv_c_t[sv_off(i, t)] = c; sv_h_t[sv_off(i, t)] = h[i]; }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i)                               // h slot: last read by the gates, one barrier ago
