@@ -68,7 +68,7 @@ void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, 
 // da_* and r*h_{t-1} go to HBM for the weight-gradient reductions; the constant-input sums dxg, dxc give dx_z.
 // ------------------------------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decoder_bwd(DecBwdArgs a) {
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
     float* A1 = smem;                    // [32][LD1]   da_c
@@ -84,12 +84,16 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
     float* my1 = A1 + (4 * (lane >> 5)) * LD1 + col;
     float* my2 = A2 + (4 * (lane >> 5)) * LD2 + col;
     f32x16 dh = zero16(), sxr = zero16(), sxu = zero16(), sxc = zero16();
-    int rowi[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rowi[i] = min(row0 + acc_row(i), a.R - 1);
+    auto rowi = [&](int i) { return min(row0 + acc_row(i), a.R - 1); };
+    // saved activations / gradient streams: (uniform tile base) + (32-bit offset inside the tile); rows past R clamp to the last one
+    const int nloc = min(TM, a.R - row0);
+    auto tl = [&](int i, int t) { return (unsigned)(min(acc_row(i), nloc - 1) * a.T + t); };
+    const size_t tb = (size_t)row0 * a.T;
+    const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H; const float* svh = a.sv_h + tb * H;
+    float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
     if (a.dh_init) {                                       // encoders: the gradient arrives at the final state
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = a.dh_init[(size_t)rowi[i] * a.ld_init + col];
+        for (int i = 0; i < 16; ++i) dh[i] = a.dh_init[(size_t)rowi(i) * a.ld_init + col];
     }
 
     for (int t = a.T - 1; t >= 0; --t) {
@@ -99,27 +103,36 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
             if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
             dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
         }
+        if (t == 0) {                                      // h_{-1} = Hx[agent] (decoder) or 0 (encoders): staged in A1, each element
+            for (int i = tid; i < TM * (H >> 2); i += NTHR) {   // is read by its owner right before it is overwritten with da_c
+                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.Hx) v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno) * a.ldhx + c4 * 4);
+                *reinterpret_cast<float4*>(A1 + r * LD1 + c4 * 4) = v;
+            }
+        }
         __syncthreads();
-        f32x16 dhp, du, rr, hp, uu;
+        f32x16 dhp, rr, hp;
         const float w0 = wo[col * 2], w1 = wo[col * 2 + 1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            const size_t ix = ((size_t)rowi[i] * a.T + t) * H + col;
-            const float u = a.sv_u[ix], c = a.sv_c[ix], r = a.sv_r[ix];
-            const float hprev = (t > 0) ? a.sv_h[ix - H]
-                                        : (a.Hx ? a.Hx[(size_t)agent_of_row(rowi[i], a.K, a.mno) * a.ldhx + col] : 0.f);
+            const unsigned ix = tl(i, t) * H + col;
+            const float u = svu[ix], c = svc[ix], r = svr[ix];
+            const float hprev = (t > 0) ? svh[ix - H] : my1[((i & 3) + 8 * (i >> 2)) * LD1];
             const float dht = dh[i] + dy[rl * 2] * w0 + dy[rl * 2 + 1] * w1;
-            du[i] = dht * (hprev - c);
+            const float dau = dht * (hprev - c) * u * (1.0f - u);
             const float dc = dht * (1.0f - u);
             dhp[i] = dht * u;
             const float dac = dc * (1.0f - c * c);
             my1[((i & 3) + 8 * (i >> 2)) * LD1] = dac;
-            a.dac[ix] = dac;
-            a.rh[ix] = r * hprev;
-            a.hprev[ix] = hprev;
-            sxc[i] += dac;
-            rr[i] = r; hp[i] = hprev; uu[i] = u;
+            my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = dau;
+            o_dac[ix] = dac;
+            o_rh[ix] = r * hprev;
+            o_hp[ix] = hprev;
+            o_dag[tl(i, t) * 2 * H + H + col] = dau;
+            sxc[i] += dac; sxu[i] += dau;
+            rr[i] = r; hp[i] = hprev;
         }
         __syncthreads();
         f32x16 drh = zero16();
@@ -129,12 +142,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
             const float dr = drh[i] * hp[i];
             dhp[i] += drh[i] * rr[i];
             const float dar = dr * rr[i] * (1.0f - rr[i]);
-            const float dau = du[i] * uu[i] * (1.0f - uu[i]);
             my2[((i & 3) + 8 * (i >> 2)) * LD2] = dar;
-            my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = dau;
-            const size_t ig = ((size_t)rowi[i] * a.T + t) * 2 * H + col;
-            a.dag[ig] = dar; a.dag[ig + H] = dau;
-            sxr[i] += dar; sxu[i] += dau;
+            o_dag[tl(i, t) * 2 * H + col] = dar;
+            sxr[i] += dar;
         }
         __syncthreads();
         f32x16 dhg = zero16();
@@ -148,10 +158,10 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (row0 + acc_row(i) < a.R) {
-            a.dHx_rows[(size_t)rowi[i] * H + col] = dh[i];
-            a.dxg[(size_t)rowi[i] * 2 * H + col] = sxr[i];
-            a.dxg[(size_t)rowi[i] * 2 * H + H + col] = sxu[i];
-            a.dxc[(size_t)rowi[i] * H + col] = sxc[i];
+            a.dHx_rows[(size_t)rowi(i) * H + col] = dh[i];
+            a.dxg[(size_t)rowi(i) * 2 * H + col] = sxr[i];
+            a.dxg[(size_t)rowi(i) * 2 * H + H + col] = sxu[i];
+            a.dxc[(size_t)rowi(i) * H + col] = sxc[i];
         }
         my2[((i & 3) + 8 * (i >> 2)) * LD2] = sxr[i];
         my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = sxu[i];
@@ -163,14 +173,14 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_decode
     mma1b(dxz, a1_lane, a.WcT_x + ((size_t)cb * GH) * 64 + lane, GH);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        if (row0 + acc_row(i) < a.R) a.dxz[(size_t)rowi[i] * H + col] = dxz[i];
+        if (row0 + acc_row(i) < a.R) a.dxz[(size_t)rowi(i) * H + col] = dxz[i];
 }
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
     const int H = a.H;
     const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 64 + 2 * H) * sizeof(float);
     const dim3 grid((a.R + 31) / 32);
     if (H == 256) { allow_big_lds(k_decoder_bwd<256>); hipLaunchKernelGGL(k_decoder_bwd<256>, grid, dim3(512), lds, s, a); }
-    else if (H == 128) hipLaunchKernelGGL(k_decoder_bwd<128>, grid, dim3(256), lds, s, a);
+    else if (H == 128) { allow_big_lds(k_decoder_bwd<128>); hipLaunchKernelGGL(k_decoder_bwd<128>, grid, dim3(256), lds, s, a); }
     else hipLaunchKernelGGL(k_decoder_bwd<64>, grid, dim3(128), lds, s, a);
 }
 
