@@ -148,11 +148,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    # DESIRE_BENCH_ONE_GPU=1: a smoke test of the multi-rank code path on a box with a single GPU (all ranks share cuda:0 and
+    # rendezvous over gloo, because RCCL refuses two ranks on one device).  Never set for a measurement.
+    one_gpu = os.environ.get("DESIRE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     d = Dims(n_scenes=a.windows, mno=a.mno, bf16=int(a.bf16), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
              nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)

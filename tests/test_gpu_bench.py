@@ -1,0 +1,53 @@
+"""bench.py's contract, exercised on the GPU box: one JSON line with the fields the driver reads, and the multi-rank code
+path (barrier / max-over-ranks timing / sharded work) run as two ranks that share the single GPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_contract_fields():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--windows", "16"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = _last_json(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 2 and o["warmup"] == 1 and o["vs_baseline"] is None and o["scaling"] == "weak"
+    r = o["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = o["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert abs(o["value"] - o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--train"], ["--shard", "agents", "--mno", "16"]])
+def test_two_ranks_on_one_gpu(extra):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, DESIRE_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "8"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    o = _last_json(p.stdout)
+    assert o["n_gpus"] == 2 and o["value"] > 0
+    if not extra:
+        assert o["config"]["rows_per_gpu"] == 8 * 32 * 20
+        assert abs(o["value"] - 2 * o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
