@@ -45,6 +45,12 @@ __device__ __forceinline__ f32x16 splat16h(float v) {
 #ifndef IOC16_OCC
 #define IOC16_OCC 2
 #endif
+#ifndef IOC16_SPLIT
+#define IOC16_SPLIT 1
+#endif
+#ifndef IOC16_TWO_SETS
+#define IOC16_TWO_SETS 1
+#endif
 template <int MT, int NB>
 __device__ __forceinline__ void mma16_chunk(f32x16 (&acc)[NB][MT], const u16* const (&ap)[MT], int g, const uint4 (&b)[NB][CH16]) {
 #pragma unroll
@@ -129,6 +135,9 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
     float* red = wv + 3 * EV;                                         // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                  // [2] bins that hold a neighbour anywhere in the tile
+    constexpr bool SPLIT = IOC16_SPLIT && NT <= 4;                          // pooling split over BINS between the waves of a row block
+    float* EX = reinterpret_cast<float*>(smem_raw + ((reinterpret_cast<unsigned char*>(occ + 2) - smem_raw + 15) & ~15));   // [WM][NT][1024]
+    float* EXB = EX + WM * NT * 1024;                                       // [WM * NT / 2][1024] second set's upper half (B <= 32)
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
@@ -172,10 +181,14 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
     };
 
     for (int it = 0; it < a.iters; ++it) {
+        // an opaque zero, redefined per pass: the prologue / epilogue address math below depends on it, so it cannot be hoisted
+        // out of the pass and sit in (spilled) registers across the whole time loop
+        int row0p;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
         f32x16 h, sp = zero16();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = min(row0 + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
+            const int row = min(row0p + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
             h[i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
         }
         __syncthreads();                                  // previous iteration's readers of Xb / Ht are done
@@ -221,15 +234,112 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             TICK16(1)
             __syncthreads();
             TICK16(2)
-            // ---- P2: social pooling chain -> e_r (no LDS traffic besides h^T fragments, no barriers) ----
+            // ---- P2: social pooling chain -> e_r ----
+            unsigned long long om_all = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+            om_all |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+            if constexpr (SPLIT) {
+                // The occupied bins are dealt round-robin to the NT waves of a row block.  A wave runs the whole chain of ITS
+                // bins -- link 1 once per hidden block (no longer repeated by every wave), link 2 into all NT column blocks --
+                // and keeps NT partial e_r tiles; slot k belongs to column block (cb + k) % NT, so every register index is
+                // static.  The partials are then summed in a fixed order through a 4 KB-per-wave LDS exchange (NT - 1 rounds).
+                const unsigned long long om = om_all;
+                unsigned long long mine = 0ull;
+                {
+                    int k = 0;
+                    for (unsigned long long tmp = om; tmp; tmp &= tmp - 1, ++k)
+                        if (k % NT == cb) mine |= tmp & (0ull - tmp);
+                }
+                f32x16 soc[NT];
+                soc[0] = zero16();                                 // (biases are added after the contractions: a splat would pin 16 registers)
+#pragma unroll
+                for (int k = 1; k < NT; ++k) soc[k] = zero16();
+                auto wptr = [&](int b, int hb, int k) {           // fragments of W_b[hidden block hb][column block (cb+k)%NT], 2 k-groups
+                    const int cbo = (cb + k) % NT;
+                    return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
+                };
+                uint4 wq[2 * NT];                                   // W fragments of one hidden block, refreshed in place
+                if (mine) {
+                    const int b0 = __ffsll((long long)mine) - 1;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) { const uint4* p = wptr(b0, 0, k); wq[2 * k] = p[0]; wq[2 * k + 1] = p[64]; }
+                }
+#pragma clang loop unroll(disable)
+                while (mine) {
+                    const int b = __ffsll((long long)mine) - 1;
+                    mine &= mine - 1;
+                    const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                    uint4 mf[JGM];
+                    const unsigned long long m64 = masks[(mt * 32 + c31) * LDM + b];
+#pragma unroll
+                    for (int jg = 0; jg < JGM; ++jg) {
+                        if (jg < JG) {
+                            const unsigned bits = (unsigned)(m64 >> (jbase + 16 * jg + 8 * hi)) & 0xffu;
+                            const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                            mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        }
+                    }
+                    auto chain = [&](int hb) {
+                        f32x16 d1 = zero16();
+                        const u16* hp = Ht + (hb * 32 + c31) * LDT + jbase + 8 * hi;
+#pragma unroll
+                        for (int jg = 0; jg < JGM; ++jg)
+                            if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], d1);
+                        return d1;
+                    };
+#pragma unroll
+                    for (int hb = 0; hb < NT; ++hb) {
+                        const f32x16 da = chain(hb);
+                        const uint4 p0 = make_uint4(pk_bf16(da[0], da[1]), pk_bf16(da[2], da[3]), pk_bf16(da[4], da[5]), pk_bf16(da[6], da[7]));
+                        const uint4 p1 = make_uint4(pk_bf16(da[8], da[9]), pk_bf16(da[10], da[11]), pk_bf16(da[12], da[13]), pk_bf16(da[14], da[15]));
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {            // slot k's fragments are re-requested right after their last use:
+                            soc[k] = mfma16(p0, wq[2 * k], soc[k]);          // next hidden block of this bin, or block 0 of my next bin
+                            soc[k] = mfma16(p1, wq[2 * k + 1], soc[k]);
+                            const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+                            wq[2 * k] = p[0]; wq[2 * k + 1] = p[64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);         // one hidden block at a time: keeps the live set to one chain result
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // fixed-order sum of the partial tiles: round s hands slot s to the wave s column blocks further on.  Rounds
+                // alternate between two slot sets (the second one lives partly in the r*h tile, idle during P2), so one barrier
+                // per round is enough; with more than 32 bins the masks leave no room for the second set and a round costs two.
+                if (om) {                                          // (workgroup-uniform)
+                    const bool two_sets = IOC16_TWO_SETS && B <= 32;
+                    auto slot = [&](int set, int wv) {
+                        if (set == 0 || !two_sets) return EX + (size_t)wv * 1024;
+                        constexpr int nh = NT * WM / 2;
+                        return wv < nh ? reinterpret_cast<float*>(RHb) + (size_t)wv * 1024 : EXB + (size_t)(wv - nh) * 1024;
+                    };
+#pragma unroll
+                    for (int sft = 1; sft < NT; ++sft) {
+                        const int set = (sft - 1) & 1;
+                        if (sft > 1 && !two_sets) __syncthreads();  // single set: the previous round's readers must be done with my slot
+                        float4* dst = reinterpret_cast<float4*>(slot(set, mt * NT + cb)) + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            dst[q * 64] = make_float4(soc[sft][4 * q], soc[sft][4 * q + 1], soc[sft][4 * q + 2], soc[sft][4 * q + 3]);
+                        __syncthreads();
+                        const float4* src = reinterpret_cast<const float4*>(slot(set, mt * NT + (cb + NT - sft) % NT)) + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = src[q * 64];
+                            soc[0][4 * q] += v.x; soc[0][4 * q + 1] += v.y; soc[0][4 * q + 2] += v.z; soc[0][4 * q + 3] += v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[0][i] + bso, 0.f));
+            } else
             {
-                f32x16 soc = splat16h(bso);
+                f32x16 soc = zero16();
                 // this wave's n-tile of W_b (H/16 k-groups, chain order) lives in ONE register set that is refreshed in
                 // place: the fragments of bin b+1 are requested right after their last use in bin b, so every load is in
                 // flight for a whole bin of MFMAs
                 // Only bins that hold a neighbour somewhere in the tile are visited (an empty bin contributes exact zeros).
-                unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
-                om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                unsigned long long om = om_all;
                 uint4 wb[2 * NT];
                 if (om) {
                     const uint4* wsrc = Wsoc + ((size_t)((__ffsll((long long)om) - 1) * NT + cb) * GH16) * 64 + lane;
@@ -277,7 +387,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i], 0.f));
+                    Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i] + bso, 0.f));
             }
             TICK16(3)
             __syncthreads();
@@ -285,14 +395,14 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             // ---- P4: gates over [x | h] ----
             f32x16 u;
             {
-                f32x16 g2[2][1] = {{splat16h(bgr)}, {splat16h(bgu)}};
+                f32x16 g2[2][1] = {{zero16()}, {zero16()}};
                 const uint4* bl[2] = {Wg + ((size_t)cb * G16) * 64 + lane, Wg + ((size_t)(cb + NT) * G16) * 64 + lane};
                 mma16_groups<1, 2>(g2, xp, bl, G16);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float r = sigmoidf_(g2[0][0][i]);
+                    const float r = sigmoidf_(g2[0][0][i] + bgr);
                     RHb[(arow + (i & 3) + 8 * (i >> 2)) * LDRB + col] = bf16_of(r * h[i]);
-                    u[i] = sigmoidf_(g2[1][0][i]);
+                    u[i] = sigmoidf_(g2[1][0][i] + bgu);
                 }
             }
             TICK16(5)
@@ -300,14 +410,14 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             TICK16(6)
             // ---- P5: candidate over [x | r*h], blend, score; publish h_t ----
             {
-                f32x16 ac[1][1] = {{splat16h(bcc)}};
+                f32x16 ac[1][1] = {{zero16()}};
                 const uint4* bx[1] = {Wc + ((size_t)cb * G16) * 64 + lane};
                 mma16_groups<1, 1>(ac, xp, bx, GX16);
                 const uint4* bh[1] = {Wc + ((size_t)cb * G16 + GX16) * 64 + lane};
                 mma16_groups<1, 1>(ac, rp, bh, GH16);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float c = tanhf_(ac[0][0][i]);
+                    const float c = tanhf_(ac[0][0][i] + bcc);
                     h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                 }
@@ -331,11 +441,12 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             if (c31 == 0) red[cb * TM + arow + (i & 3) + 8 * (i >> 2)] = v;
         }
         __syncthreads();
-        if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
+        if (tid < TM && row0p + tid < a.R && it == a.iters - 1) {
             float sc = 0.f;
 #pragma unroll
             for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
-            a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+            a.score[row0p + tid] = sc + (float)a.T * a.b_score[0];
         }
         // ---- regression: Y += h_T W_r + b_r ----
         for (int nt = cb; nt < a.NTreg; nt += NT) {
@@ -348,7 +459,7 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                 const float bb = a.b_reg[cc];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = row0 + arow + (i & 3) + 8 * (i >> 2);
+                    const int row = row0p + arow + (i & 3) + 8 * (i >> 2);
                     if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][0][i] + bb); }
                 }
             }
@@ -365,6 +476,7 @@ static size_t ioc16_lds(const IocArgs& a, int WM) {
     const int H = a.H, TM = 32 * WM, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
     size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2;
     b += (size_t)TM * (B + 1) * 8 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 64;
+    if (IOC16_SPLIT && NT <= 4) b += (size_t)WM * NT * 4096 + 16 + (B <= 32 ? (size_t)WM * NT * 2048 : 0);   // partial-tile exchange
     return b;
 }
 template <int H, int WM>
