@@ -457,7 +457,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             //      tracks most of the window is empty).  build(next) and the contraction of the current bin sit between
             //      the same two barriers, so waves that finish building early start their MFMAs while others build
             {
-                f32x16 soc = splat16(bso);
+                f32x16 soc = zero16();          // biases join after the contraction (a splat start value would pin 16 registers)
                 unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
                 om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
                 int buf = 0;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 }
                 if (active) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+                    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
                 }
             }
             __syncthreads();
@@ -495,12 +495,12 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             // ---- P4: gates over [x | h]; r*h goes to its own LDS tile so no "done reading h" barrier is needed ----
             f32x16 rh, u;
             if (active) {
-                rh = splat16(bgr); u = splat16(bgu);
+                rh = zero16(); u = zero16();
                 mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
                 mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float r = sigmoidf_(rh[i]);
+                    const float r = sigmoidf_(rh[i] + bgr);
                     if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) sv_r_t[sv_off(i, t)] = r;
                     rh[i] = r * h[i];
                 }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    u[i] = sigmoidf_(u[i]);
+                    u[i] = sigmoidf_(u[i] + bgu);
                     if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) sv_u_t[sv_off(i, t)] = u[i];
                 }
             }
@@ -516,12 +516,12 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             TICK(7)
             // ---- P5: candidate over [x | r*h], blend, score ----
             if (active) {
-                f32x16 ac = splat16(bcc);
+                f32x16 ac = zero16();
                 mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
                 mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float c = tanhf_(ac[i]);
+                    const float c = tanhf_(ac[i] + bcc);
                     h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                     if (TRAIN && row0 + mt * 32 + acc_row(i) < a.R) { sv_c_t[sv_off(i, t)] = c; sv_h_t[sv_off(i, t)] = h[i]; }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
                 };
-                f32x16 soc = splat16(bso);
+                f32x16 soc = zero16();          // biases join after the contraction (a splat start value would pin 16 registers)
                 unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
                 om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
                 int buf = 0;
@@ -783,26 +783,26 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     buf ^= 1;
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+                for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
                 __syncthreads();
-                f32x16 rh = splat16(bgr), u = splat16(bgu);
+                f32x16 rh = zero16(), u = zero16();
                 mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
                 mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
+                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
+                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
                 __syncthreads();
                 {
-                    f32x16 ac = splat16(bcc);
+                    f32x16 ac = zero16();
                     mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
                     mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
                     float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)(row0 + 4 * (lane >> 5)) * H + col;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i]));
+                        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
                         sp[i] = fmaf(h[i], wsc, sp[i]);
                     }
 #pragma unroll
@@ -978,7 +978,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
 #pragma unroll
         for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = s[c];
     };
-    f32x16 soc = splat16(bso);
+    f32x16 soc = zero16();          // biases join after the contraction (a splat start value would pin 16 registers)
     unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
     om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
     int buf = 0;
@@ -993,24 +993,24 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         buf ^= 1;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i], 0.f);
+    for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
     __syncthreads();
-    f32x16 rh = splat16(bgr), u = splat16(bgu);
+    f32x16 rh = zero16(), u = zero16();
     mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
     mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i]) * h[i];
+    for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i]);
+    for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
     __syncthreads();
-    f32x16 ac = splat16(bcc);
+    f32x16 ac = zero16();
     mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
     mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i]));
+        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
         const int row = row0 + acc_row(i);
         if (row < a.R) a.st_h_out[(size_t)row * H + col] = h[i];
         float v = h[i] * wsc;
