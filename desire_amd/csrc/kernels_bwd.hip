@@ -87,7 +87,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
     auto rowi = [&](int i) { return min(row0 + acc_row(i), a.R - 1); };
     // saved activations / gradient streams: (uniform tile base) + (32-bit offset inside the tile); rows past R clamp to the last one
     const int nloc = min(TM, a.R - row0);
-    auto tl = [&](int i, int t) { return (unsigned)(min(acc_row(i), nloc - 1) * a.T + t); };
+    int nlv = nloc;                                        // re-defined opaquely per step: the per-element row clamps below are then
+                                                           // recomputed (two VALU ops) instead of hoisted out of the time loop and spilled
+    auto tl = [&](int i, int t) { return (unsigned)(min(acc_row(i), nlv - 1) * a.T + t); };
     const size_t tb = (size_t)row0 * a.T;
     const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H; const float* svh = a.sv_h + tb * H;
     float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
@@ -97,6 +99,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
     }
 
     for (int t = a.T - 1; t >= 0; --t) {
+        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
         __syncthreads();                                   // previous step's A2 / dy consumers are done
         if (tid < TM) {
             float2 v = make_float2(0.f, 0.f);
@@ -835,7 +838,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
     // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
     const int nloc = min(TM, a.R - row0);
-    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nloc - 1) * a.T + t); };   // (local row, t) index
+    int nlv = nloc;                                        // re-defined opaquely per step (see k_decoder_bwd)
+    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nlv - 1) * a.T + t); };   // (local row, t) index
     const size_t tb = (size_t)row0 * a.T;
     const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
     const float* svx = a.sv_x + tb * E;
@@ -857,6 +861,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     mma1b(dh, DR + (lane & 31) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
 
     for (int t = a.T - 1; t >= 0; --t) {
+        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
         __syncthreads();
         // ---- P0: positions, cleared masks, h_{t-1} tile ----
         if (tid < TM) {
