@@ -76,7 +76,13 @@ __device__ __forceinline__ void load_b4(float4 (&b)[4], const float4* __restrict
 template <int MT, bool SWAP = false>
 __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
                                                const float4* __restrict__ b_lane, int G) {
-    const int nch = G >> 2;
+    const int nch = G >> 2, rem = G & 3;
+    // the G % 4 groups after the whole chunks are requested up front, so they are in flight for the whole contraction
+    // instead of costing one exposed L2 round trip each at the end
+    float4 bt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < rem) bt[j] = b_lane[(4 * nch + j) * 64];
     int c = 0;
     if (nch > 0) {
         float4 b0[4], b1[4];
@@ -94,18 +100,21 @@ __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* c
         }
         if (c < nch) { mma_chunk<MT, SWAP>(acc, ap, 4 * c, b0); ++c; }
     }
-#pragma clang loop unroll(disable)
-    for (int g = 4 * c; g < G; ++g) {
-        const float4 b = b_lane[g * 64];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const float4 a = *reinterpret_cast<const float4*>(ap[m] + g * 8);
-            if (SWAP) {
-                acc[m] = mfma32(b.x, a.x, acc[m]); acc[m] = mfma32(b.y, a.y, acc[m]);
-                acc[m] = mfma32(b.z, a.z, acc[m]); acc[m] = mfma32(b.w, a.w, acc[m]);
-            } else {
-                acc[m] = mfma32(a.x, b.x, acc[m]); acc[m] = mfma32(a.y, b.y, acc[m]);
-                acc[m] = mfma32(a.z, b.z, acc[m]); acc[m] = mfma32(a.w, b.w, acc[m]);
+    for (int j = 0; j < 3; ++j) {
+        if (j < rem) {
+            const int g = 4 * nch + j;
+            const float4 b = bt[j];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 a = *reinterpret_cast<const float4*>(ap[m] + g * 8);
+                if (SWAP) {
+                    acc[m] = mfma32(b.x, a.x, acc[m]); acc[m] = mfma32(b.y, a.y, acc[m]);
+                    acc[m] = mfma32(b.z, a.z, acc[m]); acc[m] = mfma32(b.w, a.w, acc[m]);
+                } else {
+                    acc[m] = mfma32(a.x, b.x, acc[m]); acc[m] = mfma32(a.y, b.y, acc[m]);
+                    acc[m] = mfma32(a.z, b.z, acc[m]); acc[m] = mfma32(a.w, b.w, acc[m]);
+                }
             }
         }
     }
