@@ -73,38 +73,41 @@ __device__ __forceinline__ void load_b4(float4 (&b)[4], const float4* __restrict
     for (int j = 0; j < 4; ++j) b[j] = b_lane[(g + j) * 64];
 }
 
-template <int MT, bool SWAP = false>
-__device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
-                                               const float4* __restrict__ b_lane, int G) {
+// B fragments a contraction starts with: the first chunk and the G % 4 tail groups.  mma_begin only issues the loads, so a
+// caller can place it ahead of unrelated work (building the next LDS operand, a barrier) and have the L2 latency overlap it.
+struct MmaHead { float4 b0[4]; float4 bt[3]; };
+__device__ __forceinline__ void mma_begin(MmaHead& hd, const float4* __restrict__ b_lane, int G) {
     const int nch = G >> 2, rem = G & 3;
-    // the G % 4 groups after the whole chunks are requested up front, so they are in flight for the whole contraction
-    // instead of costing one exposed L2 round trip each at the end
-    float4 bt[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-        if (j < rem) bt[j] = b_lane[(4 * nch + j) * 64];
+        if (j < rem) hd.bt[j] = b_lane[(4 * nch + j) * 64];
+    if (nch > 0) load_b4(hd.b0, b_lane, 0);
+}
+template <int MT, bool SWAP = false>
+__device__ __forceinline__ void mma_run(f32x16 (&acc)[MT], const float* const (&ap)[MT],
+                                        const float4* __restrict__ b_lane, int G, MmaHead& hd) {
+    const int nch = G >> 2, rem = G & 3;
     int c = 0;
     if (nch > 0) {
-        float4 b0[4], b1[4];
-        load_b4(b0, b_lane, 0);
+        float4 b1[4];
 #pragma clang loop unroll(disable)
         for (; c + 2 <= nch; c += 2) {
             load_b4(b1, b_lane, 4 * c + 4);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<MT, SWAP>(acc, ap, 4 * c, b0);
+            mma_chunk<MT, SWAP>(acc, ap, 4 * c, hd.b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (c + 2 < nch) load_b4(b0, b_lane, 4 * c + 8);
+            if (c + 2 < nch) load_b4(hd.b0, b_lane, 4 * c + 8);
             __builtin_amdgcn_sched_barrier(0);
             mma_chunk<MT, SWAP>(acc, ap, 4 * c + 4, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (c < nch) { mma_chunk<MT, SWAP>(acc, ap, 4 * c, b0); ++c; }
+        if (c < nch) { mma_chunk<MT, SWAP>(acc, ap, 4 * c, hd.b0); ++c; }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (j < rem) {
             const int g = 4 * nch + j;
-            const float4 b = bt[j];
+            const float4 b = hd.bt[j];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const float4 a = *reinterpret_cast<const float4*>(ap[m] + g * 8);
@@ -118,6 +121,13 @@ __device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* c
             }
         }
     }
+}
+template <int MT, bool SWAP = false>
+__device__ __forceinline__ void mma_groups_ptr(f32x16 (&acc)[MT], const float* const (&ap)[MT],
+                                               const float4* __restrict__ b_lane, int G) {
+    MmaHead hd;
+    mma_begin(hd, b_lane, G);
+    mma_run<MT, SWAP>(acc, ap, b_lane, G, hd);
 }
 
 // a_lane: LDS pointer to A[lane&31][4*(lane>>5)] of M-tile 0 (row stride lda floats,

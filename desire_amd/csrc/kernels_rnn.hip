@@ -467,11 +467,17 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 while (om) {
                     const int b = ffs_(om) - 1;
                     om &= om - 1;
+                    const float4* wb = a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane;
+                    MmaHead hd;
+                    if (active) mma_begin(hd, wb, GH);             // this bin's first weight fragments travel while the next operand is built
                     if (om) build(ffs_(om) - 1, buf ^ 1);
                     TICK(3)
-                    if (active)
-                        mma1(soc, AB + buf * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5),
-                             a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                    if (active) {
+                        f32x16 t1[1] = {soc};
+                        const float* ap1[1] = {AB + buf * TM * LDB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5)};
+                        mma_run<1>(t1, ap1, wb, GH, hd);
+                        soc = t1[0];
+                    }
                     TICK(4)
                     __syncthreads();
                     TICK(5)
