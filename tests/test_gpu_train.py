@@ -308,3 +308,31 @@ def test_hipgraph_replay_of_forward_backward_clip(grads_case):
         h.graph_launch(gid + 7, sp)
     with pytest.raises(_lib.DesireError):
         h.graph_begin(0)                                 # the default stream cannot be captured
+
+
+def test_gradients_are_bitwise_reproducible():
+    """Every reduction of the backward pass sums in a fixed order (slices, then slices of slices; no float atomics), so two
+    runs on the same inputs give the same bits -- at a size where the weight-gradient GEMMs use several slices."""
+    import torch
+    from desire_amd import _lib
+    d = small_dims(n_scenes=24, mno=32, K=5, T_obs=8, T_pred=12, n_grids=1)
+    w = init_weights(d, 71)
+    past, fut, eps, grids, gos = make_case(d, seed=72, n_absent=3)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev); sc = torch.zeros((d.R,), device=dev)
+    runs = []
+    for _ in range(2):
+        h = _lib.Handle(d)
+        h.set_weights(w)
+        h.set_training(True)
+        h.set_scene_grids(g.data_ptr(), gos)
+        for _ in range(2):                                   # the second pass of each handle reuses warm buffers
+            h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+            h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+            torch.cuda.synchronize()
+            runs.append(h.grad_tensor().clone())
+    assert float(runs[0].abs().max()) > 0
+    for r in runs[1:]:
+        assert torch.equal(runs[0], r)
