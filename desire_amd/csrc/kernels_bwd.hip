@@ -804,10 +804,17 @@ void launch_score_grad(const float* Y0, const float* fut, const float* score, co
 #ifndef IOC_BWD_OCC
 #define IOC_BWD_OCC 2
 #endif
-template <int H, int EV, int C>
-__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) void k_ioc_bwd(IocBwdArgs a) {
+template <int TM> struct BwdMask { typedef unsigned long long type; };
+template <> struct BwdMask<32> { typedef unsigned type; };
+__device__ __forceinline__ int ffsm(unsigned m) { return __ffs((int)m); }
+__device__ __forceinline__ int ffsm(unsigned long long m) { return __ffsll((long long)m); }
+// TM = 32: whole groups of up to 32 agents per tile, 4 waves at H = 128, two workgroups per CU.  TM = 64: groups of 64 agents
+// (one per tile), wave (mt, cb) owns rows [32mt, 32mt+32) x columns [32cb, 32cb+32), one workgroup per CU (144 KB of LDS).
+template <int H, int EV, int C, int TM>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 4) ? IOC_BWD_OCC : ((H / 32) * (TM / 32) <= 8 ? 2 : 1)) void k_ioc_bwd(IocBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
+    constexpr int NT = H / 32, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
+    typedef typename BwdMask<TM>::type mask_t;
     constexpr int E = EV + C + H, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
     const int B = a.G * a.G;
     const int KR = (2 * a.T + 7) / 8 * 8, LDR = KR + 4;                   // regression-head operand width
@@ -816,8 +823,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     float* A2 = A1 + TM * LD1;                // [32][LD2]  da_r | da_u;  then dpool_b, double buffered
     float* A3 = A2 + 2 * TM * LD1;            // [32][LD1]  dpre_r  (2 LD1 > LD2: the two dpool tiles are the larger tenant)
     float* DP = A2, *HP = A1, *NB = A1;
-    unsigned* masks = reinterpret_cast<unsigned*>(A3 + TM * LD1);     // [32][B] neighbours of i in bin b (bit = slot)
-    unsigned* obs = masks + TM * B;                                   // [32][B] observers of j in bin b
+    mask_t* masks = reinterpret_cast<mask_t*>(A3 + TM * LD1);         // [TM][B] neighbours of i in bin b (bit = slot)
+    mask_t* obs = masks + TM * B;                                     // [TM][B] observers of j in bin b
     float* pc = reinterpret_cast<float*>(obs + TM * B);   // [32][2]
     float* dsc = pc + TM * 2;                 // [32]
     float* wsc = dsc + TM;                    // [H]
@@ -825,16 +832,17 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);            // [2] bins that hold a neighbour anywhere in the tile
     float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
 
-    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w % NT, mt = w / NT;
     const int row0 = blockIdx.x * TM;
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
     const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
-    const float* a1_lane = A1 + (lane & 31) * LD1 + 4 * (lane >> 5);
-    const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
-    const float* a3_lane = A3 + (lane & 31) * LD1 + 4 * (lane >> 5);
-    const int rofs = (4 * (lane >> 5));       // + (i&3) + 8*(i>>2) = local row of accumulator element i
+    const float* a1_lane = A1 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
+    const float* a2_lane = A2 + (mt * 32 + (lane & 31)) * LD2 + 4 * (lane >> 5);
+    const float* a3_lane = A3 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
+    const int rofs = mt * 32 + 4 * (lane >> 5);   // + (i&3) + 8*(i>>2) = local row of accumulator element i
     auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
     // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
     const int nloc = min(TM, a.R - row0);
@@ -858,7 +866,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     }
     __syncthreads();
     f32x16 dh = zero16();
-    mma1b(dh, DR + (lane & 31) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+    mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
 
     for (int t = a.T - 1; t >= 0; --t) {
         asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
@@ -873,7 +881,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
             else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
             if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
         }
-        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0u;            // masks and obs are contiguous
+        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
         if (tid < 2) occ[tid] = 0;
         auto load_hprev = [&]() {                                              // h_{t-1} tile -> A1's space
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {
@@ -893,8 +901,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
                 if (j == my_slot || !vld[grp_base + j]) continue;
                 const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                 if (b >= 0) {
-                    atomicOr(&masks[r8 * B + b], 1u << j);
-                    atomicOr(&obs[(grp_base + j) * B + b], 1u << my_slot);
+                    atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
+                    atomicOr(&obs[(grp_base + j) * B + b], (mask_t)1 << my_slot);
                     atomicOr(&occ[b >> 5], 1u << (b & 31));
                 }
             }
@@ -974,9 +982,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
                 float4 s[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                unsigned m2 = masks[r8 * B + b];
+                mask_t m2 = masks[r8 * B + b];
                 while (m2) {
-                    const int j = __ffs((int)m2) - 1;
+                    const int j = ffsm(m2) - 1;
                     m2 &= m2 - 1;
                     const float* src = HP + (grp_base + j) * LD1 + q8 * 4;
 #pragma unroll
@@ -999,9 +1007,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
 #pragma unroll
             for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
             __syncthreads();
-            unsigned m2 = obs[r8 * B + b];
+            mask_t m2 = obs[r8 * B + b];
             while (m2) {
-                const int i2 = __ffs((int)m2) - 1;
+                const int i2 = ffsm(m2) - 1;
                 m2 &= m2 - 1;
                 const float* src = dp + (grp_base + i2) * LD1 + q8 * 4;
 #pragma unroll
@@ -1019,17 +1027,25 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? IOC_BWD_OCC : 1) voi
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        if (row0 + acc_row(i) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
+        if (row0 + rofs + (i & 3) + 8 * (i >> 2) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
 }
-static size_t ioc_bwd_lds(const IocBwdArgs& a) {
-    const int H = a.H, LD1 = H + 4, LD2 = 2 * H + 4, B = a.G * a.G;
-    size_t f = (size_t)32 * LD1 * 4 + (size_t)32 * B * 2 + 64 + 32 + H;
-    return f * sizeof(float) + 64;
+static size_t ioc_bwd_lds(const IocBwdArgs& a, int TM) {
+    const int H = a.H, LD1 = H + 4, B = a.G * a.G;
+    size_t f = (size_t)TM * LD1 * 4 + (size_t)TM * B * (TM == 32 ? 2 : 4) + TM * 2 + TM + H;
+    return f * sizeof(float) + TM + 64;
 }
+template <int H, int TM>
+static void launch_ioc_bwd_t(const IocBwdArgs& a, hipStream_t s) {
+    allow_big_lds(k_ioc_bwd<H, 16, 32, TM>);
+    hipLaunchKernelGGL((k_ioc_bwd<H, 16, 32, TM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * (TM / 32) * 64), ioc_bwd_lds(a, TM), s, a);
+}
+// groups of up to 32 agents: 32-row tiles; 64 agents per scene (H <= 128): one 64-row tile per group
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s) {
-    const dim3 grid((a.R + 31) / 32);
-    const size_t lds = ioc_bwd_lds(a);
-    if (a.H == 256) { allow_big_lds(k_ioc_bwd<256, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<256, 16, 32>), grid, dim3(512), lds, s, a); }
-    else if (a.H == 128) { allow_big_lds(k_ioc_bwd<128, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<128, 16, 32>), grid, dim3(256), lds, s, a); }
-    else { allow_big_lds(k_ioc_bwd<64, 16, 32>); hipLaunchKernelGGL((k_ioc_bwd<64, 16, 32>), grid, dim3(128), lds, s, a); }
+    if (a.mno > 32) {
+        if (a.H == 128) launch_ioc_bwd_t<128, 64>(a, s); else launch_ioc_bwd_t<64, 64>(a, s);
+        return;
+    }
+    if (a.H == 256) launch_ioc_bwd_t<256, 32>(a, s);
+    else if (a.H == 128) launch_ioc_bwd_t<128, 32>(a, s);
+    else launch_ioc_bwd_t<64, 32>(a, s);
 }

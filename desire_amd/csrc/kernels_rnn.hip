@@ -593,9 +593,11 @@ static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
 template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * (TM / 32) * 64);
-    if (a.sv_h && TM == 32) {                                  // training-mode forward: keeps x_t, r, u, c, h per step
-        allow_big_lds(k_ioc<H, 16, 32, 32, true>);
-        hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+    if (a.sv_h) {                                              // training-mode forward: keeps x_t, r, u, c, h per step
+        if constexpr (H <= 128 || TM == 32) {
+            allow_big_lds(k_ioc<H, 16, 32, TM, true>);
+            hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+        }
         return;
     }
     allow_big_lds(k_ioc<H, 16, 32, TM, false>);

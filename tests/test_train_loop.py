@@ -76,6 +76,25 @@ def test_training_loop_runs_saves_and_learns(tmp_path):
 
 
 @pytest.mark.gpu
+def test_training_with_the_reference_default_slot_count(tmp_path):
+    """train.py's default --max_num_obj is 60: the model pads it to 64 slots, i.e. one 64-row IOC tile per (scene, sample)
+    in the forward AND the backward pass (crowded SDD scenes need it: up to 66 objects per frame)."""
+    from desire_amd.data_loader import DataLoader
+    rng = np.random.default_rng(1)
+    frames = [_synthetic_video(60, 60, 45, rng)]
+    a = T.build_parser().parse_args(["--batch_size", "2", "--seq_length", "4", "--pred_length", "5", "--d_dim", "64",
+                                     "--latent_size", "64", "--num_samples", "2", "--num_epochs", "2", "--learning_rate", "0.0005",
+                                     "--neighborhood_size", "256", "--save_dir", str(tmp_path / "save")])
+    assert a.max_num_obj == 60
+    dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
+    import random
+    random.seed(0)
+    losses = T.train(a, data_loader=dl, log=lambda l: None)
+    assert len(losses) == a.num_epochs * dl.num_batches and np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+@pytest.mark.gpu
 def test_training_on_a_real_sdd_slice_improves_best_of_k_ade(tmp_path):
     """End to end on real Stanford Drone Dataset frames (bookstore/video6, the 160 preprocessed frames kept as a loader
     golden): reference-layout DataLoader -> desire_amd.train loop -> prior sampling -> ADE/FDE harness."""
