@@ -254,7 +254,8 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         return fail(DESIRE_ERR_STATE, "training supports up to 64 agents per scene (32 at H = 256): larger groups run the cluster-form IOC, which has no backward yet");
     if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");
-    if (d.grid_size > 4) return fail(DESIRE_ERR_STATE, "training supports grid_size <= 4 (LDS budget of the IOC backward tile)");
+    if (d.grid_size > 4 && d.mno > 32)
+        return fail(DESIRE_ERR_STATE, "training with more than 16 social bins needs mno <= 32 (LDS budget of the 64-row IOC backward tile)");
     if (h->slots.empty()) {
         size_t off = 0;
         for (auto& kv : h->want) { h->slots[kv.first] = WSlot{off, kv.second}; off += (kv.second + 3) / 4 * 4; }

@@ -240,6 +240,8 @@ def test_full_size_gradient_is_the_mean_of_its_halves():
 
 @pytest.mark.parametrize("kw", [dict(bin_mode=1, nb_w=0.45, nb_h=0.04),        # log-polar rings x sectors
                                 dict(nb_w=0.05, nb_h=0.05, mno=32),            # sparse rectangular windows: empty bins skipped
+                                dict(grid_size=6, nb_w=0.5, nb_h=0.5, mno=32, K=2),          # the paper's 36 bins (rectangular)
+                                dict(grid_size=6, bin_mode=1, nb_w=0.45, nb_h=0.04, K=2),    # ... and as 6 rings x 6 sectors
                                 dict(mno=64, n_scenes=1, K=2),                 # 64 agents per scene: 64-row IOC tiles forward and backward
                                 dict(mno=64, n_scenes=2, K=3, H=64, T_pred=5, nb_w=0.08, nb_h=0.08)])
 def test_gradients_with_logpolar_or_sparse_pooling(kw):
