@@ -567,7 +567,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
-    const bool cluster = d.mno > 64 || (d.mno == 64 && d.H == 256) || (a.variant == 4 && d.mno >= 64);
+    const bool cluster = !d.bf16 && ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
         const size_t n_groups = (size_t)h->R / d.mno;
         if (!h->ws.count("hex")) {

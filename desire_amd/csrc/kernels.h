@@ -96,6 +96,17 @@ struct IocArgs {
     const float* bin_tab;                                  // log-polar bin table (common.h:neighbor_bin_dev) or nullptr = rectangular grid
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
+// Which IOC form serves (mno, H, bins): the cluster form (32-row tiles exchanging hidden states through global memory) takes every
+// group that does not fit ONE workgroup's LDS tile -- more than 64 agents, 64 agents at H = 256, or 64 agents with so many
+// social bins (> 25 at H = 128) that the 64-row tile's neighbour masks push it past 160 KB.
+inline bool ioc_uses_cluster(int mno, int H, int bins, int variant) {
+    if (mno > 64 || (mno == 64 && H == 256) || (variant == 4 && mno >= 64)) return true;
+    if (mno == 64) {
+        const size_t tile = ((size_t)65 * (2 * H + 52) + 2 * 64 * (H + 4) + 64 * 4 + 48 + (H / 32) * 64) * 4 + (size_t)64 * bins * 8 + 128;
+        return tile > 160 * 1024;
+    }
+    return false;
+}
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
 // agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
 struct IocStepArgs {

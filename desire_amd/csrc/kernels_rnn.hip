@@ -606,7 +606,7 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
 void launch_ioc_cluster(const IocArgs& a, hipStream_t s);
 void launch_ioc(const IocArgs& a, hipStream_t s) {
     // groups larger than one workgroup tile (mno > 64, or mno = 64 at H = 256) or variant=4: cluster form
-    if (a.mno > 64 || (a.mno == 64 && a.H == 256) || (a.variant == 4 && a.mno >= 64)) { launch_ioc_cluster(a, s); return; }
+    if (ioc_uses_cluster(a.mno, a.H, a.G * a.G, a.variant)) { launch_ioc_cluster(a, s); return; }
     // 32-row tiles (two workgroups per CU at H <= 128) whenever whole (scene,k) groups fit; variant=2 forces 64 rows (A/B)
     const bool small = (a.mno <= 32) && a.variant != 2;
     if (a.H == 256) launch_ioc_t<256, 32>(a, s);                  // mno = 64 at H = 256 exceeds the 160 KB LDS tile

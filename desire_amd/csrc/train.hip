@@ -250,7 +250,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
     if (d.bf16) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0)");
     if (d.bn_mode) return fail(DESIRE_ERR_STATE, "training runs with frozen batch-norm statistics (dims.bn_mode = 0)");
-    if (d.mno > 64 || (d.mno == 64 && d.H == 256))
+    if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0))
         return fail(DESIRE_ERR_STATE, "training supports up to 64 agents per scene (32 at H = 256): larger groups run the cluster-form IOC, which has no backward yet");
     if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");

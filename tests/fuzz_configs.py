@@ -1,0 +1,77 @@
+"""Randomised configuration sweep (not collected by pytest: run by hand on a GPU box, `python -m tests.fuzz_configs N SEED`).
+Draws dims from the whole supported range, runs the HIP path through the C ABI and compares it with the oracle."""
+import sys
+import traceback
+
+import numpy as np
+
+
+def main():
+    import torch
+    from desire_amd import _lib
+    from desire_amd.spec import init_weights
+    from oracle import desire_oracle as O
+    from tests.helpers import make_case, small_dims, to_oracle_layout
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for it in range(n):
+        mno = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 64, 96, 128]))
+        H = int(rng.choice([64, 128, 128, 256]))
+        kw = dict(mno=mno, H=H, K=int(rng.integers(1, 6)), T_pred=int(rng.integers(1, 14)), T_obs=int(rng.integers(2, 9)),
+                  n_scenes=int(rng.integers(1, 4)) if mno <= 32 else 1, grid_size=int(rng.integers(1, 7)),
+                  posterior=int(rng.integers(0, 2)), iters=int(rng.choice([1, 1, 2])), L=int(rng.choice([64, 128])),
+                  nb_w=float(rng.choice([0.05, 0.2, 0.5])), nb_h=float(rng.choice([0.05, 0.25, 0.5])))
+        kw["n_grids"] = int(rng.integers(1, kw["n_scenes"] + 1))
+        if kw["grid_size"] > 4 and H > 128:
+            kw["grid_size"] = 4
+        if rng.random() < 0.25:
+            kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04, grid_size=max(2, kw["grid_size"]))
+        bf16 = int(rng.random() < 0.3 and mno <= 64)
+        try:
+            d = small_dims(**kw)
+            w = init_weights(d, 100 + it)
+            past, fut, eps, grids, gos = make_case(d, seed=200 + it, n_absent=min(int(rng.integers(0, 4)), d.mno - 1))
+            tab = None
+            h = _lib.Handle(d.replace(bf16=bf16))
+            h.set_weights(w)
+            if d.bin_mode == 1:
+                tab = h.bin_table()
+            q = O.bf16_round if bf16 else None
+            fo = to_oracle_layout(fut) if d.posterior else None
+            ref = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab)
+            if bf16:                                         # IOC stage against the oracle with the kernels' operand rounding
+                r16 = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab, Y_override=ref["Y0"], ioc_q=q)
+                ref = dict(ref, Y=r16["Y"])
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+            p, f, e, g = t(past), t(fut), t(eps), t(grids)
+            h.set_scene_grids(g.data_ptr(), gos)
+            Y = t(ref["Y0"].astype(np.float32)).clone(); sc = torch.zeros((d.R,), device="cuda")
+            h.encode(p.data_ptr(), f.data_ptr() if d.posterior else 0)
+            Ys = torch.zeros_like(Y)
+            h.sample(e.data_ptr(), Ys.data_ptr())
+            torch.cuda.synchronize()
+            e0 = float(np.abs(Ys.cpu().numpy() - ref["Y0"]).max())
+            h.ioc_refine(Y.data_ptr(), sc.data_ptr())
+            torch.cuda.synchronize()
+            if d.iters == 1 and not bf16:
+                e1 = float(np.abs(Y.cpu().numpy() - ref["Y"]).max())
+                ok = e0 < 1e-3 and e1 < 1e-3
+            else:                                            # re-binning after a refinement pass / bf16 operands: looser
+                e1 = float(np.abs(Y.cpu().numpy() - ref["Y"]).mean())
+                ok = e0 < (2e-2 if bf16 else 1e-3) and e1 < 2e-2 and bool(np.isfinite(Y.cpu().numpy()).all())
+            print("%3d %s bf16=%d  Y0 err %.2e  Y err %.2e  %s" % (it, kw, bf16, e0, e1, "ok" if ok else "MISMATCH"), flush=True)
+            bad += 0 if ok else 1
+        except Exception as ex:                              # noqa: BLE001
+            msg = str(ex)
+            refused = isinstance(ex, _lib.DesireError)
+            print("%3d %s bf16=%d  %s: %s" % (it, kw, bf16, "refused" if refused else "EXCEPTION", msg[:160]), flush=True)
+            if not refused:
+                traceback.print_exc()
+                bad += 1
+    print("bad =", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -95,6 +95,8 @@ def test_stagewise_parity_small(torch_cuda):
     dict(nb_w=0.04, nb_h=0.04, K=2),                     # sparse windows: most bins empty in a tile -> skipped, some tiles skip all
     dict(grid_size=6, nb_w=0.08, nb_h=0.08, K=2),        # sparse, 36 bins (occupancy word 1 in use)
     dict(nb_w=0.05, nb_h=0.05, K=2, mno=64, n_scenes=1, n_grids=1),   # sparse, 64-row tile
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=1, mno=64, n_scenes=1, n_grids=1, T_pred=5),   # 36 bins x 64 agents: the 64-row tile's
+                                                                                            # masks no longer fit -> cluster form
 ])
 def test_end_to_end_variants(torch_cuda, kw):
     kw = dict(kw)
