@@ -1,0 +1,90 @@
+"""Randomised sweep of the training path (run by hand on a GPU box: `python -m tests.fuzz_train N SEED`): random dims inside
+the supported training range, every weight gradient against float64 autograd of the oracle."""
+import sys
+import traceback
+
+import numpy as np
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
+
+
+def main():
+    import torch
+    from desire_amd import _lib
+    from desire_amd.spec import init_weights
+    from oracle import desire_torch as OT
+    from tests.helpers import make_case, small_dims, to_oracle_layout
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for it in range(n):
+        mno = int(rng.choice([2, 4, 8, 16, 32, 32, 64]))
+        H = int(rng.choice([64, 128, 128, 256])) if mno <= 32 else int(rng.choice([64, 128]))
+        gs = int(rng.integers(1, 7)) if mno <= 32 and H <= 128 else int(rng.integers(1, 5))
+        kw = dict(mno=mno, H=H, K=int(rng.integers(2, 5)), T_pred=int(rng.integers(2, 9)), T_obs=int(rng.integers(2, 7)),
+                  n_scenes=int(rng.integers(1, 4)) if mno <= 32 else 1, grid_size=gs, L=int(rng.choice([64, 128])), n_grids=1,
+                  nb_w=float(rng.choice([0.05, 0.2, 0.5])), nb_h=float(rng.choice([0.05, 0.25, 0.5])))
+        if rng.random() < 0.25 and gs >= 3:
+            kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04)
+        try:
+            d = small_dims(**kw)
+            w = init_weights(d, 300 + it)
+            for k in w:
+                if k.startswith("vae_dec/") and k.endswith("/w"):
+                    w[k] = w[k] * 3
+            w["mask_fc/w"] = w["mask_fc/w"] * 20
+            w["head/w"] = w["head/w"] * 4
+            w["ioc/score/w"] = w["ioc/score/w"] * 3
+            # relu layers start with zero biases: rows whose input is ~0 (stationary or absent agents) then sit exactly ON the
+            # kink, where fp32 and float64 pick different sides and the "gradient" differs by whole terms.  Move them off it.
+            for k in ("ioc/vel_fc/b", "ioc/social_fc/b", "fc_c/b", "mask_fc/b"):
+                w[k] = (w[k] + rng.uniform(0.02, 0.1, w[k].shape) * rng.choice([-1.0, 1.0], w[k].shape)).astype(np.float32)
+            past, fut, eps, grids, gos = make_case(d, seed=400 + it, n_absent=min(int(rng.integers(0, 4)), d.mno - 1))
+            h = _lib.Handle(d)
+            h.set_weights(w)
+            h.set_training(True)
+            tab = h.bin_table() if d.bin_mode == 1 else None
+            vals, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d, bin_tab=tab)
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+            p, f, e, g = t(past), t(fut), t(eps), t(grids)
+            h.set_scene_grids(g.data_ptr(), gos)
+            Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+            h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+            h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+            torch.cuda.synchronize()
+            worst, wname = 0.0, ""
+            detail = []
+            gscale = max(float(np.abs(np.asarray(ref[nm])).max()) for nm in ref)
+            for name in ref:
+                if "/bn/" in name or name.startswith("scene_cnn") or name.startswith("temporal"):
+                    continue
+                r = np.asarray(ref[name])
+                if np.abs(r).max() < 1e-12:
+                    continue
+                got = h.get_grad(name, w[name].shape)
+                er = rel_err(got, r)
+                detail.append((er, name, float(np.abs(r).max()), float(np.abs(got - r).max())))
+                if np.abs(r).max() < 1e-6 * gscale:          # a gradient that is numerically nothing next to the others
+                    continue
+                if er > worst:
+                    worst, wname = er, name
+            ok = worst < 5e-4
+            print("%3d %s  worst rel grad err %.2e (%s)  %s" % (it, kw, worst, wname, "ok" if ok else "MISMATCH"), flush=True)
+            bad += 0 if ok else 1
+            if not ok:
+                for er, name, sc_, ab in sorted(detail, reverse=True)[:4]:
+                    print("       %-28s rel %.2e  |ref|max %.2e  abs err %.2e   (largest gradient in the model %.2e)" % (name, er, sc_, ab, gscale))
+        except Exception as ex:                              # noqa: BLE001
+            refused = isinstance(ex, _lib.DesireError)
+            print("%3d %s  %s: %s" % (it, kw, "refused" if refused else "EXCEPTION", str(ex)[:160]), flush=True)
+            if not refused:
+                traceback.print_exc()
+                bad += 1
+    print("bad =", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
