@@ -28,9 +28,18 @@ def main():
         if rng.random() < 0.25:
             kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04, grid_size=max(2, kw["grid_size"]))
         bf16 = int(rng.random() < 0.3 and mno <= 64)
+        bn_per_object = (not bf16) and rng.random() < 0.2
+        if bn_per_object:
+            kw["bn_mode"] = 1
         try:
             d = small_dims(**kw)
             w = init_weights(d, 100 + it)
+            if bn_per_object:                                # non-trivial affine parameters
+                for k in list(w):
+                    if k.endswith("/bn/gamma"):
+                        w[k] = (1.0 + 0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+                    if k.endswith("/bn/beta"):
+                        w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
             past, fut, eps, grids, gos = make_case(d, seed=200 + it, n_absent=min(int(rng.integers(0, 4)), d.mno - 1))
             tab = None
             h = _lib.Handle(d.replace(bf16=bf16))
@@ -39,7 +48,8 @@ def main():
                 tab = h.bin_table()
             q = O.bf16_round if bf16 else None
             fo = to_oracle_layout(fut) if d.posterior else None
-            ref = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab)
+            okw = dict(bn_mode="per_object") if bn_per_object else {}
+            ref = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab, **okw)
             if bf16:                                         # IOC stage against the oracle with the kernels' operand rounding
                 r16 = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab, Y_override=ref["Y0"], ioc_q=q)
                 ref = dict(ref, Y=r16["Y"])
