@@ -71,9 +71,30 @@ def window_to_slots(window: np.ndarray, seq_length: int, max_num_obj: int) -> Tu
     src = np.zeros((seq_length, max_num_obj, 3))
     tgt = np.zeros((seq_length, max_num_obj, 3))
     nz = ids != 0
-    if nz.any() and slot[nz].max() >= max_num_obj:
-        raise IndexError("index %d is out of bounds for axis 1 with size %d"
-                         % (int(slot[nz].max()), max_num_obj))
+    # The reference fails in two ways while it fills the slots (utils/data_loader.py:215-229), in loop order (frame, slot,
+    # source before target): IndexError when a PRESENT object's slot is >= max_num_obj, ValueError when an id occurs twice
+    # in one frame (a (k,3) block cannot be assigned to one (3,) slot).  Same exception, decided by the same first event.
+    events = []
+    for which, fr in ((0, slice(0, seq_length)), (1, slice(1, seq_length + 1))):
+        m = nz[fr]
+        if not m.any():
+            continue
+        tt = np.broadcast_to(np.arange(seq_length)[:, None], m.shape)[m]
+        ss = slot[fr][m]
+        over = ss >= max_num_obj
+        if over.any():
+            k = np.lexsort((ss[over], tt[over]))[0]
+            events.append((int(tt[over][k]), int(ss[over][k]), which, "index"))
+        key = tt.astype(np.int64) * (len(uniq) + 1) + ss
+        uk, cnt = np.unique(key, return_counts=True)
+        if (cnt > 1).any():
+            k0 = int(uk[cnt > 1].min())
+            events.append((k0 // (len(uniq) + 1), k0 % (len(uniq) + 1), which, "dup:%d" % int(cnt[uk == k0][0])))
+    if events:
+        ev = min(events)
+        if ev[3] == "index":
+            raise IndexError("index %d is out of bounds for axis 1 with size %d" % (ev[1], max_num_obj))
+        raise ValueError("could not broadcast input array from shape (%s,3) into shape (3,)" % ev[3][4:])
     t_idx = np.broadcast_to(np.arange(seq_length + 1)[:, None], ids.shape)
     m = nz[:seq_length]
     src[t_idx[:seq_length][m], slot[:seq_length][m]] = window[:seq_length][m]

@@ -54,6 +54,19 @@ def test_too_many_unique_ids_raises_like_reference():
         window_to_slots(win, 2, 2)
 
 
+def test_duplicate_id_in_a_window_frame_raises_like_reference():
+    # utils/data_loader.py:224-229: a (2,3) block cannot be assigned to one (3,) slot -> ValueError (found by
+    # tests/golden/fuzz_loader_vs_reference.py, which runs both loaders on random tables in the build container)
+    win = np.zeros((3, 3, 3))
+    win[:, 0] = [4, 1.0, 2.0]
+    win[1, 1] = [4, 5.0, 6.0]
+    with pytest.raises(ValueError):
+        window_to_slots(win, 2, 3)
+    win[1, 1] = [9, 5.0, 6.0]
+    src, tgt = window_to_slots(win, 2, 3)
+    assert src[1, 1, 0] == 9 and tgt[0, 1, 0] == 9
+
+
 def test_id_zero_track_is_dropped_like_reference():
     # SDD track id 0 is indistinguishable from padding (utils/data_loader.py:221-222)
     data = np.array([[0, 0, 1, 1], [0, 5, 0, 5], [1.0, 2.0, 3.0, 4.0], [1.0, 2.0, 3.0, 4.0]])
