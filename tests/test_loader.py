@@ -64,7 +64,7 @@ def test_duplicate_id_in_a_window_frame_raises_like_reference():
         window_to_slots(win, 2, 3)
     win[1, 1] = [9, 5.0, 6.0]
     src, tgt = window_to_slots(win, 2, 3)
-    assert src[1, 1, 0] == 9 and tgt[0, 1, 0] == 9
+    assert src[1, 2, 0] == 9 and tgt[0, 2, 0] == 9 and src[1, 1, 0] == 4       # slots = rank among the window's unique ids (0 first)
 
 
 def test_id_zero_track_is_dropped_like_reference():
