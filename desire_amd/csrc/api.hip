@@ -831,6 +831,7 @@ extern "C" int desire_build_windows(desire_handle* h, const float* dev_frames, i
     HIPCHK(hipMemcpyAsync(&err, h->ws["bw_err"].p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (err & 2) return fail(DESIRE_ERR_ARG, "a window holds more unique ids than max_num_obj slots (utils/data_loader.py:227 IndexError)");
+    if (err & 4) return fail(DESIRE_ERR_ARG, "a track id occurs twice in one frame of a window (utils/data_loader.py:224-229 ValueError)");
     if (err & 1) return fail(DESIRE_ERR_ARG, "track id outside [0, 65536)");
     return DESIRE_OK;
 }

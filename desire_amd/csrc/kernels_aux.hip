@@ -136,7 +136,8 @@ void launch_losses(const float* params, const float* Y, const float* fut, const 
 // the ids of the W = T_obs+T_pred frames go into a presence bitmap, slot = rank of the id among the
 // window's sorted unique ids (0 counts when any padding row exists, exactly like np.unique), rows
 // are copied.  Pure integer/copy work: bit-exact against DataLoader.window_to_slots.
-// err[0] |= 1: id out of bitmap range, |= 2: more unique ids than slots (the reference's IndexError).
+// err[0] |= 1: id out of bitmap range, |= 2: more unique ids than slots (the reference's IndexError), |= 4: an id twice in
+// one frame (the reference's ValueError).
 // ------------------------------------------------------------------------------------------------
 #define BW_WORDS 2048        // ids < 65536
 __global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__ frames, int F, int mno_in,
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__
         if (slot >= (unsigned)mno) { atomicOr(err, 2); continue; }
         float* dst = (t < T_obs) ? past + (((size_t)wdw * T_obs + t) * mno + slot) * 3
                                  : fut + (((size_t)wdw * T_pred + (t - T_obs)) * mno + slot) * 3;
-        dst[0] = idf; dst[1] = src[1]; dst[2] = src[2];
+        // an id that occurs twice in one frame cannot go to one slot: the reference's ValueError (utils/data_loader.py:224-229)
+        if (atomicExch(dst, idf) != 0.f) { atomicOr(err, 4); continue; }
+        dst[1] = src[1]; dst[2] = src[2];
     }
 }
 void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,

@@ -135,7 +135,8 @@ int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float*
  * first frame of window i; each window spans T_obs+T_pred consecutive frames; slot = rank of the id among the
  * window's sorted unique ids (np.unique semantics, 0 included when padding exists).  Outputs
  * dev_past [n_windows, T_obs, mno, 3], dev_fut [n_windows, T_pred, mno, 3].  Returns DESIRE_ERR_ARG where the
- * reference raises IndexError (:227).  Synchronises the stream (error word read-back). */
+ * reference raises IndexError (:227: more unique ids than slots) or ValueError (:224-229: an id twice in one frame).
+ * Synchronises the stream (error word read-back). */
 int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
                          const int32_t* host_starts, int32_t n_windows, float* dev_past, float* dev_fut, void* stream);
 /* N3: bivariate-Gaussian head of sample() (model/model.py:552-565,595-611,661-669): dev_params [n,5] raw head
