@@ -112,6 +112,23 @@ def main():
         for u, v in zip(a, b):
             assert u.dtype == v.dtype and u.shape == v.shape and np.array_equal(u, v), (it, kw, u.shape, v.shape)
         same += 1
+    # on-disk interchange: the pickle desire_amd.formats.write_cpkl produces, read by the REFERENCE's load_preprocessed / next_batch
+    from desire_amd.formats import write_cpkl
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "loader_bookstore6_T8.npz"))
+    tmp = tempfile.mkdtemp(prefix="desire_fuzz_")
+    try:
+        pk = os.path.join(tmp, "trajectories.cpkl")
+        write_cpkl(pk, [g["data0"]], [g["frame_list0"].tolist()], [g["num_obj0"].tolist()])
+        rdl = object.__new__(ref.DataLoader)                  # (its __init__ always re-preprocesses and overwrites the pickle)
+        rdl.batch_size, rdl.seq_length, rdl.max_num_obj = 4, 8, 32
+        with contextlib.redirect_stdout(io.StringIO()):
+            rdl.load_preprocessed(pk)
+            rdl.reset_batch_pointer()
+            x, y, _ = rdl.next_batch(random_update=False)
+        assert np.array_equal(np.stack(x), g["x"][0]) and np.array_equal(np.stack(y), g["y"][0]) and rdl.num_batches == int(g["num_batches"])
+        print("reference loader reads the pickle written by desire_amd.formats.write_cpkl: batches identical")
+    finally:
+        shutil.rmtree(tmp)
     print("loader fuzz: %d cases identical, %d raised the same exception type in both, %d where the reference never returns "
           "(video shorter than one window) and ours does" % (same, raised, hung))
     return 0
