@@ -68,3 +68,44 @@ def test_null_arguments_are_refused_not_dereferenced():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
     assert "null sweep ok" in p.stdout
+
+
+def test_destroy_returns_the_device_memory():
+    """Handles own their workspace, packed weights, training buffers and captured graphs: create / use / destroy in a loop
+    must not grow the device footprint."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from desire_amd import _lib
+    from desire_amd.spec import init_weights
+    from tests.helpers import make_case, small_dims
+    d = small_dims(n_scenes=4, K=4)
+    w = init_weights(d, 0)
+    past, fut, eps, grids, gos = make_case(d, seed=1)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+
+    def cycle(train, bf16):
+        h = _lib.Handle(d.replace(bf16=bf16))
+        h.set_weights(w)
+        if train:
+            h.set_training(True)
+        h.set_scene_grids(g.data_ptr(), gos)
+        h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+        if train:
+            h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+            h.adam_step(1e-4)
+        torch.cuda.synchronize()
+        h.close()
+
+    for args in ((False, 0), (True, 0), (False, 1)):
+        cycle(*args)                                         # first use of each mode: runtime-side one-off allocations
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(24):
+        cycle(i % 3 == 1, int(i % 3 == 2))
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 << 20, (free0 - free1) / 2**20
