@@ -660,7 +660,9 @@ void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStrea
 // the two single-channel ends of the stack (deconv4: Lg = d(xhat-conv) [n,32,32], S = d3 [n,16,16,32];
 // conv1: Lg = vae_in [n,32,32], S = d(conv1 output) [n,16,16,32]):  dW[tap][c] = sum_{n,p} Lg[n, 2p+k-1] * S[n,p,c]
 __global__ __launch_bounds__(256) void k_w1ch_grad(const float* __restrict__ Lg, const float* __restrict__ S, int n, float* __restrict__ partial) {
-    __shared__ float lg[32 * 32];
+    // the 32x32 image sits in LDS with a one-pixel zero border ([35][40], image at +1,+1): no bounds tests, and the five taps of
+    // a row come from two aligned 16-byte reads instead of five scalar ones (the kernel is LDS-instruction bound)
+    __shared__ __attribute__((aligned(16))) float lg[36 * 40];
     __shared__ float red[8][25 * 32 + 1];
     const int tid = threadIdx.x, c = tid & 31, pg = tid >> 5;
     const int per = (n + gridDim.x - 1) / gridDim.x;
@@ -668,23 +670,26 @@ __global__ __launch_bounds__(256) void k_w1ch_grad(const float* __restrict__ Lg,
     float acc[25];
 #pragma unroll
     for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+    for (int i = tid; i < 36 * 40; i += 256) lg[i] = 0.f;
     for (int smp = lo; smp < hi; ++smp) {
         __syncthreads();
-        for (int i = tid; i < 1024; i += 256) lg[i] = Lg[(size_t)smp * 1024 + i];
+        for (int i = tid; i < 1024; i += 256) lg[((i >> 5) + 1) * 40 + (i & 31) + 1] = Lg[(size_t)smp * 1024 + i];
         __syncthreads();
         for (int p = pg; p < 256; p += 8) {
             const float sv = S[((size_t)smp * 256 + p) * 32 + c];
             const int py = p >> 4, px = p & 15;
+            const int base = (2 * px) & ~3;                  // padded column of tap kx = 2 px + kx; its 8-float aligned window
+            const bool odd = px & 1;                         // 2 px - base = 0 (even px) or 2 (odd px); uniform in the wave
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
-                const int qy = 2 * py + ky - 1;
-                if (qy < 0 || qy >= 32) continue;
-#pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int qx = 2 * px + kx - 1;
-                    if (qx < 0 || qx >= 32) continue;
-                    acc[ky * 5 + kx] = fmaf(lg[qy * 32 + qx], sv, acc[ky * 5 + kx]);
-                }
+                const float* row = lg + (2 * py + ky) * 40 + base;
+                const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+                const float t0 = odd ? v0.z : v0.x, t1 = odd ? v0.w : v0.y, t2 = odd ? v1.x : v0.z, t3 = odd ? v1.y : v0.w, t4 = odd ? v1.z : v1.x;
+                acc[ky * 5 + 0] = fmaf(t0, sv, acc[ky * 5 + 0]);
+                acc[ky * 5 + 1] = fmaf(t1, sv, acc[ky * 5 + 1]);
+                acc[ky * 5 + 2] = fmaf(t2, sv, acc[ky * 5 + 2]);
+                acc[ky * 5 + 3] = fmaf(t3, sv, acc[ky * 5 + 3]);
+                acc[ky * 5 + 4] = fmaf(t4, sv, acc[ky * 5 + 4]);
             }
         }
     }
