@@ -22,27 +22,34 @@
 // conv1 (VALU): one workgroup per agent
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DS_WG) void k_conv1(ConvArgs a) {
-    __shared__ float in_s[32 * 32];
-    __shared__ float w_s[25 * 32];
+    // image with a one-pixel zero border ([35][40], image at +1,+1): no bounds tests, the five taps of a row come from two
+    // aligned 16-byte LDS reads; the lane's 25 weights (its output channel) live in registers
+    __shared__ __attribute__((aligned(16))) float in_s[36 * 40];
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 1024; i += DS_WG) in_s[i] = a.in[(size_t)n * 1024 + i];
-    for (int i = tid; i < 800; i += DS_WG) w_s[i] = a.w_raw[i];      // [ky][kx][0][co]
+    for (int i = tid; i < 36 * 40; i += DS_WG) in_s[i] = 0.f;
     __syncthreads();
+    for (int i = tid; i < 1024; i += DS_WG) in_s[((i >> 5) + 1) * 40 + (i & 31) + 1] = a.in[(size_t)n * 1024 + i];
     const int co = tid & 31, pg = tid >> 5;
+    float wr[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) wr[k] = a.w_raw[k * 32 + co];       // [ky][kx][0][co]
+    __syncthreads();
     const float sc = a.scale[co], sh = a.shift[co];
     for (int p = pg; p < 256; p += 8) {
         const int oy = p >> 4, ox = p & 15;
+        const int base = (2 * ox) & ~3;
+        const bool odd = ox & 1;                                      // uniform in the wave (one pixel per wave)
         float acc = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky) {
-            const int iy = 2 * oy + ky - 1;
-            if (iy < 0 || iy >= 32) continue;
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int ix = 2 * ox + kx - 1;
-                if (ix < 0 || ix >= 32) continue;
-                acc = fmaf(in_s[iy * 32 + ix], w_s[(ky * 5 + kx) * 32 + co], acc);
-            }
+            const float* row = in_s + (2 * oy + ky) * 40 + base;
+            const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+            const float t0 = odd ? v0.z : v0.x, t1 = odd ? v0.w : v0.y, t2 = odd ? v1.x : v0.z, t3 = odd ? v1.y : v0.w, t4 = odd ? v1.z : v1.x;
+            acc = fmaf(t0, wr[ky * 5 + 0], acc);                      // same tap order as before: ky outer, kx inner
+            acc = fmaf(t1, wr[ky * 5 + 1], acc);
+            acc = fmaf(t2, wr[ky * 5 + 2], acc);
+            acc = fmaf(t3, wr[ky * 5 + 3], acc);
+            acc = fmaf(t4, wr[ky * 5 + 4], acc);
         }
         { const size_t ix = ((size_t)n * 256 + p) * 32 + co; a.out[ix] = conv_epilogue(acc, sc, sh, a.mode, false, a.yprev, ix); }
     }
