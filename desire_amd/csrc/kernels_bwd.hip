@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
         if (more) gload(m0 + 32);
         const float* ap = &As[buf][hi * BK + wk * 64 + 2 * c];
         const float* gp = &Gs[buf][hi * BN + wn * 64 + 2 * c];
+        if (bk + wk * 64 < a.Kd && bn + wn * 64 < a.N)      // a wave whose whole strip lies past Kd / N has only zeros to multiply
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const float2 av = *reinterpret_cast<const float2*>(ap + p * 2 * BK);
