@@ -70,6 +70,9 @@ class DESIREModel(object):
         self._weights = weights
         self._seed = seed
         self._handles: Dict[Tuple[int, int], _lib.Handle] = {}
+        self._trained = None                 # the handle train_step updates (weights + Adam moments live on the device)
+        self._version = 0                    # bumped by every optimiser step
+        self._weights_ver = 0                # version self._weights (host copy) corresponds to
         self._grids = None
         self._grid_of_scene = None
         # reference attribute names (model/model.py:62-75)
@@ -89,8 +92,16 @@ class DESIREModel(object):
             if self._weights is None:
                 self._weights = init_weights(d, self._seed)
             h.set_weights(self._weights)
+            h._wver = getattr(self, "_version", 0) if getattr(self, "_weights_ver", 0) == getattr(self, "_version", 0) else -1
             self._handles[key] = h
-        return self._handles[key]
+        h = self._handles[key]
+        trained = getattr(self, "_trained", None)
+        if trained is not None and h is not trained and getattr(h, "_wver", 0) != self._version:
+            # the optimiser updates the weights inside the handle it trains on; any other handle (another batch size, the
+            # prior path) gets the current values before it runs
+            h.set_weights(self.sync_weights())
+            h._wver = self._version
+        return h
 
     def set_scene_grids(self, grids: np.ndarray, grid_of_scene: Sequence[int]) -> None:
         """grids [n_grids, Gh, Gw, C] scene features rho(I); grid_of_scene[i] = grid index of window i."""
@@ -99,6 +110,10 @@ class DESIREModel(object):
 
     def _pad_windows(self, batch: Sequence[np.ndarray], mno: int):
         x = np.stack([np.asarray(b) for b in batch]).astype(np.float32)      # [n, T, MNO, 3]
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("windows must be [T, MNO, 3] arrays (id, x, y), got %s" % (x.shape[1:],))
+        if x.shape[2] > mno:
+            raise ValueError("windows hold %d object slots, the model was built for max_num_obj=%d" % (x.shape[2], self.max_num_obj))
         if x.shape[2] < mno:
             x = np.concatenate([x, np.zeros(x.shape[:2] + (mno - x.shape[2], 3), np.float32)], axis=2)
         return self.torch.as_tensor(np.ascontiguousarray(x), device=self.device)
@@ -155,6 +170,11 @@ class DESIREModel(object):
         evaluated BEFORE the update (what `sess.run([cost, train_op])` would have returned)."""
         from .dist import allreduce_mean_
         h = self._handle(len(x_batch), True)
+        prev = getattr(self, "_trained", None)
+        if prev is not None and prev is not h:
+            raise ValueError("train_step was called with %d windows after training with %d: the Adam moments live in the handle "
+                             "of one batch size (keep the batch size fixed, as DataLoader.next_batch does)"
+                             % (len(x_batch), prev.dims.n_scenes))
         if not getattr(h, "_training_on", False):
             h.set_training(True)
             h._training_on = True
@@ -169,14 +189,16 @@ class DESIREModel(object):
         terms = h.train_loss(fut.data_ptr(), stream)
         h.adam_step(self.learning_rate, stream=stream)
         self._trained = h
+        self._version = getattr(self, "_version", 0) + 1
+        h._wver = self._version
         return terms
 
     def sync_weights(self) -> Dict[str, np.ndarray]:
         """Pull the trained weights back from the device; other handles (batch sizes / prior path) are rebuilt lazily."""
         h = getattr(self, "_trained", None)
-        if h is not None:
+        if h is not None and getattr(self, "_weights_ver", 0) != self._version:
             self._weights = {k: h.get_weight(k, np.shape(v)) for k, v in self._weights.items()}
-            self._handles = {k: v for k, v in self._handles.items() if v is h}
+            self._weights_ver = self._version
         return self._weights
 
     def forward_from_video(self, frames, starts: Sequence[int], posterior: bool = True, eps=None, seed: int = 0):

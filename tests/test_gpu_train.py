@@ -340,3 +340,42 @@ def test_gradients_are_bitwise_reproducible():
     assert float(runs[0].abs().max()) > 0
     for r in runs[1:]:
         assert torch.equal(runs[0], r)
+
+
+def test_other_batch_sizes_see_the_trained_weights(tmp_path):
+    """The optimiser updates the weights inside ONE handle (its batch size); a forward with another number of windows, or the
+    prior path, must run on the current values -- also after further training steps -- and a changed training batch size is
+    refused (the Adam moments would be lost)."""
+    import torch
+    from types import SimpleNamespace
+    from desire_amd.model import DESIREModel
+    args = SimpleNamespace(seq_length=4, pred_length=5, stride=1, e_dim=16, d_dim=64, rnn_size=512, num_layers=1, batch_size=2,
+                           latent_size=64, max_num_obj=8, learning_rate=0.002, grad_clip=10.0, neighborhood_size=256, grid_size=4,
+                           num_samples=2)
+    rng = np.random.default_rng(0)
+    def windows(n, T):
+        w = np.zeros((n, T, 8, 3), np.float64)
+        w[:, :, :5, 0] = np.arange(1, 6)
+        w[:, :, :5, 1:] = rng.uniform(200, 1200, (n, 1, 5, 2)) + np.cumsum(rng.normal(0, 4, (n, T, 5, 2)), 1)
+        return list(w)
+    x2, y2, x3, y3 = windows(2, 4), windows(2, 5), windows(3, 4), windows(3, 5)
+    m = DESIREModel(args, seed=3)
+    Y_before, _ = m.forward(x3, y3, seed=1)
+    Y_before = Y_before.cpu().numpy().copy()
+    for _ in range(3):
+        m.train_step(x2, y2, seed=2)
+    Y_after, _ = m.forward(x3, y3, seed=1)
+    Y_after = Y_after.cpu().numpy().copy()
+    assert np.abs(Y_after - Y_before).max() > 1e-6                      # the 3-window handle was refreshed
+    m.save(str(tmp_path / "w.npz"))
+    Y_restored, _ = DESIREModel.restore(args, str(tmp_path / "w.npz")).forward(x3, y3, seed=1)
+    np.testing.assert_array_equal(Y_after, Y_restored.cpu().numpy())
+    m.train_step(x2, y2, seed=2)
+    Y_again, _ = m.forward(x3, y3, seed=1)
+    assert np.abs(Y_again.cpu().numpy() - Y_after).max() > 1e-7         # ... and again after the next step
+    Yp, _ = m.forward(x3, None, seed=1)                                  # prior path: its own handle, current weights
+    assert bool(torch.isfinite(Yp).all())
+    with pytest.raises(ValueError, match="Adam moments"):
+        m.train_step(x3, y3, seed=2)
+    with pytest.raises(ValueError, match="object slots"):
+        m.forward([np.zeros((4, 9, 3))] * 2, None)
