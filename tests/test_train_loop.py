@@ -132,3 +132,25 @@ def test_training_on_a_real_sdd_slice_improves_best_of_k_ade(tmp_path):
           % (losses[0], losses[-1], np.round(before, 4), np.round(after, 4)))
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])
     assert after[0] < before[0] and after[2] < before[2]             # mean-of-K and best-of-K ADE both improve
+
+
+@pytest.mark.gpu
+def test_command_line_entry_on_a_csv_directory(tmp_path, golden_dir):
+    """`python -m desire_amd.train --data_dir ...` end to end: the reference's directory layout (data/<scene>/<video>/
+    annotations_processed.csv), preprocessing, the loop, the log lines, a checkpoint and config.pkl."""
+    import subprocess
+    import sys
+    g = np.load(os.path.join(golden_dir, "loader_bookstore6_T8.npz"))
+    vid = tmp_path / "data" / "bookstore" / "video6"
+    vid.mkdir(parents=True)
+    np.savetxt(vid / "annotations_processed.csv", g["csv"].astype(np.float64), delimiter=",", fmt="%.1f")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "desire_amd.train", "--data_dir", str(tmp_path / "data") + "/", "--save_dir", str(tmp_path / "save"),
+           "--batch_size", "4", "--seq_length", "8", "--pred_length", "12", "--max_num_obj", "32", "--d_dim", "64", "--latent_size", "64",
+           "--num_samples", "3", "--num_epochs", "3", "--save_every", "4", "--learning_rate", "0.0005",
+           "--neighborhood_size", "64"]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert p.stdout.count("train_loss") == 6 and "model saved to" in p.stdout      # 160 frames -> 2 batches per epoch (:175-184)
+    assert os.path.exists(tmp_path / "save" / "config.pkl") and os.path.exists(tmp_path / "save" / "social_model-4.npz")
+    assert os.path.exists(tmp_path / "data" / "trajectories.cpkl")       # the reference's preprocessed pickle, written on first use
