@@ -1,7 +1,8 @@
 """TRAINING ORACLE (test infrastructure, CPU only): the frozen spec of DESIGN.md sections 2 and 8 restated in
 PyTorch so that autograd provides the reference gradients the HIP backward is checked against.
 
-Only tests/ may import this module.  Forward values are pinned against oracle/desire_oracle.py (numpy) in
+Only tests/ (incl. the tests/fuzz_*.py sweeps) and bench.py's cpu_baseline leg (which times its float32, no-grad forward as
+the batched CPU restatement) may import this module.  Forward values are pinned against oracle/desire_oracle.py (numpy) in
 tests/test_train_oracle.py; gradients are then whatever autograd derives from that same graph.
 
 Loss (the reference's `cost` is recon + kld with the id==0 masking rule, model/model.py:339-376; its recon term has
