@@ -150,6 +150,10 @@ def main():
     ap.add_argument("--nb", type=float, default=0.15,
                     help="social window (normalised units, square).  0.15 keeps every bin of every tile populated (the dense case the "
                          "headline is quoted on); the reference's flags -- 32 px on SDD frames -- are about 0.023, where most bins are empty")
+    ap.add_argument("--compact", action="store_true",
+                    help="row-compacted social pooling (DESIRE_IOC_VARIANT=8, fp32, groups of up to 32 agents): the pooling MFMAs run "
+                         "on the rows that have a neighbour in the bin only; NOT the headline (fewer flops are executed than the "
+                         "dense formula credits)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
                          "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")
@@ -162,6 +166,8 @@ def main():
         # pooled operand at 128 windows), so it stays at the size its profile was taken at
         a.windows = 128 if (a.train or a.bf16 or a.shard == "agents") else 512
 
+    if a.compact:
+        os.environ["DESIRE_IOC_VARIANT"] = "8"
     import torch
     import torch.distributed as dist
     from desire_amd import _lib
@@ -315,6 +321,10 @@ def main():
                          "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / peak},
             "kernel_ms": kern_ms,
         }
+        if a.compact:
+            out["config"]["workload"] += "; row-compacted pooling (opt-in)"
+            out["roofline"]["note"] = ("row-compacted pooling executes fewer flops than the dense formula credits: achieved / frac are "
+                                       "dense-equivalent figures, not utilisation")
         if a.nb != 0.15:      # sparse windows: bins that are empty across a whole tile are skipped, so fewer flops are EXECUTED
             out["config"]["workload"] += "; social window %.3g (non-default: sparse bins)" % a.nb
             out["roofline"]["note"] = ("achieved / frac credit the dense algorithm's flops; with --nb below 0.15 part of the social "

@@ -356,6 +356,20 @@ int desire_pack_all(desire_ctx* h) {
         }
         bad |= up("ioc/Wsoc", all);
     }
+    {   // the same weights for the row-compacted pooling (16x16x4 MFMA tiles, kernels_rnn.hip k_ioc<..., CP>): per bin, per
+        // 16-column tile ct and 16-k group g, lane (col = lane&15, q = lane>>4) holds W_b[16g + 4q + 0..3][16ct + col]
+        const auto& ws = hw["ioc/social_fc/w"];
+        const int T16 = H / 16;
+        std::vector<float> all((size_t)B * H * H);
+        for (int b = 0; b < B; ++b)
+            for (int ct = 0; ct < T16; ++ct)
+                for (int g = 0; g < T16; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            all[((((size_t)b * T16 + ct) * T16 + g) * 64 + lane) * 4 + j] =
+                                ws[((size_t)b * H + 16 * g + 4 * (lane >> 4) + j) * H + 16 * ct + (lane & 15)];
+        bad |= up("ioc/Wsoc_c", all);
+    }
     bad |= up("ioc/soc_b", hw["ioc/social_fc/b"]);
     bad |= up("ioc/score_w", hw["ioc/score/w"]); bad |= up("ioc/score_b", hw["ioc/score/b"]);
     bad |= up("ioc/Wreg", pack_b(H, 2 * d.T_pred, rowmajor(hw["ioc/reg/w"], 2 * d.T_pred, 0)));
@@ -562,7 +576,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
     a.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
     a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b");
-    a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b");
+    a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b"); a.Wsoc_c = D4(h, "ioc/Wsoc_c");
     a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;

@@ -86,6 +86,7 @@ struct IocArgs {
     const float* grids; const int32_t* grid_of_scene;
     const float* w_vel; const float* b_vel;                // [2,E_v], [E_v]
     const float4* Wsoc; const float* b_soc;                // packed per bin: [B][NT][H/8][64]
+    const float4* Wsoc_c;                                  // same weights in 16x16x4 fragment order (row-compacted pooling, variant 8)
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c;   // K = E+H
     const float* w_score; const float* b_score;            // [H], [1]
     const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed

@@ -298,7 +298,13 @@ __device__ __forceinline__ int ffs_(unsigned long long m) { return __ffsll((long
 #else
 #define TICK(k)
 #endif
-template <int H, int EV, int C, int TM, bool TRAIN>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// CP ("compact pooling", opt-in: DESIRE_IOC_VARIANT=8, TM = 32): only the rows that have a neighbour in bin b are built,
+// packed into the first rows of the operand tile, contracted as 16-row v_mfma_f32_16x16x4_f32 tiles and added into the rows
+// they belong to -- at the bench's density (about a quarter of the rows per bin) that halves the pooling MFMAs and builds a
+// quarter of the operand rows.  Per-bin partial sums are added in ascending bin order (not one running accumulator), so the
+// result differs from the default form by fp32 rounding only.
+template <int H, int EV, int C, int TM, bool TRAIN, bool CP = false>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2) ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -321,6 +327,8 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     float* red = wv + 3 * EV;                           // [NT][TM] score reduction
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);  // [TM]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                 // [2] bins that hold a neighbour anywhere in the tile
+    unsigned* rowbits = occ + 2;                                           // CP: [B] rows of the tile with a neighbour in bin b
+    unsigned* rowlist = rowbits + 36;                                      // CP: [2][TM/4] packed u8: tile row of operand row s
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
@@ -414,6 +422,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         }
         for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
         if (tid < 2) occ[tid] = 0;
+        if (CP && tid < B) rowbits[tid] = 0;
         __syncthreads();
         const float* rh_lane = AB + (mt * 32 + (lane & 31)) * LDB + 4 * (lane >> 5);     // r*h operand (AB buffer 0)
         float* my_rh = AB + (mt * 32 + 4 * (lane >> 5)) * LDB + col;
@@ -447,11 +456,103 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
                                                    a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) { atomicOr(&masks[r8 * B + b], (mask_t)1 << j); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
+                    if (b >= 0) {
+                        atomicOr(&masks[r8 * B + b], (mask_t)1 << j); atomicOr(&occ[b >> 5], 1u << (b & 31));
+                        if (CP) atomicOr(&rowbits[b], 1u << r8);
+                    }
+                }
+                if (CP) {                                           // e_r columns double as the accumulation tile of the bin loop
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        *reinterpret_cast<float4*>(XH + r8 * LDX + EV + C + q8 * 4 + c * 4 * TPR) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             __syncthreads();
             TICK(1)
+            // ---- P2/P3 (compact form) ----
+            if constexpr (CP) {
+                unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+                om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                constexpr int T16 = H / 16;                          // 16-column tiles per row / 16-k groups per contraction
+                // operand row s of bin b = the s-th tile row that has a neighbour there (ascending rows)
+                auto build_c = [&](int b, int buf) {
+                    const unsigned rb = rowbits[b];
+                    if (!((rb >> r8) & 1u)) return;
+                    const int slot = __popc(rb & ((1u << r8) - 1u));
+                    float* ab = AB + buf * TM * LDB + slot * LDB;
+                    mask_t m2 = masks[r8 * B + b];
+                    float4 sacc[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) sacc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    while (m2) {
+                        const int j = ffs_(m2) - 1;
+                        m2 &= m2 - 1;
+                        const float* src = XH + (grp_base + j) * LDX + E + q8 * 4;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
+                            sacc[c].x += v.x; sacc[c].y += v.y; sacc[c].z += v.z; sacc[c].w += v.w;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(ab + q8 * 4 + c * 4 * TPR) = sacc[c];
+                    if (q8 == 0) reinterpret_cast<unsigned char*>(rowlist + buf * (TM / 4))[slot] = (unsigned char)r8;
+                };
+                int buf = 0;
+                if (om) build_c(ffs_(om) - 1, 0);
+                __syncthreads();
+                while (om) {
+                    const int b = ffs_(om) - 1;
+                    om &= om - 1;
+                    // this wave's two 16-column tiles of W_b, all T16 k-groups: requested now, consumed after the next build
+                    const float4* w0 = a.Wsoc_c + ((size_t)(b * T16 + 2 * cb) * T16) * 64 + lane;
+                    float4 wf[2][T16];
+                    if (active) {
+#pragma unroll
+                        for (int g = 0; g < T16; ++g) { wf[0][g] = w0[g * 64]; wf[1][g] = w0[(T16 + g) * 64]; }
+                    }
+                    if (om) build_c(ffs_(om) - 1, buf ^ 1);
+                    const int nrows = __popc(__builtin_amdgcn_readfirstlane((int)rowbits[b]));
+                    if (active) {
+                        for (int c16 = 0; c16 * 16 < nrows; ++c16) {
+                            f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                            const float* ap = AB + buf * TM * LDB + (16 * c16 + (lane & 15)) * LDB + 4 * (lane >> 4);
+#pragma unroll
+                            for (int g = 0; g < T16; ++g) {
+                                const float4 av = *reinterpret_cast<const float4*>(ap + 16 * g);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wf[0][g].x, a0, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wf[1][g].x, a1, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wf[0][g].y, a0, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wf[1][g].y, a1, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wf[0][g].z, a0, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wf[1][g].z, a1, 0, 0, 0);
+                                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wf[0][g].w, a0, 0, 0, 0);
+                                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wf[1][g].w, a1, 0, 0, 0);
+                            }
+                            // accumulator element i of a lane = operand row 16 c16 + 4 (lane>>4) + i, column (lane&15) of the tile
+                            const unsigned rl4 = rowlist[buf * (TM / 4) + 4 * c16 + (lane >> 4)];
+                            float* ex = XH + EV + C + cb * 32 + (lane & 15);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (16 * c16 + 4 * (lane >> 4) + i < nrows) {
+                                    float* dst = ex + ((rl4 >> (8 * i)) & 0xffu) * LDX;
+                                    dst[0] += a0[i];
+                                    dst[16] += a1[i];
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    buf ^= 1;
+                }
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* e = my_x + ((i & 3) + 8 * (i >> 2)) * LDX + EV + C;
+                        *e = fmaxf(*e + bso, 0.f);
+                    }
+                }
+            } else
             // ---- P2/P3: social pooling -> e_r, over the bins that hold a neighbour somewhere in this tile only
             //      (an empty bin's pooled operand is all zeros: skipping it drops exact-zero products, and on real
             //      tracks most of the window is empty).  build(next) and the contraction of the current bin sit between
@@ -543,6 +644,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             }
             for (int i = tid; i < TM * B; i += NTHR) masks[i] = 0;
             if (tid < 2) occ[tid] = 0;
+            if (CP && tid < B) rowbits[tid] = 0;
             __syncthreads();
             TICK(8)
         }
@@ -588,7 +690,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 static size_t ioc_lds_bytes(const IocArgs& a, int TM) {
     const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G;
     size_t f = (size_t)(TM + 1) * LDX + 2 * TM * LDB + (size_t)TM * B * (TM == 32 ? 1 : 2) + TM * 4 + 3 * EV + NT * TM;
-    return f * sizeof(float) + TM + 64;
+    return f * sizeof(float) + TM + 64 + 256;              // + occupancy words, CP row bitmaps / row lists
 }
 template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
@@ -599,6 +701,13 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
         }
         return;
+    }
+    if constexpr (TM == 32 && H <= 128) {
+        if (a.variant == 8) {                                  // opt-in: row-compacted pooling (see k_ioc)
+            allow_big_lds(k_ioc<H, 16, 32, 32, false, true>);
+            hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+            return;
+        }
     }
     allow_big_lds(k_ioc<H, 16, 32, TM, false>);
     hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, false>), grid, block, ioc_lds_bytes(a, TM), s, a);

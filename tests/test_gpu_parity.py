@@ -584,3 +584,40 @@ def test_per_object_batch_norm_is_fp32_inference_only(torch_cuda):
     h.set_weights(init_weights(d, 0))
     with pytest.raises(_lib.DesireError):
         h.set_training(True)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                              # dense windows, 32-agent groups
+    dict(mno=16, n_scenes=3, K=5),                       # two groups per tile, ragged last tile
+    dict(mno=8, n_scenes=5, K=3),
+    dict(H=64, T_pred=7, K=3),
+    dict(nb_w=0.04, nb_h=0.04, K=2),                     # sparse: most bins skipped, the rest hold one or two rows
+    dict(grid_size=2, nb_w=0.6, nb_h=0.6, K=2),          # 4 crowded bins: more than 16 rows per bin -> two operand chunks
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),          # 36 bins
+    dict(grid_size=4, bin_mode=1, nb_w=0.45, nb_h=0.04, K=2),
+    dict(iters=2, K=2),
+    dict(mno=1, n_scenes=3, K=2, n_absent=0),
+])
+def test_row_compacted_pooling_form(torch_cuda, kw, monkeypatch):
+    """DESIRE_IOC_VARIANT=8: the pooling contraction runs on the rows that have a neighbour in the bin only (packed into
+    16-row MFMA tiles, results added back into their rows).  Same function as the default form up to fp32 summation order:
+    checked against the oracle and against the default form."""
+    kw = dict(kw)
+    n_absent = kw.pop("n_absent", 3)
+    d = small_dims(**kw)
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos = make_case(d, seed=4, n_absent=min(n_absent, d.mno - 1))
+    from desire_amd import _lib
+    tab = None
+    if d.bin_mode == 1:
+        tab = _lib.Handle(d).bin_table()
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos, **({"bin_tab": tab} if tab is not None else {}))
+    _, Yd, sd = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    monkeypatch.setenv("DESIRE_IOC_VARIANT", "8")
+    _, Yc, sc = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    if d.iters == 1:
+        assert np.abs(Yc - ref["Y"]).max() < TOL_Y, np.abs(Yc - ref["Y"]).max()
+        assert np.abs(sc - ref["score"]).max() < 5e-3
+        assert np.abs(Yc - Yd).max() < 2e-5 and np.abs(sc - sd).max() < 2e-4
+    else:                                                # a second pass re-bins from refined positions (bin-edge caveat)
+        assert np.abs(Yc - Yd).mean() < 1e-3
