@@ -481,9 +481,18 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     const int slot = __popc(rb & ((1u << r8) - 1u));
                     float* ab = AB + buf * TM * LDB + slot * LDB;
                     mask_t m2 = masks[r8 * B + b];
+                    // first two neighbours branch-free (a missing second one reads the all-zero row TM), the rare rest in a loop
+                    const int o0 = (grp_base + ffs_(m2) - 1) * LDX;
+                    m2 &= m2 - 1;
+                    const int o1 = m2 ? (grp_base + ffs_(m2) - 1) * LDX : TM * LDX;
+                    m2 &= m2 - 1;
                     float4 sacc[NCH];
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) sacc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int c = 0; c < NCH; ++c) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(XH + o0 + E + q8 * 4 + c * 4 * TPR);
+                        const float4 v1 = *reinterpret_cast<const float4*>(XH + o1 + E + q8 * 4 + c * 4 * TPR);
+                        sacc[c].x = v0.x + v1.x; sacc[c].y = v0.y + v1.y; sacc[c].z = v0.z + v1.z; sacc[c].w = v0.w + v1.w;
+                    }
                     while (m2) {
                         const int j = ffs_(m2) - 1;
                         m2 &= m2 - 1;
