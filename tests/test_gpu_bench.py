@@ -51,3 +51,14 @@ def test_two_ranks_on_one_gpu(extra):
     if not extra:
         assert o["config"]["rows_per_gpu"] == 8 * 32 * 20
         assert abs(o["value"] - 2 * o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
+
+
+def test_compact_flag_is_labelled():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--windows", "16", "--compact", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = _last_json(p.stdout)
+    assert "row-compacted" in o["config"]["workload"] and "note" in o["roofline"] and o["value"] > 0
