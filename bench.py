@@ -98,8 +98,30 @@ def cpu_baseline(d_full, seed):
     w = init_weights(d, seed)
     past, fut, eps, grids, gos = make_case(d, seed=seed + 1)
     t0 = time.perf_counter()
-    O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
+    ref = O.forward(tr(past), tr(fut), eps, grids, gos, w, d)
     dt = time.perf_counter() - t0
+    # accuracy gate of the metric: the HIP path on the SAME 4 windows against that oracle run.  Sample
+    # generation end to end; the IOC pass from the oracle's own Y0, so that a neighbour sitting within 1e-7 of a bin edge
+    # cannot land in different bins on the two sides.
+    from desire_amd import _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tt_ = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+    hh = _lib.Handle(d)
+    hh.set_weights(w)
+    p_t, f_t, e_t, g_t = tt_(past), tt_(fut), tt_(eps), tt_(grids)
+    hh.set_scene_grids(g_t.data_ptr(), gos)
+    Yg = torch.zeros((d.R, d.T_pred, 2), device=dev); sg = torch.zeros((d.R,), device=dev)
+    hh.encode(p_t.data_ptr(), f_t.data_ptr())
+    hh.sample(e_t.data_ptr(), Yg.data_ptr())
+    torch.cuda.synchronize()
+    e_y0 = float(np.abs(Yg.cpu().numpy() - ref["Y0"]).max())
+    Yg.copy_(tt_(ref["Y0"].astype(np.float32)))
+    hh.ioc_refine(Yg.data_ptr(), sg.data_ptr())
+    torch.cuda.synchronize()
+    dY = Yg.cpu().numpy() - ref["Y"]
+    accuracy = {"max_abs_err_Y0": e_y0, "max_abs_err_Y": float(np.abs(dY).max()), "ade_vs_oracle": float(np.sqrt((dY ** 2).sum(-1)).mean()),
+                "gate": 1e-3, "units": "normalised frame coordinates", "sample": "%d samples (4 windows), HIP path vs oracle/desire_oracle.py" % d.R}
+    hh.close()
     # the reference's own structure (model/model.py:211): one object at a time, batch dimension 1, for the
     # sample-generation stages (the IOC stage needs the whole group and stays batched above)
     d1 = d.replace(n_scenes=1, mno=1, iters=1)
@@ -118,7 +140,7 @@ def cpu_baseline(d_full, seed):
         xz = O.softmax(O.relu(xh @ w["mask_fc/w"] + w["mask_fc/b"])) * Hr
         O.decode(xz, Hr, O.rows_from_agents(pn[-1], d1), w, d1)
     dt1 = (time.perf_counter() - t1) / n_obj
-    return {"value": rt / tt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
+    return {"accuracy": accuracy, "value": rt / tt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
             "sample": "oracle/desire_torch.py forward (torch fp32, batched, %d threads: the fastest of 8..128) on %d windows = %d samples, %.1f s; "
                       "CPU restatement, not TF1 (reference graph does not build)" % (threads, rt // (d.K * d.mno), rt, tt),
             "numpy_oracle": {"value": d.R / dt, "unit": "agent-trajectory-samples/s",
@@ -331,6 +353,8 @@ def main():
                                        "contraction is skipped (exact zeros), so frac can exceed 1 and is not a utilisation figure")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.seed)
+            out["accuracy"] = out["cpu_baseline"].pop("accuracy")
+            assert out["accuracy"]["max_abs_err_Y0"] < 1e-3 and out["accuracy"]["max_abs_err_Y"] < 1e-3, out["accuracy"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -26,11 +26,12 @@ def test_default_contract_fields():
     assert p.returncode == 0, p.stderr[-2000:]
     o = _last_json(p.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "accuracy"):
         assert k in o, k
     assert o["n_gpus"] == 1 and o["steps"] == 2 and o["warmup"] == 1 and o["vs_baseline"] is None and o["scaling"] == "weak"
     r = o["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert o["accuracy"]["max_abs_err_Y"] < o["accuracy"]["gate"] == 1e-3 and o["accuracy"]["max_abs_err_Y0"] < 1e-3
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert abs(o["value"] - o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
