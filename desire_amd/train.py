@@ -21,7 +21,7 @@ import os
 import pickle
 import sys
 import time
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 

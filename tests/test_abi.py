@@ -5,7 +5,6 @@ import ctypes
 import os
 import re
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -270,7 +270,7 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
     import os
     torch = torch_cuda
     from desire_amd import _lib
-    from desire_amd.data_loader import DataLoader, window_to_slots
+    from desire_amd.data_loader import window_to_slots
     from oracle import desire_oracle as O
     g = np.load(os.path.join(golden_dir, "loader_bookstore6_T8.npz"))
     frames = g["data0"].astype(np.float32)                       # [160, 32, 3] preprocessed by the REFERENCE loader
