@@ -286,11 +286,18 @@ def main():
     fence()
     if not a.graph:                                  # per-kernel hipEvents are host-side records: not part of a replayed graph
         h.set_profiling(True)
+    # per-step device times for the median SURVEY.md D1 asks for: one event per step boundary on the launch stream (the
+    # records are asynchronous and sit between kernels that are already serialised on that stream)
+    ev_stream = side if a.graph else torch.cuda.current_stream()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record(ev_stream)
+    for i in range(a.steps):
         step()
+        marks[i + 1].record(ev_stream)
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     h.set_profiling(False)
     prof = h.get_profile()
     if world > 1:
@@ -326,7 +333,8 @@ def main():
         out = {
             "metric": "agent-trajectory-samples/sec (K=20, T_pred=40)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / a.steps * 1e3, "step_ms_median": step_ms[len(step_ms) // 2], "step_ms_min": step_ms[0],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 operands (IOC kernel), f32 accumulate/state; other kernels f32" if a.bf16 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SDD-like synthetic windows, 32 agent slots/window, K=20, "
                                    "T_obs=8/T_pred=40, H=128, L=128, fp32, posterior CVAE, IOC 1 refinement, "
