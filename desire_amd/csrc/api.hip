@@ -285,6 +285,19 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pk.begin(), pk.end());
         }
         bad |= up("ioc/WsT", all);
+        {   // the same transposed blocks in 16x16x4 fragment order (row-compacted dpool of k_ioc_bwd): per bin, 16-column tile
+            // ct, 16-k group g, lane (col = lane&15, q = lane>>4) holds WsT_b[16g + 4q + 0..3][16ct + col] = W_b[16ct + col][16g + 4q + ..]
+            const int T16 = H / 16;
+            std::vector<float> tc((size_t)B * H * H);
+            for (int b = 0; b < B; ++b)
+                for (int ct = 0; ct < T16; ++ct)
+                    for (int g = 0; g < T16; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j)
+                                tc[((((size_t)b * T16 + ct) * T16 + g) * 64 + lane) * 4 + j] =
+                                    ws[((size_t)b * H + 16 * ct + (lane & 15)) * H + 16 * g + 4 * (lane >> 4) + j];
+            bad |= up("ioc/WsT_c", tc);
+        }
     }
     if (d.bf16) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
         const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];

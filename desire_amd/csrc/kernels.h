@@ -188,6 +188,7 @@ struct IocBwdArgs {
     int R, K, mno, T, H, G; float nb_w, nb_h;
     const float4* WrT; const float4* WcT_h; const float4* WcT_er; const float4* WcT_ev;
     const float4* WgT_h; const float4* WgT_er; const float4* WgT_ev; const float4* WsT;
+    const float4* WsT_c;                                   // WsT in 16x16x4 fragment order (row-compacted dpool, 32-row tiles)
     float* dag; float* dac; float* rh; float* hprev; float* dpre_r; float* dpre_v; float* vel; float* pooled;
     float* dHx_rows;
     const float* bin_tab;

@@ -810,6 +810,7 @@ void launch_score_grad(const float* Y0, const float* fut, const float* score, co
 #ifndef IOC_BWD_OCC
 #define IOC_BWD_OCC 2
 #endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int TM> struct BwdMask { typedef unsigned long long type; };
 template <> struct BwdMask<32> { typedef unsigned type; };
 __device__ __forceinline__ int ffsm(unsigned m) { return __ffs((int)m); }
@@ -836,6 +837,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     float* wsc = dsc + TM;                    // [H]
     unsigned char* vld = reinterpret_cast<unsigned char*>(wsc + H);   // [32]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);            // [2] bins that hold a neighbour anywhere in the tile
+    unsigned* rowbits = occ + 2;                                      // CPB: [B] rows of the tile with a neighbour in bin b
+    unsigned char* rowlist = reinterpret_cast<unsigned char*>(rowbits + 36);   // CPB: per wave 32 bytes, packed row -> tile row
+    // CPB (32-row tiles): dpool_b is only ever gathered from rows that HAVE a neighbour in bin b -- contract those rows only,
+    // as 16-row v_mfma_f32_16x16x4_f32 tiles whose A rows are fetched through the row list (no packed copy needed)
+    constexpr bool CPB = (TM == 32) && (H <= 128);
     float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
@@ -889,6 +895,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         }
         for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
         if (tid < 2) occ[tid] = 0;
+        if (CPB && tid < B) rowbits[tid] = 0;
         auto load_hprev = [&]() {                                              // h_{t-1} tile -> A1's space
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {
                 const int r = i / (H >> 2), c4 = i - r * (H >> 2);
@@ -910,6 +917,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
                     atomicOr(&obs[(grp_base + j) * B + b], (mask_t)1 << my_slot);
                     atomicOr(&occ[b >> 5], 1u << (b & 31));
+                    if (CPB) atomicOr(&rowbits[b], 1u << r8);
                 }
             }
         }
@@ -1006,18 +1014,54 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 }
             }
             if (!live) continue;
-            f32x16 dpl = zero16();
-            mma1b(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
             float* dp = DP + buf * TM * LD1;
             buf ^= 1;
+            unsigned rb = 0;
+            if constexpr (CPB) {
+                constexpr int T16 = H / 16;
+                rb = (unsigned)__builtin_amdgcn_readfirstlane((int)rowbits[b]);
+                const int n = __popc(rb);
+                unsigned char* wrl = rowlist + w * 32;
+                if (lane < TM && ((rb >> lane) & 1u)) wrl[__popc(rb & ((1u << lane) - 1u))] = (unsigned char)lane;
+                const float4* w0 = a.WsT_c + ((size_t)(b * T16 + 2 * cb) * T16) * 64 + lane;
+                for (int c16 = 0; c16 * 16 < n; ++c16) {
+                    const int sl = 16 * c16 + (lane & 15);
+                    const float* ap = A3 + (sl < n ? (int)wrl[sl] : 0) * LD1 + 4 * (lane >> 4);   // rows past n: any finite row, result unused
+                    f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
+                    for (int g = 0; g < T16; ++g) {
+                        const float4 av = *reinterpret_cast<const float4*>(ap + 16 * g);
+                        const float4 b0 = w0[g * 64], b1 = w0[(T16 + g) * 64];
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, a1, 0, 0, 0);
+                    }
+                    // packed rows of dpool_b: element i of a lane = packed row 16 c16 + 4 (lane>>4) + i, column (lane&15) of each tile
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* d = dp + (16 * c16 + 4 * (lane >> 4) + i) * LD1 + cb * 32 + (lane & 15);
+                        d[0] = a0[i]; d[16] = a1[i];
+                    }
+                }
+            } else {
+                f32x16 dpl = zero16();
+                mma1b(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
+            }
             __syncthreads();
             mask_t m2 = obs[r8 * B + b];
             while (m2) {
                 const int i2 = ffsm(m2) - 1;
                 m2 &= m2 - 1;
-                const float* src = dp + (grp_base + i2) * LD1 + q8 * 4;
+                // dense form: row of agent i2; packed form: its rank among the rows that have a neighbour in this bin
+                const int srow = CPB ? __popc(rb & ((1u << (grp_base + i2)) - 1u)) : grp_base + i2;
+                const float* src = dp + srow * LD1 + q8 * 4;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
@@ -1038,7 +1082,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 static size_t ioc_bwd_lds(const IocBwdArgs& a, int TM) {
     const int H = a.H, LD1 = H + 4, B = a.G * a.G;
     size_t f = (size_t)TM * LD1 * 4 + (size_t)TM * B * (TM == 32 ? 2 : 4) + TM * 2 + TM + H;
-    return f * sizeof(float) + TM + 64;
+    return f * sizeof(float) + TM + 64 + 512;               // + occupancy words, row bitmaps / row lists of the packed dpool
 }
 template <int H, int TM>
 static void launch_ioc_bwd_t(const IocBwdArgs& a, hipStream_t s) {
