@@ -705,6 +705,13 @@ template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * (TM / 32) * 64);
     if (a.sv_h) {                                              // training-mode forward: keeps x_t, r, u, c, h per step
+        if constexpr (TM == 32 && H <= 128) {                  // 32-row tiles: the row-compacted pooling (k_ioc CP) also while training
+            if (a.variant != 9) {                              // (variant 9: dense pooling, A/B)
+                allow_big_lds(k_ioc<H, 16, 32, 32, true, true>);
+                hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, true, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+                return;
+            }
+        }
         if constexpr (H <= 128 || TM == 32) {
             allow_big_lds(k_ioc<H, 16, 32, TM, true>);
             hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
