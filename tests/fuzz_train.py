@@ -68,6 +68,8 @@ def main():
                 detail.append((er, name, float(np.abs(r).max()), float(np.abs(got - r).max())))
                 if np.abs(r).max() < 1e-6 * gscale:          # a gradient that is numerically nothing next to the others
                     continue
+                if np.abs(got - r).max() < 1e-7 * gscale:    # ... or whose absolute error is fp32 cancellation noise at the model's scale
+                    continue
                 if er > worst:
                     worst, wname = er, name
             ok = worst < 5e-4
