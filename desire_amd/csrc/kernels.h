@@ -167,7 +167,10 @@ struct DecBwdArgs {
     const float* dh_init; int ld_init;                     // optional gradient w.r.t. the FINAL state (encoders)
 };
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
-struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial; };
+struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial;
+                // optional block-sparsity of A: flags[m] bit b set <=> columns [b*fcols, (b+1)*fcols) of row m can be non-zero.  A 32-row
+                // chunk whose flags are clear over the workgroup's whole k-block is skipped (no loads, no MFMAs).
+                const unsigned long long* flags; int fcols; };
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
@@ -189,6 +192,7 @@ struct IocBwdArgs {
     const float4* WrT; const float4* WcT_h; const float4* WcT_er; const float4* WcT_ev;
     const float4* WgT_h; const float4* WgT_er; const float4* WgT_ev; const float4* WsT;
     const float4* WsT_c;                                   // WsT in 16x16x4 fragment order (row-compacted dpool, 32-row tiles)
+    unsigned long long* pool_flags;                        // [R, T] out: bit b = bin b of this (row, t) holds a neighbour (nullptr: not wanted)
     float* dag; float* dac; float* rh; float* hprev; float* dpre_r; float* dpre_v; float* vel; float* pooled;
     float* dHx_rows;
     const float* bin_tab;

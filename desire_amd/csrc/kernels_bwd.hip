@@ -301,12 +301,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
 #pragma unroll
         for (int j = 0; j < PG; ++j) *reinterpret_cast<float4*>(&Gs[buf][(rg0 + (256 / QG) * j) * BN + 4 * qg]) = rg[j];
     };
-    if (m_lo < m_hi) { gload(m_lo); lstore(0); }
+    // block-sparse A (a.flags): only chunks with a set flag bit inside this workgroup's k-block are visited
+    unsigned long long kmask = ~0ull;
+    if (a.flags) {
+        const int b_lo = bk / a.fcols, b_hi = min((bk + BK - 1) / a.fcols, 63);
+        kmask = (b_hi - b_lo >= 63) ? ~0ull : (((1ull << (b_hi - b_lo + 1)) - 1ull) << b_lo);
+    }
+    auto next_live = [&](long m0) {                       // first chunk start >= m0 that has something in the k-block (uniform)
+        if (!a.flags) return m0;
+        for (; m0 < m_hi; m0 += 32) {                    // one flag word per lane, OR-reduced over the wave (same value in every wave)
+            unsigned long long f = (c < 32 && hi == 0 && m0 + c < m_hi) ? a.flags[m0 + c] & kmask : 0ull;
+            unsigned lo32 = (unsigned)f | (unsigned)(f >> 32);
+            const unsigned long long any = __ballot(lo32 != 0u);
+            if (any) break;
+        }
+        return m0;
+    };
+    long m0 = next_live(m_lo);
+    if (m0 < m_hi) { gload(m0); lstore(0); }
     __syncthreads();
     int buf = 0;
-    for (long m0 = m_lo; m0 < m_hi; m0 += 32) {
-        const bool more = m0 + 32 < m_hi;
-        if (more) gload(m0 + 32);
+    while (m0 < m_hi) {
+        const long m1 = next_live(m0 + 32);
+        const bool more = m1 < m_hi;
+        if (more) gload(m1);
         const float* ap = &As[buf][hi * BK + wk * 64 + 2 * c];
         const float* gp = &Gs[buf][hi * BN + wn * 64 + 2 * c];
         if (bk + wk * 64 < a.Kd && bn + wn * 64 < a.N)      // a wave whose whole strip lies past Kd / N has only zeros to multiply
@@ -322,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+        m0 = m1;
     }
     float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
 #pragma unroll
@@ -922,6 +941,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             }
         }
         // ---- GRU cell backward, part 1 ----
+        if (a.pool_flags && q8 == 0 && row0 + r8 < a.R) {      // which bins of this (row, t) hold a neighbour: the weight-gradient
+            unsigned long long fl = 0ull;                       // GEMM skips the all-zero blocks of the pooled operand
+            for (int b = 0; b < B; ++b) fl |= (unsigned long long)(masks[r8 * B + b] != 0) << b;
+            a.pool_flags[(size_t)my_row * a.T + t] = fl;
+        }
         f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -19,9 +19,9 @@ float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slo
 
 // weight gradient block: out[Kd, N] = A^T G over M rows, written into a [.., ldo] matrix
 void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M, int Kd, int N, float* out, int ldo,
-        int accumulate, hipStream_t s) {
+        int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0) {
     TnArgs a{};
-    a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N;
+    a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
     long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
@@ -278,7 +278,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"ioc_sv_h", R * T * H * f}, {"Y_ref", R * T * 2 * f}, {"score_sv", R * f}, {"dYr", R * T * 2 * f}, {"dscore", R * f},
         {"dscoreT", R * T * f}, {"ioc_dag", R * T * 2 * H * f}, {"ioc_dac", R * T * H * f}, {"ioc_rh", R * T * H * f},
         {"ioc_hprev", R * T * H * f}, {"ioc_dpre_r", R * T * H * f}, {"ioc_dpre_v", R * T * d.E_v * f}, {"ioc_vel", R * T * 2 * f},
-        {"ioc_pooled", R * T * (size_t)h->B * H * f},
+        {"ioc_pooled", R * T * (size_t)h->B * H * f}, {"ioc_pool_flags", R * T * sizeof(unsigned long long)},
         {"enc_dag", (size_t)h->A * Tm * 2 * H * f}, {"enc_dac", (size_t)h->A * Tm * H * f}, {"enc_rh", (size_t)h->A * Tm * H * f},
         {"enc_hprev", (size_t)h->A * Tm * H * f},
         {"ex_sv_r", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_u", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_c", (size_t)h->A * d.T_obs * H * f},
@@ -348,6 +348,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT"); q.WsT_c = D4(h, "ioc/WsT_c");
         q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
         q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
+        q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
         q.dHx_rows = W(h, "dHx_rows");
         q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
         launch_ioc_bwd(q, s);
@@ -364,7 +365,8 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         tn(h, W(h, "ioc_sv_x"), E, W(h, "ioc_dac"), H, RT, E, H, ck, H, 0, s);
         tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, 0, s);
         colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), 0, s);
-        tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, 0, s);
+        tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, 0, s,
+           static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p), H);     // empty (row, t, bin) blocks are skipped
         colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), 0, s);
         tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, 0, s);
         colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), 0, s);
