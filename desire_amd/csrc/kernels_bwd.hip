@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
             const int r = i >> 6, cc = i & 63;
             const long m = m0 + r;
             const bool ok = m < m_hi;
-            As[r * TN_LD + cc] = (ok && bk + cc < a.Kd) ? a.A[(size_t)m * a.lda + bk + cc] : 0.f;
+            float av = (ok && bk + cc < a.Kd) ? a.A[(size_t)m * a.lda + bk + cc] : 0.f;
+            if (a.flags && ok && !((a.flags[m] >> ((bk + cc) / a.fcols)) & 1ull)) av = 0.f;     // block-sparse A: unwritten block
+            As[r * TN_LD + cc] = av;
             Gs[r * TN_LD + cc] = (ok && bn + cc < a.N) ? a.G[(size_t)m * a.ldg + bn + cc] : 0.f;
         }
         __syncthreads();
@@ -285,6 +287,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
                 } else {
                     v = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + kcol);
+                    // block-sparse A: a block whose flag is clear was never written by the producer (stale memory): read as zero
+                    if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             ra[j] = v;
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                         s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
                     }
                 }
-                if (row0 + r8 < a.R) {
+                if (row0 + r8 < a.R && (!a.pool_flags || masks[r8 * B + b] != 0)) {     // (flagged-empty blocks are never read)
                     float* dst = a.pooled + (((size_t)my_row * a.T + t) * B + b) * H + q8 * 4;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
