@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     int ky = 0, kx = 0, cl = 0;
     if (CONV) { const int tap = kcol / cg.Cl; cl = kcol - tap * cg.Cl; ky = tap / 5; kx = tap - ky * 5; }
     const int PP = cg.Ps * cg.Ps;
+    const int ps_sh = (CONV && cg.Ps > 0 && (cg.Ps & (cg.Ps - 1)) == 0) ? __ffs(cg.Ps) - 1 : -1;
     float4 ra[PA], rg[PG];
     auto gload = [&](long m0) {
 #pragma unroll
@@ -280,8 +281,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < m_hi && ka) {
                 if (CONV) {
-                    const long n = m / PP; const int p = (int)(m - n * PP);
-                    const int py = p / cg.Ps, px = p - py * cg.Ps;
+                    long n; int p, py, px;                       // (sample, small-grid pixel) of row m
+                    if (ps_sh >= 0) {                            // power-of-two grid side (every layer of this model): shifts, no divisions
+                        n = m >> (2 * ps_sh); p = (int)(m & (PP - 1));
+                        py = p >> ps_sh; px = p & (cg.Ps - 1);
+                    } else {
+                        n = m / PP; p = (int)(m - n * PP);
+                        py = p / cg.Ps; px = p - py * cg.Ps;
+                    }
                     const int qy = cg.stride * py + ky - cg.pad, qx = cg.stride * px + kx - cg.pad;
                     if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
