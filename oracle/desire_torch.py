@@ -121,7 +121,7 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
         h = gru_cell(xz, h, *_gw(w, "dec"))
         ys.append(p_last + h @ w["head/w"] + w["head/b"])
     Y0 = torch.stack(ys, 1)                                                    # [R, T, 2]
-    out.update(Hx=Hx, Hy=Hy, z_mean=mu, z_log_sigma_sq=ls, z=z, xhat=xhat, xz=xz, Y0=Y0)
+    out.update(Hx=Hx, Hy=Hy, vae_in=vae_in, z_mean=mu, z_log_sigma_sq=ls, z=z, xhat=xhat, xz=xz, Y0=Y0)
 
     # ---- IOC on detached trajectories ----
     Yd = Y0.detach() if fixed is None else _t(fixed["Yd"])

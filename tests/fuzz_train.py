@@ -68,7 +68,7 @@ def main():
                 detail.append((er, name, float(np.abs(r).max()), float(np.abs(got - r).max())))
                 if np.abs(r).max() < 1e-6 * gscale:          # a gradient that is numerically nothing next to the others
                     continue
-                if np.abs(got - r).max() < 1e-7 * gscale:    # ... or whose absolute error is fp32 cancellation noise at the model's scale
+                if er > 5e-4 and np.abs(got - r).max() < 1e-7 * gscale:   # ... or whose error is fp32 cancellation noise at the model's scale
                     continue
                 if er > worst:
                     worst, wname = er, name
@@ -121,9 +121,14 @@ def main():
                     vr = np.repeat(np.tile((past[:, d.T_obs - 1, :, 0] != 0)[:, None, :], (1, d.K, 1)).reshape(-1), 1)
                     cols = np.r_[0:d.E_v, d.E_v + d.C:E]
                     flips = int((((xk > 0) != (xo > 0))[vr][:, :, cols]).sum())
+                    va = past[:, d.T_obs - 1, :, 0].reshape(-1) != 0                     # ... and the relu of fc_c (CVAE encoder input)
+                    flips += int(((h.read_buffer("vae_in", (d.A, d.V)) > 0) != (o2["vae_in"].detach().numpy() > 0))[va].sum())
                     print("       relu elements active in one evaluation and not in the other: %d (of %d)" % (flips, int(vr.sum()) * d.T_pred * len(cols)))
                     ok = flips > 0
-            print("%3d %s  worst rel grad err %.2e (%s)  %s" % (it, kw, worst, wname, "ok" if ok else "MISMATCH"), flush=True)
+            print("%3d %s  worst rel grad err %.2e (%s)  largest |grad| %.2e  %s" % (it, kw, worst, wname, gscale, "ok" if ok else "MISMATCH"), flush=True)
+            if not np.isfinite(gscale) or wname == "":
+                print("       NOTHING COMPARED (gradient scale %r)" % gscale)
+                bad += 1
             bad += 0 if ok else 1
             if not ok:
                 for er, name, sc_, ab in sorted(detail, reverse=True)[:4]:
