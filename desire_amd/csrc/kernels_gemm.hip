@@ -12,7 +12,7 @@
 #define LDA_C (KC + 4)    // 260 = 4*65: ds_read_b128 conflict-free
 
 template <int EPI, int NTW>
-__global__ __launch_bounds__(DS_WG) void k_gemm_rows(GemmArgs a) {
+__global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * DS_TM;
