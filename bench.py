@@ -52,7 +52,8 @@ def committed_traffic(windows, bf16=False):
     with open(path) as fh:
         pmc = json.load(fh)
     for name, c in pmc.items():
-        hit = ("k_ioc_bf16ILi128" in name) if bf16 else ("k_iocILi128" in name or name.startswith("void k_ioc<128"))
+        hit = ("k_ioc_bf16ILi128" in name) if bf16 else (("k_iocILi128" in name or name.startswith("void k_ioc<128"))
+                                                          and "ELb0ELb1E" not in name)     # (not the opt-in compact form of the `alt` pass)
         if hit and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return None
