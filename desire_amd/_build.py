@@ -31,8 +31,13 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "desire_hip.h")), os.path.getmtime(__file__))
+
     def cc(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj                       # object newer than its source and every header: keep it
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -30,13 +30,13 @@ class DesireDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_scenes", "mno", "K", "T_obs", "T_pred", "H", "L", "S", "C", "Gh", "Gw", "n_grids",
                  "grid_size", "E_v", "iters", "posterior")] + \
-               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bn_mode", C.c_int32), ("bf16", C.c_int32)]
+               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bn_mode", C.c_int32), ("bf16", C.c_int32), ("ref_compat", C.c_int32), ("n_dec", C.c_int32)]
 
     @classmethod
     def from_dims(cls, d: Dims) -> "DesireDims":
         return cls(d.n_scenes, d.mno, d.K, d.T_obs, d.T_pred, d.H, d.L, d.S, d.C, d.Gh, d.Gw, d.n_grids,
                    d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy, int(getattr(d, "bin_mode", 0)),
-                   int(getattr(d, "bn_mode", 0)), int(getattr(d, "bf16", 0)))
+                   int(getattr(d, "bn_mode", 0)), int(getattr(d, "bf16", 0)), int(getattr(d, "ref_compat", 0)), int(getattr(d, "n_dec", 0)))
 
 
 class DesireError(RuntimeError):
@@ -150,7 +150,7 @@ class Handle:
         _chk(self.lib.desire_ioc_refine(self._h, yhat_ptr, score_ptr, stream or None))
 
     def forward(self, past_ptr: int, fut_ptr: int, eps_ptr: int, yhat_ptr: int, score_ptr: int, stream: int = 0) -> None:
-        _chk(self.lib.desire_forward(self._h, past_ptr, fut_ptr or None, eps_ptr, yhat_ptr, score_ptr, stream or None))
+        _chk(self.lib.desire_forward(self._h, past_ptr, fut_ptr or None, eps_ptr, yhat_ptr, score_ptr or None, stream or None))
 
     def read_buffer(self, name: str, shape: Tuple[int, ...], stream: int = 0) -> np.ndarray:
         out = np.empty(shape, np.float32)

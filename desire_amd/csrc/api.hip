@@ -58,12 +58,41 @@ int desire_upload(desire_ctx* h, const std::string& name, const std::vector<floa
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 
+static void embed_walk(const Embed& em, const std::function<void(size_t, size_t)>& f) {
+    size_t cl = 0, cp = 0;
+    for (auto& c : em.cols.seg) { cl += c.first; cp += c.second; }
+    size_t rl = 0, rp = 0;
+    for (auto& r : em.rows.seg) {
+        for (int i = 0; i < r.first; ++i) {
+            size_t ol = 0, op = 0;
+            for (auto& c : em.cols.seg) {
+                for (int j = 0; j < c.first; ++j) f((rl + i) * cl + ol + j, (rp + i) * cp + op + j);
+                ol += c.first; op += c.second;
+            }
+        }
+        rl += r.first; rp += r.second;
+    }
+}
+std::vector<float> desire_embed(const desire_ctx* h, const std::string& name, const float* user) {
+    auto it = h->emb.find(name);
+    const size_t np = h->want.at(name);
+    if (it == h->emb.end()) return std::vector<float>(user, user + np);
+    std::vector<float> out(np, 0.f);
+    embed_walk(it->second, [&](size_t il, size_t ip) { out[ip] = user[il]; });
+    return out;
+}
+void desire_extract(const desire_ctx* h, const std::string& name, const float* phys, float* user) {
+    auto it = h->emb.find(name);
+    if (it == h->emb.end()) { std::memcpy(user, phys, h->want.at(name) * sizeof(float)); return; }
+    embed_walk(it->second, [&](size_t il, size_t ip) { user[il] = phys[ip]; });
+}
+
 namespace {
 
-void shapes(desire_ctx* h) {
+void shapes(desire_ctx* h, int H, std::map<std::string, size_t>& s) {
     const desire_dims& d = h->d;
-    const int H = d.H, L = d.L, V = h->V;
-    auto& s = h->want;
+    const int L = d.L, V = h->V;
+    const int E = d.E_v + d.C + H;
     auto gru = [&](const std::string& p, int n_in) {
         s[p + "/gates/kernel"] = (size_t)(n_in + H) * 2 * H;
         s[p + "/gates/bias"] = 2 * H;
@@ -90,13 +119,37 @@ void shapes(desire_ctx* h) {
     s["head/w"] = 2 * H; s["head/b"] = 2;
     s["ioc/vel_fc/w"] = 2 * d.E_v; s["ioc/vel_fc/b"] = d.E_v;
     s["ioc/social_fc/w"] = (size_t)h->B * H * H; s["ioc/social_fc/b"] = H;
-    gru("ioc", h->E);
+    gru("ioc", E);
     s["ioc/score/w"] = H; s["ioc/score/b"] = 1;
     s["ioc/reg/w"] = (size_t)H * 2 * d.T_pred; s["ioc/reg/b"] = 2 * d.T_pred;
     s["scene_cnn/conv1/w"] = 25 * 3 * 16; s["scene_cnn/conv1/b"] = 16;
     s["scene_cnn/conv2/w"] = 25 * 16 * 32; s["scene_cnn/conv2/b"] = 32;
     s["scene_cnn/conv3/w"] = (size_t)25 * 32 * d.C; s["scene_cnn/conv3/b"] = d.C;
     s["temporal/w"] = (size_t)d.T_obs * 2 * 100; s["temporal/b"] = 200;
+}
+
+// logical -> physical embedding of every weight that has a hidden-width axis (ctx.h: Embed)
+void embeddings(desire_ctx* h) {
+    const desire_dims& d = h->d;
+    const std::pair<int, int> Hs{h->Hl, d.H};
+    auto fix = [](int n) { return std::pair<int, int>{n, n}; };
+    auto& e = h->emb;
+    auto gru = [&](const std::string& p, std::vector<std::pair<int, int>> in) {
+        in.push_back(Hs);
+        e[p + "/gates/kernel"] = Embed{{in}, {{Hs, Hs}}};
+        e[p + "/gates/bias"] = Embed{{{fix(1)}}, {{Hs, Hs}}};
+        e[p + "/candidate/kernel"] = Embed{{in}, {{Hs}}};
+        e[p + "/candidate/bias"] = Embed{{{fix(1)}}, {{Hs}}};
+    };
+    gru("enc_x", {fix(2)}); gru("enc_y", {fix(2)}); gru("dec", {Hs}); gru("ioc", {fix(d.E_v + d.C), Hs});
+    e["fc_c/w"] = Embed{{{Hs, Hs}}, {{fix(h->V)}}};
+    e["mask_fc/w"] = Embed{{{fix(h->V)}}, {{Hs}}};
+    e["mask_fc/b"] = Embed{{{fix(1)}}, {{Hs}}};
+    e["head/w"] = Embed{{{Hs}}, {{fix(2)}}};
+    e["ioc/social_fc/w"] = Embed{{std::vector<std::pair<int, int>>(h->B, Hs)}, {{Hs}}};
+    e["ioc/social_fc/b"] = Embed{{{fix(1)}}, {{Hs}}};
+    e["ioc/score/w"] = Embed{{{Hs}}, {{fix(1)}}};
+    e["ioc/reg/w"] = Embed{{{Hs}}, {{fix(2 * d.T_pred)}}};
 }
 
 // frozen batch-norm + bias -> (scale, shift); float64 then one rounding (desire_amd/spec.py:fold_bn)
@@ -116,7 +169,8 @@ int check_dims(const desire_dims& d) {
     if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
     if (d.mno < 1 || d.mno > 128 || (d.mno <= 32 ? (32 % d.mno) : (d.mno % 32)))
         return fail(DESIRE_ERR_ARG, "mno must divide 32 or be 64, 96 or 128");
-    if (d.H != 64 && d.H != 128 && d.H != 256) return fail(DESIRE_ERR_ARG, "H must be 64, 128 or 256");
+    if (d.H != 16 && d.H != 32 && d.H != 64 && d.H != 128 && d.H != 256)
+        return fail(DESIRE_ERR_ARG, "H must be 16, 32 (run zero-padded on the 64-wide tile), 64, 128 or 256");
 
     if (d.L % 8 || d.L < 8) return fail(DESIRE_ERR_ARG, "L must be a positive multiple of 8");
     if (d.C != 32 || d.E_v != 16) return fail(DESIRE_ERR_ARG, "C=32 and E_v=16 are the instantiated IOC widths in this round");
@@ -132,6 +186,12 @@ int check_dims(const desire_dims& d) {
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
     if (d.bf16 && d.mno > 64) return fail(DESIRE_ERR_ARG, "bf16 operands: mno must divide 32 or be 64 in this round");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
+    if (d.ref_compat != 0 && d.ref_compat != 1) return fail(DESIRE_ERR_ARG, "ref_compat must be 0 or 1");
+    if (d.ref_compat) {
+        if (d.K != 1 || !d.posterior || d.bn_mode != 1 || d.bf16 || d.n_dec < 1 || d.H != 2 * d.T_obs || d.T_pred != d.T_obs)
+            return fail(DESIRE_ERR_ARG, "ref_compat (the reference graph as written, model/model.py:116-311) needs K = 1 (one eps per object, "
+                                        ":262-263), posterior = 1, bn_mode = 1, bf16 = 0, H == 2*T_obs (:286-289), T_pred == T_obs and n_dec >= 1 (:280 runs 7)");
+    } else if (d.n_dec != 0) return fail(DESIRE_ERR_ARG, "n_dec belongs to ref_compat (0 otherwise)");
     return 0;
 }
 
@@ -151,20 +211,25 @@ extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
         return fail(DESIRE_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     desire_ctx* h = new desire_ctx();
     h->d = *dims;
+    h->Hl = dims->H;
+    if (dims->H < 64) h->d.H = 64;          // narrowest instantiated recurrent tile; the padding is exact (ctx.h: EmbedAxis)
     h->A = dims->n_scenes * dims->mno;
     h->R = h->A * dims->K;
     h->V = dims->S * dims->S;
     h->B = dims->grid_size * dims->grid_size;
-    h->E = dims->E_v + dims->C + dims->H;
-    shapes(h);
+    h->E = dims->E_v + dims->C + h->d.H;
+    shapes(h, h->d.H, h->want);
+    shapes(h, h->Hl, h->want_user);
+    if (h->Hl != h->d.H) embeddings(h);
     const desire_dims& d = h->d;
     const size_t A = h->A, R = h->R, f = sizeof(float);
     struct WS { const char* n; size_t bytes; };
     const WS list[] = {
-        {"HxHy", A * 2 * d.H * f}, {"p_last", A * 2 * f}, {"valid", A}, {"vae_in", A * h->V * f},
+        {"HxHy", A * 2 * d.H * f}, {"p_last", A * 2 * f}, {"valid", A}, {"lmask", A}, {"nfut", A * f}, {"vae_in", A * h->V * f},
         {"c1", A * 8192 * f}, {"c2", A * 4096 * f}, {"c3", A * 2048 * f}, {"params", A * 2 * d.L * f},
         {"z", R * d.L * f}, {"d1", R * 2048 * f}, {"d2", R * 4096 * f}, {"d3", R * 8192 * f},
-        {"xhat", R * 1024 * f}, {"xz", R * d.H * f}, {"Y0", R * d.T_pred * 2 * f},
+        {"xhat", R * 1024 * f}, {"xz", R * d.H * f}, {"Y0", R * (size_t)(d.n_dec > d.T_pred ? d.n_dec : d.T_pred) * 2 * f},
+        {"dec_states", d.ref_compat ? R * (size_t)d.n_dec * d.H * f : 0},
         {"grid_of_scene", (size_t)d.n_scenes * sizeof(int32_t)},
     };
     for (const WS& w : list) {
@@ -208,12 +273,12 @@ extern "C" int desire_destroy(desire_handle* h) {
 
 extern "C" int desire_set_weight(desire_handle* h, const char* name, const float* host_data, size_t n) {
     if (!h || !name || !host_data) return fail(DESIRE_ERR_ARG, "null argument");
-    auto it = h->want.find(name);
-    if (it == h->want.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
+    auto it = h->want_user.find(name);
+    if (it == h->want_user.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
     if (it->second != n)
         return fail(DESIRE_ERR_ARG, std::string("weight ") + name + ": expected " + std::to_string(it->second) +
                                         " values, got " + std::to_string(n));
-    h->host_w[name].assign(host_data, host_data + n);
+    h->host_w[name] = desire_embed(h, name, host_data);
     h->finalized = false;
     h->training = false;            // the optimiser's master copy is rebuilt by the next desire_set_training(h, 1)
     return DESIRE_OK;
@@ -553,7 +618,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
           if (pobn) launch_instnorm_act(W(h, "xhat"), R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), D(h, "vae_dec/deconv4/beta"), 1, s); }
     }
     MaskArgs m{};
-    m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.K = d.K; m.mno = d.mno;
+    m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = d.mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
     if (h->training) m.sv_p = W(h, "mask_sv_p");
     if (d.bf16) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
@@ -564,13 +629,17 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
     a.Y = W(h, "Y0"); a.hdump = nullptr;
+    if (d.ref_compat) { a.T = d.n_dec; a.hdump = W(h, "dec_states"); }       // model/model.py:280-285: 7 steps, the states are the output
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
     if (d.bf16) {
         a.Whg = D4(h, "dec/Whg16"); a.Whc = D4(h, "dec/Whc16");
         Timer t(h, s, "decoder"); launch_decoder_bf16(a, s);
     } else
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
-    launch_copy_f32(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2, s);
+    if (d.ref_compat)      // model/model.py:286-289: each state [H] re-read as T_obs points (x, y) -> [A, n_dec, T_obs, 2]
+        launch_copy_cols(dev_Yhat, W(h, "dec_states"), (size_t)R * d.n_dec, h->Hl, H, s);
+    else
+        launch_copy_f32(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2, s);
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }
@@ -578,6 +647,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
 extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream) {
     if (int rc = desire_ready(h)) return rc;
     if (!dev_Yhat || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
+    if (h->d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat: the reference graph has no ranking/refinement module (model/model.py:312-313)");
     if (!h->grids_set) return fail(DESIRE_ERR_STATE, "scene grids not set (desire_set_scene_grids)");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -653,6 +723,7 @@ extern "C" int desire_forward(desire_handle* h, const float* dev_past, const flo
                               float* dev_Yhat, float* dev_score, void* stream) {
     if (int rc = desire_encode(h, dev_past, dev_fut, stream)) return rc;
     if (int rc = desire_sample(h, dev_eps, dev_Yhat, stream)) return rc;
+    if (h && h->d.ref_compat) return DESIRE_OK;          // the reference graph ends at the decoder states (dev_score untouched)
     return desire_ioc_refine(h, dev_Yhat, dev_score, stream);
 }
 
@@ -668,13 +739,14 @@ extern "C" int desire_read_buffer(desire_handle* h, const char* name, float* hos
         HIPCHK(hipMemcpy2D(host_out, cols * f, src, pitch_cols * f, cols * f, rows, hipMemcpyDeviceToHost));
         return 0;
     };
-    if (nm == "Hx") return strided(W(h, "HxHy"), d.H, 2 * d.H, A);
-    if (nm == "Hy") return strided(W(h, "HxHy") + d.H, d.H, 2 * d.H, A);
+    if (nm == "Hx") return strided(W(h, "HxHy"), h->Hl, 2 * d.H, A);
+    if (nm == "Hy") return strided(W(h, "HxHy") + d.H, h->Hl, 2 * d.H, A);
+    if (nm == "xz") return strided(W(h, "xz"), h->Hl, d.H, R);
     if (nm == "z_mean") return strided(W(h, "params"), d.L, 2 * d.L, A);
     if (nm == "z_log_sigma_sq") return strided(W(h, "params") + d.L, d.L, 2 * d.L, A);
     struct P { const char* n; size_t cnt; };
     const P plain[] = {{"vae_in", A * h->V}, {"c1", A * 8192}, {"c2", A * 4096}, {"c3", A * 2048}, {"z", R * d.L},
-                       {"d1", R * 2048}, {"d2", R * 4096}, {"d3", R * 8192}, {"xhat", R * 1024}, {"xz", R * d.H},
+                       {"d1", R * 2048}, {"d2", R * 4096}, {"d3", R * 8192}, {"xhat", R * 1024},
                        {"Y0", R * d.T_pred * 2}, {"p_last", A * 2}};
     for (const P& p : plain)
         if (nm == p.n) {
@@ -812,8 +884,12 @@ extern "C" int desire_losses(desire_handle* h, const float* dev_fut, const float
     if (!dev_fut || !dev_Yhat || !dev_kld || !dev_recon || !dev_cost) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "losses need the posterior path (dims.posterior = 1)");
-    launch_losses(W(h, "params"), dev_Yhat, dev_fut, static_cast<const uint8_t*>(h->ws["valid"].p), dev_kld, dev_recon,
-                  dev_cost, d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy, static_cast<hipStream_t>(stream));
+    if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat has no trajectory head: the reference's cost has undefined inputs (model/model.py:342)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    launch_loss_mask(static_cast<const uint8_t*>(h->ws["valid"].p), dev_fut, static_cast<uint8_t*>(h->ws["lmask"].p), W(h, "nfut"),
+                     d.n_scenes, d.mno, d.T_pred, s);
+    launch_losses(W(h, "params"), dev_Yhat, dev_fut, static_cast<const uint8_t*>(h->ws["lmask"].p), W(h, "nfut"), dev_kld, dev_recon,
+                  dev_cost, d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy, s);
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }
@@ -831,7 +907,8 @@ extern "C" int desire_temporal_conv(desire_handle* h, const float* dev_past, flo
 extern "C" int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float* dev_rho, float* dev_out, void* stream) {
     if (!h || !dev_Yhat || !dev_rho || !dev_out) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
-    launch_feature_pooling(dev_Yhat, dev_rho, dev_out, h->R, d.T_pred, d.K, d.mno, static_cast<hipStream_t>(stream));
+    // ref_compat: dev_Yhat = output_states [A, n_dec, T_obs, 2] -> [A, n_dec*T_obs, 200] (model/model.py:291-311 over the 7 states)
+    launch_feature_pooling(dev_Yhat, dev_rho, dev_out, h->R, d.ref_compat ? d.n_dec * d.T_obs : d.T_pred, d.K, d.mno, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

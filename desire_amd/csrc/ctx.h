@@ -35,9 +35,20 @@ struct Prof { std::string name; hipEvent_t e0, e1; };
 
 struct WSlot { size_t off; size_t n; };                       // a named tensor inside the flat training buffers
 
+// One axis of a weight's natural layout as a list of (logical, physical) segment lengths: when the caller's hidden width
+// is below the narrowest instantiated recurrent tile (dims.H = 16 or 32, the reference's own default d_dim = 16,
+// train.py:85), the kernels run at a physical width of 64 with the extra hidden units' weights, biases and initial state
+// exactly zero -- such a unit stays at 0 for ever (c = tanh(0) = 0, h' = u*0 + (1-u)*0) and feeds nothing, and the
+// added products are exact zeros, so the logical units' values do not change.
+struct EmbedAxis { std::vector<std::pair<int, int>> seg; };
+struct Embed { EmbedAxis rows, cols; };
+
 struct desire_ctx {
-    desire_dims d;
+    desire_dims d;                                           // d.H is the PHYSICAL hidden width the kernels run at
+    int Hl = 0;                                              // logical hidden width = dims.H as given to desire_create
     int A, R, V, B, E;
+    std::map<std::string, size_t> want_user;                 // name -> element count in the caller's (logical) layout
+    std::map<std::string, Embed> emb;                        // weights whose logical layout differs from the physical one
     std::map<std::string, std::vector<float>> host_w;       // raw weights as set
     std::map<std::string, size_t> want;                      // name -> element count
     std::map<std::string, DevBuf> dev;                       // raw / packed / folded device tensors
@@ -82,6 +93,9 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
 // bf16 fragment order (v_mfma_f32_32x32x16_bf16): out16[((nt*G + g)*64 + lane)*8 + e] = bf16(W(k = kmap(g, lane>>5, e), n = nt*32 + (lane&31))),
 // G = ceil(K/16); returned as floats holding two bf16 bit patterns each (so the float upload path carries it)
 std::vector<float> pack_b16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at);
+// logical (caller) layout <-> physical layout of one named weight (identity when the weight has no Embed entry)
+std::vector<float> desire_embed(const desire_ctx* h, const std::string& name, const float* user);
+void desire_extract(const desire_ctx* h, const std::string& name, const float* phys, float* user);
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v);
 int desire_ready(desire_handle* h);
 int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

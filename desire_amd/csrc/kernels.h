@@ -30,6 +30,7 @@ void launch_reparam(const float* params, const float* eps, float* z, int R, int 
 
 struct MaskArgs {
     const float* xhat; int R; int V; int H; int K; int mno;
+    int Hl;                                        // logical width: the softmax runs over columns [0, Hl) (Hl < H: zero-padded tile)
     const float4* Wp; const float* bias; const float* Hx; int ldhx; float* xz;
     float* sv_p;                                   // optional [R,H]: relu(xhat W + b) kept for the backward softmax
 };
@@ -138,14 +139,16 @@ void launch_scene_cells(const float* pos, int32_t* cells, int n, int Gh, int Gw,
 // ---- cold rows (kernels_aux.hip) ----
 void launch_fill_f32(float* dst, size_t n, float v, hipStream_t s);
 void launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
+void launch_copy_cols(float* dst, const float* src, size_t rows, int cols, int ld, hipStream_t s);
 void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s);
 void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
                         int Co, int stride, int relu, hipStream_t s);
 void launch_temporal_conv(const float* frames, const float* w, const float* b, float* rho, int n_scenes, int T, int mno,
                           hipStream_t s);
 void launch_feature_pooling(const float* Y, const float* rho, float* out, int R, int T, int K, int mno, hipStream_t s);
-void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, float* kld, float* recon,
-                   float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s);
+void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* lmask, const float* nfut, float* kld,
+                   float* recon, float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s);
+void launch_loss_mask(const uint8_t* valid, const float* fut, uint8_t* lmask, float* nfut, int n_scenes, int mno, int T, hipStream_t s);
 void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,
                           int mno, float* past, float* fut, int32_t* err, hipStream_t s);
 void launch_gaussian_sample(const float* p, const float* nrm, float* out, int n, hipStream_t s);
@@ -154,8 +157,8 @@ void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, 
 
 // ---- backward (kernels_bwd.hip) ----
 void launch_count_valid(const uint8_t* valid, int A, float* out, hipStream_t s);
-void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, const float* nvalid, float* dY, int n_scenes,
-                        int mno, int K, int T, float sx, float sy, hipStream_t s);
+void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* lmask, const float* nfut, const float* nvalid, float* dY,
+                        int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s);
 struct DecBwdArgs {
     const float* dY0;                                      // [R,T,2]
     const float* sv_r; const float* sv_u; const float* sv_c; const float* sv_h;   // [R,T,H] from the training-mode forward
@@ -174,7 +177,7 @@ struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
-                     int K, int mno, hipStream_t s);
+                     int Hl, int K, int mno, hipStream_t s);
 struct ConvWgradArgs { const float* S; int Cs; int Ps; const float* Lg; int Cl; int Pl; int stride; int pad; int n; float* partial; };
 void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s);
 void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s);

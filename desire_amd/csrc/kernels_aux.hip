@@ -85,8 +85,8 @@ void launch_feature_pooling(const float* Y, const float* rho, float* out, int R,
 
 // ---- losses: one workgroup per agent; cost reduced by a single-block second kernel (deterministic) ----
 __global__ void k_losses(const float* __restrict__ params, const float* __restrict__ Y, const float* __restrict__ fut,
-                         float* __restrict__ kld, float* __restrict__ recon, int n_scenes, int mno, int K, int T, int L,
-                         float sx, float sy) {
+                         const float* __restrict__ nfut, float* __restrict__ kld, float* __restrict__ recon, int n_scenes, int mno,
+                         int K, int T, int L, float sx, float sy) {
     __shared__ float red[256];
     const int a = blockIdx.x, tid = threadIdx.x;
     const int sc = a / mno, slot = a - sc * mno;
@@ -105,13 +105,31 @@ __global__ void k_losses(const float* __restrict__ params, const float* __restri
         const int k = i / T, t = i - k * T;
         const size_t r = ((size_t)sc * K + k) * mno + slot;
         const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+        if (f[0] == 0.f) continue;                     // the object is not in this target frame (model/model.py:351-366)
         const float dx = Y[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
         d += sqrtf(dx * dx + dy * dy);
     }
     red[tid] = d;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-    if (tid == 0) recon[a] = red[0] / (float)(K * T);
+    if (tid == 0) recon[a] = nfut[a] > 0.f ? red[0] / ((float)K * nfut[a]) : 0.f;
+}
+// Which agents and frames enter a loss (the reference's rule, model/model.py:351-366: an object that does not exist, or does not
+// exist in the target frame, does not contribute): present(a, t) = id != 0 in future frame t; nfut[a] = number of present
+// frames; lmask[a] = present at the last observed frame AND in at least one future frame.
+__global__ void k_loss_mask(const uint8_t* __restrict__ valid, const float* __restrict__ fut, uint8_t* __restrict__ lmask,
+                            float* __restrict__ nfut, int n_scenes, int mno, int T) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_scenes * mno) return;
+    const int sc = a / mno, slot = a - sc * mno;
+    int n = 0;
+    for (int t = 0; t < T; ++t) n += fut[(((size_t)sc * T + t) * mno + slot) * 3] != 0.f ? 1 : 0;
+    nfut[a] = (float)n;
+    lmask[a] = (valid[a] && n > 0) ? 1 : 0;
+}
+void launch_loss_mask(const uint8_t* valid, const float* fut, uint8_t* lmask, float* nfut, int n_scenes, int mno, int T, hipStream_t s) {
+    const int A = n_scenes * mno;
+    hipLaunchKernelGGL(k_loss_mask, dim3((A + 127) / 128), dim3(128), 0, s, valid, fut, lmask, nfut, n_scenes, mno, T);
 }
 __global__ void k_cost(const float* __restrict__ kld, const float* __restrict__ recon, const uint8_t* __restrict__ valid,
                        float* __restrict__ cost, int A) {
@@ -124,10 +142,10 @@ __global__ void k_cost(const float* __restrict__ kld, const float* __restrict__ 
     for (int st = 128; st > 0; st >>= 1) { if (tid < st) { rs[tid] += rs[tid + st]; rn[tid] += rn[tid + st]; } __syncthreads(); }
     if (tid == 0) { cost[0] = rs[0] / fmaxf(rn[0], 1.f); cost[1] = rn[0]; }
 }
-void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, float* kld, float* recon,
-                   float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s) {
-    const int A = n_scenes * mno;
-    hipLaunchKernelGGL(k_losses, dim3(A), dim3(256), 0, s, params, Y, fut, kld, recon, n_scenes, mno, K, T, L, sx, sy);
+void launch_losses(const float* params, const float* Y, const float* fut, const uint8_t* valid, const float* nfut, float* kld,
+                   float* recon, float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s) {
+    const int A = n_scenes * mno;                       // valid = the loss mask of k_loss_mask
+    hipLaunchKernelGGL(k_losses, dim3(A), dim3(256), 0, s, params, Y, fut, nfut, kld, recon, n_scenes, mno, K, T, L, sx, sy);
     hipLaunchKernelGGL(k_cost, dim3(1), dim3(256), 0, s, kld, recon, valid, cost, A);
 }
 
@@ -231,13 +249,15 @@ __global__ void k_ade_fde(const float* __restrict__ Y, const float* __restrict__
     for (int k = 0; k < K; ++k) {
         const size_t r = ((size_t)sc * K + k) * mno + slot;
         float s = 0.f, last = 0.f;
-        for (int t = 0; t < T; ++t) {
+        int np = 0;
+        for (int t = 0; t < T; ++t) {                  // frames the object is absent from carry no ground truth: skipped
             const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+            if (f[0] == 0.f) continue;
             const float dx = Y[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
-            last = sqrtf(dx * dx + dy * dy);
-            s += last;
+            last = sqrtf(dx * dx + dy * dy);           // FDE = the error at the last frame the object is present in
+            s += last; ++np;
         }
-        s /= (float)T;
+        s = np ? s / (float)np : 0.f;
         am += s; fm += last;
         amin = fminf(amin, s); fmin_ = fminf(fmin_, last);
     }
@@ -317,4 +337,17 @@ void launch_fill_f32(float* dst, size_t n, float v, hipStream_t s) {
 void launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
     const size_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_copy_f32, dim3((unsigned)(nb < 2048 ? (nb ? nb : 1) : 2048)), dim3(256), 0, s, dst, src, n);
+}
+
+// dst[r, c] = src[r * ld + c] for c < cols: the logical columns of a (zero-padded) row-major tensor
+__global__ void k_copy_cols(float* __restrict__ dst, const float* __restrict__ src, size_t rows, int cols, int ld) {
+    const size_t n = rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols;
+        dst[i] = src[r * ld + (i - r * cols)];
+    }
+}
+void launch_copy_cols(float* dst, const float* src, size_t rows, int cols, int ld, hipStream_t s) {
+    const size_t nb = (rows * cols + 255) / 256;
+    hipLaunchKernelGGL(k_copy_cols, dim3((unsigned)(nb < 2048 ? (nb ? nb : 1) : 2048)), dim3(256), 0, s, dst, src, rows, cols, ld);
 }

@@ -994,7 +994,7 @@ __global__ __launch_bounds__(DS_WG) void k_mask_bf16(MaskArgs a) {
     for (int c = 0; c < per; ++c) {
         const float e = expf(tile[r * LDT + q4 * per + c] - mx);
         tile[r * LDT + q4 * per + c] = e;
-        sum += e;
+        sum += (q4 * per + c < a.Hl) ? e : 0.f;         // padded columns (relu(0) = 0 <= mx) are not in the softmax
     }
     sum += __shfl_xor(sum, 1);
     sum += __shfl_xor(sum, 2);

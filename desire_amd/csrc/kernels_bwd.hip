@@ -33,10 +33,10 @@ void launch_count_valid(const uint8_t* valid, int A, float* out, hipStream_t s) 
     hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(256), 0, s, valid, A, out);
 }
 
-// ---- d L_sgm / d Y0:  valid / (N K T) * (Y0 - gt) / ||Y0 - gt|| ------------------------------------------------
+// ---- d L_sgm / d Y0:  lmask(a) present(a,t) / (N K nfut(a)) * (Y0 - gt) / ||Y0 - gt|| ------------------------------
 __global__ void k_loss_grad_y(const float* __restrict__ Y, const float* __restrict__ fut, const uint8_t* __restrict__ valid,
-                              const float* __restrict__ nvalid, float* __restrict__ dY, int n_scenes, int mno, int K, int T,
-                              float sx, float sy) {
+                              const float* __restrict__ nfut, const float* __restrict__ nvalid, float* __restrict__ dY,
+                              int n_scenes, int mno, int K, int T, float sx, float sy) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long R = (long)n_scenes * K * mno;
     if (i >= R * T) return;
@@ -47,14 +47,14 @@ __global__ void k_loss_grad_y(const float* __restrict__ Y, const float* __restri
     const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
     const float dx = Y[i * 2] - __fmul_rn(f[1], sx), dy = Y[i * 2 + 1] - __fmul_rn(f[2], sy);
     const float nrm = sqrtf(dx * dx + dy * dy);
-    const float g = (valid[a] && nrm > 0.f) ? 1.0f / (nvalid[0] * (float)K * (float)T * nrm) : 0.f;
+    const float g = (valid[a] && f[0] != 0.f && nrm > 0.f) ? 1.0f / (nvalid[0] * (float)K * nfut[a] * nrm) : 0.f;
     dY[i * 2] = g * dx;
     dY[i * 2 + 1] = g * dy;
 }
-void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, const float* nvalid, float* dY, int n_scenes,
-                        int mno, int K, int T, float sx, float sy, hipStream_t s) {
+void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, const float* nfut, const float* nvalid, float* dY,
+                        int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s) {
     const long n = (long)n_scenes * K * mno * T;
-    hipLaunchKernelGGL(k_loss_grad_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Y, fut, valid, nvalid, dY, n_scenes,
+    hipLaunchKernelGGL(k_loss_grad_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Y, fut, valid, nfut, nvalid, dY, n_scenes,
                        mno, K, T, sx, sy);
 }
 
@@ -562,7 +562,7 @@ void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* p
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ p, const float* __restrict__ dxz,
                                                   const float* __restrict__ Hx, int ldhx, float* __restrict__ dq,
-                                                  float* __restrict__ dHx_rows, int R, int H, int K, int mno) {
+                                                  float* __restrict__ dHx_rows, int R, int H, int Hl, int K, int mno) {
     const int r = blockIdx.x * 64 + (threadIdx.x >> 2), q4 = threadIdx.x & 3;
     const int row = min(r, R - 1);
     const int per = H >> 2;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ p, c
     for (int c = 0; c < per; ++c) mx = fmaxf(mx, pr[c]);
     mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
     float sum = 0.f;
-    for (int c = 0; c < per; ++c) sum += expf(pr[c] - mx);
+    for (int c = 0; c < per; ++c) sum += (q4 * per + c < Hl) ? expf(pr[c] - mx) : 0.f;     // padded columns are not in the softmax
     sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
     float dot = 0.f;
     for (int c = 0; c < per; ++c) { const float b = expf(pr[c] - mx) / sum; dot += b * gx[c] * hx[c]; }
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float* __restrict__ p, c
     }
 }
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
-                     int K, int mno, hipStream_t s) {
-    hipLaunchKernelGGL(k_mask_bwd, dim3((R + 63) / 64), dim3(256), 0, s, p, dxz, Hx, ldhx, dq, dHx_rows, R, H, K, mno);
+                     int Hl, int K, int mno, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_bwd, dim3((R + 63) / 64), dim3(256), 0, s, p, dxz, Hx, ldhx, dq, dHx_rows, R, H, Hl, K, mno);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -801,6 +801,7 @@ __global__ void k_score_grad(const float* __restrict__ Y0, const float* __restri
         float dm = 0.f;
         for (int t = 0; t < T; ++t) {
             const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+            if (f[0] == 0.f) continue;                   // frames without the object carry no ground truth
             const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
             dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
         }

@@ -91,7 +91,8 @@ __global__ void k_refold(const float* __restrict__ w, float* __restrict__ shift,
 // per-agent loss terms of DESIGN.md section 8: out[a] = {recon, kld, ce, reg} (0 for absent agents)
 __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restrict__ Yr, const float* __restrict__ fut,
                              const float* __restrict__ score, const float* __restrict__ params, const uint8_t* __restrict__ valid,
-                             float* __restrict__ out, int n_scenes, int mno, int K, int T, int L, float sx, float sy) {
+                             const float* __restrict__ nfut, float* __restrict__ out, int n_scenes, int mno, int K, int T, int L,
+                             float sx, float sy) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_scenes * mno) return;
     const int sc = a / mno, slot = a - sc * mno;
@@ -103,6 +104,7 @@ __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restri
             float dm = 0.f;
             for (int t = 0; t < T; ++t) {
                 const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                if (f[0] == 0.f) continue;               // absent in this target frame (model/model.py:351-366)
                 const float gx = __fmul_rn(f[1], sx), gy = __fmul_rn(f[2], sy);
                 float dx = Y0[(r * T + t) * 2] - gx, dy = Y0[(r * T + t) * 2 + 1] - gy;
                 const float e0 = sqrtf(dx * dx + dy * dy);
@@ -118,6 +120,7 @@ __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restri
             float dm = 0.f;
             for (int t = 0; t < T; ++t) {
                 const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                if (f[0] == 0.f) continue;
                 const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
                 dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
             }
@@ -129,6 +132,7 @@ __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restri
             float dm = 0.f;
             for (int t = 0; t < T; ++t) {
                 const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+                if (f[0] == 0.f) continue;
                 const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
                 dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
             }
@@ -139,7 +143,7 @@ __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restri
             const float mu = params[(size_t)a * 2 * L + j], ls = params[(size_t)a * 2 * L + L + j];
             kl += 1.f + ls - mu * mu - expf(ls);
         }
-        o = make_float4(e0s / (K * T), -0.5f * kl, ce, e1s / (K * T));
+        o = make_float4(e0s / ((float)K * nfut[a]), -0.5f * kl, ce, e1s / ((float)K * nfut[a]));
     }
     reinterpret_cast<float4*>(out)[a] = o;
 }
@@ -249,6 +253,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
     if (d.bf16) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0)");
+    if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
     if (d.bn_mode) return fail(DESIRE_ERR_STATE, "training runs with frozen batch-norm statistics (dims.bn_mode = 0)");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0))
         return fail(DESIRE_ERR_STATE, "training supports up to 64 agents per scene (32 at H = 256): larger groups run the cluster-form IOC, which has no backward yet");
@@ -305,10 +310,14 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     const int H = d.H, T = d.T_pred;
     const long R = h->R;
     launch_fill_f32(W(h, "Gflat"), h->n_params, 0.f, s);
-    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["valid"].p);
+    // loss mask: present at the last observed frame and in at least one target frame; every loss term below is masked per
+    // target frame (model/model.py:351-366).  `valid` (presence at the last observed frame) stays what social pooling uses.
+    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["lmask"].p);
+    launch_loss_mask(static_cast<const uint8_t*>(h->ws["valid"].p), dev_fut, static_cast<uint8_t*>(h->ws["lmask"].p), W(h, "nfut"),
+                     d.n_scenes, d.mno, T, s);
     launch_count_valid(valid, h->A, W(h, "nvalid"), s);
     // ---- sample-generation module ----
-    launch_loss_grad_y(W(h, "Y0"), dev_fut, valid, W(h, "nvalid"), W(h, "dY0"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
+    launch_loss_grad_y(W(h, "Y0"), dev_fut, valid, W(h, "nfut"), W(h, "nvalid"), W(h, "dY0"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
     DecBwdArgs b{};
     b.dY0 = W(h, "dY0"); b.sv_r = W(h, "dec_sv_r"); b.sv_u = W(h, "dec_sv_u"); b.sv_c = W(h, "dec_sv_c"); b.sv_h = W(h, "dec_sv_h");
     b.Hx = W(h, "HxHy"); b.ldhx = 2 * H; b.w_head = D(h, "head/w");
@@ -335,11 +344,11 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     {
         Timer t(h, s, "bwd_ioc");
         const int E = h->E, B = h->B;
-        launch_loss_grad_y(W(h, "Y_ref"), dev_fut, valid, W(h, "nvalid"), W(h, "dYr"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
+        launch_loss_grad_y(W(h, "Y_ref"), dev_fut, valid, W(h, "nfut"), W(h, "nvalid"), W(h, "dYr"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
         launch_score_grad(W(h, "Y0"), dev_fut, W(h, "score_sv"), valid, W(h, "nvalid"), W(h, "dscore"), W(h, "dscoreT"), d.n_scenes,
                           d.mno, d.K, T, d.sx, d.sy, s);
         IocBwdArgs q{};
-        q.Y0 = W(h, "Y0"); q.p_last = W(h, "p_last"); q.valid = valid; q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
+        q.Y0 = W(h, "Y0"); q.p_last = W(h, "p_last"); q.valid = static_cast<const uint8_t*>(h->ws["valid"].p); q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
         q.dYr = W(h, "dYr"); q.dscore = W(h, "dscore");
         q.sv_x = W(h, "ioc_sv_x"); q.sv_r = W(h, "ioc_sv_r"); q.sv_u = W(h, "ioc_sv_u"); q.sv_c = W(h, "ioc_sv_c"); q.sv_h = W(h, "ioc_sv_h");
         q.w_score = D(h, "ioc/score_w");
@@ -374,7 +383,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     // ---- mask fc ----
     {
         Timer t(h, s, "bwd_mask");
-        launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), W(h, "HxHy"), 2 * H, W(h, "dq_mask"), W(h, "dHx_rows"), (int)R, H, d.K, d.mno, s);
+        launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), W(h, "HxHy"), 2 * H, W(h, "dq_mask"), W(h, "dHx_rows"), (int)R, H, h->Hl, d.K, d.mno, s);
         colsum(h, W(h, "dq_mask"), H, R, H, G(h, "mask_fc/b"), 0, s);
         tn(h, W(h, "xhat"), V, W(h, "dq_mask"), H, R, V, H, G(h, "mask_fc/w"), H, 0, s);
         GemmArgs g{};
@@ -485,10 +494,13 @@ extern "C" int desire_get_grad(desire_handle* h, const char* name, float* host_o
     if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
     auto it = h->slots.find(name);
     if (it == h->slots.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
-    if (it->second.n != n) return fail(DESIRE_ERR_ARG, std::string(name) + ": expected " + std::to_string(it->second.n) + " values");
+    const size_t nu = h->want_user.at(name);
+    if (nu != n) return fail(DESIRE_ERR_ARG, std::string(name) + ": expected " + std::to_string(nu) + " values");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipMemcpy(host_out, W(h, "Gflat") + it->second.off, n * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> phys(it->second.n);
+    HIPCHK(hipMemcpy(phys.data(), W(h, "Gflat") + it->second.off, phys.size() * sizeof(float), hipMemcpyDeviceToHost));
+    desire_extract(h, name, phys.data(), host_out);
     return DESIRE_OK;
 }
 
@@ -506,9 +518,11 @@ extern "C" int desire_train_loss(desire_handle* h, const float* dev_fut, float* 
     if (!dev_fut || !host_out5) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["valid"].p);
+    const uint8_t* valid = static_cast<const uint8_t*>(h->ws["lmask"].p);
+    launch_loss_mask(static_cast<const uint8_t*>(h->ws["valid"].p), dev_fut, static_cast<uint8_t*>(h->ws["lmask"].p), W(h, "nfut"),
+                     d.n_scenes, d.mno, d.T_pred, s);
     hipLaunchKernelGGL(k_train_loss, dim3((h->A + 63) / 64), dim3(64), 0, s, W(h, "Y0"), W(h, "Y_ref"), dev_fut, W(h, "score_sv"),
-                       W(h, "params"), valid, W(h, "loss_pa"), d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy);
+                       W(h, "params"), valid, W(h, "nfut"), W(h, "loss_pa"), d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy);
     hipLaunchKernelGGL(k_sum_loss, dim3(1), dim3(256), 0, s, W(h, "loss_pa"), valid, h->A, W(h, "loss_out"));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
@@ -531,18 +545,21 @@ extern "C" int desire_adam_step(desire_handle* h, float lr, float beta1, float b
 
 extern "C" int desire_get_weight(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
     if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
-    auto w = h->want.find(name);
-    if (w == h->want.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
+    auto w = h->want_user.find(name);
+    if (w == h->want_user.end()) return fail(DESIRE_ERR_ARG, std::string("unknown weight: ") + name);
     if (w->second != n) return fail(DESIRE_ERR_ARG, std::string(name) + ": expected " + std::to_string(w->second) + " values");
     if (h->training) {
         hipStream_t s = static_cast<hipStream_t>(stream);
         HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipMemcpy(host_out, W(h, "Wflat") + h->slots.at(name).off, n * sizeof(float), hipMemcpyDeviceToHost));
+        const WSlot& sl = h->slots.at(name);
+        std::vector<float> phys(sl.n);
+        HIPCHK(hipMemcpy(phys.data(), W(h, "Wflat") + sl.off, sl.n * sizeof(float), hipMemcpyDeviceToHost));
+        desire_extract(h, name, phys.data(), host_out);
         return DESIRE_OK;
     }
     auto it = h->host_w.find(name);
     if (it == h->host_w.end()) return fail(DESIRE_ERR_STATE, std::string("weight not set: ") + name);
-    std::memcpy(host_out, it->second.data(), n * sizeof(float));
+    desire_extract(h, name, it->second.data(), host_out);
     return DESIRE_OK;
 }
 

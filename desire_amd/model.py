@@ -34,15 +34,21 @@ def _next_divisor_of_64(n: int) -> int:
     raise ValueError("max_num_obj > 128 is not supported in this round")
 
 
-def dims_from_args(args, n_scenes: int, posterior: bool = True) -> Dims:
+def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool = False) -> Dims:
     S = int(np.sqrt(2 * args.rnn_size))                       # model/model.py:57-58
     mno = _next_divisor_of_64(int(args.max_num_obj))
+    if ref_compat:
+        # the reference graph as written (model/model.py:116-311): raw pixels (:216-231), one eps per object (:262-263), 7 decoder
+        # states re-read as seq_length points (:280-289), batch-norm in train phase on a batch of one object (:453,471)
+        return Dims(n_scenes=n_scenes, mno=mno, K=1, T_obs=int(args.seq_length), T_pred=int(args.seq_length), H=int(args.d_dim),
+                    L=int(args.latent_size), S=S, grid_size=int(getattr(args, "grid_size", 4)), posterior=1, sx=1.0, sy=1.0,
+                    bn_mode=1, ref_compat=1, n_dec=int(getattr(args, "n_dec", 7)))
     w_img = float(getattr(args, "img_width", 2048.0))
     h_img = float(getattr(args, "img_height", 2048.0))
     nb = float(getattr(args, "neighborhood_size", 32))
     return Dims(
         n_scenes=n_scenes, mno=mno, K=int(getattr(args, "num_samples", 20)),
-        T_obs=int(args.seq_length), T_pred=int(getattr(args, "pred_length", args.seq_length)),
+        T_obs=int(args.seq_length), T_pred=int(getattr(args, "pred_length", None) or args.seq_length),
         H=int(args.d_dim), L=int(args.latent_size), S=S,
         C=int(getattr(args, "scene_channels", 32)), Gh=int(getattr(args, "scene_grid", 64)),
         Gw=int(getattr(args, "scene_grid", 64)), n_grids=int(getattr(args, "n_grids", 1)),
@@ -69,7 +75,7 @@ class DESIREModel(object):
         self.batch_size = int(getattr(args, "batch_size", 1))
         self._weights = weights
         self._seed = seed
-        self._handles: Dict[Tuple[int, int], _lib.Handle] = {}
+        self._handles: Dict[Tuple[int, int, int], _lib.Handle] = {}
         self._trained = None                 # the handle train_step updates (weights + Adam moments live on the device)
         self._version = 0                    # bumped by every optimiser step
         self._weights_ver = 0                # version self._weights (host copy) corresponds to
@@ -84,10 +90,10 @@ class DESIREModel(object):
         self.final_output = None
 
     # ---- plumbing -------------------------------------------------------------------------------
-    def _handle(self, n_scenes: int, posterior: bool) -> _lib.Handle:
-        key = (n_scenes, int(posterior))
+    def _handle(self, n_scenes: int, posterior: bool, ref_compat: bool = False) -> _lib.Handle:
+        key = (n_scenes, int(posterior), int(ref_compat))
         if key not in self._handles:
-            d = dims_from_args(self.args, n_scenes, posterior)
+            d = dims_from_args(self.args, n_scenes, posterior, ref_compat)
             h = _lib.Handle(d)
             if self._weights is None:
                 self._weights = init_weights(d, self._seed)
@@ -160,6 +166,38 @@ class DESIREModel(object):
         else:
             self.cost = None
         return Y, score
+
+    def forward_ref_compat(self, x_batch: Sequence[np.ndarray], y_batch: Sequence[np.ndarray],
+                           eps: Optional[np.ndarray] = None, seed: int = 0) -> Dict[str, "object"]:
+        """The reference graph AS WRITTEN (model/model.py:116-311; dims.ref_compat) on loader batches: x_batch / y_batch are
+        DataLoader.next_batch's x and y (y = x shifted one frame, utils/data_loader.py:206-207), [seq_length, MNO, 3] each, raw
+        pixels.  Needs d_dim == 2*seq_length (:286-289).  eps [n, mno, L]: ONE draw per object (:262-263).  Returns device
+        tensors: rho [n, mno, 200] (O1, :116-133), Hx / Hy [n, mno, H], output_states [n, mno, n_dec, seq_length, 2] (:280-289)
+        and feature_pooling [n, mno, n_dec, seq_length, 200] (O11, :291-311).  The reference's graph stops there (:312-313)."""
+        torch = self.torch
+        n = len(x_batch)
+        h = self._handle(n, True, ref_compat=True)
+        d = h.dims
+        past, fut = self._pad_windows(x_batch, d.mno), self._pad_windows(y_batch, d.mno)
+        if past.shape[1] != d.T_obs or fut.shape[1] != d.T_obs:
+            raise ValueError("ref_compat windows are seq_length frames each")
+        if eps is None:
+            g = torch.Generator(device=self.device).manual_seed(seed)
+            eps_t = torch.randn((d.A, d.L), generator=g, device=self.device, dtype=torch.float32)
+        else:
+            eps_t = torch.as_tensor(np.ascontiguousarray(eps, np.float32), device=self.device).reshape(d.A, d.L)
+        stream = torch.cuda.current_stream().cuda_stream
+        states = torch.empty((n, d.mno, d.n_dec, d.T_obs, 2), device=self.device)
+        rho = torch.empty((n, d.mno, 200), device=self.device)
+        fp = torch.empty((n, d.mno, d.n_dec, d.T_obs, 200), device=self.device)
+        h.forward(past.data_ptr(), fut.data_ptr(), eps_t.data_ptr(), states.data_ptr(), 0, stream)
+        h.temporal_conv(past.data_ptr(), rho.data_ptr(), stream)
+        h.feature_pooling(states.data_ptr(), rho.data_ptr(), fp.data_ptr(), stream)
+        self._keep = (past, fut, eps_t)
+        self.input_data, self.target_data = x_batch, y_batch
+        HxHy = h.device_tensor("HxHy").view(n, d.mno, 2, -1)[..., : d.H]
+        self.final_output = states
+        return {"rho": rho, "Hx": HxHy[:, :, 0], "Hy": HxHy[:, :, 1], "output_states": states, "feature_pooling": fp}
 
     # ---- training (train.py:140-181 runs only `cost`; the Adam op of model/model.py:386-403 is never applied) ----
     def train_step(self, x_batch: Sequence[np.ndarray], y_batch: Sequence[np.ndarray], eps: Optional[np.ndarray] = None,
@@ -264,7 +302,7 @@ class DESIREModel(object):
         torch = self.torch
         traj = np.asarray(traj, np.float64)
         args = SimpleNamespace(**vars(self.args))
-        t_pred = int(getattr(self.args, "pred_length", self.args.seq_length))
+        t_pred = int(getattr(self.args, "pred_length", None) or self.args.seq_length)
         if num > t_pred:
             raise ValueError("num=%d exceeds the model's pred_length=%d (the IOC regression head is sized by it)"
                              % (num, t_pred))

@@ -52,6 +52,8 @@ class Dims:
     bin_mode: int = 0      # social bins: 0 rectangular window nb_w x nb_h; 1 log-polar (rings nb_h .. nb_w x sectors)
     bn_mode: int = 0       # CVAE batch-norm: 0 frozen moving statistics; 1 per-object statistics (the reference's batch of one)
     bf16: int = 0          # 1: bf16 MFMA operands (fp32 accumulate / state) in the IOC kernel; inference only
+    ref_compat: int = 0    # 1: the reference graph as written (model/model.py:116-311): n_dec decoder states re-read as T_obs points
+    n_dec: int = 0         # ref_compat only: decoder steps (the reference hard-codes 7, model/model.py:280)
 
     @property
     def A(self) -> int:
@@ -79,10 +81,16 @@ class Dims:
             raise ValueError("CVAE stack closes only for S=32 (rnn_size=512), model/model.py:465-468")
         if not (1 <= self.mno <= 128) or (32 % self.mno if self.mno <= 32 else self.mno % 32):
             raise ValueError("mno must divide 32 or be 64, 96 or 128 (host pads max_num_obj up)")
-        if self.H % 32 or self.L % 8 or self.C % 8 or self.E_v % 8:
-            raise ValueError("H%32, L%8, C%8, E_v%8 required by the MFMA tiling")
-        if self.H not in (64, 128, 256):
-            raise ValueError("H must be 64, 128 or 256 (instantiated recurrent tiles)")
+        if self.L % 8 or self.C % 8 or self.E_v % 8:
+            raise ValueError("L%8, C%8, E_v%8 required by the MFMA tiling")
+        if self.H not in (16, 32, 64, 128, 256):
+            raise ValueError("H must be 16, 32 (run zero-padded on the 64-wide recurrent tile), 64, 128 or 256")
+        if self.ref_compat:
+            if not (self.K == 1 and self.posterior and self.bn_mode == 1 and not self.bf16 and self.n_dec >= 1
+                    and self.H == 2 * self.T_obs and self.T_pred == self.T_obs):
+                raise ValueError("ref_compat (model/model.py:116-311): K=1, posterior, bn_mode=1, fp32, H == 2*T_obs, T_pred == T_obs, n_dec >= 1")
+        elif self.n_dec:
+            raise ValueError("n_dec belongs to ref_compat")
         if self.C != 32 or self.E_v != 16:
             raise ValueError("C=32, E_v=16 are the instantiated IOC widths in this round")
         if min(self.n_scenes, self.K, self.T_obs, self.T_pred, self.n_grids, self.iters) < 1:

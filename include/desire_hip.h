@@ -52,7 +52,15 @@ typedef struct desire_dims {
                               object (model/model.py:453-462,471-481), i.e. per-sample per-channel moments over the layer's
                               pixels.  fp32 operands, inference only. */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
-                              for the recurrent IOC kernel (BASELINE configs[2]); inference only, mno <= 64 */
+                              for the recurrent IOC kernel (BASELINE configs[2]); inference only */
+    int32_t ref_compat;    /* 1: the reference graph AS WRITTEN (model/model.py:116-311) instead of the frozen spec: the GRU
+                              decoder runs n_dec steps (7, :280) and every output state [H] is re-read as T_obs (x, y) points
+                              (:286-289, needs H == 2*T_obs); one eps per object (K = 1, :262-263); target window = input
+                              shifted one frame (T_pred == T_obs, utils/data_loader.py:206-207); per-object batch-norm
+                              (bn_mode = 1); no head, no IOC (:312-313).  desire_sample / desire_forward then write
+                              dev_Yhat [A, n_dec, T_obs, 2] = output_states; desire_ioc_refine is an error.  sx = sy = 1
+                              reproduces the raw-pixel inputs of :216-231. */
+    int32_t n_dec;         /* ref_compat only: decoder steps (the reference hard-codes 7); 0 otherwise */
 } desire_dims;
 
 typedef struct desire_ctx desire_handle;
@@ -118,8 +126,11 @@ int desire_scene_cells(desire_handle* h, const float* dev_pos, int32_t* dev_cell
 int desire_scene_cnn(desire_handle* h, const float* dev_image, int32_t Hi, int32_t Wi, float* dev_grids, void* stream);
 
 /* Train-path scalars after desire_forward (posterior mode): dev_kld [A] (model/model.py:587-589 per agent),
- * dev_recon [A] = mean_k mean_t ||Y_gt - Yhat_k|| (paper; the reference's NLL has undefined inputs, :342),
- * dev_cost [2] = {mean over existing agents of recon+kld (masking rule :351-366,374-376), #agents}. */
+ * dev_recon [A] = mean_k mean_{t present} ||Y_gt - Yhat_k|| (paper; the reference's NLL has undefined inputs, :342),
+ * dev_cost [2] = {mean of recon+kld over the agents that count, #such agents}.  Masking rule of :351-366,374-376: an object
+ * counts when it exists (id != 0 at the last observed frame) and exists in the target; with a multi-frame target that is
+ * per frame -- a target frame whose id is 0 carries no ground truth and is skipped, an object absent from every target
+ * frame does not count at all.  The training loss, its gradients and desire_ade_fde use the same rule. */
 int desire_losses(desire_handle* h, const float* dev_fut, const float* dev_Yhat, float* dev_kld, float* dev_recon,
                   float* dev_cost, void* stream);
 
@@ -143,7 +154,8 @@ int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_fr
  * outputs, dev_normals [n,2] ~ N(0,1); dev_out [n,2] sample clipped to <= 1.0. */
 int desire_gaussian_sample(desire_handle* h, const float* dev_params, const float* dev_normals, float* dev_out,
                            int32_t n, void* stream);
-/* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K). */
+/* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K) over the target frames
+ * the object is present in (FDE: the last such frame); zeros for an object absent from every target frame. */
 int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);
 
 /* ---- hipGraph capture: desire_graph_begin(h, stream); any stream-ordered desire_* calls on that stream (desire_forward,

@@ -534,18 +534,23 @@ def feature_pooling(Y, rho, d):
     return np.concatenate([Y[..., 0:1] * rr[:, None, :100], Y[..., 1:2] * rr[:, None, 100:]], -1).astype(np.float32)
 
 
-def losses(z_mean, z_log_sigma_sq, Y, fut_n, valid, d, dt=np.float32):
+def losses(z_mean, z_log_sigma_sq, Y, fut_n, valid, d, dt=np.float32, present=None):
     """Train-path scalars.  kld[a]: model/model.py:587-589 per agent (the reference then means over
-    its batch of 1).  recon[a]: the paper's sample-generation loss, mean over k and t of
+    its batch of 1).  recon[a]: the paper's sample-generation loss, mean over k and the PRESENT target frames of
     ||Y_gt - Yhat_k||_2 (the reference's Gaussian NLL has undefined inputs, :342).  cost: mean of
-    (recon + kld) over agents that exist (id != 0), the reference's masking rule :351-366,374-376.
-    Y [R,T,2], fut_n [T,A,2] normalised, valid [A]."""
+    (recon + kld) over the agents that count -- the reference's masking rule :351-366,374-376: the object exists
+    (id != 0 at the last observed frame) and exists in the target; per target frame here: `present` [T, A] bool
+    (id != 0 in that future frame; default all), a frame without the object is skipped, an object in no target
+    frame does not count.  Y [R,T,2], fut_n [T,A,2] normalised, valid [A]."""
     kld = (-0.5 * np.sum(1.0 + z_log_sigma_sq - np.square(z_mean) - np.exp(z_log_sigma_sq), axis=1)).astype(dt)
     Yk = Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2).astype(dt)
     gt = fut_n.transpose(1, 0, 2).reshape(d.n_scenes, 1, d.mno, d.T_pred, 2).astype(dt)
     dist = np.sqrt(np.square(Yk - gt).sum(-1))                           # [n,K,mno,T]
-    recon = dist.mean(axis=(1, 3)).reshape(d.A).astype(dt)
-    v = np.asarray(valid, bool)
+    pm = np.ones((d.T_pred, d.A), bool) if present is None else np.asarray(present, bool)
+    pm_ = pm.T.reshape(d.n_scenes, 1, d.mno, d.T_pred)
+    nf = pm.sum(0).astype(dt)                                            # [A] present target frames
+    recon = ((dist * pm_).sum(axis=(1, 3)).reshape(d.A) / (d.K * np.maximum(nf, 1))).astype(dt)
+    v = np.asarray(valid, bool) & (nf > 0)
     n = int(v.sum())
     cost = float(((recon + kld) * v).sum() / max(n, 1))
     return kld, recon, cost, n
@@ -563,12 +568,19 @@ def gaussian_sample(params, normals):
     return np.stack([np.minimum(x, 1.0), np.minimum(y, 1.0)], -1).astype(np.float32)
 
 
-def ade_fde_k(Y, fut_n, d):
-    """Y [R,T,2], fut_n [T,A,2] -> [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K)."""
+def ade_fde_k(Y, fut_n, d, present=None):
+    """Y [R,T,2], fut_n [T,A,2] -> [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K) over the target
+    frames the object is present in (`present` [T, A] bool, default all; FDE at the LAST present frame); zeros for an
+    object that is in no target frame."""
     Yk = Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2).astype(np.float32)
     gt = fut_n.transpose(1, 0, 2).reshape(d.n_scenes, 1, d.mno, d.T_pred, 2).astype(np.float32)
     e = np.sqrt(np.square(Yk - gt).sum(-1))                    # [n,K,mno,T]
-    ade, fde = e.mean(-1), e[..., -1]
+    pm = np.ones((d.T_pred, d.A), bool) if present is None else np.asarray(present, bool)
+    pm_ = pm.T.reshape(d.n_scenes, 1, d.mno, d.T_pred)
+    nf = pm_.sum(-1)
+    ade = (e * pm_).sum(-1) / np.maximum(nf, 1)
+    last = np.where(pm_.any(-1), d.T_pred - 1 - np.argmax(pm_[..., ::-1], -1), 0)
+    fde = np.take_along_axis(e, np.broadcast_to(last[..., None], e.shape[:3] + (1,)), -1)[..., 0] * (nf > 0)
     out = np.stack([ade.mean(1), fde.mean(1), ade.min(1), fde.min(1)], -1)
     return out.reshape(d.A, 4).astype(np.float32)
 

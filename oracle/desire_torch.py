@@ -8,9 +8,9 @@ tests/test_train_oracle.py; gradients are then whatever autograd derives from th
 Loss (the reference's `cost` is recon + kld with the id==0 masking rule, model/model.py:339-376; its recon term has
 undefined inputs, so the paper's losses are used):
 
-    L_sgm = mean_valid_a [ mean_k mean_t ||Y_gt - Y0_k||  +  kld_a ]
-    L_ioc = mean_valid_a [ CE(softmax_k(-max_t ||Y_gt - Y0_k||) , softmax_k(score_k))  +  mean_k mean_t ||Y_gt - (Y0_k + dY_k)|| ]
-    L     = L_sgm + L_ioc
+    L_sgm = mean_counted_a [ mean_k mean_{t present} ||Y_gt - Y0_k||  +  kld_a ]
+    L_ioc = mean_counted_a [ CE(softmax_k(-max_{t present} ||Y_gt - Y0_k||) , softmax_k(score_k))  +  mean_k mean_{t present} ||Y_gt - (Y0_k + dY_k)|| ]
+    L     = L_sgm + L_ioc        present(a,t): id != 0 in target frame t; counted: id != 0 at the last observed frame and some t present
 
 with Y0 DETACHED inside the IOC module (sampled trajectories are inputs of the ranking/refinement module: positions
 enter it only through non-differentiable cell/bin indices and the velocity embedding) -- the two modules share
@@ -156,19 +156,25 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     out.update(score=score, dY=dY, Y=Y, ioc_relu_margin=pre_min, ioc_x=torch.stack(x_steps, 1))      # ioc_x [R, T, E]
 
     # ---- losses ----
-    v = valid.to(DT)
+    # masking rule of model/model.py:351-366 per target frame: present[t, a] = id != 0 in future frame t; an object counts when
+    # it exists at the last observed frame and in at least one target frame; absent frames carry no ground truth
+    pres = torch.as_tensor(np.asarray(fut)[:, :, 0] != 0)                                   # [T, A]
+    pm = pres.T.reshape(d.n_scenes, 1, d.mno, d.T_pred).to(DT)
+    nf = pres.sum(0).to(DT)                                                                 # [A]
+    nfc = torch.clamp(nf, min=1.0)
+    v = (valid & (nf > 0)).to(DT)
     n_valid = torch.clamp(v.sum(), min=1.0)
     gt = fn.permute(1, 0, 2).reshape(d.n_scenes, 1, d.mno, d.T_pred, 2)
-    e0 = torch.sqrt(((Y0.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2) - gt) ** 2).sum(-1) + 0.0)   # [n,K,mno,T]
-    recon = e0.mean(dim=(1, 3)).reshape(d.A)
+    e0 = torch.sqrt(((Y0.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2) - gt) ** 2).sum(-1) + 1e-300)   # [n,K,mno,T]
+    recon = (e0 * pm).sum(dim=(1, 3)).reshape(d.A) / (d.K * nfc)
     kld = -0.5 * (1.0 + ls - mu ** 2 - torch.exp(ls)).sum(1)
     L_sgm = ((recon + kld) * v).sum() / n_valid
-    dmax = e0.detach().max(dim=3).values if fixed is None else _t(fixed["dmax"])   # [n,K,mno]
+    dmax = (e0.detach() * pm).max(dim=3).values if fixed is None else _t(fixed["dmax"])   # [n,K,mno] over present frames
     Pt = torch.softmax(-dmax, dim=1)
     logQ = torch.log_softmax(score.reshape(d.n_scenes, d.K, d.mno), dim=1)
     ce = -(Pt * logQ).sum(1).reshape(d.A)
-    e1 = torch.sqrt(((Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2) - gt) ** 2).sum(-1))
-    reg = e1.mean(dim=(1, 3)).reshape(d.A)
+    e1 = torch.sqrt(((Y.reshape(d.n_scenes, d.K, d.mno, d.T_pred, 2) - gt) ** 2).sum(-1) + 1e-300)
+    reg = (e1 * pm).sum(dim=(1, 3)).reshape(d.A) / (d.K * nfc)
     L_ioc = ((ce + reg) * v).sum() / n_valid
     out.update(recon=recon, kld=kld, ce=ce, reg=reg, L_sgm=L_sgm, L_ioc=L_ioc, loss=L_sgm + L_ioc, Yd=Yd, dmax=dmax)
     return out

@@ -1,0 +1,200 @@
+"""The reference's OWN dims on the HIP path: d_dim = 16 (train.py:85) and 32 run zero-padded on the
+64-wide recurrent tile (csrc/ctx.h: EmbedAxis -- exact, the added products are zeros), the literal graph of
+model/model.py:116-311 runs as dims.ref_compat against oracle.forward_ref_compat on the reference loader's golden batch,
+raw pixels (sx = sy = 1, :216-231) meet the 1e-3 bar in PIXELS, and DESIREModel(train.py defaults) constructs, runs and
+trains."""
+import os
+
+import numpy as np
+import pytest
+
+from desire_amd.spec import Dims, init_weights
+from tests.helpers import make_case, small_dims, to_oracle_layout
+from tests.test_gpu_parity import oracle_forward, run_gpu, torch_cuda  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(H=16, T_pred=8, K=3),                                   # the reference's d_dim (train.py:85)
+    dict(H=16, T_pred=8, K=2, mno=64, n_scenes=1, n_grids=1),    # ... with its max_num_obj = 60 padded to 64 slots
+    dict(H=32, K=2, iters=2),
+    dict(H=16, K=2, posterior=0),
+    dict(H=32, K=2, bn_mode=1),
+    dict(H=16, K=2, grid_size=6, nb_w=0.5, nb_h=0.5),
+])
+def test_small_hidden_stagewise(torch_cuda, kw):
+    d = small_dims(**kw)
+    w = init_weights(d, 11)
+    assert w["dec/gates/kernel"].shape == (2 * d.H, 2 * d.H)         # the caller's (logical) shapes
+    past, fut, eps, grids, gos = make_case(d, seed=12, n_absent=min(3, d.mno - 1))
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos, bn_mode="per_object" if d.bn_mode else "frozen")
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    A, R = d.A, d.R
+    shapes = {"Hx": (A, d.H), "xhat": (R, 1024), "xz": (R, d.H), "Y0": (R, d.T_pred, 2)}
+    if d.posterior:
+        shapes.update({"Hy": (A, d.H), "vae_in": (A, d.V), "z_mean": (A, d.L)})
+    for name, shp in shapes.items():
+        err = float(np.abs(h.read_buffer(name, shp) - ref[name].reshape(shp)).max())
+        assert err < (1e-3 if name == "Y0" else 2e-4), (name, err)
+    _, Y2, score2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref["Y"]).max() < 1e-3
+    assert np.abs(score2 - ref["score"]).max() < 5e-3
+    # weights come back in the caller's layout
+    for name in ("ioc/gates/kernel", "ioc/social_fc/w", "fc_c/w", "mask_fc/b", "dec/candidate/kernel"):
+        assert np.array_equal(h.get_weight(name, w[name].shape), w[name]), name
+
+
+def test_small_hidden_bf16(torch_cuda):
+    from oracle import desire_oracle as O
+    d = small_dims(H=16, K=2, bf16=1)
+    w = init_weights(d, 13)
+    past, fut, eps, grids, gos = make_case(d, seed=14)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    assert np.abs(h.read_buffer("Y0", (d.R, d.T_pred, 2)) - ref["Y0"]).max() < 1e-3
+    assert np.isfinite(Y).all() and np.isfinite(score).all()
+    del O
+
+
+def test_raw_pixel_units(torch_cuda):
+    """sx = sy = 1: the reference feeds raw pixels (model/model.py:216-231).  The 1e-3 bar in PIXEL units, on positions of
+    the SDD range (0..1400); neighbourhood 32 px / 4 x 4 (train.py:68-72)."""
+    d = small_dims(sx=1.0, sy=1.0, nb_w=32.0, nb_h=32.0, K=3, T_pred=12, Gh=64, Gw=64)
+    w = init_weights(d, 15)
+    past, fut, eps, grids, gos = make_case(d, seed=16)
+    assert past[..., 1].max() > 100.0            # make_case hands out PIXELS (the loader layout)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    scale = float(np.abs(ref["Y0"]).max())
+    assert scale > 100.0, "positions must be in pixels for this test to mean anything"
+    err = float(np.abs(Y0 - ref["Y0"]).max())
+    print("raw-pixel decoder error: %.3e px on coordinates up to %.0f px" % (err, scale))
+    assert err < 1e-3
+    _, Y2, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y2 - ref["Y"]).max() < 1e-3
+
+
+def _ref_args(**kw):
+    from desire_amd.train import build_parser
+    args = build_parser().parse_args([])
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return args
+
+
+def test_ref_compat_on_reference_loader_batch(torch_cuda):
+    """HIP dims.ref_compat vs oracle.forward_ref_compat (model/model.py:116-311 as written) on the batch the REFERENCE's own
+    DataLoader produced (tests/golden/loader_bookstore6_T8.npz: next_batch x / y, raw pixels, T = 8, 32 slots)."""
+    from desire_amd.model import DESIREModel, dims_from_args
+    from oracle import desire_oracle as O
+    g = np.load(os.path.join(HERE, "loader_bookstore6_T8.npz"))
+    x, y = g["x"][0], g["y"][0]                              # [4, 8, 32, 3]
+    args = _ref_args(max_num_obj=32)                         # every other flag at the reference default: d_dim 16, seq_length 8
+    d = dims_from_args(args, 4, True, ref_compat=True)
+    assert (d.H, d.T_obs, d.K, d.n_dec, d.sx, d.bn_mode) == (16, 8, 1, 7, 1.0, 1)
+    w = init_weights(d, 5, ref_init=True)                    # N(0,1) fc_c / mask_fc as model/model.py:434-443
+    eps = np.random.default_rng(6).standard_normal((4, 32, d.L)).astype(np.float32)
+    m = DESIREModel(args, weights=w)
+    out = m.forward_ref_compat(list(x), list(y), eps)
+    torch_cuda.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for i in range(4):
+        ref = O.forward_ref_compat(x[i].transpose(1, 0, 2), y[i].transpose(1, 0, 2), eps[i], w, H=16, L=d.L, n_dec=7)
+        np.testing.assert_allclose(got["rho"][i], ref["rho"], rtol=1e-6, atol=1e-3)
+        assert np.abs(got["Hx"][i] - ref["Hx"]).max() < 2e-5
+        assert np.abs(got["Hy"][i] - ref["Hy"]).max() < 2e-5
+        assert np.abs(got["output_states"][i] - ref["output_states"]).max() < 1e-4
+        np.testing.assert_allclose(got["feature_pooling"][i], ref["feature_pooling"], rtol=2e-4, atol=0.5)
+    h = m._handle(4, True, ref_compat=True)
+    xhat = h.read_buffer("xhat", (d.R, 1024)).reshape(4, 32, 1024)
+    ref0 = O.forward_ref_compat(x[0].transpose(1, 0, 2), y[0].transpose(1, 0, 2), eps[0], w, H=16, L=d.L, n_dec=7)
+    assert np.abs(xhat[0] - ref0["xhat"]).max() < 1e-4
+    with pytest.raises(Exception):                            # the reference graph has no IOC (model/model.py:312-313)
+        h.ioc_refine(out["output_states"].data_ptr(), out["output_states"].data_ptr())
+
+
+def test_model_with_reference_defaults_runs_and_trains(torch_cuda, tmp_path):
+    """DESIREModel(train.py:30-88 defaults): d_dim 16, seq_length 8, max_num_obj 60, grid 4, neighbourhood 32 px -- every MODEL
+    flag at the reference's value, through desire_amd.train's loop on the real bookstore slice.  Only the optimiser's step is
+    lowered: Adam at the reference's 0.005 (a rate the reference never ran, train.py:181) blows the KL term up through
+    exp(log sigma^2) within three steps."""
+    import random
+    from desire_amd import train as T
+    from desire_amd.data_loader import DataLoader
+    from desire_amd.model import DESIREModel
+    g = np.load(os.path.join(HERE, "loader_bookstore6_T8.npz"))
+    args = T.build_parser().parse_args(["--learning_rate", "0.001", "--num_epochs", "3", "--batch_size", "4", "--num_samples", "4",
+                                        "--save_dir", str(tmp_path / "save")])
+    assert (args.d_dim, args.seq_length, args.max_num_obj, args.rnn_size, args.latent_size, args.grid_size) == (16, 8, 60, 512, 128, 4)
+    m = DESIREModel(args, seed=3)
+    frames = [np.pad(g["data0"], ((0, 0), (0, 28), (0, 0)))]          # [160, 60, 3] as the loader builds it for max_num_obj = 60
+    dl = DataLoader(args.batch_size, 16, args.max_num_obj, frames=frames)
+    random.seed(0)
+    losses = T.train(args, data_loader=dl, model=m, log=lambda l: None)
+    assert len(losses) >= 6 and np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    x, _, _ = dl.next_batch(random_update=False)
+    past, fut = T.split_windows(x, 8)
+    Y, score = m.forward(past, fut, seed=1)
+    torch_cuda.cuda.synchronize()
+    assert tuple(Y.shape) == (4, 4, 64, 8, 2) and bool(torch_cuda.isfinite(Y).all())
+    assert m.sync_weights()["dec/gates/kernel"].shape == (32, 32)
+
+
+def test_small_hidden_gradients_match_autograd(torch_cuda):
+    """All trainable tensors at d_dim = 16 against float64 autograd: the zero-padded units carry exactly zero gradient, so the
+    logical blocks are the whole gradient."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    from oracle import desire_torch as OT
+    d = small_dims(n_scenes=2, mno=32, K=3, T_obs=6, T_pred=7, n_grids=1, H=16)
+    w = init_weights(d, 41)
+    for k in w:
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    past, fut, eps, grids, gos = make_case(d, seed=42, n_absent=4)
+    vals, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda")
+    score = torch.zeros((d.R,), device="cuda")
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+    torch.cuda.synchronize()
+    bad = {}
+    for name in ref:
+        if name not in w or name.startswith(("scene_cnn", "temporal")) or "/bn/" in name:
+            continue
+        got = h.get_grad(name, w[name].shape)
+        if name == "ioc/score/b":
+            assert np.abs(got).max() < 1e-6
+            continue
+        e = float(np.abs(got - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12))
+        if not e < 3e-4:
+            bad[name] = e
+    assert not bad, bad
+    # the padded units never move: after Adam steps a fresh handle built from the read-back (logical) weights gives the same forward
+    for _ in range(3):
+        h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+        h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+        h.adam_step(0.01)
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    torch.cuda.synchronize()
+    Y1 = Y.cpu().numpy().copy()
+    w2 = {k: h.get_weight(k, v.shape) for k, v in w.items()}
+    h2 = _lib.Handle(d)
+    h2.set_weights(w2)
+    h2.set_scene_grids(grids_t.data_ptr(), gos)
+    h2.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(Y.cpu().numpy() - Y1).max() < 1e-6
