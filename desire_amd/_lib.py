@@ -22,7 +22,7 @@ EXPORTS = [
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
-    "desire_graph_begin", "desire_graph_end", "desire_graph_launch",
+    "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout",
 ]
 
 
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.desire_build_windows.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), i32, f32p, f32p, vp]
     lib.desire_gaussian_sample.argtypes = [vp, f32p, f32p, f32p, i32, vp]
     lib.desire_ade_fde.argtypes = [vp, f32p, f32p, f32p, vp]
+    lib.desire_rollout.argtypes = [vp, f32p, f32p, i32, f32p, vp]
     lib.desire_set_training.argtypes = [vp, C.c_int]
     lib.desire_backward.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_get_grad.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
@@ -183,6 +184,9 @@ class Handle:
 
     def gaussian_sample(self, params_ptr: int, normals_ptr: int, out_ptr: int, n: int, stream: int = 0) -> None:
         _chk(self.lib.desire_gaussian_sample(self._h, params_ptr, normals_ptr, out_ptr, n, stream or None))
+
+    def rollout(self, past_ptr: int, normals_ptr: int, num: int, out_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_rollout(self._h, past_ptr, normals_ptr, num, out_ptr, stream or None))
 
     def ade_fde(self, yhat_ptr: int, fut_ptr: int, out_ptr: int, stream: int = 0) -> None:
         _chk(self.lib.desire_ade_fde(self._h, yhat_ptr, fut_ptr, out_ptr, stream or None))

@@ -126,6 +126,7 @@ void shapes(desire_ctx* h, int H, std::map<std::string, size_t>& s) {
     s["scene_cnn/conv2/w"] = 25 * 16 * 32; s["scene_cnn/conv2/b"] = 32;
     s["scene_cnn/conv3/w"] = (size_t)25 * 32 * d.C; s["scene_cnn/conv3/b"] = d.C;
     s["temporal/w"] = (size_t)d.T_obs * 2 * 100; s["temporal/b"] = 200;
+    s["gauss_head/w"] = (size_t)H * 5; s["gauss_head/b"] = 5;       // sample()'s 5-wide output layer (model/model.py:315-321,445-449)
 }
 
 // logical -> physical embedding of every weight that has a hidden-width axis (ctx.h: Embed)
@@ -150,6 +151,7 @@ void embeddings(desire_ctx* h) {
     e["ioc/social_fc/b"] = Embed{{{fix(1)}}, {{Hs}}};
     e["ioc/score/w"] = Embed{{{Hs}}, {{fix(1)}}};
     e["ioc/reg/w"] = Embed{{{Hs}}, {{fix(2 * d.T_pred)}}};
+    e["gauss_head/w"] = Embed{{{Hs}}, {{fix(5)}}};
 }
 
 // frozen batch-norm + bias -> (scale, shift); float64 then one rounding (desire_amd/spec.py:fold_bn)
@@ -485,7 +487,7 @@ int desire_pack_all(desire_ctx* h) {
         bad |= up("vae_dec/deconv1/W", pack_b(L, 2048, [&](int k, int n) { return w1[(size_t)n * L + k]; }));
     }
     for (const char* n : {"scene_cnn/conv1/w", "scene_cnn/conv1/b", "scene_cnn/conv2/w", "scene_cnn/conv2/b",
-                          "scene_cnn/conv3/w", "scene_cnn/conv3/b", "temporal/w", "temporal/b"})
+                          "scene_cnn/conv3/w", "scene_cnn/conv3/b", "temporal/w", "temporal/b", "gauss_head/w", "gauss_head/b"})
         bad |= up(n, hw[n]);
     {   // operands of the backward data-gradient passes (the forward kernels run with swapped roles)
         const auto& wm = hw["mask_fc/w"]; const auto& wfc = hw["vae_enc/fc/w"]; const auto& wcc = hw["fc_c/w"];
@@ -945,6 +947,29 @@ extern "C" int desire_gaussian_sample(desire_handle* h, const float* dev_params,
     if (!h || !dev_params || !dev_normals || !dev_out || n < 0) return fail(DESIRE_ERR_ARG, "bad argument");
     if (n == 0) return DESIRE_OK;
     launch_gaussian_sample(dev_params, dev_normals, dev_out, n, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+// sample()'s autoregressive rollout (model/model.py:623-688): warm-up over the observed frames with the X-encoder GRU (the
+// reference's loop :623-632 carrying `states`), then `num` prediction steps, each: 5-wide Gaussian head on the state (:651,
+// 661-663) -> draw (:665) -> clip (:666-669) -> feed the drawn position back as the next input (:680-681).
+extern "C" int desire_rollout(desire_handle* h, const float* dev_past, const float* dev_normals, int32_t num, float* dev_out,
+                              void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!dev_past || !dev_normals || !dev_out) return fail(DESIRE_ERR_ARG, "null argument");
+    if (num < 1) return fail(DESIRE_ERR_ARG, "num must be >= 1");
+    const desire_dims& d = h->d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->ws.count("roll_h") && h->ws["roll_h"].alloc((size_t)h->A * d.H * sizeof(float))) return fail(DESIRE_ERR_HIP, "hipMalloc failed");
+    EncArgs e{};
+    e.n_scenes = d.n_scenes; e.mno = d.mno; e.sx = d.sx; e.sy = d.sy; e.H = d.H;
+    e.frames = dev_past; e.T = d.T_obs;
+    e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
+    e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
+    e.out = W(h, "roll_h"); e.ldo = d.H;
+    e.n_roll = num; e.w5 = D(h, "gauss_head/w"); e.b5 = D(h, "gauss_head/b"); e.normals = dev_normals; e.roll_out = dev_out;
+    { Timer t(h, s, "rollout"); launch_encoder(e, s); }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }

@@ -62,6 +62,10 @@ struct EncArgs {
     float* p_last;                                         // optional [A,2]: normalised last pos
     uint8_t* valid;                                        // optional [A]: id != 0 at last frame
     float* sv_r; float* sv_u; float* sv_c; float* sv_h; float* sv_x;   // optional training saves [A,T,H] x4, [A,T,2]
+    // autoregressive rollout after the T observed frames (sample(), model/model.py:643-681): n_roll more steps whose input is
+    // the position drawn from the bivariate Gaussian the 5-wide head reads off the current state
+    int n_roll; const float* w5; const float* b5;          // head [H,5], [5]
+    const float* normals; float* roll_out;                 // [n_roll, A, 2] N(0,1) draws in, sampled positions (clipped <= 1) out
 };
 void launch_encoder(const EncArgs& a, hipStream_t s);
 void launch_encoder_bf16(const EncArgs& a, hipStream_t s);    // kernels_bf16.hip; Whg / Whc = bf16 packs

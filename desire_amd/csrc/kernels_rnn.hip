@@ -33,7 +33,7 @@ __device__ __forceinline__ void mma1(f32x16& acc, const float* a_lane, const flo
 // ------------------------------------------------------------------------------------------------
 // Encoder: tile = 64 agents, T steps, input (x,y) normalised in-kernel: one fp32 multiply each.
 // ------------------------------------------------------------------------------------------------
-template <int H, int TM>
+template <int H, int TM, bool ROLL = false>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64;
@@ -57,7 +57,34 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
     const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
     float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;       // + acc-row offset * LDH
 
-    for (int t = 0; t < a.T; ++t) {
+    const int n_steps = ROLL ? a.T + a.n_roll : a.T;
+    for (int t = 0; t < n_steps; ++t) {
+        if (ROLL && t >= a.T) {
+            // sample() prediction step (model/model.py:643-681): the 5-wide head reads (mux, muy, log sx, log sy, corr) off the
+            // state, a point is drawn from that bivariate Gaussian (:661-665, Cholesky form, caller's normals), clipped to <= 1.0
+            // (:666-669) and becomes this step's input (:680-681 prev_data = newpos)
+            __syncthreads();                               // hs holds h_{t-1} of every wave
+            if (tid < TM) {
+                const int ag = min(a0 + tid, A - 1);
+                float p5[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) p5[j] = 0.f;
+                for (int c = 0; c < H; ++c) {
+                    const float hv = hs[tid * LDH + c];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) p5[j] = fmaf(hv, a.w5[c * 5 + j], p5[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) p5[j] += a.b5[j];
+                const size_t ix = ((size_t)(t - a.T) * A + ag) * 2;
+                const float sdx = expf(p5[2]), sdy = expf(p5[3]), rho = tanhf(p5[4]);
+                const float n0 = a.normals[ix], n1 = a.normals[ix + 1];
+                const float x = fminf(p5[0] + sdx * n0, 1.0f);
+                const float y = fminf(p5[1] + sdy * (rho * n0 + sqrtf(fmaxf(1.0f - rho * rho, 0.f)) * n1), 1.0f);
+                xs[tid * 2] = x; xs[tid * 2 + 1] = y;
+                if (a0 + tid < A) { a.roll_out[ix] = x; a.roll_out[ix + 1] = y; }
+            }
+        } else
         if (tid < TM) {
             const int ag = min(a0 + tid, A - 1);
             const int sc = ag / a.mno, slot = ag - sc * a.mno;
@@ -135,6 +162,12 @@ void launch_encoder(const EncArgs& a, hipStream_t s) {
     constexpr int TM = 32;
     const size_t lds = (TM * (a.H + 4) + TM * 2) * sizeof(float);
     const dim3 grid((A + TM - 1) / TM);
+    if (a.n_roll > 0) {
+        if (a.H == 256) hipLaunchKernelGGL((k_encoder<256, TM, true>), grid, dim3(512), lds, s, a);
+        else if (a.H == 128) hipLaunchKernelGGL((k_encoder<128, TM, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_encoder<64, TM, true>), grid, dim3(128), lds, s, a);
+        return;
+    }
     if (a.H == 256) hipLaunchKernelGGL((k_encoder<256, TM>), grid, dim3(512), lds, s, a);
     else if (a.H == 128) hipLaunchKernelGGL((k_encoder<128, TM>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((k_encoder<64, TM>), grid, dim3(128), lds, s, a);

@@ -294,33 +294,87 @@ class DESIREModel(object):
         return cls(args, weights=load_weights(path))
 
     # ---- reference-shaped sampling API (model/model.py:613-688) ------------------------------------
-    def sample(self, sess, traj, grid, dimensions, true_traj, num=10):
-        """traj [obs, MNO, 3] observed frames; returns [obs+num, MNO, 3]: the observed frames followed by
-        the top-scored (IOC) refined sample per object, in pixel units, ids carried over
-        (model/model.py:680-688).  `sess` is ignored; `grid` may be a [Gh,Gw,C] scene feature grid;
-        `dimensions` = (width, height) of the frame in pixels."""
+    def _sample_model(self, obs_len: int, dimensions) -> "DESIREModel":
+        """The model sample() runs on: same weights, observation length = the trajectory's, frame size = `dimensions`.
+        Cached per (obs_len, dimensions); refreshed when the optimiser has moved the weights since (train_step keeps them on
+        the device: sync_weights pulls them back)."""
+        key = (int(obs_len), None if dimensions is None else (float(dimensions[0]), float(dimensions[1])))
+        cache = self.__dict__.setdefault("_sample_models", {})
+        wts = self.sync_weights()
+        if wts is None:
+            self._handle(1, False)                       # first use: draws the initial weights
+            wts = self._weights
+        sub, ver = cache.get(key, (None, -1))
+        if sub is None or ver != self._version:
+            args = SimpleNamespace(**vars(self.args))
+            args.seq_length = int(obs_len)
+            args.pred_length = int(getattr(self.args, "pred_length", None) or self.args.seq_length)
+            if key[1] is not None:
+                args.img_width, args.img_height = key[1]
+            w = dict(wts)
+            tw = np.asarray(w["temporal/w"])
+            if tw.shape[1] != obs_len:                   # O1's window is seq_length wide; sample() does not use it
+                fit = np.zeros((1, obs_len, 2, 100), np.float32)
+                n = min(obs_len, tw.shape[1])
+                fit[:, :n] = tw[:, :n]
+                w["temporal/w"] = fit
+            if sub is None:
+                sub = DESIREModel(args, w, self._seed)
+            else:
+                sub._weights = w
+                for hd in sub._handles.values():
+                    hd.set_weights(w)
+            cache[key] = (sub, self._version)
+        return sub
+
+    def sample(self, sess, traj, grid, dimensions, true_traj, num=10, mode: str = "rollout", normals=None, seed: int = 0):
+        """traj [obs, MNO, 3] observed frames; returns [obs+num, MNO, 3]: the observed frames followed by `num` predicted
+        frames in pixel units, ids carried over from the last observed frame (model/model.py:680-688).  `sess` is ignored;
+        `dimensions` = (width, height) of the frame in pixels (default: args.img_width / img_height).
+
+        mode "rollout" (default) is the reference's loop (:623-688) on the device in one launch: warm-up over the observed
+        frames, then per step the 5-wide Gaussian head "gauss_head/w|b" -> a draw (`normals` [num, MNO, 2] ~ N(0,1), or
+        torch's generator seeded with `seed`) -> clip to <= 1.0 in normalised units (:666-669) -> fed back as the next input.
+        Like the reference, objects with id 0 are stepped too and keep id 0.  `true_traj` only feeds the reference's cost
+        print-outs (:649,684-685) and is unused.
+        mode "ioc": the top-scored IOC-refined sample of the frozen-spec forward (prior path); `grid` may be a [Gh,Gw,C]
+        scene feature grid; num <= pred_length."""
         torch = self.torch
         traj = np.asarray(traj, np.float64)
-        args = SimpleNamespace(**vars(self.args))
-        t_pred = int(getattr(self.args, "pred_length", None) or self.args.seq_length)
-        if num > t_pred:
-            raise ValueError("num=%d exceeds the model's pred_length=%d (the IOC regression head is sized by it)"
-                             % (num, t_pred))
-        args.seq_length, args.pred_length = traj.shape[0], t_pred
-        if dimensions is not None:
-            args.img_width, args.img_height = float(dimensions[0]), float(dimensions[1])
-        sub = DESIREModel(args, self._weights, self._seed)
-        if grid is not None and np.ndim(grid) == 3:
-            sub.set_scene_grids(np.asarray(grid, np.float32)[None], [0])
-        Y, score = sub.forward([traj], None)
-        d = sub._handle(1, False).dims
-        best = score[0].argmax(dim=0)                                        # [mno]
-        idx = best.view(1, -1, 1, 1).expand(1, d.mno, d.T_pred, 2)
-        top = torch.gather(Y[0], 0, idx)[0].cpu().numpy()[:, :num]           # [mno, num, 2]
+        sub = self._sample_model(traj.shape[0], dimensions)
         out = np.zeros((traj.shape[0] + num, traj.shape[1], 3))
         out[: traj.shape[0]] = traj
         m = traj.shape[1]
         out[traj.shape[0]:, :, 0] = traj[-1, :, 0]
+        if mode == "rollout":
+            h = sub._handle(1, False)
+            d = h.dims
+            past = sub._pad_windows([traj], d.mno)
+            if normals is None:
+                g = torch.Generator(device=self.device).manual_seed(seed)
+                nrm = torch.randn((num, d.A, 2), generator=g, device=self.device, dtype=torch.float32)
+            else:
+                nrm = torch.zeros((num, d.A, 2), device=self.device)
+                nrm[:, :m] = torch.as_tensor(np.asarray(normals, np.float32), device=self.device)
+            pos = torch.empty((num, d.A, 2), device=self.device)
+            h.rollout(past.data_ptr(), nrm.data_ptr(), int(num), pos.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            p = pos.cpu().numpy()[:, :m]
+            out[traj.shape[0]:, :, 1] = p[..., 0] / d.sx
+            out[traj.shape[0]:, :, 2] = p[..., 1] / d.sy
+            return out
+        if mode != "ioc":
+            raise ValueError("sample(mode=...): 'rollout' (the reference's loop) or 'ioc' (top-scored refined sample)")
+        t_pred = int(getattr(self.args, "pred_length", None) or self.args.seq_length)
+        if num > t_pred:
+            raise ValueError("num=%d exceeds the model's pred_length=%d (the IOC regression head is sized by it)"
+                             % (num, t_pred))
+        if grid is not None and np.ndim(grid) == 3:
+            sub.set_scene_grids(np.asarray(grid, np.float32)[None], [0])
+        Y, score = sub.forward([traj], None, seed=seed)
+        d = sub._handle(1, False).dims
+        best = score[0].argmax(dim=0)                                        # [mno]
+        idx = best.view(1, -1, 1, 1).expand(1, d.mno, d.T_pred, 2)
+        top = torch.gather(Y[0], 0, idx)[0].cpu().numpy()[:, :num]           # [mno, num, 2]
         out[traj.shape[0]:, :, 1] = (top[:m, :, 0] / d.sx).T
         out[traj.shape[0]:, :, 2] = (top[:m, :, 1] / d.sy).T
         out[traj.shape[0]:][:, traj[-1, :, 0] == 0] = 0

@@ -177,6 +177,11 @@ def weight_shapes(d: Dims) -> Dict[str, Tuple[int, ...]]:
     # ---- temporal convolution O1 (model/model.py:116-133, weights :427-431) ----
     s["temporal/w"] = (1, d.T_obs, 2, 100)
     s["temporal/b"] = (200,)
+    # ---- sample()'s 5-wide output layer (mux, muy, log sx, log sy, corr): the reference's commented-out output_w / output_b
+    # (model/model.py:315-321,445-449), read by the autoregressive rollout (:643-681).  LAST on purpose: init_weights draws
+    # in this order, so everything above keeps the values the committed goldens were made with. ----
+    s["gauss_head/w"] = (H, 5)
+    s["gauss_head/b"] = (5,)
     return s
 
 

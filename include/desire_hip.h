@@ -154,6 +154,13 @@ int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_fr
  * outputs, dev_normals [n,2] ~ N(0,1); dev_out [n,2] sample clipped to <= 1.0. */
 int desire_gaussian_sample(desire_handle* h, const float* dev_params, const float* dev_normals, float* dev_out,
                            int32_t n, void* stream);
+/* N3: sample()'s autoregressive rollout (model/model.py:623-688) in one launch: warm-up over dev_past [n_scenes, T_obs, mno, 3]
+ * with the X-encoder GRU (the loop :623-632), then `num` prediction steps: the 5-wide output layer "gauss_head/w|b"
+ * (the reference's output_w / output_b, :315-321,445-449) reads (mux, muy, log sx, log sy, corr) off the state, a position is
+ * drawn from that bivariate Gaussian with the caller's dev_normals [num, A, 2] (:661-665), clipped to <= 1.0 (:666-669) and fed
+ * back as the next input (:680-681).  dev_out [num, A, 2], normalised units.  Objects with id 0 are stepped like any other
+ * (the reference does the same and carries the id over, :680). */
+int desire_rollout(desire_handle* h, const float* dev_past, const float* dev_normals, int32_t num, float* dev_out, void* stream);
 /* N4: evaluation harness: dev_out [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K) over the target frames
  * the object is present in (FDE: the last such frame); zeros for an object absent from every target frame. */
 int desire_ade_fde(desire_handle* h, const float* dev_Yhat, const float* dev_fut, float* dev_out, void* stream);

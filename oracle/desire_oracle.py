@@ -568,6 +568,27 @@ def gaussian_sample(params, normals):
     return np.stack([np.minimum(x, 1.0), np.minimum(y, 1.0)], -1).astype(np.float32)
 
 
+def rollout(past, w, d, normals, dt=np.float32):
+    """sample()'s autoregressive path, model/model.py:623-688, restated on this spec's cells: warm-up = the X-encoder GRU over
+    the observed frames carrying its state (:623-632); then for each of the `num` steps (:643): the 5-wide output layer on the
+    state -> get_coef-style exp / exp / tanh (:661-663) -> one draw from the bivariate Gaussian (:665, Cholesky form with the
+    caller's normals) -> clip to <= 1.0 (:666-669) -> the drawn position is the next input (:680-681).  Objects with id 0 are
+    stepped like the others (the reference loops over every object, :660).  past [T_obs, A, 3] loader layout, normals
+    [num, A, 2] -> positions [num, A, 2] in normalised units."""
+    pn = normalise(past, d, dt)
+    Wg, bg, Wc, bc = _gru_w(w, "enc_x", dt)
+    h = np.zeros((pn.shape[1], Wc.shape[1]), dt)
+    for t in range(pn.shape[0]):
+        h = gru_cell(pn[t], h, Wg, bg, Wc, bc)
+    W5, b5 = w["gauss_head/w"].astype(dt), w["gauss_head/b"].astype(dt)
+    out = []
+    for s in range(normals.shape[0]):
+        pos = gaussian_sample(h @ W5 + b5, normals[s]).astype(dt)
+        out.append(pos)
+        h = gru_cell(pos, h, Wg, bg, Wc, bc)
+    return np.stack(out, 0)
+
+
 def ade_fde_k(Y, fut_n, d, present=None):
     """Y [R,T,2], fut_n [T,A,2] -> [A,4] = (ADE mean-of-K, FDE mean-of-K, ADE best-of-K, FDE best-of-K) over the target
     frames the object is present in (`present` [T, A] bool, default all; FDE at the LAST present frame); zeros for an

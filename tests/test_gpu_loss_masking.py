@@ -13,9 +13,9 @@ def _leaving_case(d, seed):
     fut = fut.copy()
     fut[0, 3:, 1] = 0          # scene 0 slot 1 leaves after 3 target frames
     fut[0, 1:, 4] = 0          # slot 4 after one frame
-    fut[0, :, 6] = 0           # slot 6 is never in the target: must not count (but still pools: present at the last observed frame)
+    fut[0, :, 3] = 0           # slot 3 is never in the target: must not count (but still pools: present at the last observed frame)
     fut[1, 2:5, 2] = 0         # scene 1 slot 2 is missing in the middle (track gap)
-    fut[1, d.T_pred - 1:, 7] = 0
+    fut[1, d.T_pred - 1:, 0] = 0
     return past, fut, eps, grids, gos
 
 
@@ -56,7 +56,7 @@ def test_losses_ade_fde_and_gradients_with_leaving_objects():
     present = fo[:, :, 0] != 0
     valid = po[d.T_obs - 1, :, 0] != 0
     counted = valid & present.any(0)
-    assert counted.sum() == valid.sum() - 1            # slot 6 of scene 0 dropped
+    assert counted.sum() == valid.sum() - 1            # slot 3 of scene 0 dropped
     h = _lib.Handle(d)
     h.set_weights(w)
     h.set_training(True)

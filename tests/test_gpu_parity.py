@@ -247,7 +247,7 @@ def test_cold_rows_scene_cnn_losses_temporal_pooling(torch_cuda):
     zm, zl = h.read_buffer("z_mean", (d.A, d.L)), h.read_buffer("z_log_sigma_sq", (d.A, d.L))
     futn = O.normalise(to_oracle_layout(fut), d)
     valid = to_oracle_layout(past)[d.T_obs - 1, :, 0] != 0
-    k_ref, r_ref, c_ref, n_ref = O.losses(zm, zl, Y.cpu().numpy(), futn, valid, d)
+    k_ref, r_ref, c_ref, n_ref = O.losses(zm, zl, Y.cpu().numpy(), futn, valid, d, present=to_oracle_layout(fut)[:, :, 0] != 0)
     assert np.abs(kld.cpu().numpy() - k_ref).max() < 1e-3 * max(1.0, np.abs(k_ref).max())
     assert np.abs(recon.cpu().numpy() - r_ref).max() < 1e-5
     assert abs(float(cost[0]) - c_ref) < 1e-3 * max(1.0, abs(c_ref)) and int(cost[1]) == n_ref
@@ -324,7 +324,7 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
     af = torch.zeros((d.A, 4), device=dev)
     h.ade_fde(Y.data_ptr(), ft_t.data_ptr(), af.data_ptr())
     torch.cuda.synchronize()
-    ref = O.ade_fde_k(Y.cpu().numpy(), O.normalise(to_oracle_layout(ft), d), d)
+    ref = O.ade_fde_k(Y.cpu().numpy(), O.normalise(to_oracle_layout(ft), d), d, present=to_oracle_layout(ft)[:, :, 0] != 0)
     assert np.abs(af.cpu().numpy() - ref).max() < 1e-5
     assert (af[:, 2] <= af[:, 0] + 1e-6).all() and (af[:, 3] <= af[:, 1] + 1e-6).all()
 
