@@ -207,7 +207,7 @@ def test_model_api_and_sample_layout(torch_cuda):
         m2 = DESIREModel.restore(args, _os.path.join(td, "w.npz"))
         Y2, _ = m2.forward(x, y)
         np.testing.assert_array_equal(Y2.cpu().numpy(), Y.cpu().numpy())
-    out = m.sample(None, x[0], None, (1400.0, 1100.0), np.concatenate([x[0], y[0]]), num=10)
+    out = m.sample(None, x[0], None, (1400.0, 1100.0), np.concatenate([x[0], y[0]]), num=10, mode="ioc")
     assert out.shape == (18, 30, 3)
     np.testing.assert_array_equal(out[:8], x[0])
     np.testing.assert_array_equal(out[8:, :, 0], np.broadcast_to(x[0][-1, :, 0], (10, 30)))
