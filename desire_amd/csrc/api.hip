@@ -186,7 +186,6 @@ int check_dims(const desire_dims& d) {
     if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
     if (d.bin_mode == 1 && (d.grid_size < 3 || !(d.nb_h > 0.f) || !(d.nb_w > d.nb_h)))
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
-    if (d.bf16 && d.mno > 64) return fail(DESIRE_ERR_ARG, "bf16 operands: mno must divide 32 or be 64 in this round");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
     if (d.ref_compat != 0 && d.ref_compat != 1) return fail(DESIRE_ERR_ARG, "ref_compat must be 0 or 1");
     if (d.ref_compat) {
@@ -666,7 +665,9 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
-    const bool cluster = !d.bf16 && ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
+    // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
+    const bool cluster = d.bf16 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
+                                : ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
         const size_t n_groups = (size_t)h->R / d.mno;
         if (!h->ws.count("hex")) {
@@ -690,7 +691,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
         a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
         Timer t(h, s, "ioc");
-        launch_ioc_bf16(a, s);
+        if (cluster) { if (launch_ioc_bf16_cluster(a, s)) return fail(DESIRE_ERR_HIP, "bf16 cluster IOC: no resident grid for this shape"); }
+        else launch_ioc_bf16(a, s);
     } else
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
     if (h->training) {

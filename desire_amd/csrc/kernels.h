@@ -114,6 +114,9 @@ inline bool ioc_uses_cluster(int mno, int H, int bins, int variant) {
     return false;
 }
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
+// bf16 cluster form (kernels_bf16_cl.hip): groups of 64 / 96 / 128 agents over mno/32 workgroups; returns != 0 when the
+// persistent grid cannot be made resident
+int launch_ioc_bf16_cluster(const IocArgs& a, hipStream_t s);
 // agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
 struct IocStepArgs {
     int t; int rank; int nranks; int m_loc; int n_scenes; int K; int R;       // R = local rows = n_scenes * K * m_loc

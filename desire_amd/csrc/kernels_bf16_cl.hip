@@ -1,0 +1,380 @@
+// kernels_bf16_cl.hip -- cluster form of the bf16-operand IOC kernel: (scene, k) groups of 64 / 96 / 128 agents
+// (BASELINE configs[2]: a real SDD deathCircle window holds 65+ track ids, i.e. mno = 96 or 128).
+//
+// A group of mno = 32 * tpg agents spans tpg 32-row tiles = tpg workgroups (the tile body is k_ioc_bf16's 32-row form: wave
+// cb owns hidden columns [32cb, 32cb+32) of the tile's 32 rows; state, gate math and accumulators fp32, MFMA operands bf16).
+// What the members exchange once per step is exactly the pooling operand: the TRANSPOSED bf16 image of their hidden-state
+// tile, Ht[hidden][row] (8 KB at H = 128), through a global buffer hex16[2][n_tiles][H][32] and the hand-off of cluster.h.
+// Every member keeps the whole group's Ht[H][mno] in LDS and runs the pooling chain over mno/16 neighbour chunks:
+//       P_b^T[hidden, i] = Ht[hidden, j] . M_b^T[j, i]      (B operand = the 128-bit neighbour mask of row i, expanded to bf16 0/1)
+//       e_r            += cvt(P_b^T) . W_b                   (chain-ordered weights, no shuffle / LDS / barrier in between)
+// The step's position-only work (velocity embedding, scene-feature gather, neighbour bins of my rows against all mno agents)
+// runs BEFORE the wait for the neighbours' h_{t-1}, so part of the hand-off latency hides under it.
+// Grid: persistent, a multiple of tpg, never more workgroups than are co-resident (occupancy query), members adjacent.
+#include "bf16.h"
+#include "cluster.h"
+#include "kernels.h"
+
+#define CLMAXM 128
+
+template <int H, int EV, int C, bool SPLIT>
+__global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_bf16_cl(IocArgs a, u16* __restrict__ hex16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = H >> 5, TM = 32, E = EV + C + H, KX = E + H;
+    constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = CLMAXM + 8;      // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
+    constexpr int JGM = CLMAXM / 16;                                   // most 16-neighbour chunks a row can have
+    const int B = a.G * a.G, LDM = B + 1;
+    const int tpg = a.mno / 32;                                        // tiles (workgroups) per group
+    const int JG = a.mno / 16;
+    u16* Xb = reinterpret_cast<u16*>(smem_raw);                        // [TM][LDXB]  e_v | e_s | e_r | h   (my rows)
+    u16* RHb = Xb + TM * LDXB;                                         // [TM][LDRB]  r * h
+    u16* Ht = RHb + TM * LDRB;                                         // [H][LDT]    h transposed, the WHOLE group
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(Ht + H * LDT);   // [TM][B+1][2], bit = group-local slot
+    uint2* lut = reinterpret_cast<uint2*>(masks + TM * LDM * 2);       // [16] nibble -> 4 bf16 (0.0 / 1.0)
+    float* pg = reinterpret_cast<float*>(lut + 16);                    // [CLMAXM][2] positions of the whole group
+    float* pp = pg + CLMAXM * 2;                                       // [TM][2] previous position of my rows
+    float* wv = pp + TM * 2;                                           // [3][EV]
+    float* red = wv + 3 * EV;                                          // [NT][TM]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [CLMAXM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + CLMAXM);              // [2] bins that hold a neighbour anywhere in the tile
+    float* EX = reinterpret_cast<float*>(smem_raw + ((reinterpret_cast<unsigned char*>(occ + 2) - smem_raw + 15) & ~15));   // [NT][1024]
+    float* EXB = EX + NT * 1024;                                            // [NT / 2][1024] second set's upper half (B <= 32)
+
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int col = cb * 32 + c31;
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int tile_pos = blockIdx.x % tpg;                             // my tile inside its group
+    const int n_tiles = a.R / TM;
+    const int my_slot = tile_pos * TM + r8;                            // group-local slot of my VALU row
+
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < 16) {
+        const unsigned lo = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        lut[tid] = make_uint2(lo, hi2);
+    }
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const uint4* Wg = reinterpret_cast<const uint4*>(a.Wg);
+    const uint4* Wc = reinterpret_cast<const uint4*>(a.Wc);
+    const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
+    const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
+    const u16* xp[1] = {Xb + c31 * LDXB + 8 * hi};
+    const u16* rp[1] = {RHb + c31 * LDRB + 8 * hi};
+    const int arow = 4 * hi;                                           // + (i&3) + 8(i>>2): local row of accumulator element i
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * TM;
+        const int grow0 = row0 - tile_pos * TM;                        // first row of the group
+        const int group = grow0 / a.mno;
+        int* cnt = a.grp_cnt + group;
+        const int scene = grow0 / (a.K * a.mno);
+        const float* grid = a.grids + (size_t)a.grid_of_scene[scene] * a.Gh * a.Gw * C;
+        __syncthreads();
+        for (int i = tid; i < a.mno; i += NTHR) vld[i] = a.valid[agent_of_row(grow0 + i, a.K, a.mno)];
+        // h (fp32, accumulator layout) -> the bf16 images: my rows of Xb, my columns of Ht and (steps only) the exchange buffer
+        auto publish_h = [&](const f32x16& h, u16* gdst) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + E + col] = bf16_of(h[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 v = make_uint2(pk_bf16(h[4 * q], h[4 * q + 1]), pk_bf16(h[4 * q + 2], h[4 * q + 3]));
+                *reinterpret_cast<uint2*>(Ht + col * LDT + tile_pos * TM + arow + 8 * q) = v;
+                if (gdst) *reinterpret_cast<uint2*>(gdst + (size_t)col * TM + arow + 8 * q) = v;
+            }
+        };
+
+        for (int it = 0; it < a.iters; ++it) {
+            if (it > 0) group_wait(cnt, tpg * (it * (a.T + 1)), a.err);          // everybody's Y += dY has landed
+            f32x16 h, sp = zero16();
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                h[i] = a.Hx[(size_t)agent_of_row(row0 + arow + (i & 3) + 8 * (i >> 2), a.K, a.mno) * a.ldhx + col];
+            __syncthreads();                                  // previous pass's readers of Xb / Ht are done
+            publish_h(h, nullptr);
+            // h_{-1} = Hx of the OTHER tiles' agents: every member computes it itself (no hand-off before step 0)
+            for (int i = tid; i < a.mno * (H >> 2); i += NTHR) {
+                const int j = i / (H >> 2), c4 = i - j * (H >> 2);
+                if ((j >> 5) == tile_pos) continue;
+                const float4 v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(grow0 + j, a.K, a.mno) * a.ldhx + c4 * 4);
+                Ht[(c4 * 4 + 0) * LDT + j] = bf16_of(v.x); Ht[(c4 * 4 + 1) * LDT + j] = bf16_of(v.y);
+                Ht[(c4 * 4 + 2) * LDT + j] = bf16_of(v.z); Ht[(c4 * 4 + 3) * LDT + j] = bf16_of(v.w);
+            }
+            if (tid < TM) {
+                const int ag = agent_of_row(row0 + tid, a.K, a.mno);
+                pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            }
+
+            for (int t = 0; t < a.T; ++t) {
+                for (int i = tid; i < a.mno; i += NTHR) {
+                    const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + i) * a.T + t) * 2);
+                    pg[i * 2] = y.x; pg[i * 2 + 1] = y.y;
+                }
+                for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
+                if (tid < 2) occ[tid] = 0;
+                __syncthreads();
+                // ---- P1: e_v, e_s, neighbour bits of my rows against the whole group (positions only: no hidden state needed) ----
+                {
+                    const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
+                    const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                    for (int j = 2 * q8; j < EV; j += 2 * TPR) {
+                        const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                        const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
+                        *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = pk_bf16(e0, e1);
+                    }
+                    int cy, cx;
+                    scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                    const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                    for (int j = 4 * q8; j < C; j += 4 * TPR) {
+                        const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
+                        *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(pk_bf16(g4.x, g4.y), pk_bf16(g4.z, g4.w));
+                    }
+                    for (int j = q8; j < a.mno; j += TPR) {
+                        if (j == my_slot || !vld[j]) continue;
+                        const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
+                        if (b >= 0) { atomicOr(&masks[(r8 * LDM + b) * 2 + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
+                    }
+                }
+                // ---- neighbours' h_{t-1}: published by their tiles at the end of step t-1 (parity (t-1)&1) ----
+                if (t > 0) {
+                    group_wait(cnt, tpg * (it * (a.T + 1) + t), a.err);
+                    const u16* src0 = hex16 + (size_t)((t + 1) & 1) * n_tiles * H * TM;
+                    for (int tp = 0; tp < tpg; ++tp) {
+                        if (tp == tile_pos) continue;
+                        const uint4* src = reinterpret_cast<const uint4*>(src0 + (size_t)(tile - tile_pos + tp) * H * TM);
+                        for (int i = tid; i < H * 4; i += NTHR)
+                            *reinterpret_cast<uint4*>(Ht + (i >> 2) * LDT + tp * TM + 8 * (i & 3)) = src[i];
+                    }
+                }
+                __syncthreads();
+                // ---- P2: social pooling chain -> e_r ----
+                unsigned long long om_all = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+                om_all |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                auto frag_bits = [&](int b, uint4 (&mf)[JGM]) {           // neighbour bits of row c31 in bin b -> bf16 B fragments
+                    const unsigned long long m0 = masks[(c31 * LDM + b) * 2], m1 = masks[(c31 * LDM + b) * 2 + 1];
+#pragma unroll
+                    for (int jg = 0; jg < JGM; ++jg) {
+                        if (jg < JG) {
+                            const unsigned bits = (unsigned)((jg < 4 ? m0 : m1) >> (16 * (jg & 3) + 8 * hi)) & 0xffu;
+                            const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                            mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        }
+                    }
+                };
+                auto chain = [&](int hb, const uint4 (&mf)[JGM]) {
+                    f32x16 d1 = zero16();
+                    const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
+#pragma unroll
+                    for (int jg = 0; jg < JGM; ++jg)
+                        if (jg < JG) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], d1);
+                    return d1;
+                };
+                if constexpr (SPLIT) {
+                    // occupied bins dealt round-robin to the NT waves; a wave runs the whole chain of ITS bins into NT partial e_r
+                    // tiles (slot k = column block (cb + k) % NT), summed in fixed order through an LDS exchange (kernels_bf16.hip)
+                    const unsigned long long om = om_all;
+                    unsigned long long mine = 0ull;
+                    {
+                        int k = 0;
+                        for (unsigned long long tmp = om; tmp; tmp &= tmp - 1, ++k)
+                            if (k % NT == cb) mine |= tmp & (0ull - tmp);
+                    }
+                    f32x16 soc[NT];
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) soc[k] = zero16();
+                    auto wptr = [&](int b, int hb, int k) {
+                        const int cbo = (cb + k) % NT;
+                        return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
+                    };
+                    uint4 wq[2 * NT];
+                    if (mine) {
+                        const int b0 = __ffsll((long long)mine) - 1;
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) { const uint4* p = wptr(b0, 0, k); wq[2 * k] = p[0]; wq[2 * k + 1] = p[64]; }
+                    }
+#pragma clang loop unroll(disable)
+                    while (mine) {
+                        const int b = __ffsll((long long)mine) - 1;
+                        mine &= mine - 1;
+                        const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                        uint4 mf[JGM];
+                        frag_bits(b, mf);
+#pragma unroll
+                        for (int hb = 0; hb < NT; ++hb) {
+                            const f32x16 da = chain(hb, mf);
+                            const uint4 p0 = make_uint4(pk_bf16(da[0], da[1]), pk_bf16(da[2], da[3]), pk_bf16(da[4], da[5]), pk_bf16(da[6], da[7]));
+                            const uint4 p1 = make_uint4(pk_bf16(da[8], da[9]), pk_bf16(da[10], da[11]), pk_bf16(da[12], da[13]), pk_bf16(da[14], da[15]));
+#pragma unroll
+                            for (int k = 0; k < NT; ++k) {
+                                soc[k] = mfma16(p0, wq[2 * k], soc[k]);
+                                soc[k] = mfma16(p1, wq[2 * k + 1], soc[k]);
+                                const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+                                wq[2 * k] = p[0]; wq[2 * k + 1] = p[64];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (om) {                                          // (workgroup-uniform)
+                        const bool two_sets = B <= 32;
+                        auto slot = [&](int set, int wvi) {
+                            if (set == 0 || !two_sets) return EX + (size_t)wvi * 1024;
+                            constexpr int nh = NT / 2;
+                            return wvi < nh ? reinterpret_cast<float*>(RHb) + (size_t)wvi * 1024 : EXB + (size_t)(wvi - nh) * 1024;
+                        };
+#pragma unroll
+                        for (int sft = 1; sft < NT; ++sft) {
+                            const int set = (sft - 1) & 1;
+                            if (sft > 1 && !two_sets) __syncthreads();
+                            float4* dst = reinterpret_cast<float4*>(slot(set, cb)) + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                dst[q * 64] = make_float4(soc[sft][4 * q], soc[sft][4 * q + 1], soc[sft][4 * q + 2], soc[sft][4 * q + 3]);
+                            __syncthreads();
+                            const float4* src = reinterpret_cast<const float4*>(slot(set, (cb + NT - sft) % NT)) + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 v = src[q * 64];
+                                soc[0][4 * q] += v.x; soc[0][4 * q + 1] += v.y; soc[0][4 * q + 2] += v.z; soc[0][4 * q + 3] += v.w;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[0][i] + bso, 0.f));
+                } else {
+                    f32x16 soc = zero16();
+                    unsigned long long om = om_all;
+                    uint4 wb[2 * NT];                                   // this wave's n-tile of W_b, refreshed in place one bin ahead
+                    if (om) {
+                        const uint4* wsrc = Wsoc + ((size_t)((__ffsll((long long)om) - 1) * NT + cb) * GH16) * 64 + lane;
+#pragma unroll
+                        for (int g = 0; g < 2 * NT; ++g) wb[g] = wsrc[g * 64];
+                    }
+#pragma clang loop unroll(disable)
+                    while (om) {
+                        const int b = __ffsll((long long)om) - 1;
+                        om &= om - 1;
+                        const uint4* wnext = Wsoc + ((size_t)((om ? __ffsll((long long)om) - 1 : b) * NT + cb) * GH16) * 64 + lane;
+                        uint4 mf[JGM];
+                        frag_bits(b, mf);
+#pragma unroll
+                        for (int hb = 0; hb < NT; ++hb) {
+                            const f32x16 da = chain(hb, mf);
+                            const uint4 p0 = make_uint4(pk_bf16(da[0], da[1]), pk_bf16(da[2], da[3]), pk_bf16(da[4], da[5]), pk_bf16(da[6], da[7]));
+                            const uint4 p1 = make_uint4(pk_bf16(da[8], da[9]), pk_bf16(da[10], da[11]), pk_bf16(da[12], da[13]), pk_bf16(da[14], da[15]));
+                            soc = mfma16(p0, wb[2 * hb], soc);
+                            soc = mfma16(p1, wb[2 * hb + 1], soc);
+                            wb[2 * hb] = wnext[(2 * hb) * 64];
+                            wb[2 * hb + 1] = wnext[(2 * hb + 1) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i] + bso, 0.f));
+                }
+                __syncthreads();
+                // ---- P4: gates over [x | h] ----
+                f32x16 u;
+                {
+                    f32x16 g2[2][1] = {{zero16()}, {zero16()}};
+                    const uint4* bl[2] = {Wg + ((size_t)cb * G16) * 64 + lane, Wg + ((size_t)(cb + NT) * G16) * 64 + lane};
+                    mma16_groups<1, 2>(g2, xp, bl, G16);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float r = sigmoidf_(g2[0][0][i] + bgr);
+                        RHb[(arow + (i & 3) + 8 * (i >> 2)) * LDRB + col] = bf16_of(r * h[i]);
+                        u[i] = sigmoidf_(g2[1][0][i] + bgu);
+                    }
+                }
+                __syncthreads();
+                // ---- P5: candidate over [x | r*h], blend, score; publish h_t (LDS images + exchange buffer, parity t&1) ----
+                {
+                    f32x16 ac[1][1] = {{zero16()}};
+                    const uint4* bx[1] = {Wc + ((size_t)cb * G16) * 64 + lane};
+                    mma16_groups<1, 1>(ac, xp, bx, GX16);
+                    const uint4* bh[1] = {Wc + ((size_t)cb * G16 + GX16) * 64 + lane};
+                    mma16_groups<1, 1>(ac, rp, bh, GH16);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float c = tanhf_(ac[0][0][i] + bcc);
+                        h[i] = gru_blend(u[i], h[i], c);
+                        sp[i] = fmaf(h[i], wsc, sp[i]);
+                    }
+                    publish_h(h, hex16 + ((size_t)(t & 1) * n_tiles + tile) * H * TM);
+                }
+                if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
+                group_publish(cnt);                          // includes the end-of-step __syncthreads
+            }
+            // ---- score ----
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sp[i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+                if (c31 == 0) red[cb * TM + arow + (i & 3) + 8 * (i >> 2)] = v;
+            }
+            __syncthreads();
+            if (tid < TM && it == a.iters - 1) {
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+                a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+            }
+            // ---- regression: Y += h_T W_r + b_r ----
+            for (int nt = cb; nt < a.NTreg; nt += NT) {
+                f32x16 acc[1][1] = {{zero16()}};
+                const u16* hp2[1] = {xp[0] + E};
+                const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
+                mma16_groups<1, 1>(acc, hp2, br, GH16);
+                const int cc = nt * 32 + c31;
+                if (cc < 2 * a.T) {
+                    const float bb = a.b_reg[cc];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* y = a.Y + (size_t)(row0 + arow + (i & 3) + 8 * (i >> 2)) * 2 * a.T + cc;
+                        *y = *y + (acc[0][0][i] + bb);
+                    }
+                }
+            }
+            group_publish(cnt);                              // pass end: my rows of Y are final for this pass
+        }
+    }
+}
+
+static size_t ioc16_cl_lds(const IocArgs& a, bool split) {
+    const int H = a.H, TM = 32, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
+    size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (CLMAXM + 8) * 2;
+    b += (size_t)TM * (B + 1) * 16 + 16 * 8 + (size_t)CLMAXM * 2 * 4 + TM * 2 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + CLMAXM + 8 + 64;
+    if (split) b += (size_t)NT * 4096 + (B <= 32 ? (size_t)NT * 2048 : 0);
+    return b;
+}
+template <int H, bool SPLIT>
+static int launch16_cl(const IocArgs& a, u16* hex16, hipStream_t s) {
+    auto kern = k_ioc_bf16_cl<H, 16, 32, SPLIT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = ioc16_cl_lds(a, SPLIT);
+    const int threads = (H / 32) * 64;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) return -1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    const int tpg = a.mno / 32, n_tiles = a.R / 32;
+    long cap = (long)per_cu * prop.multiProcessorCount;
+    int grid = n_tiles < cap ? n_tiles : (int)cap;           // every workgroup of the grid is resident: members of a group never wait on an unscheduled one
+    grid -= grid % tpg;
+    if (grid < tpg) return -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a, hex16);
+    return 0;
+}
+// a.hex = the exchange buffer (as bf16: 2 * n_tiles * H * 32 elements), a.grp_cnt / a.err as for the fp32 cluster form.
+// a.variant == 6 selects the bin-split pooling (one workgroup per CU: its partial-tile exchange does not leave room for two).
+int launch_ioc_bf16_cluster(const IocArgs& a, hipStream_t s) {
+    u16* hex16 = reinterpret_cast<u16*>(a.hex);
+    const bool split = a.variant == 6 && a.H <= 128;
+    if (a.H == 128) return split ? launch16_cl<128, true>(a, hex16, s) : launch16_cl<128, false>(a, hex16, s);
+    if (a.H == 64) return split ? launch16_cl<64, true>(a, hex16, s) : launch16_cl<64, false>(a, hex16, s);
+    return launch16_cl<256, false>(a, hex16, s);
+}

@@ -784,29 +784,7 @@ void launch_ioc(const IocArgs& a, hipStream_t s) {
 // after every group member has published the step in between, i.e. finished reading parity p.
 // Serves mno in {64, 96, 128} (and H = 256 with mno = 64, which does not fit one workgroup's LDS).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool group_wait(int* cnt, int target, int* err) {
-    bool ok = true;
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > 40000000L) { atomicOr(err, 1); ok = false; break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return ok;
-}
-__device__ __forceinline__ void group_publish(int* cnt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
+#include "cluster.h"
 template <int H, int EV, int C>
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
