@@ -28,7 +28,10 @@ CASES = [
     ("bookstore6_T8", "bookstore/video6", (0, 160), dict(batch_size=4, seq_length=8, max_num_obj=32), 3),
     ("bookstore6_T48", "bookstore/video6", (0, 160), dict(batch_size=2, seq_length=48, max_num_obj=32), 1),
     ("deathcircle2_T8", "deathCircle/video2", (0, 60), dict(batch_size=2, seq_length=8, max_num_obj=70), 2),
+    # BASELINE configs[2]: a deathCircle window of T_obs + T_pred = 48 frames; video4 holds 65 track ids in every frame
+    ("deathcircle4_T48", "deathCircle/video4", (0, 50), dict(batch_size=1, seq_length=48, max_num_obj=70), 1),
 ]
+ONLY = set(sys.argv[1:])            # optional: tags to (re)generate; default all
 
 
 def load_ref_loader():
@@ -41,6 +44,8 @@ def load_ref_loader():
 def main():
     mod = load_ref_loader()
     for tag, rel, (f0, f1), kw, nb in CASES:
+        if ONLY and tag not in ONLY:
+            continue
         raw = np.genfromtxt(os.path.join(REF, "data", rel, "annotations_processed.csv"), delimiter=",")
         keep = (raw[0] >= f0) & (raw[0] < f1)
         sub = raw[:, keep]

@@ -1,0 +1,86 @@
+"""BASELINE configs[2]: "SDD deathCircle, 128 agents, K=20, scene-CNN 64x64x32 grid, 1xMI355X bf16 (MFMA)" on the data it
+names.  deathCircle/video4 holds 65 track ids in every frame (the reference's loader needs max_num_obj >= 66 and drops id 0,
+utils/data_loader.py:140,221-222), so one 8 + 40 frame window is run in 128 slots (bf16 cluster form, four workgroups per
+(scene, k) group); deathCircle/video2 (35 ids) gives the 2 x 64-slot case.  Windows = tests/golden/loader_deathcircle*.npz,
+made by the reference's own DataLoader.  Checked against the oracle with the kernels' bf16 rounding points (same tolerances as
+tests/test_gpu_bf16.py) and, for what bf16 costs, against plain fp32."""
+import os
+
+import numpy as np
+import pytest
+
+from desire_amd.data_loader import window_to_slots
+from desire_amd.spec import Dims, init_weights
+from tests.test_gpu_parity import oracle_forward, run_gpu, torch_cuda  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+IMG = (1432.0, 1948.0)                   # deathCircle frame extent in the annotations (x up to 1432, y up to 1947.5)
+
+
+def _windows(tag, starts, mno):
+    g = np.load(os.path.join(HERE, "loader_%s.npz" % tag))
+    past, fut = [], []
+    for s0 in starts:
+        src, _ = window_to_slots(g["data0"][s0:s0 + 49], 48, g["data0"].shape[1])      # the loader's slot assignment
+        if src.shape[1] > mno:                           # slots beyond the window's unique ids are empty: the model's slot count is enough
+            assert not src[:, mno:].any()
+            src = src[:, :mno]
+        src = np.pad(src, ((0, 0), (0, mno - src.shape[1]), (0, 0)))
+        past.append(src[:8]); fut.append(src[8:])
+    return np.stack(past).astype(np.float32), np.stack(fut).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["video4_1x128", "video2_2x64"])
+def test_config2_deathcircle_bf16(torch_cuda, case):
+    from oracle import desire_oracle as O
+    if case == "video4_1x128":
+        past, fut = _windows("deathcircle4_T48", [0], 128)
+        n, mno = 1, 128
+    else:
+        past, fut = _windows("deathcircle2_T8", [0, 11], 64)
+        n, mno = 2, 64
+    present = (past[:, -1, :, 0] != 0).sum(1)
+    assert present.min() >= (60 if mno == 128 else 30)                 # the crowded scene the config names
+    d32 = Dims(n_scenes=n, mno=mno, K=20, T_obs=8, T_pred=40, H=128, L=128, C=32, Gh=64, Gw=64, n_grids=1, grid_size=4,
+               sx=1.0 / IMG[0], sy=1.0 / IMG[1], nb_w=160.0 / IMG[0], nb_h=160.0 / IMG[1])
+    w = init_weights(d32, 21)
+    rng = np.random.default_rng(22)
+    eps = rng.standard_normal((d32.R, d32.L)).astype(np.float32)
+    grids = rng.uniform(-1, 1, (1, 64, 64, 32)).astype(np.float32)     # scene-CNN output grid (no SDD imagery in the tree)
+    gos = np.zeros(n, np.int32)
+    ref32 = oracle_forward(d32, w, past, fut, eps, grids, gos)
+    ref16 = oracle_forward(d32, w, past, fut, eps, grids, gos, Y_override=ref32["Y0"], ioc_q=O.bf16_round)
+    d16 = d32.replace(bf16=1)
+    h, Yfull, _ = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos)                       # whole bf16 path
+    Y0 = h.read_buffer("Y0", (d32.R, 40, 2))
+    e0 = float(np.abs(Y0 - ref32["Y0"]).max())
+    _, Y, score = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])      # IOC on the oracle's samples
+    dY = ref16["Y"] - ref32["Y0"]
+    scale = max(1.0, float(np.abs(dY).max()))
+    err, err32 = float(np.abs(Y - ref16["Y"]).max()), float(np.abs(Y - ref32["Y"]).max())
+    print("%s: decoder (bf16 vs fp32 oracle) %.2e | IOC vs rounding oracle %.2e, vs fp32 %.2e, |dY|max %.2e"
+          % (case, e0, err, err32, np.abs(dY).max()))
+    assert e0 < 1e-3                                   # sampled trajectories: inside the fp32 bar even with bf16 operands
+    assert err < 7e-3 * scale and err32 < 3e-2 * scale
+    assert np.abs(score - ref16["score"]).max() < 2e-2 * max(1.0, np.abs(ref16["score"]).max())
+    assert np.isfinite(Yfull).all()
+    valid = np.repeat((past[:, -1, :, 0] != 0)[:, None, :], d32.K, axis=1).reshape(-1)
+    assert np.abs(Yfull - ref32["Y"])[valid].mean() < 5e-3
+
+
+def test_config2_fp32_cluster_on_deathcircle(torch_cuda):
+    """The same 128-slot deathCircle window through the fp32 cluster form against the plain oracle (1e-3 bar)."""
+    past, fut = _windows("deathcircle4_T48", [0], 128)
+    d = Dims(n_scenes=1, mno=128, K=4, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, sx=1.0 / IMG[0], sy=1.0 / IMG[1],
+             nb_w=160.0 / IMG[0], nb_h=160.0 / IMG[1])
+    w = init_weights(d, 23)
+    rng = np.random.default_rng(24)
+    eps = rng.standard_normal((d.R, d.L)).astype(np.float32)
+    grids = rng.uniform(-1, 1, (1, 64, 64, 32)).astype(np.float32)
+    gos = np.zeros(1, np.int32)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    assert np.abs(h.read_buffer("Y0", (d.R, 40, 2)) - ref["Y0"]).max() < 1e-3
+    _, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y - ref["Y"]).max() < 1e-3 and np.abs(score - ref["score"]).max() < 5e-3

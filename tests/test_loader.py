@@ -7,7 +7,7 @@ import pytest
 
 from desire_amd.data_loader import DataLoader, frames_from_csv, window_to_slots
 
-TAGS = ["bookstore6_T8", "bookstore6_T48", "deathcircle2_T8"]
+TAGS = ["bookstore6_T8", "bookstore6_T48", "deathcircle2_T8", "deathcircle4_T48"]
 
 
 @pytest.mark.parametrize("tag", TAGS)
