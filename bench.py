@@ -46,9 +46,13 @@ def committed_traffic(windows, bf16=False):
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
     name = {(128, False): "r01_final_bench_pmc_per_kernel.json", (128, True): "r01_bf16_bench_pmc_per_kernel.json",
             (512, False): "r01_final_bench_w512_pmc_per_kernel.json"}.get((windows, bool(bf16)))
+    for newer in ("r02_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else ""),):
+        if os.path.exists(os.path.join(ROOT, "profiles", newer)):
+            name = newer
     path = os.path.join(ROOT, "profiles", name) if name else None
     if path is None or not os.path.exists(path):
         return None
+    committed_traffic.source = "profiles/" + name
     with open(path) as fh:
         pmc = json.load(fh)
     for name, c in pmc.items():
@@ -57,6 +61,26 @@ def committed_traffic(windows, bf16=False):
         if hit and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return None
+
+
+committed_traffic.source = None
+
+
+def sdd_windows(n_windows, mno):
+    """Real Stanford Drone Dataset windows for the `sdd` leg: the committed 160-frame slice of bookstore/video6 (the reference
+    loader's own preprocessing of it, tests/golden/loader_bookstore6_T48.npz: data0 [160, 32, 3] = [id, x_px, y_px]) cut into
+    every 8 + 40-frame window with the loader's slot assignment, tiled to n_windows.  Absent slots stay absent (7.5 objects per
+    frame on average, BASELINE configs[1]'s "SDD bookstore")."""
+    from desire_amd.data_loader import window_to_slots
+    g = np.load(os.path.join(ROOT, "tests", "golden", "loader_bookstore6_T48.npz"))
+    frames = g["data0"]
+    wins = []
+    for s0 in range(0, frames.shape[0] - 48, 4):
+        src, _ = window_to_slots(frames[s0:s0 + 49], 48, frames.shape[1])
+        wins.append(np.pad(src[:, :mno], ((0, 0), (0, max(0, mno - src.shape[1])), (0, 0))))
+    wins = np.stack(wins).astype(np.float32)                               # [n_real, 48, mno, 3]
+    idx = np.arange(n_windows) % wins.shape[0]
+    return np.ascontiguousarray(wins[idx, :8]), np.ascontiguousarray(wins[idx, 8:]), wins.shape[0]
 
 
 def cpu_baseline(d_full, seed):
@@ -141,7 +165,8 @@ def cpu_baseline(d_full, seed):
         xz = O.softmax(O.relu(xh @ w["mask_fc/w"] + w["mask_fc/b"])) * Hr
         O.decode(xz, Hr, O.rows_from_agents(pn[-1], d1), w, d1)
     dt1 = (time.perf_counter() - t1) / n_obj
-    return {"accuracy": accuracy, "value": rt / tt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "kind": "port",
+    return {"accuracy": accuracy, "value": rt / tt, "unit": "agent-trajectory-samples/s", "cores": int(threads), "threads": int(threads),
+            "host_cores": int(os.cpu_count() or 0), "kind": "port",
             "sample": "oracle/desire_torch.py forward (torch fp32, batched, %d threads: the fastest of 8..128) on %d windows = %d samples, %.1f s; "
                       "CPU restatement, not TF1 (reference graph does not build)" % (threads, rt // (d.K * d.mno), rt, tt),
             "numpy_oracle": {"value": d.R / dt, "unit": "agent-trajectory-samples/s",
@@ -180,6 +205,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
                          "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")
+    ap.add_argument("--data", choices=["both", "synthetic"], default="both",
+                    help="'both' (default): the headline on dense synthetic windows (every slot present, every social bin populated) "
+                         "plus an `sdd` object measured, outside the timed region, on real SDD bookstore windows; 'synthetic' skips it")
     ap.add_argument("--train", action="store_true",
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
@@ -323,6 +351,42 @@ def main():
         finally:
             del os.environ["DESIRE_IOC_VARIANT"]
 
+    # outside the timed region: the same path on REAL SDD windows (BASELINE configs[1] names "SDD bookstore"): tiled bookstore/video6
+    # windows with their absent slots and the reference's 32-px neighbourhood (train.py:68-70) on the 1424 x 1088 frame
+    sdd = None
+    if world == 1 and not (a.train or a.graph or a.compact) and a.shard == "scenes" and a.mno >= 32 and a.data == "both":
+        W_IMG, H_IMG = 1424.0, 1088.0
+        d2 = d.replace(nb_w=32.0 / W_IMG, nb_h=32.0 / H_IMG, sx=1.0 / W_IMG, sy=1.0 / H_IMG)
+        p2, f2, n_real = sdd_windows(d.n_scenes, d.mno)
+        h2 = _lib.Handle(d2)
+        h2.set_weights(w)
+        h2.set_scene_grids(grids_t.data_ptr(), gos)
+        p2_t, f2_t = t(p2), t(f2)
+        n2 = max(3, a.steps // 2)
+        for _ in range(2):
+            h2.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
+        torch.cuda.synchronize()
+        h2.set_profiling(True)
+        ts = time.perf_counter()
+        for _ in range(n2):
+            h2.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sdd_dt = (time.perf_counter() - ts) / n2
+        h2.set_profiling(False)
+        k2 = {}
+        for name, ms in h2.get_profile():
+            k2.setdefault(name, []).append(ms)
+        present = float((p2[:, -1, :, 0] != 0).sum()) / p2.shape[0]
+        sdd = {"value": d.R / sdd_dt, "unit": "samples/s (all %d slots x K counted, as in the headline)" % d.mno,
+               "value_present_agents_only": present * d.K * d.n_scenes / sdd_dt, "ms_per_step": sdd_dt * 1e3,
+               "ioc_ms": float(np.mean(k2["ioc"])) if "ioc" in k2 else None,
+               "data": "SDD bookstore/video6, %d distinct 8+40-frame windows of the committed 160-frame slice tiled to %d; %.1f of %d slots "
+                       "present at the last observed frame; neighbourhood 32 px (train.py:68-70), grid 4 x 4" % (n_real, d.n_scenes, present, d.mno),
+               "note": "bins that are empty across a tile are skipped (exact zeros), so fewer flops are executed than on the dense synthetic "
+                       "workload the headline and its roofline are quoted on"}
+        assert bool(torch.isfinite(Y).all())
+        h2.close()
+
     per_kernel = {}
     for name, ms in prof:
         per_kernel.setdefault(name, []).append(ms)
@@ -330,6 +394,10 @@ def main():
     ioc_ms = kern_ms.get("ioc")
     ioc_tflops = ioc_flops_per_row(d) * d.R / (ioc_ms * 1e-3) / 1e12 if ioc_ms else None
     whole_tflops = flops_per_sample(d) * d.R * a.steps / dt / 1e12
+    # the decoder hoists the constant-input half of its per-step contraction out of the time loop (x_z is the same at every step,
+    # model/model.py:280): SURVEY.md D4 credits T*6H*2H, the kernel executes T*6H*H + 6H*H
+    executed_per_sample = flops_per_sample(d) - (d.T_pred - 1) * 6.0 * d.H * d.H
+    whole_exec_tflops = executed_per_sample * d.R * a.steps / dt / 1e12
 
     peak = BF16_MFMA_PEAK_TFLOPS if a.bf16 else FP32_MFMA_PEAK_TFLOPS
     if rank == 0 and a.train:
@@ -361,11 +429,17 @@ def main():
                        "flops_per_sample": flops_per_sample(d)},
             "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1>" if a.bf16 else "k_ioc<128,16,32>", "achieved": ioc_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": (ioc_tflops / peak) if ioc_tflops else None,
-                         "traffic": committed_traffic(a.windows, a.bf16), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic": committed_traffic(a.windows, a.bf16) if a.mno == 32 and a.H == 128 and a.grid == 4 else None,
+                         "traffic_unit": "bytes/launch", "traffic_source": "from_profile: %s (rocprofv3 --pmc passes of this command, committed; "
+                                                                           "not measured in this run)" % committed_traffic.source,
                          "algorithmic_hbm_bytes_per_launch": d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4,
                          "kernel_ms": ioc_ms,
                          "algorithmic_flops_per_launch": ioc_flops_per_row(d) * d.R,
-                         "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / peak},
+                         "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / peak,
+                         "whole_path_frac_executed": whole_exec_tflops / peak,
+                         "whole_path_note": "whole_path_frac credits SURVEY.md D4's formula (%.1f MF/sample); whole_path_frac_executed counts what the "
+                                            "kernels execute (%.1f MF/sample: the decoder's constant-input contraction is hoisted)"
+                                            % (flops_per_sample(d) / 1e6, executed_per_sample / 1e6)},
             "kernel_ms": kern_ms,
         }
         if a.compact:
@@ -376,8 +450,20 @@ def main():
             out["config"]["workload"] += "; social window %.3g (non-default: sparse bins)" % a.nb
             out["roofline"]["note"] = ("achieved / frac credit the dense algorithm's flops; with --nb below 0.15 part of the social "
                                        "contraction is skipped (exact zeros), so frac can exceed 1 and is not a utilisation figure")
+        if a.bf16:
+            out["metric"] += " -- bf16 operands"
+            out["config"]["workload"] = ("BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate / state): synthetic windows, %d agent "
+                                         "slots/window%s, K=%d, T_obs=8/T_pred=40, H=%d, scene grid 64x64x32; %d windows/step/GPU = %d agents"
+                                         % (d.mno, " (cluster form: %d workgroups per group)" % (d.mno // 32) if d.mno > 64 else "", d.K, d.H, a.windows, d.A))
+            out["roofline"]["kernel"] = ("k_ioc_bf16_cl<%d>" % d.H) if d.mno > 64 else "k_ioc_bf16<%d,16,32,%d>" % (d.H, 2 if d.mno > 32 else 1)
+        elif a.mno != 32 or a.H != 128 or a.K != 20 or a.grid != 4:
+            out["config"]["workload"] = ("non-default shape: %d agent slots/window, K=%d, H=%d, social grid %dx%d, T_obs=8/T_pred=40, fp32; "
+                                         "%d windows/step/GPU" % (d.mno, d.K, d.H, a.grid, a.grid, a.windows))
+            out["roofline"]["kernel"] = "k_ioc%s<%d,16,32>" % ("_cl" if d.mno > 64 else "", d.H)
         if alt:
             out["alt"] = alt
+        if sdd:
+            out["sdd"] = sdd
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, a.seed)
             out["accuracy"] = out["cpu_baseline"].pop("accuracy")
