@@ -90,8 +90,9 @@ class ShardedIoc:
     def local_state(self):
         """(Hx rows [R_loc, H], p_last [A_loc, 2], valid [A_loc] uint8, Y0 [R_loc, T, 2]) views / copies on the device."""
         d = self.h.dims
-        HxHy = self.h.device_tensor("HxHy")[: d.A * 2 * d.H].view(d.A, 2 * d.H)
-        Hx = HxHy[:, : d.H].reshape(d.n_scenes, 1, d.mno, d.H).expand(d.n_scenes, d.K, d.mno, d.H).reshape(d.R, d.H).contiguous()
+        H = max(d.H, 64)                                       # physical width of the recurrent tile (d_dim 16 / 32 run zero-padded)
+        HxHy = self.h.device_tensor("HxHy")[: d.A * 2 * H].view(d.A, 2 * H)
+        Hx = HxHy[:, : H].reshape(d.n_scenes, 1, d.mno, H).expand(d.n_scenes, d.K, d.mno, H).reshape(d.R, H).contiguous()
         p_last = self.h.device_tensor("p_last")[: d.A * 2].view(d.A, 2)
         valid = self.h.device_tensor("valid", "|u1")[: d.A]
         Y0 = self.h.device_tensor("Y0")[: d.R * d.T_pred * 2].view(d.R, d.T_pred, 2)
@@ -125,3 +126,57 @@ class ShardedIoc:
                 self.step(ctx, t, Hall, stream)
             self.finish(ctx, Y_loc, score_loc, stream)
         return Y_loc, score_loc
+
+
+class PipelinedShardedIoc:
+    """The same agent-sharded IOC with the per-step neighbour all-gather HIDDEN behind compute ("overlap
+    step-t all-gather with ... the local rows").  The rank's scenes are split into micro-batches (one ShardedIoc / handle each,
+    normally two); their steps alternate on the compute stream while the all-gathers run on a separate communication stream:
+
+        comm   :  gather A(t)   gather B(t)   gather A(t+1)   gather B(t+1) ...
+        compute:               step A(t)     step B(t)        step A(t+1)  ...
+
+    gather m(t+1) waits (event) for step m(t) and runs while the OTHER micro-batch computes; step m(t) waits for gather m(t).
+    A step is data-dependent on its own gather (social pooling needs every neighbour's h_{t-1}), so a single batch cannot
+    overlap with itself -- two independent halves can, with results bit-identical to ShardedIoc.run.  Per rank and step the
+    collective moves R_loc * H * 4 bytes in and world times that out (configs[3]: 13.1 MB, about 86 us on one xGMI link per
+    peer); a micro-batch's step kernel at that shape runs several hundred microseconds, so the transfer is covered."""
+
+    def __init__(self, parts):
+        import torch
+        self.parts = list(parts)
+        self.comm = torch.cuda.Stream()
+
+    def run(self, Ys, scores):
+        import torch
+        compute = torch.cuda.current_stream()
+        d = self.parts[0].h.dims
+        for _ in range(d.iters):
+            ctxs = [p.prepare(Y) for p, Y in zip(self.parts, Ys)]      # per-pass gathers (positions, flags), on the compute stream
+            ready = []
+            for _m in self.parts:
+                e = torch.cuda.Event(); e.record(compute); ready.append(e)
+            for t in range(d.T_pred):
+                got = []
+                for m, p in enumerate(self.parts):
+                    with torch.cuda.stream(self.comm):
+                        self.comm.wait_event(ready[m])                  # h_{t-1} of micro-batch m is final
+                        Hall = p.gather(ctxs[m]["hst"])                 # RCCL all-gather (torch.distributed) on the comm stream
+                        Hall.record_stream(compute)
+                        e = torch.cuda.Event(); e.record(self.comm)
+                    got.append((Hall, e))
+                for m, p in enumerate(self.parts):
+                    compute.wait_event(got[m][1])
+                    p.step(ctxs[m], t, got[m][0], compute.cuda_stream)
+                    e = torch.cuda.Event(); e.record(compute); ready[m] = e
+            for p, c, Y, sc in zip(self.parts, ctxs, Ys, scores):
+                p.finish(c, Y, sc, compute.cuda_stream)
+        return Ys, scores
+
+    def comm_bytes_per_step(self, world: int):
+        """(sent, received) bytes per rank per IOC step: the hidden states of the local rows out, everybody's in."""
+        n = 0
+        for p in self.parts:
+            d = p.h.dims
+            n += d.R * max(d.H, 64) * 4
+        return n, n * world

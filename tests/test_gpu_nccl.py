@@ -1,0 +1,111 @@
+"""The RCCL code path itself (backend "nccl" on ROCm), two ranks on two GPUs: scene-sharded forward + result gather, the
+agent-sharded IOC with its per-step neighbour all-gather (plain and pipelined behind compute), and the flat-gradient
+all-reduce.  Skipped when fewer than two devices are visible (the 1-GPU test boxes); on a multi-GPU node it is the test
+that has the collectives run for real."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from desire_amd import _lib
+        from desire_amd.dist import PipelinedShardedIoc, ShardedIoc, allreduce_mean_, gather_results, shard_windows
+        from desire_amd.spec import init_weights
+        from tests.helpers import make_case, small_dims
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+        out = {}
+        d = small_dims(n_scenes=4, K=3, n_grids=1, T_pred=9)
+        w = init_weights(d, 31)
+        past, fut, eps, grids, gos = make_case(d, seed=32, n_absent=3)
+        epsr = eps.reshape(d.n_scenes, -1, d.L)
+
+        def run(dd, p, f, e, g_of_s):
+            h = _lib.Handle(dd); h.set_weights(w)
+            ten = dict(p=t(p), f=t(f), e=t(e), g=t(grids))
+            h.set_scene_grids(ten["g"].data_ptr(), g_of_s)
+            Y = torch.zeros((dd.R, dd.T_pred, 2), device=dev); sc = torch.zeros(dd.R, device=dev)
+            h.forward(ten["p"].data_ptr(), ten["f"].data_ptr(), ten["e"].data_ptr(), Y.data_ptr(), sc.data_ptr())
+            torch.cuda.synchronize()
+            return h, ten, Y, sc
+        # ---- 1. scene sharding: windows split over the ranks, results all-gathered in window order ----
+        _, _, Yfull, _ = run(d, past, fut, eps, gos)
+        lo, hi = shard_windows(d.n_scenes, rank, world)
+        dl = d.replace(n_scenes=hi - lo)
+        _, _, Yl, _ = run(dl, past[lo:hi], fut[lo:hi], epsr[lo:hi].reshape(-1, d.L), gos[lo:hi])
+        got = gather_results(Yl.view(hi - lo, -1), d.n_scenes)
+        out["scene"] = float((got.reshape(-1) - Yfull.reshape(-1)).abs().max())
+        # ---- 2. agent sharding: slots split over the ranks, h all-gathered per IOC step ----
+        m_loc = d.mno // world
+        da = d.replace(mno=m_loc)
+        sl = slice(rank * m_loc, (rank + 1) * m_loc)
+        eps4 = eps.reshape(d.n_scenes, d.K, d.mno, d.L)
+        ha, tena, _, _ = run(da, past[:, :, sl], fut[:, :, sl], eps4[:, :, sl].reshape(-1, d.L), gos)
+        hU, tenU, _, _ = run(d, past, fut, eps, gos)
+        Y0U = t(hU.read_buffer("Y0", (d.R, d.T_pred, 2))); sU = torch.zeros(d.R, device=dev)
+        hU.ioc_refine(Y0U.data_ptr(), sU.data_ptr())
+        ref = Y0U.view(d.n_scenes, d.K, d.mno, d.T_pred, 2)[:, :, sl].reshape(da.R, d.T_pred, 2)
+        Ya = t(ha.read_buffer("Y0", (da.R, d.T_pred, 2))); sa = torch.zeros(da.R, device=dev)
+        ShardedIoc(ha, rank, world).run(Ya, sa)
+        torch.cuda.synchronize()
+        out["agents"] = float((Ya - ref).abs().max())
+        # ---- 3. the same with the gathers hidden behind a second micro-batch ----
+        dh = da.replace(n_scenes=2)
+        parts, Ys, scs, keep = [], [], [], []
+        for half in range(2):
+            hs = slice(2 * half, 2 * half + 2)
+            hh, tt_, _, _ = run(dh, past[hs][:, :, sl], fut[hs][:, :, sl], eps4[hs][:, :, sl].reshape(-1, d.L), gos[hs])
+            parts.append(ShardedIoc(hh, rank, world)); keep.append(tt_)
+            Ys.append(t(hh.read_buffer("Y0", (dh.R, d.T_pred, 2)))); scs.append(torch.zeros(dh.R, device=dev))
+        PipelinedShardedIoc(parts).run(Ys, scs)
+        torch.cuda.synchronize()
+        out["pipelined"] = float((torch.cat(Ys) - ref).abs().max())
+        # ---- 4. flat-gradient all-reduce ----
+        hg = _lib.Handle(dl); hg.set_weights(w); hg.set_training(True)
+        tg = dict(p=t(past[lo:hi]), f=t(fut[lo:hi]), e=t(epsr[lo:hi].reshape(-1, d.L)), g=t(grids))
+        hg.set_scene_grids(tg["g"].data_ptr(), gos[lo:hi])
+        Yg = torch.zeros((dl.R, d.T_pred, 2), device=dev); sg = torch.zeros(dl.R, device=dev)
+        hg.forward(tg["p"].data_ptr(), tg["f"].data_ptr(), tg["e"].data_ptr(), Yg.data_ptr(), sg.data_ptr())
+        hg.backward(tg["p"].data_ptr(), tg["f"].data_ptr(), tg["e"].data_ptr())
+        flat = hg.grad_tensor()
+        mine = flat.clone()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        allreduce_mean_(flat)
+        torch.cuda.synchronize()
+        out["allreduce"] = float((flat - sum(both) / world).abs().max() / (flat.abs().max() + 1e-30))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rccl_ranks():
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out["scene"] == 0.0, out                       # same kernels on the same windows: identical
+        assert out["agents"] < 2e-6 and out["pipelined"] < 2e-6, out
+        assert out["allreduce"] < 1e-6, out
