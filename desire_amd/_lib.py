@@ -22,7 +22,7 @@ EXPORTS = [
     "desire_set_training", "desire_backward", "desire_get_grad", "desire_grad_buffer",
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
-    "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout",
+    "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout", "desire_build_windows_la", "desire_adam_state",
 ]
 
 
@@ -75,6 +75,7 @@ def load() -> C.CDLL:
     lib.desire_temporal_conv.argtypes = [vp, f32p, f32p, vp]
     lib.desire_feature_pooling.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_build_windows.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), i32, f32p, f32p, vp]
+    lib.desire_build_windows_la.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), i32, i32, f32p, f32p, vp]
     lib.desire_gaussian_sample.argtypes = [vp, f32p, f32p, f32p, i32, vp]
     lib.desire_ade_fde.argtypes = [vp, f32p, f32p, f32p, vp]
     lib.desire_rollout.argtypes = [vp, f32p, f32p, i32, f32p, vp]
@@ -84,6 +85,7 @@ def load() -> C.CDLL:
     lib.desire_grad_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_train_loss.argtypes = [vp, f32p, C.POINTER(C.c_float), vp]
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    lib.desire_adam_state.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_clip_grads.argtypes = [vp, C.c_float, C.POINTER(C.c_float), vp]
     lib.desire_get_bin_table.argtypes = [vp, C.POINTER(C.c_float)]
@@ -177,10 +179,11 @@ class Handle:
     def feature_pooling(self, yhat_ptr: int, rho_ptr: int, out_ptr: int, stream: int = 0) -> None:
         _chk(self.lib.desire_feature_pooling(self._h, yhat_ptr, rho_ptr, out_ptr, stream or None))
 
-    def build_windows(self, frames_ptr: int, n_frames: int, mno_in: int, starts, past_ptr: int, fut_ptr: int, stream: int = 0) -> None:
+    def build_windows(self, frames_ptr: int, n_frames: int, mno_in: int, starts, past_ptr: int, fut_ptr: int, stream: int = 0,
+                      lookahead: int = 0) -> None:
         st = np.ascontiguousarray(starts, dtype=np.int32)
-        _chk(self.lib.desire_build_windows(self._h, frames_ptr, n_frames, mno_in, st.ctypes.data_as(C.POINTER(C.c_int32)),
-                                           st.size, past_ptr, fut_ptr, stream or None))
+        _chk(self.lib.desire_build_windows_la(self._h, frames_ptr, n_frames, mno_in, st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            st.size, int(lookahead), past_ptr, fut_ptr, stream or None))
 
     def gaussian_sample(self, params_ptr: int, normals_ptr: int, out_ptr: int, n: int, stream: int = 0) -> None:
         _chk(self.lib.desire_gaussian_sample(self._h, params_ptr, normals_ptr, out_ptr, n, stream or None))
@@ -265,6 +268,23 @@ class Handle:
 
     def adam_step(self, lr: float = 0.005, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, stream: int = 0) -> None:
         _chk(self.lib.desire_adam_step(self._h, C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), stream or None))
+
+    def opt_state(self) -> Dict[str, np.ndarray]:
+        """Adam moments (flat, the gradient buffer's layout) and step counter of a training handle."""
+        t = C.c_int32(0)
+        _chk(self.lib.desire_adam_state(self._h, C.byref(t), 0))
+        return {"m": self.device_tensor("Mflat").cpu().numpy(), "v": self.device_tensor("Vflat").cpu().numpy(),
+                "t": np.array([t.value], np.int64)}
+
+    def set_opt_state(self, st: Dict[str, np.ndarray]) -> None:
+        import torch
+        m, v = self.device_tensor("Mflat"), self.device_tensor("Vflat")
+        if st["m"].size != m.numel() or st["v"].size != v.numel():
+            raise DesireError("optimiser state of %d values does not fit this model (%d)" % (st["m"].size, m.numel()))
+        m.copy_(torch.as_tensor(np.ascontiguousarray(st["m"], np.float32), device=m.device))
+        v.copy_(torch.as_tensor(np.ascontiguousarray(st["v"], np.float32), device=v.device))
+        t = C.c_int32(int(np.asarray(st["t"]).reshape(-1)[0]))
+        _chk(self.lib.desire_adam_state(self._h, C.byref(t), 1))
 
     def get_weight(self, name: str, shape: Tuple[int, ...], stream: int = 0) -> np.ndarray:
         out = np.empty(shape, np.float32)

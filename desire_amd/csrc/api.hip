@@ -919,7 +919,14 @@ extern "C" int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, c
 
 extern "C" int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
                                     const int32_t* host_starts, int32_t n_windows, float* dev_past, float* dev_fut, void* stream) {
+    return desire_build_windows_la(h, dev_frames, n_frames, mno_in, host_starts, n_windows, 0, dev_past, dev_fut, stream);
+}
+
+extern "C" int desire_build_windows_la(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
+                                     const int32_t* host_starts, int32_t n_windows, int32_t lookahead, float* dev_past, float* dev_fut,
+                                     void* stream) {
     if (!h || !dev_frames || !host_starts || !dev_past || !dev_fut) return fail(DESIRE_ERR_ARG, "null argument");
+    if (lookahead != 0 && lookahead != 1) return fail(DESIRE_ERR_ARG, "lookahead must be 0 or 1");
     const desire_dims& d = h->d;
     if (n_windows < 1 || n_windows > d.n_scenes) return fail(DESIRE_ERR_ARG, "n_windows must be 1..n_scenes");
     if (mno_in < 1 || n_frames < d.T_obs + d.T_pred) return fail(DESIRE_ERR_ARG, "video shorter than one window");
@@ -934,7 +941,7 @@ extern "C" int desire_build_windows(desire_handle* h, const float* dev_frames, i
     HIPCHK(hipMemcpyAsync(h->ws["bw_starts"].p, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->ws["bw_err"].p, 0, sizeof(int32_t), s));
     launch_build_windows(dev_frames, n_frames, mno_in, static_cast<const int32_t*>(h->ws["bw_starts"].p), n_windows, d.T_obs,
-                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws["bw_err"].p), s);
+                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws["bw_err"].p), lookahead, s);
     int32_t err = 0;
     HIPCHK(hipMemcpyAsync(&err, h->ws["bw_err"].p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

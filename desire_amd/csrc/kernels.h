@@ -157,7 +157,7 @@ void launch_losses(const float* params, const float* Y, const float* fut, const 
                    float* recon, float* cost, int n_scenes, int mno, int K, int T, int L, float sx, float sy, hipStream_t s);
 void launch_loss_mask(const uint8_t* valid, const float* fut, uint8_t* lmask, float* nfut, int n_scenes, int mno, int T, hipStream_t s);
 void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,
-                          int mno, float* past, float* fut, int32_t* err, hipStream_t s);
+                          int mno, float* past, float* fut, int32_t* err, int lookahead, hipStream_t s);
 void launch_gaussian_sample(const float* p, const float* nrm, float* out, int n, hipStream_t s);
 void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, int mno, int K, int T, float sx, float sy,
                     hipStream_t s);

@@ -161,7 +161,7 @@ void launch_losses(const float* params, const float* Y, const float* fut, const 
 __global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__ frames, int F, int mno_in,
                                                        const int32_t* __restrict__ starts, int T_obs, int T_pred, int mno,
                                                        float* __restrict__ past, float* __restrict__ fut,
-                                                       int32_t* __restrict__ err) {
+                                                       int32_t* __restrict__ err, int lookahead) {
     __shared__ unsigned int bits[BW_WORDS];
     __shared__ unsigned int pref[BW_WORDS];
     __shared__ unsigned int part[256];
@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__
     for (int i = tid; i < T_pred * mno * 3; i += 256) fut[(size_t)wdw * T_pred * mno * 3 + i] = 0.f;
     __syncthreads();
     const int n = W * mno_in;
-    for (int i = tid; i < n; i += 256) {
+    // lookahead: the loader ranks the ids of seq_length + 1 frames (its target is the window shifted by one frame,
+    // utils/data_loader.py:203-209), so a DataLoader(seq_length = W) window takes its slots from frame f0 + W as well
+    const int Wu = (lookahead && f0 + W < F) ? W + 1 : W;
+    for (int i = tid; i < Wu * mno_in; i += 256) {
         const int t = i / mno_in, s = i - t * mno_in;
         const int f = min(f0 + t, F - 1);
         const float idf = frames[((size_t)f * mno_in + s) * 3];
@@ -214,10 +217,23 @@ __global__ __launch_bounds__(256) void k_build_windows(const float* __restrict__
         if (atomicExch(dst, idf) != 0.f) { atomicOr(err, 4); continue; }
         dst[1] = src[1]; dst[2] = src[2];
     }
+    if (Wu > W) {        // the look-ahead frame is only ranked, not copied; the reference would still fail on it while filling its target
+        __syncthreads();
+        for (int s = tid; s < mno_in; s += 256) {
+            const float idf = frames[((size_t)(f0 + W) * mno_in + s) * 3];
+            if (!(idf > 0.f)) continue;
+            const unsigned id = (unsigned)idf;
+            if (id >= BW_WORDS * 32u) continue;
+            const unsigned slot = pref[id >> 5] + __popc(bits[id >> 5] & ((1u << (id & 31)) - 1u));
+            if (slot >= (unsigned)mno) atomicOr(err, 2);
+            for (int s2 = 0; s2 < s; ++s2)
+                if (frames[((size_t)(f0 + W) * mno_in + s2) * 3] == idf) { atomicOr(err, 4); break; }
+        }
+    }
 }
 void launch_build_windows(const float* frames, int F, int mno_in, const int32_t* starts, int n, int T_obs, int T_pred,
-                          int mno, float* past, float* fut, int32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_windows, dim3(n), dim3(256), 0, s, frames, F, mno_in, starts, T_obs, T_pred, mno, past, fut, err);
+                          int mno, float* past, float* fut, int32_t* err, int lookahead, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_windows, dim3(n), dim3(256), 0, s, frames, F, mno_in, starts, T_obs, T_pred, mno, past, fut, err, lookahead);
 }
 
 // ---- N3: bivariate-Gaussian head of sample() (model/model.py:552-565,595-611,661-669) ----------------

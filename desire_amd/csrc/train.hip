@@ -543,6 +543,16 @@ extern "C" int desire_adam_step(desire_handle* h, float lr, float beta1, float b
     return repack(h, s);
 }
 
+// Optimiser state for checkpoints: the Adam moments are the workspace tensors "Mflat" / "Vflat" (desire_device_buffer; same flat
+// layout as the gradient buffer), the step counter t of the bias correction is read (set = 0) or written (set = 1) here.
+extern "C" int desire_adam_state(desire_handle* h, int32_t* step, int set) {
+    if (!h || !step) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (set) { if (*step < 0) return fail(DESIRE_ERR_ARG, "step must be >= 0"); h->adam_t = *step; }
+    else *step = h->adam_t;
+    return DESIRE_OK;
+}
+
 extern "C" int desire_get_weight(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
     if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
     auto w = h->want_user.find(name);

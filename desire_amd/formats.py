@@ -83,9 +83,9 @@ def cpkl_to_bin(cpkl_path: str, bin_path: str) -> None:
 
 
 def save_weights(path: str, weights: Dict[str, np.ndarray]) -> None:
-    np.savez(path, **{k.replace("/", "__"): np.asarray(v, np.float32) for k, v in weights.items()})
+    np.savez(path, **{k.replace("/", "__"): (np.asarray(v) if k == "opt/t" else np.asarray(v, np.float32)) for k, v in weights.items()})
 
 
 def load_weights(path: str) -> Dict[str, np.ndarray]:
     with np.load(path) as z:
-        return {k.replace("__", "/"): np.ascontiguousarray(z[k], np.float32) for k in z.files}
+        return {k.replace("__", "/"): (np.asarray(z[k]) if k == "opt__t" else np.ascontiguousarray(z[k], np.float32)) for k in z.files}

@@ -216,6 +216,9 @@ class DESIREModel(object):
         if not getattr(h, "_training_on", False):
             h.set_training(True)
             h._training_on = True
+            pending = self.__dict__.pop("_opt_pending", None)
+            if pending is not None:                   # resumed run: Adam moments and step counter of the checkpoint
+                h.set_opt_state(pending)
         self.forward(x_batch, y_batch, eps, seed)
         past, fut, eps_t = self._keep
         stream = self.torch.cuda.current_stream().cuda_stream
@@ -241,8 +244,9 @@ class DESIREModel(object):
 
     def forward_from_video(self, frames, starts: Sequence[int], posterior: bool = True, eps=None, seed: int = 0):
         """Device-side batching: `frames` [F, max_num_obj, 3] is one preprocessed video
-        (DataLoader.data[i]); the windows starting at `starts` are cut and slot-assigned on the GPU with the
-        loader's exact semantics, then run through the hot path without touching the host again."""
+        (DataLoader.data[i]); the windows starting at `starts` are cut and slot-assigned on the GPU exactly like the x of
+        DataLoader(seq_length = seq_length + pred_length).next_batch (slots ranked over the window plus the loader's one
+        look-ahead frame), then run through the hot path without touching the host again."""
         torch = self.torch
         n = len(starts)
         h = self._handle(n, posterior)
@@ -251,7 +255,7 @@ class DESIREModel(object):
         past = torch.empty((n, d.T_obs, d.mno, 3), device=self.device)
         fut = torch.empty((n, d.T_pred, d.mno, 3), device=self.device)
         stream = torch.cuda.current_stream().cuda_stream
-        h.build_windows(fr.data_ptr(), fr.shape[0], fr.shape[1], starts, past.data_ptr(), fut.data_ptr(), stream)
+        h.build_windows(fr.data_ptr(), fr.shape[0], fr.shape[1], starts, past.data_ptr(), fut.data_ptr(), stream, lookahead=1)
         if eps is None:
             g = torch.Generator(device=self.device).manual_seed(seed)
             eps_t = torch.randn((d.R, d.L), generator=g, device=self.device, dtype=torch.float32)
@@ -286,12 +290,22 @@ class DESIREModel(object):
         from .formats import save_weights
         if self._weights is None:
             raise ValueError("no weights yet: run forward() once or pass weights=")
-        save_weights(path, self.sync_weights())
+        blob = dict(self.sync_weights())
+        h = getattr(self, "_trained", None)
+        if h is not None:                             # the reference's Saver keeps the optimiser slots too (train.py:114)
+            for k, v in h.opt_state().items():
+                blob["opt/" + k] = v
+        save_weights(path, blob)
 
     @classmethod
     def restore(cls, args, path: str) -> "DESIREModel":
         from .formats import load_weights
-        return cls(args, weights=load_weights(path))
+        blob = load_weights(path)
+        opt = {k[4:]: blob.pop(k) for k in list(blob) if k.startswith("opt/")}
+        m = cls(args, weights=blob)
+        if opt:
+            m._opt_pending = opt                      # applied when training starts (the moments live in the training handle)
+        return m
 
     # ---- reference-shaped sampling API (model/model.py:613-688) ------------------------------------
     def _sample_model(self, obs_len: int, dimensions) -> "DESIREModel":

@@ -94,6 +94,12 @@ def train(args, data_loader=None, model=None, log: Callable[[str], None] = print
     if data_loader.seq_length != t_obs + t_pred:
         raise ValueError("the loader window must be seq_length + pred_length frames")
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    if args.batch_size < world:
+        raise ValueError("--batch_size %d is smaller than the %d ranks: every rank needs at least one window per step" % (args.batch_size, world))
+    # next_batch advances its pointer by random.randint (utils/data_loader.py:235-238): the SAME seed on every rank, so that all
+    # ranks draw the same global batch and shard_batch partitions it (and --seed makes a run reproducible)
+    import random
+    random.seed(int(args.seed))
     if rank == 0:
         os.makedirs(args.save_dir, exist_ok=True)
         with open(os.path.join(args.save_dir, "config.pkl"), "wb") as fh:

@@ -150,6 +150,13 @@ int desire_feature_pooling(desire_handle* h, const float* dev_Yhat, const float*
  * Synchronises the stream (error word read-back). */
 int desire_build_windows(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
                          const int32_t* host_starts, int32_t n_windows, float* dev_past, float* dev_fut, void* stream);
+/* The same with lookahead = 1: the slots are ranked over ONE MORE frame (f0 + T_obs + T_pred, when the video has it), which is
+ * what DataLoader(seq_length = T_obs + T_pred).next_batch does -- it takes np.unique over seq_length + 1 frames because its target
+ * is the window shifted by a frame (utils/data_loader.py:203-209) -- so the device windows equal the x of that loader exactly,
+ * including its IndexError / ValueError conditions on the extra frame.  lookahead = 0 is desire_build_windows (= a loader with
+ * seq_length = T_obs + T_pred - 1, x plus the last target frame). */
+int desire_build_windows_la(desire_handle* h, const float* dev_frames, int32_t n_frames, int32_t mno_in,
+                          const int32_t* host_starts, int32_t n_windows, int32_t lookahead, float* dev_past, float* dev_fut, void* stream);
 /* N3: bivariate-Gaussian head of sample() (model/model.py:552-565,595-611,661-669): dev_params [n,5] raw head
  * outputs, dev_normals [n,2] ~ N(0,1); dev_out [n,2] sample clipped to <= 1.0. */
 int desire_gaussian_sample(desire_handle* h, const float* dev_params, const float* dev_normals, float* dev_out,
@@ -212,6 +219,10 @@ int desire_clip_grads(desire_handle* h, float max_norm, float* host_norm_out, vo
 /* One tf.train.AdamOptimizer update (model/model.py:394; lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) of the device master weights
  * from the flat gradient buffer, followed by a device-side rebuild of every packed operand.  No host round trip. */
 int desire_adam_step(desire_handle* h, float lr, float beta1, float beta2, float eps, void* stream);
+/* Optimiser state for checkpoints (the reference's Saver stores every global variable, Adam slots included, train.py:114): the
+ * moments are the workspace tensors "Mflat" / "Vflat" (desire_device_buffer; the gradient buffer's flat layout), the step
+ * counter of the bias correction is read (set = 0) or written (set = 1) through *step. */
+int desire_adam_state(desire_handle* h, int32_t* step, int set);
 /* Current value of a weight (the trained one in training mode), natural TF layout. */
 int desire_get_weight(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
 

@@ -39,16 +39,21 @@ def main():
         fr = torch.as_tensor(frames.astype(np.float32), device="cuda")
         past = torch.full((n_win, T_obs, mno, 3), -1.0, device="cuda")
         fut = torch.full((n_win, T_pred, mno, 3), -1.0, device="cuda")
+        look = it % 2                                            # odd rounds: lookahead = 1 = the x of DataLoader(seq_length = W)
         exp, exp_err = [], None
         for s0 in starts:
             try:
-                src, tgt = window_to_slots(frames[s0:s0 + W], W - 1, mno)
-                exp.append(np.concatenate([src, tgt[-1:]], 0).astype(np.float32))
+                if look and s0 + W < n_frames:
+                    src, _ = window_to_slots(frames[s0:s0 + W + 1], W, mno)
+                    exp.append(src.astype(np.float32))
+                else:
+                    src, tgt = window_to_slots(frames[s0:s0 + W], W - 1, mno)
+                    exp.append(np.concatenate([src, tgt[-1:]], 0).astype(np.float32))
             except (IndexError, ValueError) as ex:
                 exp_err = type(ex).__name__
                 break
         try:
-            h.build_windows(fr.data_ptr(), n_frames, mno_in, starts, past.data_ptr(), fut.data_ptr())
+            h.build_windows(fr.data_ptr(), n_frames, mno_in, starts, past.data_ptr(), fut.data_ptr(), lookahead=look)
             got_err = None
         except _lib.DesireError as ex:
             got_err = str(ex)

@@ -288,6 +288,14 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
         full = np.concatenate([src, tgt[-1:]], 0)
         np.testing.assert_array_equal(past[i].cpu().numpy(), full[:d.T_obs].astype(np.float32))
         np.testing.assert_array_equal(fut[i].cpu().numpy(), full[d.T_obs:].astype(np.float32))
+    # lookahead = 1: the x of DataLoader(seq_length = W) -- slots ranked over W + 1 frames
+    h.build_windows(fr_t.data_ptr(), frames.shape[0], frames.shape[1], starts, past.data_ptr(), fut.data_ptr(), lookahead=1)
+    for i, s0 in enumerate(starts):
+        if s0 + W >= frames.shape[0]:
+            continue                                     # the video ends with the window: no look-ahead frame (and no loader window)
+        src, _ = window_to_slots(g["data0"][s0:s0 + W + 1], W, d.mno)
+        np.testing.assert_array_equal(past[i].cpu().numpy(), src[:d.T_obs].astype(np.float32))
+        np.testing.assert_array_equal(fut[i].cpu().numpy(), src[d.T_obs:].astype(np.float32))
     # the reference's own golden batch (T=8 -> 9-frame windows, x = first 8 frames)
     d9 = small_dims(n_scenes=4, mno=32, K=2, T_obs=8, T_pred=1)
     h9 = _lib.Handle(d9)
