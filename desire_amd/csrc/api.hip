@@ -684,7 +684,6 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.dbg = static_cast<long long*>(h->ws["dbg"].p);
 #endif
     if (h->training) {
-        if (cluster) return fail(DESIRE_ERR_STATE, "training supports up to 64 agents per scene (32 at H = 256)");
         a.sv_x = W(h, "ioc_sv_x"); a.sv_r = W(h, "ioc_sv_r"); a.sv_u = W(h, "ioc_sv_u"); a.sv_c = W(h, "ioc_sv_c"); a.sv_h = W(h, "ioc_sv_h");
     }
     if (d.bf16) {

@@ -208,3 +208,5 @@ struct IocBwdArgs {
     const float* bin_tab;
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);
+// cluster form (kernels_bwd_cl.hip): groups of 64 / 96 / 128 agents, H <= 128, <= 16 bins; grp_cnt zeroed per launch; != 0: shape not served
+int launch_ioc_bwd_cluster(const IocBwdArgs& a, int* grp_cnt, int* err, hipStream_t s);

@@ -785,7 +785,7 @@ void launch_ioc(const IocArgs& a, hipStream_t s) {
 // Serves mno in {64, 96, 128} (and H = 256 with mno = 64, which does not fit one workgroup's LDS).
 // ------------------------------------------------------------------------------------------------
 #include "cluster.h"
-template <int H, int EV, int C>
+template <int H, int EV, int C, bool TRAIN = false>      // TRAIN: keeps x_t, r, u, c, h per step for the cluster-form BPTT (k_ioc_bwd_cl)
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, MAXM = 128;
@@ -929,15 +929,29 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
                 __syncthreads();
+                if (TRAIN) {
+                    for (int i = tid; i < TM * (E >> 2); i += NTHR) {
+                        const int r = i / (E >> 2), c4 = i - r * (E >> 2);
+                        *reinterpret_cast<float4*>(a.sv_x + ((size_t)(row0 + r) * a.T + t) * E + c4 * 4) =
+                            *reinterpret_cast<const float4*>(XH + r * LDX + c4 * 4);
+                    }
+                }
                 f32x16 rh = zero16(), u = zero16();
                 mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
                 mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
+                for (int i = 0; i < 16; ++i) {
+                    const float r = sigmoidf_(rh[i] + bgr);
+                    if (TRAIN) a.sv_r[((size_t)(row0 + acc_row(i)) * a.T + t) * H + col] = r;
+                    rh[i] = r * h[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) my_rh[((i & 3) + 8 * (i >> 2)) * LDB] = rh[i];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
+                for (int i = 0; i < 16; ++i) {
+                    u[i] = sigmoidf_(u[i] + bgu);
+                    if (TRAIN) a.sv_u[((size_t)(row0 + acc_row(i)) * a.T + t) * H + col] = u[i];
+                }
                 __syncthreads();
                 {
                     f32x16 ac = zero16();
@@ -946,8 +960,13 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)(row0 + 4 * (lane >> 5)) * H + col;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
+                        const float c = tanhf_(ac[i] + bcc);
+                        h[i] = gru_blend(u[i], h[i], c);
                         sp[i] = fmaf(h[i], wsc, sp[i]);
+                        if (TRAIN) {
+                            const size_t ix = ((size_t)(row0 + acc_row(i)) * a.T + t) * H + col;
+                            a.sv_c[ix] = c; a.sv_h[ix] = h[i];
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -1003,7 +1022,8 @@ static void launch_ioc_cl_t(const IocArgs& a, hipStream_t s) {
     const int tpg = a.mno / 32, n_tiles = a.R / 32;
     int grid = n_tiles < 256 ? n_tiles : 256;            // one workgroup per CU: all of them resident
     grid -= grid % tpg;
-    hipLaunchKernelGGL((k_ioc_cl<H, 16, 32>), dim3(grid), dim3((H / 32) * 64), ioc_cl_lds_bytes(a), s, a);
+    if (a.sv_h) hipLaunchKernelGGL((k_ioc_cl<H, 16, 32, true>), dim3(grid), dim3((H / 32) * 64), ioc_cl_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL((k_ioc_cl<H, 16, 32>), dim3(grid), dim3((H / 32) * 64), ioc_cl_lds_bytes(a), s, a);
 }
 void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
     if (a.H == 256) launch_ioc_cl_t<256>(a, s);

@@ -255,8 +255,8 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (d.bf16) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0)");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
     if (d.bn_mode) return fail(DESIRE_ERR_STATE, "training runs with frozen batch-norm statistics (dims.bn_mode = 0)");
-    if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0))
-        return fail(DESIRE_ERR_STATE, "training supports up to 64 agents per scene (32 at H = 256): larger groups run the cluster-form IOC, which has no backward yet");
+    if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))
+        return fail(DESIRE_ERR_STATE, "training of groups larger than one workgroup tile (64 / 96 / 128 agents: cluster-form BPTT) needs H <= 128 and grid_size <= 4");
     if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");
     if (d.grid_size > 4 && d.mno > 32)
@@ -360,6 +360,13 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
         q.dHx_rows = W(h, "dHx_rows");
         q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
+        if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
+            const size_t n_groups = (size_t)h->R / d.mno;
+            HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
+            HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
+            if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
+                return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
+        } else
         launch_ioc_bwd(q, s);
         const long RT = R * T;
         tn(h, W(h, "ioc_sv_h") + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, 0, s);
@@ -486,6 +493,12 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     { Timer t(h, s, "bwd_encoder_y"); enc_bwd("enc_y", "ey", d.T_pred, H); }
     { Timer t(h, s, "bwd_encoder_x"); enc_bwd("enc_x", "ex", d.T_obs, 0); }
     HIPCHK(hipGetLastError());
+    if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
+        int e = 0;
+        HIPCHK(hipMemcpyAsync(&e, h->ws["ioc_err"].p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (e) return fail(DESIRE_ERR_HIP, "IOC cluster backward: hand-off timed out (workgroups of a group were not co-resident)");
+    }
     return DESIRE_OK;
 }
 
