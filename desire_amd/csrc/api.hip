@@ -683,9 +683,23 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
     a.dbg = static_cast<long long*>(h->ws["dbg"].p);
 #endif
-    if (h->training) {
-        a.sv_x = W(h, "ioc_sv_x"); a.sv_r = W(h, "ioc_sv_r"); a.sv_u = W(h, "ioc_sv_u"); a.sv_c = W(h, "ioc_sv_c"); a.sv_h = W(h, "ioc_sv_h");
-    }
+    if (h->training && !d.bf16) {
+        // training-mode forward: one launch per refinement pass, each keeping its own activations and the positions it ran on
+        // (the pass's input is DETACHED where it enters the features -- cells, bins, velocity embedding -- and Y_p = Y_{p-1} + dY_p
+        // carries the gradient: DESIGN.md section 8)
+        const size_t RT = (size_t)h->R * d.T_pred;
+        a.iters = 1;
+        for (int p = 0; p < d.iters; ++p) {
+            launch_copy_f32(W(h, "ioc_Yin") + (size_t)p * RT * 2, dev_Yhat, RT * 2, s);
+            a.sv_x = W(h, "ioc_sv_x") + (size_t)p * RT * h->E; a.sv_r = W(h, "ioc_sv_r") + (size_t)p * RT * d.H;
+            a.sv_u = W(h, "ioc_sv_u") + (size_t)p * RT * d.H; a.sv_c = W(h, "ioc_sv_c") + (size_t)p * RT * d.H;
+            a.sv_h = W(h, "ioc_sv_h") + (size_t)p * RT * d.H;
+            if (cluster && p > 0) HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, ((size_t)h->R / d.mno) * sizeof(int), s));
+            { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+        }
+        launch_copy_f32(W(h, "Y_ref"), dev_Yhat, RT * 2, s);
+        launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
+    } else
     if (d.bf16) {
         if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
         a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
@@ -694,10 +708,6 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         else launch_ioc_bf16(a, s);
     } else
     { Timer t(h, s, "ioc"); launch_ioc(a, s); }
-    if (h->training) {
-        launch_copy_f32(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2, s);
-        launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
-    }
 #ifdef DESIRE_IOC_TIMING
     {
         long long host[10];

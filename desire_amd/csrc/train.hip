@@ -257,7 +257,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (d.bn_mode) return fail(DESIRE_ERR_STATE, "training runs with frozen batch-norm statistics (dims.bn_mode = 0)");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))
         return fail(DESIRE_ERR_STATE, "training of groups larger than one workgroup tile (64 / 96 / 128 agents: cluster-form BPTT) needs H <= 128 and grid_size <= 4");
-    if (d.iters != 1) return fail(DESIRE_ERR_STATE, "training supports one IOC refinement pass (iters = 1)");
+    if (d.iters > 4) return fail(DESIRE_ERR_STATE, "training keeps the activations of every IOC refinement pass: iters <= 4");
     if (d.T_pred > d.H) return fail(DESIRE_ERR_STATE, "training needs T_pred <= H");
     if (d.grid_size > 4 && d.mno > 32)
         return fail(DESIRE_ERR_STATE, "training with more than 16 social bins needs mno <= 32 (LDS budget of the 64-row IOC backward tile)");
@@ -268,6 +268,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     }
     const size_t R = h->R, T = d.T_pred, H = d.H, f = sizeof(float);
     const size_t Tm = d.T_pred > d.T_obs ? d.T_pred : d.T_obs;
+    const size_t NP = d.iters;                                  // IOC passes: each keeps its own saves
     struct B { const char* n; size_t bytes; };
     const B bufs[] = {
         {"Gflat", h->n_params * f}, {"nvalid", 4 * f}, {"tn_partial", (size_t)96 << 20},
@@ -279,8 +280,9 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dz", R * d.L * f}, {"dparams", (size_t)h->A * 2 * d.L * f}, {"dconvE3", (size_t)h->A * 2048 * f},
         {"dconvE2", (size_t)h->A * 4096 * f}, {"dconvE1", (size_t)h->A * 8192 * f}, {"dq_c", (size_t)h->A * h->V * f},
         {"dHxHy", (size_t)h->A * 2 * H * f},
-        {"ioc_sv_x", R * T * (size_t)h->E * f}, {"ioc_sv_r", R * T * H * f}, {"ioc_sv_u", R * T * H * f}, {"ioc_sv_c", R * T * H * f},
-        {"ioc_sv_h", R * T * H * f}, {"Y_ref", R * T * 2 * f}, {"score_sv", R * f}, {"dYr", R * T * 2 * f}, {"dscore", R * f},
+        {"ioc_sv_x", NP * R * T * (size_t)h->E * f}, {"ioc_sv_r", NP * R * T * H * f}, {"ioc_sv_u", NP * R * T * H * f}, {"ioc_sv_c", NP * R * T * H * f},
+        {"ioc_sv_h", NP * R * T * H * f}, {"ioc_Yin", NP * R * T * 2 * f}, {"dscore0", R * f},
+        {"Y_ref", R * T * 2 * f}, {"score_sv", R * f}, {"dYr", R * T * 2 * f}, {"dscore", R * f},
         {"dscoreT", R * T * f}, {"ioc_dag", R * T * 2 * H * f}, {"ioc_dac", R * T * H * f}, {"ioc_rh", R * T * H * f},
         {"ioc_hprev", R * T * H * f}, {"ioc_dpre_r", R * T * H * f}, {"ioc_dpre_v", R * T * d.E_v * f}, {"ioc_vel", R * T * 2 * f},
         {"ioc_pooled", R * T * (size_t)h->B * H * f}, {"ioc_pool_flags", R * T * sizeof(unsigned long long)},
@@ -347,45 +349,56 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_loss_grad_y(W(h, "Y_ref"), dev_fut, valid, W(h, "nfut"), W(h, "nvalid"), W(h, "dYr"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
         launch_score_grad(W(h, "Y0"), dev_fut, W(h, "score_sv"), valid, W(h, "nvalid"), W(h, "dscore"), W(h, "dscoreT"), d.n_scenes,
                           d.mno, d.K, T, d.sx, d.sy, s);
-        IocBwdArgs q{};
-        q.Y0 = W(h, "Y0"); q.p_last = W(h, "p_last"); q.valid = static_cast<const uint8_t*>(h->ws["valid"].p); q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
-        q.dYr = W(h, "dYr"); q.dscore = W(h, "dscore");
-        q.sv_x = W(h, "ioc_sv_x"); q.sv_r = W(h, "ioc_sv_r"); q.sv_u = W(h, "ioc_sv_u"); q.sv_c = W(h, "ioc_sv_c"); q.sv_h = W(h, "ioc_sv_h");
-        q.w_score = D(h, "ioc/score_w");
-        q.R = (int)R; q.K = d.K; q.mno = d.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
-        q.WrT = D4(h, "ioc/WrT"); q.WcT_h = D4(h, "ioc/WcT_h"); q.WcT_er = D4(h, "ioc/WcT_er"); q.WcT_ev = D4(h, "ioc/WcT_ev");
-        q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT"); q.WsT_c = D4(h, "ioc/WsT_c");
-        q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
-        q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
-        q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
-        q.dHx_rows = W(h, "dHx_rows");
-        q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
-        if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
-            const size_t n_groups = (size_t)h->R / d.mno;
-            HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
-            HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
-            if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
-                return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
-        } else
-        launch_ioc_bwd(q, s);
+        // one BPTT per refinement pass, last pass first: Y_final = Y0 + sum_p dY_p, so every pass's regression head sees the same
+        // dL/dY_final; only the last pass's scores enter the loss.  Weight gradients of the passes accumulate.
         const long RT = R * T;
-        tn(h, W(h, "ioc_sv_h") + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, 0, s);
-        colsum(h, W(h, "dYr"), 2 * T, R, 2 * T, G(h, "ioc/reg/b"), 0, s);
-        tn(h, W(h, "ioc_sv_h"), H, W(h, "dscoreT"), 1, RT, H, 1, G(h, "ioc/score/w"), 1, 0, s);
-        colsum(h, W(h, "dscoreT"), 1, RT, 1, G(h, "ioc/score/b"), 0, s);
-        float* gk = G(h, "ioc/gates/kernel");            // [(E+H), 2H]
-        tn(h, W(h, "ioc_sv_x"), E, W(h, "ioc_dag"), 2 * H, RT, E, 2 * H, gk, 2 * H, 0, s);
-        tn(h, W(h, "ioc_hprev"), H, W(h, "ioc_dag"), 2 * H, RT, H, 2 * H, gk + (size_t)E * 2 * H, 2 * H, 0, s);
-        colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), 0, s);
-        float* ck = G(h, "ioc/candidate/kernel");        // [(E+H), H]
-        tn(h, W(h, "ioc_sv_x"), E, W(h, "ioc_dac"), H, RT, E, H, ck, H, 0, s);
-        tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, 0, s);
-        colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), 0, s);
-        tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, 0, s,
-           static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p), H);     // empty (row, t, bin) blocks are skipped
-        colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), 0, s);
-        tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, 0, s);
-        colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), 0, s);
+        launch_fill_f32(W(h, "dscore0"), (size_t)R, 0.f, s);
+        for (int p = d.iters - 1; p >= 0; --p) {
+            const int acc = (p != d.iters - 1) ? 1 : 0;
+            const size_t po = (size_t)p * RT;
+            const float* sv_h = W(h, "ioc_sv_h") + po * H;
+            const float* sv_x = W(h, "ioc_sv_x") + po * E;
+            IocBwdArgs q{};
+            q.Y0 = W(h, "ioc_Yin") + po * 2; q.p_last = W(h, "p_last"); q.valid = static_cast<const uint8_t*>(h->ws["valid"].p); q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
+            q.dYr = W(h, "dYr"); q.dscore = acc ? W(h, "dscore0") : W(h, "dscore");
+            q.sv_x = sv_x; q.sv_r = W(h, "ioc_sv_r") + po * H; q.sv_u = W(h, "ioc_sv_u") + po * H; q.sv_c = W(h, "ioc_sv_c") + po * H; q.sv_h = sv_h;
+            q.w_score = D(h, "ioc/score_w");
+            q.R = (int)R; q.K = d.K; q.mno = d.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
+            q.WrT = D4(h, "ioc/WrT"); q.WcT_h = D4(h, "ioc/WcT_h"); q.WcT_er = D4(h, "ioc/WcT_er"); q.WcT_ev = D4(h, "ioc/WcT_ev");
+            q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT"); q.WsT_c = D4(h, "ioc/WsT_c");
+            q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
+            q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
+            q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
+            q.dHx_rows = W(h, "dHx_rows");
+            q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
+            if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
+                const size_t n_groups = (size_t)h->R / d.mno;
+                HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
+                if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
+                if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
+                    return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
+            } else
+            launch_ioc_bwd(q, s);
+            tn(h, sv_h + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, acc, s);
+            colsum(h, W(h, "dYr"), 2 * T, R, 2 * T, G(h, "ioc/reg/b"), acc, s);
+            if (!acc) {
+                tn(h, sv_h, H, W(h, "dscoreT"), 1, RT, H, 1, G(h, "ioc/score/w"), 1, 0, s);
+                colsum(h, W(h, "dscoreT"), 1, RT, 1, G(h, "ioc/score/b"), 0, s);
+            }
+            float* gk = G(h, "ioc/gates/kernel");            // [(E+H), 2H]
+            tn(h, sv_x, E, W(h, "ioc_dag"), 2 * H, RT, E, 2 * H, gk, 2 * H, acc, s);
+            tn(h, W(h, "ioc_hprev"), H, W(h, "ioc_dag"), 2 * H, RT, H, 2 * H, gk + (size_t)E * 2 * H, 2 * H, acc, s);
+            colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), acc, s);
+            float* ck = G(h, "ioc/candidate/kernel");        // [(E+H), H]
+            tn(h, sv_x, E, W(h, "ioc_dac"), H, RT, E, H, ck, H, acc, s);
+            tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, acc, s);
+            colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
+            tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s,
+               static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p), H);     // empty (row, t, bin) blocks are skipped
+            colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
+            tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, acc, s);
+            colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), acc, s);
+        }
     }
     // ---- mask fc ----
     {

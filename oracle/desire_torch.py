@@ -128,31 +128,37 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     valid_rows = rows_from_agents(valid, d).numpy()
     gidx = np.asarray(grid_of_scene)[np.repeat(np.arange(d.n_scenes), d.K * d.mno)]
     gr = _t(grids)
-    h = Hx_rows
-    score = torch.zeros(d.R, dtype=DT)
-    prev = p_last
     pre_min = float("inf")                                   # smallest |relu input| met in the IOC module (kink distance)
-    x_steps = []                                             # [e_v | e_s | e_r] per step (what the kernels keep as ioc_sv_x)
-    for t in range(d.T_pred):
-        cur = Yd[:, t]
-        pre_v = (cur - prev) @ w["ioc/vel_fc/w"] + w["ioc/vel_fc/b"]
-        e_v = torch.relu(pre_v)
-        cy, cx = O.scene_cell(cur.numpy().astype(np.float32), d.Gh, d.Gw)
-        e_s = gr[gidx, cy, cx]
-        P = cur.numpy().astype(np.float32).reshape(d.n_scenes * d.K, d.mno, 2)
-        bins = O.neighbor_bins(P, valid_rows.reshape(d.n_scenes * d.K, d.mno), d.nb_w, d.nb_h, d.grid_size, bin_tab)
-        onehot = _t((bins[..., None] == np.arange(d.B)).astype(np.float64))     # [g, i, j, b]
-        pooled = torch.einsum("gijb,gjh->gibh", onehot, h.reshape(d.n_scenes * d.K, d.mno, d.H)).reshape(d.R, d.B * d.H)
-        pre_r = pooled @ w["ioc/social_fc/w"] + w["ioc/social_fc/b"]
-        e_r = torch.relu(pre_r)
-        vr = torch.as_tensor(valid_rows.reshape(-1))
-        pre_min = min(pre_min, float(pre_r.detach().abs()[vr].min()), float(pre_v.detach().abs()[vr].min()))
-        x_steps.append(torch.cat([e_v, e_s, e_r], -1).detach())
-        h = gru_cell(torch.cat([e_v, e_s, e_r], -1), h, *_gw(w, "ioc"))
-        score = score + (h @ w["ioc/score/w"][:, 0] + w["ioc/score/b"][0])
-        prev = cur
-    dY = (h @ w["ioc/reg/w"] + w["ioc/reg/b"]).reshape(d.R, d.T_pred, 2)
-    Y = Yd + dY
+    Ycur = Yd
+    for _it in range(d.iters):
+        # refinement pass: the positions are DETACHED where they enter the features (cells and bins are indices, the velocity
+        # embedding follows the same rule as pass 1), the additive path Y_p = Y_{p-1} + dY_p keeps the gradient
+        pos = Ycur.detach()
+        h = Hx_rows
+        score = torch.zeros(d.R, dtype=DT)
+        prev = p_last
+        x_steps = []                                         # [e_v | e_s | e_r] per step (what the kernels keep as ioc_sv_x)
+        for t in range(d.T_pred):
+            cur = pos[:, t]
+            pre_v = (cur - prev) @ w["ioc/vel_fc/w"] + w["ioc/vel_fc/b"]
+            e_v = torch.relu(pre_v)
+            cy, cx = O.scene_cell(cur.numpy().astype(np.float32), d.Gh, d.Gw)
+            e_s = gr[gidx, cy, cx]
+            P = cur.numpy().astype(np.float32).reshape(d.n_scenes * d.K, d.mno, 2)
+            bins = O.neighbor_bins(P, valid_rows.reshape(d.n_scenes * d.K, d.mno), d.nb_w, d.nb_h, d.grid_size, bin_tab)
+            onehot = _t((bins[..., None] == np.arange(d.B)).astype(np.float64))     # [g, i, j, b]
+            pooled = torch.einsum("gijb,gjh->gibh", onehot, h.reshape(d.n_scenes * d.K, d.mno, d.H)).reshape(d.R, d.B * d.H)
+            pre_r = pooled @ w["ioc/social_fc/w"] + w["ioc/social_fc/b"]
+            e_r = torch.relu(pre_r)
+            vr = torch.as_tensor(valid_rows.reshape(-1))
+            pre_min = min(pre_min, float(pre_r.detach().abs()[vr].min()), float(pre_v.detach().abs()[vr].min()))
+            x_steps.append(torch.cat([e_v, e_s, e_r], -1).detach())
+            h = gru_cell(torch.cat([e_v, e_s, e_r], -1), h, *_gw(w, "ioc"))
+            score = score + (h @ w["ioc/score/w"][:, 0] + w["ioc/score/b"][0])
+            prev = cur
+        dY = (h @ w["ioc/reg/w"] + w["ioc/reg/b"]).reshape(d.R, d.T_pred, 2)
+        Ycur = Ycur + dY
+    Y = Ycur
     out.update(score=score, dY=dY, Y=Y, ioc_relu_margin=pre_min, ioc_x=torch.stack(x_steps, 1))      # ioc_x [R, T, E]
 
     # ---- losses ----

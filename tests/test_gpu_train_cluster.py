@@ -94,3 +94,49 @@ def test_mixed_scene_training_over_every_committed_sdd_slice():
     Y, score = m.forward(past, fut, seed=0)
     ev = m.evaluate(Y, fut)
     assert ev.shape == (6 * 96, 4) and np.isfinite(ev).all()
+
+
+@pytest.mark.parametrize("kw", [dict(iters=2), dict(iters=3, mno=16, n_scenes=3, H=64, L=64), dict(iters=2, mno=96, n_scenes=1, K=2, H=64, L=64)])
+def test_training_through_several_refinement_passes(kw):
+    """iters >= 2 in training (`iters = 1` only): Y_p = Y_{p-1} + dY_p, each pass on the detached positions of the
+    previous one, every pass's activations kept, BPTT per pass with accumulated weight gradients -- against autograd of the same
+    graph (oracle/desire_torch.py)."""
+    import torch
+    from desire_amd import _lib
+    from oracle import desire_torch as OT
+    d = small_dims(T_obs=5, T_pred=6, n_grids=1, K=kw.pop("K", 3), **kw)
+    w = init_weights(d, 63)
+    for k in w:
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    w["ioc/reg/w"] = w["ioc/reg/w"] * 0.05             # small refinements: the second pass re-bins from them (no edge flips vs fp64)
+    past, fut, eps, grids, gos = make_case(d, seed=64, n_absent=3)
+    vals, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda")
+    score = torch.zeros((d.R,), device="cuda")
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(Y.cpu().numpy() - vals["Y"]).max() < 1e-3, np.abs(Y.cpu().numpy() - vals["Y"]).max()
+    got = h.train_loss(fut_t.data_ptr())
+    assert abs(got["loss"] - float(vals["loss"])) < 2e-4 * max(1.0, abs(float(vals["loss"])))
+    bad = {}
+    for name in ref:
+        if name not in w or name.startswith(("scene_cnn", "temporal", "gauss_head")) or "/bn/" in name:
+            continue
+        g = h.get_grad(name, w[name].shape)
+        if name == "ioc/score/b":
+            continue
+        e = float(np.abs(g - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12))
+        if not e < 5e-4:
+            bad[name] = e
+    assert not bad, bad
