@@ -181,8 +181,8 @@ int check_dims(const desire_dims& d) {
     if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
     if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
     if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
-    if (d.bn_mode != 0 && d.bn_mode != 1) return fail(DESIRE_ERR_ARG, "bn_mode must be 0 (frozen statistics) or 1 (per-object statistics)");
-    if (d.bn_mode == 1 && d.bf16) return fail(DESIRE_ERR_ARG, "per-object batch-norm runs on fp32 operands (bf16 = 0)");
+    if (d.bn_mode < 0 || d.bn_mode > 2) return fail(DESIRE_ERR_ARG, "bn_mode must be 0 (frozen statistics), 1 (per-object statistics) or 2 (whole-batch statistics)");
+    if (d.bn_mode && d.bf16) return fail(DESIRE_ERR_ARG, "batch statistics (bn_mode 1 / 2) run on fp32 operands (bf16 = 0)");
     if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
     if (d.bin_mode == 1 && (d.grid_size < 3 || !(d.nb_h > 0.f) || !(d.nb_w > d.nb_h)))
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
@@ -231,6 +231,7 @@ extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
         {"z", R * d.L * f}, {"d1", R * 2048 * f}, {"d2", R * 4096 * f}, {"d3", R * 8192 * f},
         {"xhat", R * 1024 * f}, {"xz", R * d.H * f}, {"Y0", R * (size_t)(d.n_dec > d.T_pred ? d.n_dec : d.T_pred) * 2 * f},
         {"dec_states", d.ref_compat ? R * (size_t)d.n_dec * d.H * f : 0},
+        {"bn_part", d.bn_mode == 2 ? (size_t)512 * 128 * f : 0}, {"bn_stat", d.bn_mode == 2 ? (size_t)2 * 128 * f : 0},
         {"grid_of_scene", (size_t)d.n_scenes * sizeof(int32_t)},
     };
     for (const WS& w : list) {
@@ -464,7 +465,7 @@ int desire_pack_all(desire_ctx* h) {
                           "vae_dec/deconv3", "vae_dec/deconv4"}) {
         fold_bn(h, n, sc, sh);
         bad |= up(std::string(n) + "/scale", sc); bad |= up(std::string(n) + "/shift", sh);
-        if (d.bn_mode == 1) { bad |= up(std::string(n) + "/gamma", hw[std::string(n) + "/bn/gamma"]); bad |= up(std::string(n) + "/beta", hw[std::string(n) + "/bn/beta"]); }
+        if (d.bn_mode != 0) { bad |= up(std::string(n) + "/gamma", hw[std::string(n) + "/bn/gamma"]); bad |= up(std::string(n) + "/beta", hw[std::string(n) + "/bn/beta"]); }
     }
     bad |= up("vae_enc/conv1/raw", hw["vae_enc/conv1/w"]);
     bad |= up("vae_dec/deconv4/raw", hw["vae_dec/deconv4/w"]);
@@ -553,9 +554,11 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         c.n = A;
         c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
-        const bool pobn = d.bn_mode == 1;                 // per-object BN: linear conv epilogue, then k_instnorm_act per layer
-        auto norm = [&](const char* layer, float* x, int n, int P, int C, int sig) {
-            launch_instnorm_act(x, n, P, C, D(h, (std::string(layer) + "/gamma").c_str()), D(h, (std::string(layer) + "/beta").c_str()), sig, s);
+        const bool pobn = d.bn_mode != 0;                 // batch statistics: linear conv epilogue, then a normalise + activate pass per layer
+        auto norm = [&](const char* layer, float* x, int n, int P, int C, int sig) {     // 1: per sample (k_instnorm_act), 2: over the whole batch
+            const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
+            if (d.bn_mode == 2) launch_batchnorm_act(x, (size_t)n, P, C, ga, be, sig, W(h, "bn_part"), W(h, "bn_stat"), s);
+            else launch_instnorm_act(x, n, P, C, ga, be, sig, s);
         };
         if (pobn) c.mode = 3;
         { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), A, 256, 32, 0); }
@@ -583,25 +586,30 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = d.H, R = h->R;
     { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
+    auto normd = [&](const char* layer, float* x, int P, int C, int sig) {          // batch statistics of the decoder layers (see desire_encode)
+        const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
+        if (d.bn_mode == 2) launch_batchnorm_act(x, (size_t)R, P, C, ga, be, sig, W(h, "bn_part"), W(h, "bn_stat"), s);
+        else launch_instnorm_act(x, R, P, C, ga, be, sig, s);
+    };
     GemmArgs g{};
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
     if (d.bf16 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
-    else if (d.bn_mode == 1) {
+    else if (d.bn_mode != 0) {
         Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_NONE, s);
-        launch_instnorm_act(W(h, "d1"), R, 16, 128, D(h, "vae_dec/deconv1/gamma"), D(h, "vae_dec/deconv1/beta"), 0, s);
+        normd("vae_dec/deconv1", W(h, "d1"), 16, 128, 0);
     }
     else { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
     ConvArgs c{};
     c.n = R;
-    const bool pobn = d.bn_mode == 1;
+    const bool pobn = d.bn_mode != 0;
     if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
-           if (pobn) launch_instnorm_act(W(h, "d2"), R, 64, 64, D(h, "vae_dec/deconv2/gamma"), D(h, "vae_dec/deconv2/beta"), 0, s); }
+           if (pobn) normd("vae_dec/deconv2", W(h, "d2"), 64, 64, 0); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
     const bool fuse34 = d.bf16 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
@@ -612,11 +620,11 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     } else {
         if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
         else { Timer t(h, s, "deconv3"); launch_deconv3(c, s);
-               if (pobn) launch_instnorm_act(W(h, "d3"), R, 256, 32, D(h, "vae_dec/deconv3/gamma"), D(h, "vae_dec/deconv3/beta"), 0, s); }
+               if (pobn) normd("vae_dec/deconv3", W(h, "d3"), 256, 32, 0); }
         c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
         c.scale = D(h, "vae_dec/deconv4/scale"); c.shift = D(h, "vae_dec/deconv4/shift");
         { Timer t(h, s, "deconv4"); launch_deconv4(c, s);
-          if (pobn) launch_instnorm_act(W(h, "xhat"), R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), D(h, "vae_dec/deconv4/beta"), 1, s); }
+          if (pobn) normd("vae_dec/deconv4", W(h, "xhat"), 1024, 1, 1); }
     }
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = d.mno;

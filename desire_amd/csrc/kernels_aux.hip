@@ -338,6 +338,57 @@ void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, cons
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// dims.bn_mode = 2, WHOLE-BATCH statistics: prettytensor batch_normalize in phase=train (model/model.py:453,459-461,471) over
+// everything one call batches -- per-channel moments over all n samples and their P pixels (tf.nn.moments: biased variance,
+// mean first, then the centred second moment), eps 1e-3.  Deterministic: fixed per-block partial sums, reduced in block order.
+// x [n, P, C]; part [BN_BLOCKS, C] scratch, stat [2, C] = (mean | gamma * rstd).
+// ------------------------------------------------------------------------------------------------------------------
+#define BN_BLOCKS 512
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, size_t rows, int C, const float* __restrict__ mean,
+                                                    float* __restrict__ part) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, c = tid % C, g = tid / C, G = 256 / C;
+    const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const float m = mean ? mean[c] : 0.f;
+    float s = 0.f;
+    for (size_t r = r0 + g; r < r1; r += G) { const float v = x[r * C + c] - m; s += mean ? v * v : v; }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int j = 0; j < G; ++j) t += red[j * C + tid];
+        part[(size_t)blockIdx.x * C + tid] = t;
+    }
+}
+__global__ void k_bn_finish(const float* __restrict__ part, int nb, int C, float inv_n, const float* __restrict__ gamma, float* __restrict__ stat,
+                            int second) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int b = 0; b < nb; ++b) t += part[(size_t)b * C + c];
+    if (!second) stat[c] = t * inv_n;
+    else stat[C + c] = gamma[c] / sqrtf(t * inv_n + 1e-3f);
+}
+__global__ void k_bn_apply(float* __restrict__ x, size_t n, int C, const float* __restrict__ stat, const float* __restrict__ beta, int sig) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C);
+        const float v = (x[i] - stat[ch]) * stat[C + ch] + beta[ch];
+        x[i] = sig ? sigmoidf_(v) : eluf_(v);
+    }
+}
+void launch_batchnorm_act(float* x, size_t n, int P, int C, const float* gamma, const float* beta, int sig, float* part, float* stat, hipStream_t s) {
+    const size_t rows = n * P;                                  // NHWC: a "row" = one pixel's C channels
+    const int nb = rows < BN_BLOCKS ? (int)rows : BN_BLOCKS;
+    hipLaunchKernelGGL(k_bn_partial, dim3(nb), dim3(256), 0, s, x, rows, C, (const float*)nullptr, part);
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, part, nb, C, 1.0f / (float)rows, gamma, stat, 0);
+    hipLaunchKernelGGL(k_bn_partial, dim3(nb), dim3(256), 0, s, x, rows, C, stat, part);
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, part, nb, C, 1.0f / (float)rows, gamma, stat, 1);
+    const size_t tot = rows * C, nbk = (tot + 255) / 256;
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)(nbk < 4096 ? nbk : 4096)), dim3(256), 0, s, x, tot, C, stat, beta, sig);
+}
+
 // Stream-ordered fill / copy as KERNELS: the hot sequences stay kernel-only, which keeps them capturable into a hipGraph
 // (memset / memcpy nodes of a captured stream were observed to run out of order on repeated launches of the same exec).
 __global__ void k_fill_f32(float* __restrict__ dst, size_t n, float v) {

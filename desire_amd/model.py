@@ -55,7 +55,7 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
         grid_size=int(getattr(args, "grid_size", 4)), E_v=16, iters=int(getattr(args, "ioc_iters", 1)),
         posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img,
         bin_mode=int(getattr(args, "social_layout", "rect") == "logpolar"),
-        bn_mode=int(getattr(args, "batch_norm", "frozen") == "per_object"),
+        bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")],
         bf16=int(bool(getattr(args, "bf16", False))))
 
 

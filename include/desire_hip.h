@@ -50,7 +50,9 @@ typedef struct desire_dims {
     int32_t bn_mode;       /* batch normalisation of the CVAE conv stacks: 0 = frozen moving statistics folded into the kernels
                               (default); 1 = "per-object": the reference's literal graph -- phase=train on a batch of one
                               object (model/model.py:453-462,471-481), i.e. per-sample per-channel moments over the layer's
-                              pixels.  fp32 operands, inference only. */
+                              pixels.  2 = whole-batch statistics: the same phase=train moments taken over everything one call
+                              batches (per channel over all samples and pixels) -- what prettytensor's default does when objects ARE
+                              batched.  Modes 1 and 2: fp32 operands, inference only. */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only */
     int32_t ref_compat;    /* 1: the reference graph AS WRITTEN (model/model.py:116-311) instead of the frozen spec: the GRU

@@ -583,6 +583,34 @@ def test_per_object_batch_norm_mode(torch_cuda, kw):
     assert np.abs(ref_frozen["xhat"] - ref["xhat"]).max() > 1e-2
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(posterior=0, K=2)])
+def test_whole_batch_batch_norm_mode(torch_cuda, kw):
+    """dims.bn_mode = 2: prettytensor's phase=train batch-norm over everything a call batches (model/model.py:453,459-461,471)
+    -- per-channel moments over all samples and pixels -- stagewise against the oracle's bn_mode="batch" (VERDICT r01 missing #5:
+    this mode existed in the oracle only)."""
+    d = small_dims(bn_mode=2, **kw)
+    w = init_weights(d, 43)
+    rng = np.random.default_rng(6)
+    for k in list(w):
+        if k.endswith("/bn/gamma"):
+            w[k] = (1.0 + 0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        if k.endswith("/bn/beta"):
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    past, fut, eps, grids, gos = make_case(d, seed=44, n_absent=2)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos, bn_mode="batch")
+    h, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    A, R = d.A, d.R
+    shapes = {"z": (R, d.L), "d1": (R, 2048), "d2": (R, 4096), "d3": (R, 8192), "xhat": (R, 1024), "xz": (R, d.H), "Y0": (R, d.T_pred, 2)}
+    if d.posterior:
+        shapes.update({"z_mean": (A, d.L), "z_log_sigma_sq": (A, d.L)})
+    report = {name: float(np.abs(h.read_buffer(name, shp) - ref[name].reshape(shp)).max()) for name, shp in shapes.items()}
+    print("whole-batch BN, max abs err per stage:", report)
+    for name, err in report.items():
+        assert err < (TOL_Y if name == "Y0" else 5e-4), (name, err, report)
+    ref_po = oracle_forward(d.replace(bn_mode=0), w, past, fut, eps, grids, gos, bn_mode="per_object")
+    assert np.abs(ref_po["xhat"] - ref["xhat"]).max() > 1e-3           # not the per-object function
+
+
 def test_per_object_batch_norm_is_fp32_inference_only(torch_cuda):
     from desire_amd import _lib
     with pytest.raises(_lib.DesireError):
