@@ -17,7 +17,7 @@ def main():
     bad = 0
     for it in range(n):
         mno = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 64, 96, 128]))
-        H = int(rng.choice([64, 128, 128, 256]))
+        H = int(rng.choice([16, 32, 64, 128, 128, 256]))
         kw = dict(mno=mno, H=H, K=int(rng.integers(1, 6)), T_pred=int(rng.integers(1, 14)), T_obs=int(rng.integers(2, 9)),
                   n_scenes=int(rng.integers(1, 4)) if mno <= 32 else 1, grid_size=int(rng.integers(1, 7)),
                   posterior=int(rng.integers(0, 2)), iters=int(rng.choice([1, 1, 2])), L=int(rng.choice([64, 128])),
@@ -27,10 +27,11 @@ def main():
             kw["grid_size"] = 4
         if rng.random() < 0.25:
             kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04, grid_size=max(2, kw["grid_size"]))
-        bf16 = int(rng.random() < 0.3 and mno <= 64)
-        bn_per_object = (not bf16) and rng.random() < 0.2
+        bf16 = int(rng.random() < 0.3)                        # mno 96 / 128: the bf16 cluster form
+        bn_mode = int(rng.choice([1, 2])) if (not bf16) and rng.random() < 0.25 else 0
+        bn_per_object = bn_mode != 0
         if bn_per_object:
-            kw["bn_mode"] = 1
+            kw["bn_mode"] = bn_mode
         try:
             d = small_dims(**kw)
             w = init_weights(d, 100 + it)
@@ -48,7 +49,7 @@ def main():
                 tab = h.bin_table()
             q = O.bf16_round if bf16 else None
             fo = to_oracle_layout(fut) if d.posterior else None
-            okw = dict(bn_mode="per_object") if bn_per_object else {}
+            okw = dict(bn_mode={1: "per_object", 2: "batch"}[bn_mode]) if bn_per_object else {}
             ref = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab, **okw)
             if bf16:                                         # IOC stage against the oracle with the kernels' operand rounding
                 r16 = O.forward(to_oracle_layout(past), fo, eps, grids, gos, w, d, bin_tab=tab, Y_override=ref["Y0"], ioc_q=q)

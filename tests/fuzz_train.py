@@ -20,11 +20,12 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(n):
-        mno = int(rng.choice([2, 4, 8, 16, 32, 32, 64]))
-        H = int(rng.choice([64, 128, 128, 256])) if mno <= 32 else int(rng.choice([64, 128]))
+        mno = int(rng.choice([2, 4, 8, 16, 32, 32, 64, 96, 128]))
+        H = int(rng.choice([16, 32, 64, 128, 128, 256])) if mno <= 32 else int(rng.choice([16, 64, 128]))
         gs = int(rng.integers(1, 7)) if mno <= 32 and H <= 128 else int(rng.integers(1, 5))
         kw = dict(mno=mno, H=H, K=int(rng.integers(2, 5)), T_pred=int(rng.integers(2, 9)), T_obs=int(rng.integers(2, 7)),
                   n_scenes=int(rng.integers(1, 4)) if mno <= 32 else 1, grid_size=gs, L=int(rng.choice([64, 128])), n_grids=1,
+                  iters=int(rng.choice([1, 1, 2])),
                   nb_w=float(rng.choice([0.05, 0.2, 0.5])), nb_h=float(rng.choice([0.05, 0.25, 0.5])))
         if rng.random() < 0.25 and gs >= 3:
             kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04)
