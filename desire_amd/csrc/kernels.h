@@ -148,6 +148,8 @@ void launch_fill_f32(float* dst, size_t n, float v, hipStream_t s);
 void launch_copy_f32(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_copy_cols(float* dst, const float* src, size_t rows, int cols, int ld, hipStream_t s);
 void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s);
+void launch_instnorm_act_oop(const float* x, float* y, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s);
+void launch_instnorm_act_bwd(float* dy, const float* x, const float* y, int n, int P, int C, const float* gamma, int sig, hipStream_t s);
 void launch_batchnorm_act(float* x, size_t n, int P, int C, const float* gamma, const float* beta, int sig, float* part, float* stat, hipStream_t s);
 void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
                         int Co, int stride, int relu, hipStream_t s);

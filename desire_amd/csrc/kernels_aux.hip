@@ -294,14 +294,15 @@ void launch_ade_fde(const float* Y, const float* fut, float* out, int n_scenes, 
 //     y = act( (x - mean_c) * gamma_c / sqrt(var_c + 1e-3) + beta_c ),  var biased (tf.nn.moments), act = ELU or sigmoid.
 // x [n, P, C] (NHWC), P*C <= 8192.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_instnorm_act(float* __restrict__ x, int n, int P, int C, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_instnorm_act(const float* x, float* y, int n, int P, int C, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int sig) {
     __shared__ float xs[8192];
     __shared__ float part[256];
     __shared__ float mean_s[128], rstd_s[128];
     const int tid = threadIdx.x, smp = blockIdx.x;
     const int N = P * C;
-    float* xp = x + (size_t)smp * N;
+    const float* xp = x + (size_t)smp * N;
+    float* yp = y + (size_t)smp * N;                // y may be x (in place: inference) or another buffer (training keeps the pre-norm x)
     for (int i = tid; i < N; i += 256) xs[i] = xp[i];
     __syncthreads();
     const int G = 256 / C;                       // threads per channel (C in {1, 32, 64, 128} -> 256, 8, 4, 2)
@@ -330,11 +331,81 @@ __global__ __launch_bounds__(256) void k_instnorm_act(float* __restrict__ x, int
     for (int i = tid; i < N; i += 256) {
         const int ch = i % C;
         const float v = (xs[i] - mean_s[ch]) * rstd_s[ch] + beta[ch];
-        xp[i] = sig ? sigmoidf_(v) : eluf_(v);
+        yp[i] = sig ? sigmoidf_(v) : eluf_(v);
     }
 }
 void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s) {
-    hipLaunchKernelGGL(k_instnorm_act, dim3(n), dim3(256), 0, s, x, n, P, C, gamma, beta, sig);
+    hipLaunchKernelGGL(k_instnorm_act, dim3(n), dim3(256), 0, s, (const float*)x, x, n, P, C, gamma, beta, sig);
+}
+void launch_instnorm_act_oop(const float* x, float* y, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s) {
+    hipLaunchKernelGGL(k_instnorm_act, dim3(n), dim3(256), 0, s, x, y, n, P, C, gamma, beta, sig);
+}
+
+// Backward of y = act(gamma * xh + beta), xh = (x - mean) * rstd with per-sample per-channel moments over the P pixels:
+//     g = dy * act'(y);   dx = gamma * rstd * ( g - mean_p(g) - xh * mean_p(g * xh) )
+// One workgroup per sample; x (pre-norm, kept by the training-mode forward) is staged in LDS, the moments are recomputed exactly
+// as the forward took them.  dy -> dx in place.  gamma / beta are constants of the training spec (no gradient).
+__global__ __launch_bounds__(256) void k_instnorm_act_bwd(float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                          int n, int P, int C, const float* __restrict__ gamma, int sig) {
+    __shared__ float xs[8192];
+    __shared__ float part[256], part2[256];
+    __shared__ float mean_s[128], rstd_s[128], mg_s[128], mgx_s[128];
+    const int tid = threadIdx.x, smp = blockIdx.x;
+    const int N = P * C;
+    const float* xp = x + (size_t)smp * N;
+    const float* yp = y + (size_t)smp * N;
+    float* gp = dy + (size_t)smp * N;
+    for (int i = tid; i < N; i += 256) xs[i] = xp[i];
+    __syncthreads();
+    const int G = 256 / C;
+    const int c = tid % C, g = tid / C;
+    float s = 0.f;
+    for (int p = g; p < P; p += G) s += xs[p * C + c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int j = 0; j < G; ++j) t += part[j * C + tid];
+        mean_s[tid] = t / (float)P;
+    }
+    __syncthreads();
+    const float m = mean_s[c];
+    s = 0.f;
+    for (int p = g; p < P; p += G) { const float dlt = xs[p * C + c] - m; s += dlt * dlt; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int j = 0; j < G; ++j) t += part[j * C + tid];
+        rstd_s[tid] = 1.0f / sqrtf(t / (float)P + 1e-3f);
+    }
+    __syncthreads();
+    const float rs = rstd_s[c];
+    float sg = 0.f, sgx = 0.f;
+    for (int p = g; p < P; p += G) {
+        const int i = p * C + c;
+        const float yv = yp[i];
+        const float gv = gp[i] * (sig ? yv * (1.0f - yv) : (yv > 0.f ? 1.0f : yv + 1.0f));
+        sg += gv; sgx += gv * (xs[i] - m) * rs;
+    }
+    part[tid] = sg; part2[tid] = sgx;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f, t2 = 0.f;
+        for (int j = 0; j < G; ++j) { t += part[j * C + tid]; t2 += part2[j * C + tid]; }
+        mg_s[tid] = t / (float)P; mgx_s[tid] = t2 / (float)P;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int ch = i % C;
+        const float yv = yp[i];
+        const float gv = gp[i] * (sig ? yv * (1.0f - yv) : (yv > 0.f ? 1.0f : yv + 1.0f));
+        const float xh = (xs[i] - mean_s[ch]) * rstd_s[ch];
+        gp[i] = gamma[ch] * rstd_s[ch] * (gv - mg_s[ch] - xh * mgx_s[ch]);
+    }
+}
+void launch_instnorm_act_bwd(float* dy, const float* x, const float* y, int n, int P, int C, const float* gamma, int sig, hipStream_t s) {
+    hipLaunchKernelGGL(k_instnorm_act_bwd, dim3(n), dim3(256), 0, s, dy, x, y, n, P, C, gamma, sig);
 }
 
 

@@ -52,7 +52,8 @@ typedef struct desire_dims {
                               object (model/model.py:453-462,471-481), i.e. per-sample per-channel moments over the layer's
                               pixels.  2 = whole-batch statistics: the same phase=train moments taken over everything one call
                               batches (per channel over all samples and pixels) -- what prettytensor's default does when objects ARE
-                              batched.  Modes 1 and 2: fp32 operands, inference only. */
+                              batched.  Modes 1 and 2: fp32 operands; mode 1 also trains (desire_backward goes through the per-sample
+                              normalisation), mode 2 is forward-only. */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only */
     int32_t ref_compat;    /* 1: the reference graph AS WRITTEN (model/model.py:116-311) instead of the frozen spec: the GRU

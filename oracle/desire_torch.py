@@ -83,6 +83,17 @@ def bn_frozen(x, w, p):
     return (x - w[p + "/bn/moving_mean"]) * (w[p + "/bn/gamma"] / torch.sqrt(w[p + "/bn/moving_var"] + O.BN_EPS)) + w[p + "/bn/beta"]
 
 
+def bn(x, w, p, d):
+    """Batch-norm of the CVAE stacks: frozen moving statistics (default) or, dims.bn_mode = 1, the reference graph's phase=train on a
+    batch of ONE object = per-sample, per-channel moments over the layer's pixels (oracle.batch_norm "per_object"); gamma / beta
+    are constants of the training spec either way."""
+    if getattr(d, "bn_mode", 0) == 1:
+        mean = x.mean(dim=(1, 2), keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+        return (x - mean) * (w[p + "/bn/gamma"] / torch.sqrt(var + O.BN_EPS)) + w[p + "/bn/beta"]
+    return bn_frozen(x, w, p)
+
+
 def rows_from_agents(x, d):
     x = x.reshape((d.n_scenes, 1, d.mno) + tuple(x.shape[1:]))
     return x.expand((d.n_scenes, d.K, d.mno) + tuple(x.shape[3:])).reshape((d.R,) + tuple(x.shape[3:]))
@@ -101,7 +112,7 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     x = vae_in.reshape(-1, 32, 32, 1)
     for name, stride, pad in (("conv1", 2, "SAME"), ("conv2", 2, "SAME"), ("conv3", 1, "VALID")):
         p = "vae_enc/" + name
-        x = F.elu(bn_frozen(conv2d_tf(x, w[p + "/w"], stride, pad) + w[p + "/b"], w, p))
+        x = F.elu(bn(conv2d_tf(x, w[p + "/w"], stride, pad) + w[p + "/b"], w, p, d))
     params = x.reshape(x.shape[0], -1) @ w["vae_enc/fc/w"] + w["vae_enc/fc/b"]
     mu, ls = params[:, :d.L], params[:, d.L:]
     z = rows_from_agents(mu, d) + torch.sqrt(torch.exp(rows_from_agents(ls, d))) * _t(eps)
@@ -109,7 +120,7 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     for name, stride, pad, act in (("deconv1", 1, "VALID", F.elu), ("deconv2", 1, "VALID", F.elu),
                                    ("deconv3", 2, "SAME", F.elu), ("deconv4", 2, "SAME", torch.sigmoid)):
         p = "vae_dec/" + name
-        x = act(bn_frozen(conv2d_transpose_tf(x, w[p + "/w"], stride, pad) + w[p + "/b"], w, p))
+        x = act(bn(conv2d_transpose_tf(x, w[p + "/w"], stride, pad) + w[p + "/b"], w, p, d))
     xhat = x.reshape(x.shape[0], -1)
     Hx_rows = rows_from_agents(Hx, d)
     beta = torch.softmax(torch.relu(xhat @ w["mask_fc/w"] + w["mask_fc/b"]), -1)

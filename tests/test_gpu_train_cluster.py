@@ -140,3 +140,62 @@ def test_training_through_several_refinement_passes(kw):
         if not e < 5e-4:
             bad[name] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, H=64, L=64), dict(H=16, K=2)])
+def test_training_through_per_object_batch_norm(kw):
+    """dims.bn_mode = 1 in training (frozen statistics only): the backward goes through the reference graph's
+    batch-of-one batch-norm -- per-sample, per-channel moments of every CVAE conv layer -- against autograd of the same graph.
+    gamma / beta stay constants of the training spec; the conv biases cancel against the mean (their gradient is exactly 0)."""
+    import torch
+    from desire_amd import _lib
+    from oracle import desire_torch as OT
+    d = small_dims(T_obs=5, T_pred=6, n_grids=1, K=kw.pop("K", 3), bn_mode=1, **kw)
+    w = init_weights(d, 65)
+    rng = np.random.default_rng(66)
+    for k in list(w):
+        if k.endswith("/bn/gamma"):
+            w[k] = (1.0 + 0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        if k.endswith("/bn/beta"):
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    past, fut, eps, grids, gos = make_case(d, seed=67, n_absent=3)
+    vals, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda")
+    score = torch.zeros((d.R,), device="cuda")
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+    torch.cuda.synchronize()
+    got = h.train_loss(fut_t.data_ptr())
+    assert abs(got["loss"] - float(vals["loss"])) < 2e-4 * max(1.0, abs(float(vals["loss"])))
+    gscale = max(float(np.abs(ref[n]).max()) for n in ref if n in w and "/bn/" not in n)
+    bad = {}
+    for name in ref:
+        if name not in w or name.startswith(("scene_cnn", "temporal", "gauss_head")) or "/bn/" in name:
+            continue
+        g = h.get_grad(name, w[name].shape)
+        if name == "ioc/score/b":
+            continue
+        if (name.startswith("vae_enc/conv") or name.startswith("vae_dec/deconv")) and name.endswith("/b"):
+            assert np.abs(g).max() < 1e-5 * gscale and np.abs(ref[name]).max() < 1e-9 * max(1.0, gscale), name      # cancels against the mean
+            continue
+        e = float(np.abs(g - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12))
+        if not e < 5e-4:
+            bad[name] = e
+    assert not bad, bad
+    for _ in range(3):                                     # and the optimiser loop runs through it
+        h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+        h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+        h.adam_step(0.001)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Y).all())
