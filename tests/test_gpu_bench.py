@@ -35,6 +35,11 @@ def test_default_contract_fields():
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert abs(o["value"] - o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
+    # round 2: the real-SDD leg next to the dense headline, executed-flops fraction, labelled traffic, host core count
+    assert o["sdd"]["value"] > 0 and "bookstore" in o["sdd"]["data"] and o["sdd"]["ms_per_step"] > 0
+    assert 0 < r["whole_path_frac_executed"] < r["whole_path_frac"] < 1
+    assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
+    assert c["host_cores"] >= c["threads"] >= 1
 
 
 @pytest.mark.parametrize("extra", [[], ["--train"], ["--shard", "agents", "--mno", "16"]])

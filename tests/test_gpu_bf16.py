@@ -231,3 +231,28 @@ def test_encoders_bf16_match_rounding_oracle(torch_cuda, kw):
         ef = np.abs(got - O.gru_encode(seq, w, pfx)).max()
         print("%s: vs rounding oracle %.2e, vs fp32 %.2e" % (name, eq, ef))
         assert eq < 1e-3 and ef < 1e-2, (name, eq, ef)
+
+
+@pytest.mark.parametrize("kw", [dict(K=2), dict(mno=64, n_scenes=1, K=2, n_grids=1), dict(mno=128, n_scenes=1, K=1, n_grids=1, T_pred=10)])
+def test_ioc_bf16_error_budget_per_pass(torch_cuda, kw):
+    """The bf16 IOC error budget, PER refinement pass (two passes were only compared in the mean).  Pass p is isolated
+    by starting it from the ORACLE's pass-(p-1) output, so a bin that flipped in an earlier pass cannot leak in:
+        against the oracle with the kernel's rounding points    <= 7e-3 of the offset scale   (logic)
+        against the exact fp32 oracle                           <= 3e-2 of the offset scale   (what bf16 operands cost)
+    per pass; errors of successive passes add (the second pass starts from positions that already carry the first one's)."""
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 9)
+    past, fut, eps, grids, gos = make_case(d32, seed=10, n_absent=3)
+    ref0 = oracle_forward(d32, w, past, fut, eps, grids, gos)
+    Yin = ref0["Y0"]
+    for p in range(2):
+        r32 = oracle_forward(d32, w, past, fut, eps, grids, gos, Y_override=Yin)
+        r16 = oracle_forward(d32, w, past, fut, eps, grids, gos, Y_override=Yin, ioc_q=O.bf16_round)
+        _, Y, score = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos, Y_in=Yin)
+        scale = max(1.0, float(np.abs(r16["Y"] - Yin).max()))
+        e16, e32 = float(np.abs(Y - r16["Y"]).max()), float(np.abs(Y - r32["Y"]).max())
+        print("pass %d: vs rounding oracle %.2e, vs fp32 %.2e (offset scale %.2e)" % (p + 1, e16, e32, scale))
+        assert e16 < 7e-3 * scale and e32 < 3e-2 * scale, (p, e16, e32)
+        assert np.abs(score - r16["score"]).max() < 2e-2 * max(1.0, np.abs(r16["score"]).max())
+        Yin = r32["Y"].astype(np.float32)              # the next pass starts from the exact first-pass result

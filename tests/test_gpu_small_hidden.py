@@ -198,3 +198,50 @@ def test_small_hidden_gradients_match_autograd(torch_cuda):
     h2.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
     torch.cuda.synchronize()
     assert np.abs(Y.cpu().numpy() - Y1).max() < 1e-6
+
+
+@pytest.mark.parametrize("T,n_dec,mno", [(16, 5, 16), (8, 1, 8)])
+def test_ref_compat_other_lengths(torch_cuda, T, n_dec, mno):
+    """ref_compat away from the reference's defaults: seq_length 16 needs d_dim 32 (H == 2T), any number of decoder steps."""
+    import torch
+    from desire_amd import _lib
+    from oracle import desire_oracle as O
+    d = Dims(n_scenes=2, mno=mno, K=1, T_obs=T, T_pred=T, H=2 * T, L=64, sx=1.0, sy=1.0, bn_mode=1, ref_compat=1, n_dec=n_dec, n_grids=1)
+    w = init_weights(d, 17, ref_init=True)
+    rng = np.random.default_rng(18)
+    x = np.zeros((2, T + 1, mno, 3), np.float32)
+    x[..., 0] = np.arange(1, mno + 1)
+    x[..., 1:] = np.round(rng.uniform(5, 1400, (2, 1, mno, 2)) + np.cumsum(rng.normal(0, 3, (2, T + 1, mno, 2)), 1))
+    x[:, :, mno - 2:] = 0                                    # two empty slots
+    past, fut = np.ascontiguousarray(x[:, :T]), np.ascontiguousarray(x[:, 1:])
+    eps = rng.standard_normal((d.A, d.L)).astype(np.float32)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p_t, f_t, e_t = t(past), t(fut), t(eps)
+    out = torch.zeros((d.A, n_dec, T, 2), device="cuda")
+    h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(2, mno, n_dec, T, 2)
+    for i in range(2):
+        ref = O.forward_ref_compat(past[i].transpose(1, 0, 2), fut[i].transpose(1, 0, 2), eps.reshape(2, mno, -1)[i], w, H=2 * T, L=64, n_dec=n_dec)
+        assert np.abs(got[i] - ref["output_states"]).max() < 1e-4
+
+
+def test_empty_and_degenerate_windows_small_hidden_and_clusters(torch_cuda):
+    """Edge inputs on the round-2 paths: a window with nobody in it and a window of coincident agents, at d_dim 16, and through the
+    fp32 / bf16 cluster forms (96 agents)."""
+    for kw, bf in ((dict(H=16, n_scenes=3, K=2), 0), (dict(mno=96, n_scenes=2, K=1, n_grids=1, T_pred=6), 0),
+                   (dict(mno=96, n_scenes=2, K=1, n_grids=1, T_pred=6), 1)):
+        d = small_dims(**kw)
+        w = init_weights(d, 19)
+        past, fut, eps, grids, gos = make_case(d, seed=20, n_absent=2)
+        past[1] = 0.0; fut[1] = 0.0                                     # window 1: nobody there
+        past[0, :, 1:6, 1:] = past[0, :, 0:1, 1:]; fut[0, :, 1:6, 1:] = fut[0, :, 0:1, 1:]   # window 0: slots 1..5 walk with slot 0
+        ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+        h, Y, score = run_gpu(torch_cuda, d.replace(bf16=bf), w, past, fut, eps, grids, gos)
+        assert np.isfinite(Y).all() and np.isfinite(score).all()
+        assert np.abs(h.read_buffer("Y0", (d.R, d.T_pred, 2)) - ref["Y0"]).max() < 1e-3
+        if not bf:
+            _, Y2, s2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+            assert np.abs(Y2 - ref["Y"]).max() < 1e-3 and np.abs(s2 - ref["score"]).max() < 5e-3
