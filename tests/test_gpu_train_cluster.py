@@ -199,3 +199,34 @@ def test_training_through_per_object_batch_norm(kw):
         h.adam_step(0.001)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(Y).all())
+
+
+def test_train_loop_over_all_eight_sdd_scenes(tmp_path):
+    """BASELINE configs[4] as far as the tree allows: desire_amd.train's loop (the reference's train.py loop shape) over a loader that
+    holds one slice of EVERY SDD scene (bookstore, coupa, deathCircle, gates, hyang, little, nexus, quad; the arrays the reference's
+    own loader produced, tests/golden/loader_mixed8_T20.npz): batches mix windows of different videos, IOC refinement on, the loss
+    goes down."""
+    import random
+    from desire_amd import train as T
+    from desire_amd.data_loader import DataLoader
+    g = np.load(os.path.join(HERE, "loader_mixed8_T20.npz"))
+    frames = [g["data%d" % i] for i in range(8)]
+    a = T.build_parser().parse_args(["--batch_size", "8", "--seq_length", "8", "--pred_length", "12", "--max_num_obj", "40",
+                                     "--d_dim", "64", "--latent_size", "64", "--num_samples", "4", "--num_epochs", "6",
+                                     "--learning_rate", "0.001", "--neighborhood_size", "160", "--save_dir", str(tmp_path / "save")])
+    a.img_width, a.img_height = 2000.0, 2000.0
+    dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
+    assert dl.num_batches >= 2
+    random.seed(0)
+    seen = set()
+    orig = dl.next_batch
+
+    def spy(*args, **kw):
+        x, y, d = orig(*args, **kw)
+        seen.update(int(v) for v in d)
+        return x, y, d
+    dl.next_batch = spy
+    losses = T.train(a, data_loader=dl, log=lambda l: None)
+    assert len(losses) == a.num_epochs * dl.num_batches and np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    assert seen == set(range(8))                           # every scene's video fed the optimiser

@@ -94,3 +94,25 @@ def test_frames_kwarg_and_random_update_deterministic_with_seed():
     random.seed(1); xb, _, _ = b.next_batch()
     np.testing.assert_array_equal(np.stack(xa), np.stack(xb))
     assert a.num_batches == 2 * ((50 // 6) // 3)
+
+
+def test_mixed_scene_batches_match_reference(golden_dir):
+    """Eight SDD scenes loaded and batched together by the REFERENCE loader (tests/golden/make_mixed_golden.py; BASELINE configs[4]'s
+    "mixed-scene" input): per-video preprocessing and the cross-video next_batch walk, bit-exact."""
+    g = np.load(os.path.join(golden_dir, "loader_mixed8_T20.npz"))
+    bs, T, mno = (int(v) for v in g["kw"])
+    n = len(g["order"])
+    assert n == 8 and len(set(g["order"].tolist())) == 8
+    frames = []
+    for i in range(n):
+        arr, _, _ = frames_from_csv(g["csv%d" % i].astype(np.float64), mno)
+        np.testing.assert_array_equal(arr, g["data%d" % i])
+        frames.append(arr)
+    dl = DataLoader(batch_size=bs, seq_length=T, max_num_obj=mno, frames=frames)      # same video order as the reference walked
+    assert dl.num_batches == int(g["num_batches"])
+    for b in range(g["x"].shape[0]):
+        x, y, d = dl.next_batch(random_update=False)
+        np.testing.assert_array_equal(np.stack(x), g["x"][b])
+        np.testing.assert_array_equal(np.stack(y), g["y"][b])
+        np.testing.assert_array_equal(np.asarray(d), g["d"][b])
+    assert len(set(g["d"][0].tolist())) > 1                                        # one batch really spans several videos
