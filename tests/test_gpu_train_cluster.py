@@ -230,3 +230,34 @@ def test_train_loop_over_all_eight_sdd_scenes(tmp_path):
     assert len(losses) == a.num_epochs * dl.num_batches and np.isfinite(losses).all()
     assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
     assert seen == set(range(8))                           # every scene's video fed the optimiser
+
+
+def test_cluster_backward_under_load_is_bitwise_stable():
+    """The cluster-form BPTT's hand-off (dpre_r published per reverse step, read by the other members) with every CU busy and each
+    workgroup walking several groups: 6 scenes x 128 agents x K = 8, T_pred = 12 -> 192 tiles... run three times: every gradient word
+    identical (a missed release / acquire would show up as a flaky word)."""
+    import torch
+    from desire_amd import _lib
+    d = small_dims(n_scenes=12, mno=128, K=8, T_obs=6, T_pred=12, n_grids=1, H=128, L=64)
+    w = init_weights(d, 71)
+    past, fut, eps, grids, gos = make_case(d, seed=72, n_absent=30)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda")
+    score = torch.zeros((d.R,), device="cuda")
+    ref = None
+    for rep in range(3):
+        h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+        h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+        torch.cuda.synchronize()
+        g = h.grad_tensor().cpu().numpy().copy()
+        assert np.isfinite(g).all()
+        if ref is None:
+            ref = g
+            assert np.abs(ref).max() > 0
+        else:
+            np.testing.assert_array_equal(g, ref)
