@@ -51,6 +51,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP / HSA runtime libraries.  The process must end up with ONE runtime: importing torch first
+    # makes the dynamic loader resolve this library's libamdhip64 / libhsa-runtime64 against what torch already mapped; the other
+    # load order leaves two runtimes in the process and the second one to initialise sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise DesireError(
             "libdesire_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'`; "

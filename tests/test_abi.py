@@ -84,3 +84,17 @@ def test_dims_from_args_reference_defaults():
     d = dims_from_args(args, 10)
     assert (d.S, d.V, d.mno, d.H, d.L, d.T_obs, d.T_pred, d.grid_size, d.B) == (32, 1024, 64, 128, 128, 8, 8, 4, 16)
     d.validate()
+
+
+def test_one_hip_runtime_in_the_process_whatever_the_import_order():
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If libdesire_hip.so is mapped BEFORE torch, the process ends up
+    with two HIP runtimes and the second one to initialise sees no device (found on the GPU box: build() followed by smoke() in one
+    process failed with DESIRE_ERR_NODEV).  _lib.load() therefore imports torch first; checked here on the mapped files."""
+    import subprocess
+    import sys
+    code = ("from desire_amd import _lib; _lib.load(); import torch, re; "
+            "m = set(re.findall(r'(/\\S*libamdhip64\\S*)', open('/proc/self/maps').read())); "
+            "import os; print(len({os.path.realpath(p) for p in m}))")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.strip().splitlines()[-1] == "1", p.stdout
