@@ -29,3 +29,34 @@ __device__ __forceinline__ void group_publish(int* cnt) {
     }
 }
 
+
+// Write-through form of the same hand-off, for payloads moved as naturally aligned 8-byte words: the producer stores them with
+// agent-scope relaxed atomic stores (global_store_dwordx2 ... sc1: written through, not left dirty in the XCD's L2), drains them
+// (s_waitcnt vmcnt(0), workgroup barrier) and bumps the arrival counter; the consumer polls the counter and reads the payload
+// with agent-scope relaxed atomic loads (sc1: served past the CU's L1).  No release / acquire fence on either side -- a release
+// writes the whole L2's dirty lines back (1.7-6.5 us per publish) and an acquire invalidates the CU's L1 (1.7-7 us), per step;
+// MI355X_MICROARCH.md lists "8-B agent atomics both sides" among the valid forms.
+__device__ __forceinline__ void st_agent_u64(void* p, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 ld_agent_u64(const void* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+__device__ __forceinline__ void group_publish_wt(int* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool group_wait_wt(int* cnt, int target, int* err) {
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 160000000L) { atomicOr(err, 1); ok = false; break; }
+        }
+    }
+    __syncthreads();
+    return ok;
+}

@@ -10,6 +10,8 @@
 //       e_r            += cvt(P_b^T) . W_b                   (chain-ordered weights, no shuffle / LDS / barrier in between)
 // The step's position-only work (velocity embedding, scene-feature gather, neighbour bins of my rows against all mno agents)
 // runs BEFORE the wait for the neighbours' h_{t-1}, so part of the hand-off latency hides under it.
+// Pooling is split over BINS between the waves of a tile (H <= 128): a bin's first chain link is run once, by its owner wave, and the
+// partial e_r tiles are summed through exchange slots that live INSIDE the Ht tile (dead between the pooling and the end of the step).
 // Grid: persistent, a multiple of tpg, never more workgroups than are co-resident (occupancy query), members adjacent.
 #include "bf16.h"
 #include "cluster.h"
@@ -39,8 +41,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
     float* red = wv + 3 * EV;                                          // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [CLMAXM]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + CLMAXM);              // [2] bins that hold a neighbour anywhere in the tile
-    float* EX = reinterpret_cast<float*>(smem_raw + ((reinterpret_cast<unsigned char*>(occ + 2) - smem_raw + 15) & ~15));   // [NT][1024]
-    float* EXB = EX + NT * 1024;                                            // [NT / 2][1024] second set's upper half (B <= 32)
+    // partial-tile exchange of the bin-split pooling: two sets of NT 4 KB slots INSIDE the Ht tile.  Ht is dead between the end of the
+    // pooling chains and the end of the step (my columns are rewritten by publish_h, the other members' by the next step's copy), so
+    // the exchange costs no LDS of its own and two workgroups still share a CU
+    float* EX = reinterpret_cast<float*>(Ht);                               // [2][NT][1024] floats = 2 * NT * 4 KB <= H * LDT * 2 bytes
 
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
             for (int q = 0; q < 4; ++q) {
                 const uint2 v = make_uint2(pk_bf16(h[4 * q], h[4 * q + 1]), pk_bf16(h[4 * q + 2], h[4 * q + 3]));
                 *reinterpret_cast<uint2*>(Ht + col * LDT + tile_pos * TM + arow + 8 * q) = v;
-                if (gdst) *reinterpret_cast<uint2*>(gdst + (size_t)col * TM + arow + 8 * q) = v;
+                if (gdst) st_agent_u64(gdst + (size_t)col * TM + arow + 8 * q, v);       // write-through (cluster.h)
             }
         };
 
@@ -139,13 +143,13 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                 }
                 // ---- neighbours' h_{t-1}: published by their tiles at the end of step t-1 (parity (t-1)&1) ----
                 if (t > 0) {
-                    group_wait(cnt, tpg * (it * (a.T + 1) + t), a.err);
+                    group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
                     const u16* src0 = hex16 + (size_t)((t + 1) & 1) * n_tiles * H * TM;
                     for (int tp = 0; tp < tpg; ++tp) {
                         if (tp == tile_pos) continue;
-                        const uint4* src = reinterpret_cast<const uint4*>(src0 + (size_t)(tile - tile_pos + tp) * H * TM);
-                        for (int i = tid; i < H * 4; i += NTHR)
-                            *reinterpret_cast<uint4*>(Ht + (i >> 2) * LDT + tp * TM + 8 * (i & 3)) = src[i];
+                        const u16* src = src0 + (size_t)(tile - tile_pos + tp) * H * TM;
+                        for (int i = tid; i < H * 8; i += NTHR)                   // 8-byte words: [H][32] bf16 = H * 8 of them
+                            *reinterpret_cast<uint2*>(Ht + (i >> 3) * LDT + tp * TM + 4 * (i & 7)) = ld_agent_u64(src + (size_t)i * 4);
                     }
                 }
                 __syncthreads();
@@ -218,22 +222,16 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (om) {                                          // (workgroup-uniform)
-                        const bool two_sets = B <= 32;
-                        auto slot = [&](int set, int wvi) {
-                            if (set == 0 || !two_sets) return EX + (size_t)wvi * 1024;
-                            constexpr int nh = NT / 2;
-                            return wvi < nh ? reinterpret_cast<float*>(RHb) + (size_t)wvi * 1024 : EXB + (size_t)(wvi - nh) * 1024;
-                        };
+                        __syncthreads();                               // every wave is done reading Ht: it now carries the exchange slots
 #pragma unroll
                         for (int sft = 1; sft < NT; ++sft) {
                             const int set = (sft - 1) & 1;
-                            if (sft > 1 && !two_sets) __syncthreads();
-                            float4* dst = reinterpret_cast<float4*>(slot(set, cb)) + lane;
+                            float4* dst = reinterpret_cast<float4*>(EX + (size_t)(set * NT + cb) * 1024) + lane;
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
                                 dst[q * 64] = make_float4(soc[sft][4 * q], soc[sft][4 * q + 1], soc[sft][4 * q + 2], soc[sft][4 * q + 3]);
                             __syncthreads();
-                            const float4* src = reinterpret_cast<const float4*>(slot(set, (cb + NT - sft) % NT)) + lane;
+                            const float4* src = reinterpret_cast<const float4*>(EX + (size_t)(set * NT + (cb + NT - sft) % NT) * 1024) + lane;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float4 v = src[q * 64];
@@ -307,7 +305,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                     publish_h(h, hex16 + ((size_t)(t & 1) * n_tiles + tile) * H * TM);
                 }
                 if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
-                group_publish(cnt);                          // includes the end-of-step __syncthreads
+                group_publish_wt(cnt);                       // includes the end-of-step __syncthreads
             }
             // ---- score ----
 #pragma unroll
@@ -348,7 +346,7 @@ static size_t ioc16_cl_lds(const IocArgs& a, bool split) {
     const int H = a.H, TM = 32, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
     size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (CLMAXM + 8) * 2;
     b += (size_t)TM * (B + 1) * 16 + 16 * 8 + (size_t)CLMAXM * 2 * 4 + TM * 2 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + CLMAXM + 8 + 64;
-    if (split) b += (size_t)NT * 4096 + (B <= 32 ? (size_t)NT * 2048 : 0);
+    (void)split;                                           // the bin-split exchange lives inside the Ht tile
     return b;
 }
 template <int H, bool SPLIT>
@@ -370,10 +368,11 @@ static int launch16_cl(const IocArgs& a, u16* hex16, hipStream_t s) {
     return 0;
 }
 // a.hex = the exchange buffer (as bf16: 2 * n_tiles * H * 32 elements), a.grp_cnt / a.err as for the fp32 cluster form.
-// a.variant == 6 selects the bin-split pooling (one workgroup per CU: its partial-tile exchange does not leave room for two).
+// Pooling split over BINS between the waves (H <= 128; a.variant == 4 selects the column-split form, A/B): the first chain link of
+// a bin is run once, by its owner wave, instead of once per wave.
 int launch_ioc_bf16_cluster(const IocArgs& a, hipStream_t s) {
     u16* hex16 = reinterpret_cast<u16*>(a.hex);
-    const bool split = a.variant == 6 && a.H <= 128;
+    const bool split = a.variant != 4 && a.H <= 128;
     if (a.H == 128) return split ? launch16_cl<128, true>(a, hex16, s) : launch16_cl<128, false>(a, hex16, s);
     if (a.H == 64) return split ? launch16_cl<64, true>(a, hex16, s) : launch16_cl<64, false>(a, hex16, s);
     return launch16_cl<256, false>(a, hex16, s);
