@@ -162,15 +162,22 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_bwd_cl(IocBwdArgs a, i
                     const unsigned ixx = tl(i, t) * E;
                     const float er = svx[ixx + EV + C + col];
                     const float dpr = er > 0.f ? der[i] : 0.f;
-                    GD[(tile_pos * TM + rl) * LD1 + col] = dpr;                 // my rows of the group tile ...
-                    o_dpr[tl(i, t) * H + col] = dpr;                             // ... and the stream the other members read after the hand-off
+                    GD[(tile_pos * TM + rl) * LD1 + col] = dpr;                 // my rows of the group tile (streamed out below)
                     if (cb == 0 && (lane & 31) < EV) {
                         const float ev = svx[ixx + (lane & 31)];
                         o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
                     }
                 }
             }
-            group_publish(cnt);                                   // dpre_r(t) of my rows is out (includes a workgroup barrier)
+            __syncthreads();
+            // dpre_r(t) of my rows -> HBM (operand of the social-fc weight gradient AND what the other members read): row-major copy with
+            // 8-byte write-through stores, then the fence-free arrival (cluster.h: *_wt)
+            for (int i = tid; i < TM * (H >> 1); i += NTHR) {
+                const int r = i / (H >> 1), c2 = i - r * (H >> 1);
+                const float2 v = *reinterpret_cast<const float2*>(GD + (tile_pos * TM + r) * LD1 + 2 * c2);
+                st_agent_u64(o_dpr + ((size_t)r * a.T + t) * H + 2 * c2, make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)));
+            }
+            group_publish_wt(cnt);                                // (includes a workgroup barrier)
             ++published;
             // ---- while the others arrive: pooled_b[i] = sum_{j in bin b of i} h_{t-1}[j] -> HBM (operand of the social-fc weight
             //      gradient); the neighbours' h_{t-1} come from the forward's saves (or Hx at t = 0), any member of the group ----
@@ -199,13 +206,13 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_bwd_cl(IocBwdArgs a, i
                 for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
             }
             // ---- the other members' dpre_r(t) ----
-            group_wait(cnt, tpg * published, err);
+            group_wait_wt(cnt, tpg * published, err);
             for (int tp = 0; tp < tpg; ++tp) {
                 if (tp == tile_pos) continue;
-                for (int i = tid; i < TM * (H >> 2); i += NTHR) {
-                    const int r = i / (H >> 2), c4 = i - r * (H >> 2);
-                    *reinterpret_cast<float4*>(GD + (tp * TM + r) * LD1 + c4 * 4) =
-                        *reinterpret_cast<const float4*>(a.dpre_r + ((size_t)(grow0 + tp * TM + r) * a.T + t) * H + c4 * 4);
+                for (int i = tid; i < TM * (H >> 1); i += NTHR) {
+                    const int r = i / (H >> 1), c2 = i - r * (H >> 1);
+                    const uint2 v = ld_agent_u64(a.dpre_r + ((size_t)(grow0 + tp * TM + r) * a.T + t) * H + 2 * c2);
+                    *reinterpret_cast<float2*>(GD + (tp * TM + r) * LD1 + 2 * c2) = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
                 }
             }
             __syncthreads();

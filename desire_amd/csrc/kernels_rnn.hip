@@ -852,7 +852,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
 
             for (int t = 0; t < a.T; ++t) {
                 // neighbours' h_{t-1}: published by their tiles at the end of step t-1
-                if (t > 0) group_wait(cnt, tpg * (base + it * (a.T + 1) + t), a.err);
+                if (t > 0) group_wait_wt(cnt, tpg * (base + it * (a.T + 1) + t), a.err);     // fence-free hand-off (cluster.h: *_wt)
                 for (int i = tid; i < a.mno; i += NTHR) {
                     const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + i) * a.T + t) * 2);
                     pg[i * 2] = y.x; pg[i * 2 + 1] = y.y;
@@ -897,10 +897,18 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                         while (m2) {
                             const int j = wd * 64 + __ffsll((long long)m2) - 1;
                             m2 &= m2 - 1;
-                            const float* src;
-                            if ((j >> 5) == tile_pos) src = XH + (j & 31) * LDX + E;
-                            else if (t == 0) src = a.Hx + (size_t)agent_of_row(grow0 + j, a.K, a.mno) * a.ldhx;
-                            else src = hex + (size_t)(grow0 + j) * H;
+                            if ((j >> 5) != tile_pos && t > 0) {                   // another member's row: written through, read past L1
+                                const float* src = hex + (size_t)(grow0 + j) * H;
+#pragma unroll
+                                for (int c = 0; c < NCH; ++c) {
+                                    const uint2 lo = ld_agent_u64(src + q8 * 4 + c * 4 * TPR), hi2 = ld_agent_u64(src + q8 * 4 + c * 4 * TPR + 2);
+                                    s[c].x += __uint_as_float(lo.x); s[c].y += __uint_as_float(lo.y);
+                                    s[c].z += __uint_as_float(hi2.x); s[c].w += __uint_as_float(hi2.y);
+                                }
+                                continue;
+                            }
+                            const float* src = ((j >> 5) == tile_pos) ? XH + (j & 31) * LDX + E
+                                                                      : a.Hx + (size_t)agent_of_row(grow0 + j, a.K, a.mno) * a.ldhx;
 #pragma unroll
                             for (int c = 0; c < NCH; ++c) {
                                 const float4 v = *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
@@ -957,7 +965,6 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                     f32x16 ac = zero16();
                     mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
                     mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
-                    float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)(row0 + 4 * (lane >> 5)) * H + col;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const float c = tanhf_(ac[i] + bcc);
@@ -971,11 +978,19 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
-                        hout[(size_t)((i & 3) + 8 * (i >> 2)) * H] = h[i];
                     }
                 }
                 if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
-                group_publish(cnt);                      // includes the end-of-step __syncthreads
+                __syncthreads();                         // h_t tile complete in LDS
+                {   // publish it: row-major copy with 8-byte write-through stores (parity t&1), then the fence-free arrival
+                    float* hout = a.hex + (size_t)(t & 1) * a.R * H + (size_t)row0 * H;
+                    for (int i = tid; i < TM * (H >> 1); i += NTHR) {
+                        const int r = i / (H >> 1), c2 = i - r * (H >> 1);
+                        const float2 v = *reinterpret_cast<const float2*>(XH + r * LDX + E + 2 * c2);
+                        st_agent_u64(hout + (size_t)r * H + 2 * c2, make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)));
+                    }
+                }
+                group_publish_wt(cnt);                   // includes the end-of-step __syncthreads
                 ++epoch;
             }
 #pragma unroll
