@@ -27,11 +27,17 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
     return out;
 }
 
-static uint16_t bf16_rne(float f) {
-    uint32_t u; std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+std::vector<float> pack_vals16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at) {
+    const int G = (K + 15) / 16, NT = (N + 31) / 32;
+    std::vector<float> o((size_t)NT * G * 64 * 8, 0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int g = 0; g < G; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kmap(g, lane >> 5, e), n = nt * 32 + (lane & 31);
+                    if (k >= 0 && k < K && n < N) o[(((size_t)nt * G + g) * 64 + lane) * 8 + e] = at(k, n);
+                }
+    return o;
 }
 std::vector<float> pack_b16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at) {
     const int G = (K + 15) / 16, NT = (N + 31) / 32;
@@ -180,9 +186,9 @@ int check_dims(const desire_dims& d) {
         return fail(DESIRE_ERR_ARG, "sizes must be >= 1");
     if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
     if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
-    if (d.bf16 != 0 && d.bf16 != 1) return fail(DESIRE_ERR_ARG, "bf16 must be 0 or 1");
+    if (d.bf16 < 0 || d.bf16 > 2) return fail(DESIRE_ERR_ARG, "bf16 must be 0 (fp32 operands), 1 (bf16 operands) or 2 (split-bf16 operands, fp32-equivalent)");
     if (d.bn_mode < 0 || d.bn_mode > 2) return fail(DESIRE_ERR_ARG, "bn_mode must be 0 (frozen statistics), 1 (per-object statistics) or 2 (whole-batch statistics)");
-    if (d.bn_mode && d.bf16) return fail(DESIRE_ERR_ARG, "batch statistics (bn_mode 1 / 2) run on fp32 operands (bf16 = 0)");
+    if (d.bn_mode && d.bf16 == 1) return fail(DESIRE_ERR_ARG, "batch statistics (bn_mode 1 / 2) run on fp32 operands (bf16 = 0 or 2)");
     if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
     if (d.bin_mode == 1 && (d.grid_size < 3 || !(d.nb_h > 0.f) || !(d.nb_w > d.nb_h)))
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
@@ -366,7 +372,36 @@ int desire_pack_all(desire_ctx* h) {
             bad |= up("ioc/WsT_c", tc);
         }
     }
-    if (d.bf16) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
+    if (d.bf16 == 2) {   // split-bf16 packs [hi | lo] of the IOC kernel (kernels_x3.hip): hi = bf16(w), lo = bf16(w - hi)
+        const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
+        const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
+        auto lin = [](int g, int hi, int e) { return 16 * g + 8 * hi + e; };
+        auto chain = [](int g, int hi, int e) { const int hb = g >> 1, r = 8 * (g & 1) + e; return 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi; };
+        // vals = one fp32 value per bf16 slot.  While the repack maps are being built (pack_mode 1: values are index codes) the
+        // value list itself is captured under "<name>#x3": it IS the gather map of the hi half, and of the lo half
+        auto up_split = [&](const std::string& name, const std::vector<float>& vals) {
+            if (h->pack_mode == 1) { h->captured[name + "#x3"] = vals; return 0; }
+            const size_t n = vals.size();
+            std::vector<uint16_t> o(2 * n);
+            for (size_t i = 0; i < n; ++i) {
+                o[i] = bf16_rne(vals[i]);
+                o[n + i] = bf16_rne(vals[i] - bf16_to_f32(o[i]));
+            }
+            std::vector<float> out(n);
+            std::memcpy(out.data(), o.data(), n * 4);
+            return up(name, out);
+        };
+        bad |= up_split("ioc/Wg16", pack_vals16(E + H, 2 * H, lin, [&](int k, int n) { return gk[(size_t)k * 2 * H + n]; }));
+        bad |= up_split("ioc/Wc16", pack_vals16(E + H, H, lin, [&](int k, int n) { return ck[(size_t)k * H + n]; }));
+        bad |= up_split("ioc/Wreg16", pack_vals16(H, 2 * d.T_pred, lin, [&](int k, int n) { return wr[(size_t)k * 2 * d.T_pred + n]; }));
+        std::vector<float> all;
+        for (int b = 0; b < B; ++b) {
+            const auto pv = pack_vals16(H, H, chain, [&](int k, int n) { return ws[((size_t)b * H + k) * H + n]; });
+            all.insert(all.end(), pv.begin(), pv.end());
+        }
+        bad |= up_split("ioc/Wsoc16", all);
+    }
+    if (d.bf16 == 1) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
         const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
         const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
         auto lin = [](int g, int hi, int e) { return 16 * g + 8 * hi + e; };
@@ -536,7 +571,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
     e.out = W(h, "HxHy"); e.ldo = 2 * H; e.p_last = W(h, "p_last"); e.valid = static_cast<uint8_t*>(h->ws["valid"].p);
     if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
-    if (d.bf16) { e.Whg = D4(h, "enc_x/Whg16"); e.Whc = D4(h, "enc_x/Whc16"); Timer t(h, s, "encoder_x"); launch_encoder_bf16(e, s); }
+    if (d.bf16 == 1) { e.Whg = D4(h, "enc_x/Whg16"); e.Whc = D4(h, "enc_x/Whc16"); Timer t(h, s, "encoder_x"); launch_encoder_bf16(e, s); }
     else { Timer t(h, s, "encoder_x"); launch_encoder(e, s); }
     if (d.posterior) {
         e.frames = dev_fut; e.T = d.T_pred;
@@ -544,7 +579,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         e.Whg = D4(h, "enc_y/Whg"); e.Whc = D4(h, "enc_y/Whc");
         e.out = W(h, "HxHy") + H; e.p_last = nullptr; e.valid = nullptr;
         if (h->training) { e.sv_r = W(h, "ey_sv_r"); e.sv_u = W(h, "ey_sv_u"); e.sv_c = W(h, "ey_sv_c"); e.sv_h = W(h, "ey_sv_h"); e.sv_x = W(h, "ey_sv_x"); }
-        if (d.bf16) { e.Whg = D4(h, "enc_y/Whg16"); e.Whc = D4(h, "enc_y/Whc16"); Timer t(h, s, "encoder_y"); launch_encoder_bf16(e, s); }
+        if (d.bf16 == 1) { e.Whg = D4(h, "enc_y/Whg16"); e.Whc = D4(h, "enc_y/Whc16"); Timer t(h, s, "encoder_y"); launch_encoder_bf16(e, s); }
         else { Timer t(h, s, "encoder_y"); launch_encoder(e, s); }
         GemmArgs g{};
         g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
@@ -568,11 +603,11 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), A, 256, 32, 0); }
         c.in = W(h, "c1"); c.out = W(h, "c2"); c.Wp = D4(h, "vae_enc/conv2/W");
         c.scale = D(h, "vae_enc/conv2/scale"); c.shift = D(h, "vae_enc/conv2/shift");
-        if (d.bf16) { c.Wp = D4(h, "vae_enc/conv2/W16"); Timer t(h, s, "conv2"); launch_conv2_bf16(c, s); }
+        if (d.bf16 == 1) { c.Wp = D4(h, "vae_enc/conv2/W16"); Timer t(h, s, "conv2"); launch_conv2_bf16(c, s); }
         else { Timer t(h, s, "conv2"); launch_conv2(c, s); if (pobn) norm("vae_enc/conv2", W(h, "c2"), A, 64, 64, 0); }
         c.in = W(h, "c2"); c.out = W(h, "c3"); c.Wp = D4(h, "vae_enc/conv3/W");
         c.scale = D(h, "vae_enc/conv3/scale"); c.shift = D(h, "vae_enc/conv3/shift");
-        if (d.bf16) { c.Wp = D4(h, "vae_enc/conv3/W16"); Timer t(h, s, "conv3"); launch_conv3_bf16(c, s); }
+        if (d.bf16 == 1) { c.Wp = D4(h, "vae_enc/conv3/W16"); Timer t(h, s, "conv3"); launch_conv3_bf16(c, s); }
         else { Timer t(h, s, "conv3"); launch_conv3(c, s); if (pobn) norm("vae_enc/conv3", W(h, "c3"), A, 16, 128, 0); }
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = A; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
@@ -603,7 +638,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
-    if (d.bf16 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
+    if (d.bf16 == 1 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
     else if (d.bn_mode != 0) {
         Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_NONE, s);
         normd("vae_dec/deconv1", W(h, "d1"), 16, 128, 0);
@@ -615,18 +650,18 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
-    if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
+    if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
            if (pobn) normd("vae_dec/deconv2", W(h, "d2"), 64, 64, 0); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
-    const bool fuse34 = d.bf16 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
+    const bool fuse34 = d.bf16 == 1 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
     if (fuse34) {
         c.Wp = D4(h, "vae_dec/deconv3/W16"); c.w_raw = D(h, "vae_dec/deconv4/W16"); c.out = W(h, "xhat");
         Timer t(h, s, "deconv34");
         launch_deconv34_bf16(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), s);
     } else {
-        if (d.bf16) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
+        if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
         else { Timer t(h, s, "deconv3"); launch_deconv3(c, s);
                if (pobn) normd("vae_dec/deconv3", W(h, "d3"), 256, 32, 0); }
         c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
@@ -638,7 +673,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = d.mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
     if (h->training) m.sv_p = W(h, "mask_sv_p");
-    if (d.bf16) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
+    if (d.bf16 == 1) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
     else { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
     DecArgs a{};
     a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");
@@ -648,7 +683,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.Y = W(h, "Y0"); a.hdump = nullptr;
     if (d.ref_compat) { a.T = d.n_dec; a.hdump = W(h, "dec_states"); }       // model/model.py:280-285: 7 steps, the states are the output
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
-    if (d.bf16) {
+    if (d.bf16 == 1) {
         a.Whg = D4(h, "dec/Whg16"); a.Whc = D4(h, "dec/Whc16");
         Timer t(h, s, "decoder"); launch_decoder_bf16(a, s);
     } else
@@ -682,7 +717,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
-    const bool cluster = d.bf16 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
+    const bool x3 = d.bf16 == 2 && !h->training && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);
+    const bool cluster = d.bf16 == 1 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
                                 : ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
         const size_t n_groups = (size_t)h->R / d.mno;
@@ -699,7 +735,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
     a.dbg = static_cast<long long*>(h->ws["dbg"].p);
 #endif
-    if (h->training && !d.bf16) {
+    if (h->training && d.bf16 != 1) {
         // training-mode forward: one launch per refinement pass, each keeping its own activations and the positions it ran on
         // (the pass's input is DETACHED where it enters the features -- cells, bins, velocity embedding -- and Y_p = Y_{p-1} + dY_p
         // carries the gradient: DESIGN.md section 8)
@@ -716,7 +752,11 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         launch_copy_f32(W(h, "Y_ref"), dev_Yhat, RT * 2, s);
         launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
     } else
-    if (d.bf16) {
+    if (x3) {   // split-bf16 operands: fp32-equivalent results on the bf16 matrix pipe (shapes without that form run the fp32 kernels)
+        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+        Timer t(h, s, "ioc"); launch_ioc_x3(a, s);
+    } else
+    if (d.bf16 == 1) {
         if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
         a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
         Timer t(h, s, "ioc");
@@ -733,9 +773,12 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                                "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
         const char* n16[10] = {"loop top", "P1 ev/es/masks", "barrier 1", "P2 pooling chain + e_r", "barrier 2", "P4 gates + r*h",
                                "barrier 3", "P5 cand + publish", "barrier 4", ""};
-        const char** names = d.bf16 ? n16 : n32;
-        long long tot = 0; for (int k = 0; k < 9; ++k) tot += host[k];
-        for (int k = 0; k < 9; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
+        const char* nx3[10] = {"step top (bar 4 wait)", "P1 ev/es/masks", "barrier 1", "P2 pooling chain", "exchange + e_r", "barrier 2",
+                               "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
+        const char** names = x3 ? nx3 : d.bf16 == 1 ? n16 : n32;
+        const int nk = x3 ? 10 : 9;
+        long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
+        for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
     }
 #endif
     HIPCHK(hipGetLastError());
@@ -837,7 +880,7 @@ extern "C" int desire_ioc_step(desire_handle* h, int32_t t, int32_t rank, int32_
     if (!h->grids_set) return fail(DESIRE_ERR_STATE, "desire_set_scene_grids first");
     if (t < 0 || t >= d.T_pred || nranks < 1 || rank < 0 || rank >= nranks) return fail(DESIRE_ERR_ARG, "bad step / rank");
     if ((long)d.mno * nranks > 256) return fail(DESIRE_ERR_ARG, "agent-sharded IOC: at most 256 agents per scene over all ranks");
-    if (d.bf16) return fail(DESIRE_ERR_STATE, "agent-sharded IOC runs on fp32 operands");
+    if (d.bf16 == 1) return fail(DESIRE_ERR_STATE, "agent-sharded IOC runs on fp32 operands");
     IocStepArgs a{};
     a.t = t; a.rank = rank; a.nranks = nranks; a.m_loc = d.mno; a.n_scenes = d.n_scenes; a.K = d.K; a.R = h->R;
     a.H = d.H; a.T = d.T_pred; a.Gh = d.Gh; a.Gw = d.Gw; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <functional>
 #include <map>
 #include <string>
@@ -70,6 +71,7 @@ struct desire_ctx {
     std::map<std::string, std::vector<float>> captured;
     int adam_t = 0;                                          // Adam step counter
     int n_seg = 0;                                           // repack segments (train.hip)
+    int n_seg16 = 0;                                         // split [hi | lo] bf16 packs among them (dims.bf16 = 2)
 };
 
 struct Timer {
@@ -93,6 +95,16 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at
 // bf16 fragment order (v_mfma_f32_32x32x16_bf16): out16[((nt*G + g)*64 + lane)*8 + e] = bf16(W(k = kmap(g, lane>>5, e), n = nt*32 + (lane&31))),
 // G = ceil(K/16); returned as floats holding two bf16 bit patterns each (so the float upload path carries it)
 std::vector<float> pack_b16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at);
+// the same element order with the fp32 VALUES kept (one float per bf16 slot, 0 where the pack pads): source of the split
+// [hi | lo] packs of kernels_x3.hip, and -- run over index-coded weights -- of their device repack map (train.hip)
+std::vector<float> pack_vals16(int K, int N, const std::function<int(int, int, int)>& kmap, const std::function<float(int, int)>& at);
+inline uint16_t bf16_rne(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
 // logical (caller) layout <-> physical layout of one named weight (identity when the weight has no Embed entry)
 std::vector<float> desire_embed(const desire_ctx* h, const std::string& name, const float* user);
 void desire_extract(const desire_ctx* h, const std::string& name, const float* phys, float* user);

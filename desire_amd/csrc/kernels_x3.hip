@@ -1,0 +1,475 @@
+// kernels_x3.hip -- fp32-equivalent contractions on the bf16 matrix pipe ("split" operands, dims.bf16 = 2).
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the flop rate of v_mfma_f32_32x32x2_f32.  An fp32 value splits exactly into
+// bf16 pieces  x = hi + lo + r,  hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-17 |x|,  so
+//      a . b  =  a_hi b_hi + a_lo b_hi + a_hi b_lo  +  O(2^-16 |a b|)
+// with every product exact in the fp32 accumulator: three bf16 MFMAs per fp32 one, at 3/16 of its matrix time, and a
+// result that differs from the fp32 kernels' by ~1e-5 relative instead of the ~4e-3 of plain bf16 operands.
+//   * activations are kept in LDS as TWO bf16 images (hi, lo) of each operand tile -- the same bytes as one fp32 tile
+//   * weights are packed as [hi pack | lo pack] ("ioc/*16" buffers of api.hip, lo = bf16(w - hi(w)))
+//   * 0/1 neighbour masks are exact in bf16: the pooling's first link costs 2 MFMAs (hi, lo), every other contraction 3
+// Structure = k_ioc_bf16's bin-split form (kernels_bf16.hip): 32-row tile = whole (scene,k) groups, wave cb owns hidden
+// columns [32cb, 32cb+32), occupied bins dealt round-robin to the waves, partial e_r tiles summed in fixed order through
+// LDS slots that alias the (then dead) h^T and r*h tiles.
+#include "common.h"
+#include "kernels.h"
+
+#include "bf16.h"
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+struct Frag2 { uint4 h, l; };
+__device__ __forceinline__ Frag2 split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    Frag2 f;
+    split2(v0, v1, f.h.x, f.l.x); split2(v2, v3, f.h.y, f.l.y); split2(v4, v5, f.h.z, f.l.z); split2(v6, v7, f.h.w, f.l.w);
+    return f;
+}
+// acc += a . b with split operands (small terms first)
+__device__ __forceinline__ f32x16 mfma_x3(uint4 ah, uint4 al, uint4 bh, uint4 bl, f32x16 c) {
+    c = mfma16(al, bh, c);
+    c = mfma16(ah, bl, c);
+    return mfma16(ah, bh, c);
+}
+
+// acc[nb] += A[32 x 16G] . B_nb[16G x 32]: A = hi image at ap, lo image at ap + alo (bf16 elements); B = hi pack at bl[nb]
+// (already + lane), lo pack blo uint4 further on.  Chunks of CHX groups, next chunk's B fragments in flight.
+#define CHX 2
+#define RD4 3                                                       // ring depth (k-groups) of the gate contraction
+template <int NB>
+__device__ __forceinline__ void load_bx(uint4 (&bh)[NB][CHX], uint4 (&bo)[NB][CHX], const uint4* const (&bl)[NB], size_t blo, int g) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < CHX; ++j) { bh[nb][j] = bl[nb][(g + j) * 64]; bo[nb][j] = bl[nb][blo + (g + j) * 64]; }
+}
+template <int NB>
+__device__ __forceinline__ void mmax_chunk(f32x16 (&acc)[NB], const u16* ap, int alo, int g, const uint4 (&bh)[NB][CHX], const uint4 (&bo)[NB][CHX]) {
+#pragma unroll
+    for (int j = 0; j < CHX; ++j) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(ap + (g + j) * 16);
+        const uint4 al = *reinterpret_cast<const uint4*>(ap + alo + (g + j) * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(al, bh[nb][j], acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(ah, bo[nb][j], acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(ah, bh[nb][j], acc[nb]);
+    }
+}
+template <int NB>
+__device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
+    const int nch = G / CHX;
+    int c = 0;
+    if (nch > 0) {
+        uint4 h0[NB][CHX], l0[NB][CHX], h1[NB][CHX], l1[NB][CHX];
+        load_bx<NB>(h0, l0, bl, blo, 0);
+#pragma clang loop unroll(disable)
+        for (; c + 2 <= nch; c += 2) {
+            load_bx<NB>(h1, l1, bl, blo, CHX * (c + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mmax_chunk<NB>(acc, ap, alo, CHX * c, h0, l0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nch) load_bx<NB>(h0, l0, bl, blo, CHX * (c + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            mmax_chunk<NB>(acc, ap, alo, CHX * (c + 1), h1, l1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nch) { mmax_chunk<NB>(acc, ap, alo, CHX * c, h0, l0); ++c; }
+    }
+#pragma clang loop unroll(disable)
+    for (int g = CHX * c; g < G; ++g) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(ap + g * 16);
+        const uint4 al = *reinterpret_cast<const uint4*>(ap + alo + g * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_x3(ah, al, bl[nb][g * 64], bl[nb][blo + g * 64], acc[nb]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// IOC scoring / refinement with split operands.  Tile = 32 rows = whole (scene,k) groups (mno divides 32), H in {64, 128}.
+// Weight pointers of IocArgs point at the [hi | lo] bf16 packs.
+// ------------------------------------------------------------------------------------------------------------------
+#ifdef DESIRE_IOC_TIMING
+#define TICKX(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICKX(k)
+#endif
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = H >> 5, TM = 32, E = EV + C + H, KX = E + H;
+    constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = TM + 8;          // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
+    constexpr int XLO = TM * LDXB, RLO = TM * LDRB, TLO = H * LDT;    // element offset of an operand tile's lo image
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
+    static_assert(2 * TLO * 2 >= NT * 4096 && 2 * RLO * 2 >= NT * 4096, "exchange slots must fit the tiles they alias");
+    const int B = a.G * a.G, LDM = B + 1;
+    u16* Xb = reinterpret_cast<u16*>(smem_raw);                       // [2][TM][LDXB]  e_v | e_s | e_r | h   (hi image, lo image)
+    u16* RHb = Xb + 2 * XLO;                                          // [2][TM][LDRB]  r * h
+    u16* Ht = RHb + 2 * RLO;                                          // [2][H][LDT]    h transposed (pooling operand)
+    unsigned* masks = reinterpret_cast<unsigned*>(Ht + 2 * TLO);      // [TM][B+1], bit = local row
+    uint2* lut = reinterpret_cast<uint2*>(masks + ((TM * LDM + 1) & ~1));   // [16] nibble -> 4 bf16 (0.0 / 1.0)
+    float* pc = reinterpret_cast<float*>(lut + 16);                   // [TM][2]
+    float* pp = pc + TM * 2;                                          // [TM][2]
+    float* wv = pp + TM * 2;                                          // [3][EV]
+    float* red = wv + 3 * EV;                                         // [NT][TM]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                  // [2] bins that hold a neighbour anywhere in the tile
+    float* EX0 = reinterpret_cast<float*>(Ht);                              // exchange set 0: inside the h^T tile (dead after the pooling)
+    float* EX1 = reinterpret_cast<float*>(RHb);                             // set 1: inside the r*h tile (idle until the gates)
+
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + c31;
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int my_scene = my_row / (a.K * a.mno);
+    const int grp_base = (r8 / a.mno) * a.mno;
+    const int my_slot = r8 - grp_base;
+
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < 16) {
+        const unsigned lo = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        lut[tid] = make_uint2(lo, hi2);
+    }
+    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
+    const uint4* Wg = reinterpret_cast<const uint4*>(a.Wg);
+    const uint4* Wc = reinterpret_cast<const uint4*>(a.Wc);
+    const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
+    const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
+    constexpr size_t WG_LO = (size_t)2 * NT * G16 * 64, WC_LO = (size_t)NT * G16 * 64;   // uint4 offset of a pack's lo half
+    const size_t WS_LO = (size_t)B * NT * GH16 * 64, WR_LO = (size_t)a.NTreg * GH16 * 64;
+
+    const u16* xp = Xb + c31 * LDXB + 8 * hi;
+    const u16* rp = RHb + c31 * LDRB + 8 * hi;
+    const int arow = 4 * hi;                                          // + (i&3) + 8(i>>2): local row of accumulator element i
+    // h (fp32, accumulator layout) -> hi / lo images of both operand tiles
+    auto publish_h = [&](const f32x16& h) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h0, l0, h1, l1;
+            split2(h[4 * q], h[4 * q + 1], h0, l0);
+            split2(h[4 * q + 2], h[4 * q + 3], h1, l1);
+            u16* x = Xb + (arow + 8 * q) * LDXB + E + col;
+            x[0] = (u16)h0; x[LDXB] = (u16)(h0 >> 16); x[2 * LDXB] = (u16)h1; x[3 * LDXB] = (u16)(h1 >> 16);
+            x[XLO] = (u16)l0; x[XLO + LDXB] = (u16)(l0 >> 16); x[XLO + 2 * LDXB] = (u16)l1; x[XLO + 3 * LDXB] = (u16)(l1 >> 16);
+            *reinterpret_cast<uint2*>(Ht + col * LDT + arow + 8 * q) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(Ht + TLO + col * LDT + arow + 8 * q) = make_uint2(l0, l1);
+        }
+    };
+
+    for (int it = 0; it < a.iters; ++it) {
+        int row0p;                                                    // opaque copy: keeps the prologue's address math out of the time loop's registers
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
+        f32x16 h, sp = zero16();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(row0p + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
+            h[i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
+        }
+        __syncthreads();                                  // previous pass's readers of Xb / Ht are done
+        publish_h(h);
+        float2 ynext = make_float2(0.f, 0.f);
+        if (tid < TM) {
+            const int row = min(row0 + tid, a.R - 1);
+            const int ag = agent_of_row(row, a.K, a.mno);
+            pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)row * a.T) * 2);
+            pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
+        }
+        for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0u;
+        if (tid < 2) occ[tid] = 0;
+        __syncthreads();
+
+        for (int t = 0; t < a.T; ++t) {
+            TICKX(0)
+            if (tid < TM && t + 1 < a.T)
+                ynext = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t + 1) * 2);
+            // ---- P1: e_v, e_s, neighbour bits (row threads) ----
+            {
+                const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+                const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                for (int j = 2 * q8; j < EV; j += 2 * TPR) {
+                    const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                    const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
+                    unsigned eh, el;
+                    split2(e0, e1, eh, el);
+                    *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = eh;
+                    *reinterpret_cast<unsigned*>(Xb + XLO + r8 * LDXB + j) = el;
+                }
+                int cy, cx;
+                scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                for (int j = 4 * q8; j < C; j += 4 * TPR) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
+                    unsigned h0, l0, h1, l1;
+                    split2(g4.x, g4.y, h0, l0); split2(g4.z, g4.w, h1, l1);
+                    *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(Xb + XLO + r8 * LDXB + EV + j) = make_uint2(l0, l1);
+                }
+                for (int j = q8; j < a.mno; j += TPR) {
+                    if (j == my_slot || !vld[grp_base + j]) continue;
+                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
+                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1u << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
+                }
+            }
+            TICKX(1)
+            __syncthreads();
+            TICKX(2)
+            // ---- P2: social pooling chain -> e_r (occupied bins dealt round-robin to the waves) ----
+            unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+            om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+            {
+                unsigned long long mine = 0ull;
+                {
+                    int k = 0;
+                    for (unsigned long long tmp = om; tmp; tmp &= tmp - 1, ++k)
+                        if (k % NT == cb) mine |= tmp & (0ull - tmp);
+                }
+                f32x16 soc[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) soc[k] = zero16();
+                auto wptr = [&](int b, int hb, int k) {           // hi fragments of W_b[hidden block hb][column block (cb+k)%NT], 2 k-groups
+                    const int cbo = (cb + k) % NT;
+                    return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
+                };
+                uint4 wh[2 * NT], wl[2 * NT];                      // W fragments of one hidden block (hi, lo), refreshed in place
+                if (mine) {
+                    const int b0 = __ffsll((long long)mine) - 1;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const uint4* p = wptr(b0, 0, k);
+                        wh[2 * k] = p[0]; wh[2 * k + 1] = p[64]; wl[2 * k] = p[WS_LO]; wl[2 * k + 1] = p[WS_LO + 64];
+                    }
+                }
+#pragma clang loop unroll(disable)
+                while (mine) {
+                    const int b = __ffsll((long long)mine) - 1;
+                    mine &= mine - 1;
+                    const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                    uint4 mf[2];
+                    const unsigned m32 = masks[c31 * LDM + b];
+#pragma unroll
+                    for (int jg = 0; jg < 2; ++jg) {
+                        const unsigned bits = (m32 >> (16 * jg + 8 * hi)) & 0xffu;
+                        const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                        mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    }
+                    // software pipeline over the hidden blocks: link 1 of block hb+1 is issued before block hb's result is split
+                    // and consumed, so the split never waits on the matrix pipe
+                    auto link1 = [&](int hb) {
+                        f32x16 d1 = zero16();
+                        const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
+#pragma unroll
+                        for (int jg = 0; jg < 2; ++jg) {
+                            d1 = mfma16(*reinterpret_cast<const uint4*>(hp + TLO + 16 * jg), mf[jg], d1);
+                            d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], d1);
+                        }
+                        return d1;
+                    };
+                    f32x16 da = link1(0), dn;
+#pragma unroll
+                    for (int hb = 0; hb < NT; ++hb) {
+                        if (hb + 1 < NT) dn = link1(hb + 1);
+                        const Frag2 p0 = split8(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
+                        const Frag2 p1 = split8(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {            // slot k's fragments are re-requested right after their last use
+                            soc[k] = mfma_x3(p0.h, p0.l, wh[2 * k], wl[2 * k], soc[k]);
+                            soc[k] = mfma_x3(p1.h, p1.l, wh[2 * k + 1], wl[2 * k + 1], soc[k]);
+                            const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+                            wh[2 * k] = p[0]; wh[2 * k + 1] = p[64]; wl[2 * k] = p[WS_LO]; wl[2 * k + 1] = p[WS_LO + 64];
+                        }
+                        if (hb + 1 < NT) da = dn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // fixed-order sum of the partial tiles: round s hands slot s to the wave s column blocks further on; rounds
+                // alternate between the two slot sets, one barrier per round
+                TICKX(3)
+                if (om) {                                          // (workgroup-uniform)
+                    __syncthreads();                               // every wave is done reading Ht: it now carries exchange set 0
+#pragma unroll
+                    for (int sft = 1; sft < NT; ++sft) {
+                        float* ex = ((sft - 1) & 1) ? EX1 : EX0;
+                        float4* dst = reinterpret_cast<float4*>(ex + (size_t)cb * 1024) + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            dst[q * 64] = make_float4(soc[sft][4 * q], soc[sft][4 * q + 1], soc[sft][4 * q + 2], soc[sft][4 * q + 3]);
+                        __syncthreads();
+                        const float4* src = reinterpret_cast<const float4*>(ex + (size_t)((cb + NT - sft) % NT) * 1024) + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = src[q * 64];
+                            soc[0][4 * q] += v.x; soc[0][4 * q + 1] += v.y; soc[0][4 * q + 2] += v.z; soc[0][4 * q + 3] += v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned h0, l0, h1, l1;
+                    split2(fmaxf(soc[0][4 * q] + bso, 0.f), fmaxf(soc[0][4 * q + 1] + bso, 0.f), h0, l0);
+                    split2(fmaxf(soc[0][4 * q + 2] + bso, 0.f), fmaxf(soc[0][4 * q + 3] + bso, 0.f), h1, l1);
+                    u16* x = Xb + (arow + 8 * q) * LDXB + EV + C + col;
+                    x[0] = (u16)h0; x[LDXB] = (u16)(h0 >> 16); x[2 * LDXB] = (u16)h1; x[3 * LDXB] = (u16)(h1 >> 16);
+                    x[XLO] = (u16)l0; x[XLO + LDXB] = (u16)(l0 >> 16); x[XLO + 2 * LDXB] = (u16)l1; x[XLO + 3 * LDXB] = (u16)(l1 >> 16);
+                }
+            }
+            TICKX(4)
+            __syncthreads();
+            TICKX(5)
+            // ---- P4: gates over [x | h], and the candidate's x part (same A fragments: three n-tiles per LDS read) ----
+            // B fragments run through a ring of RD4 k-groups, requested RD4 groups (~ 850 matrix cycles) before their use
+            f32x16 u, ac = zero16();
+            {
+                f32x16 g0 = zero16(), g1 = zero16();
+                // wave-uniform bases (scalar registers) + the lane as a 32-bit offset: no per-fragment address registers
+                // (the opaque zero is redefined every step: the 100+ fragment addresses below are cheap to form and must not be
+                // hoisted out of the time loop, where they would sit in spilled registers)
+                int z4;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z4));
+                const uint4* wg0 = Wg + ((size_t)cb * G16) * 64 + z4;
+                const uint4* wg1 = Wg + ((size_t)(cb + NT) * G16) * 64 + z4;
+                const uint4* wcx = Wc + ((size_t)cb * G16) * 64 + z4;
+                const unsigned ul = (unsigned)lane;
+                uint4 rh[RD4][3], rl[RD4][3];
+                auto req = [&](int g) {                            // (g is a compile-time constant after unrolling)
+                    const int sl = g % RD4;
+                    rh[sl][0] = (wg0 + g * 64)[ul]; rl[sl][0] = (wg0 + WG_LO + g * 64)[ul];
+                    rh[sl][1] = (wg1 + g * 64)[ul]; rl[sl][1] = (wg1 + WG_LO + g * 64)[ul];
+                    if (g < GX16) { rh[sl][2] = (wcx + g * 64)[ul]; rl[sl][2] = (wcx + WC_LO + g * 64)[ul]; }
+                };
+#pragma unroll
+                for (int g = 0; g < RD4; ++g) req(g);
+#pragma unroll
+                for (int g = 0; g < G16; ++g) {
+                    const int sl = g % RD4;
+                    const uint4 ah = *reinterpret_cast<const uint4*>(xp + g * 16);
+                    const uint4 al = *reinterpret_cast<const uint4*>(xp + XLO + g * 16);
+                    g0 = mfma16(al, rh[sl][0], g0); g1 = mfma16(al, rh[sl][1], g1);
+                    if (g < GX16) ac = mfma16(al, rh[sl][2], ac);
+                    g0 = mfma16(ah, rl[sl][0], g0); g1 = mfma16(ah, rl[sl][1], g1);
+                    if (g < GX16) ac = mfma16(ah, rl[sl][2], ac);
+                    g0 = mfma16(ah, rh[sl][0], g0); g1 = mfma16(ah, rh[sl][1], g1);
+                    if (g < GX16) ac = mfma16(ah, rh[sl][2], ac);
+                    if (g + RD4 < G16) req(g + RD4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float rhv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rhv[e] = sigmoidf_(g0[4 * q + e] + bgr) * h[4 * q + e];
+                        u[4 * q + e] = sigmoidf_(g1[4 * q + e] + bgu);
+                    }
+                    unsigned h0, l0, h1, l1;
+                    split2(rhv[0], rhv[1], h0, l0); split2(rhv[2], rhv[3], h1, l1);
+                    u16* x = RHb + (arow + 8 * q) * LDRB + col;
+                    x[0] = (u16)h0; x[LDRB] = (u16)(h0 >> 16); x[2 * LDRB] = (u16)h1; x[3 * LDRB] = (u16)(h1 >> 16);
+                    x[RLO] = (u16)l0; x[RLO + LDRB] = (u16)(l0 >> 16); x[RLO + 2 * LDRB] = (u16)l1; x[RLO + 3 * LDRB] = (u16)(l1 >> 16);
+                }
+            }
+            // the candidate's r*h part: all of its B fragments are requested before the barrier
+            uint4 ch[GH16], cl[GH16];
+            {
+                int z5;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z5));
+                const uint4* wch = Wc + ((size_t)cb * G16 + GX16) * 64 + z5;
+                const unsigned ul = (unsigned)lane;
+#pragma unroll
+                for (int g = 0; g < GH16; ++g) { ch[g] = (wch + g * 64)[ul]; cl[g] = (wch + WC_LO + g * 64)[ul]; }
+            }
+            TICKX(6)
+            __syncthreads();
+            TICKX(7)
+            // ---- P5: candidate += (r*h) part, blend, score; publish h_t ----
+            {
+#pragma unroll
+                for (int g = 0; g < GH16; ++g) {
+                    const uint4 ah = *reinterpret_cast<const uint4*>(rp + g * 16);
+                    const uint4 al = *reinterpret_cast<const uint4*>(rp + RLO + g * 16);
+                    ac = mfma_x3(ah, al, ch[g], cl[g], ac);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float c = tanhf_(ac[i] + bcc);
+                    h[i] = gru_blend(u[i], h[i], c);
+                    sp[i] = fmaf(h[i], wsc, sp[i]);
+                }
+                publish_h(h);                              // h slots of Xb / Ht were last read before the previous barrier
+            }
+            if (tid < TM) {
+                pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
+                pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
+            }
+            for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0u;
+            if (tid < 2) occ[tid] = 0;
+            TICKX(8)
+            __syncthreads();
+            TICKX(9)
+        }
+        // ---- score ----
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = sp[i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+            if (c31 == 0) red[cb * TM + arow + (i & 3) + 8 * (i >> 2)] = v;
+        }
+        __syncthreads();
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
+        if (tid < TM && row0p + tid < a.R && it == a.iters - 1) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+            a.score[row0p + tid] = sc + (float)a.T * a.b_score[0];
+        }
+        // ---- regression: Y += h_T W_r + b_r ----
+        for (int nt = cb; nt < a.NTreg; nt += NT) {
+            f32x16 acc[1] = {zero16()};
+            const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
+            mmax_groups<1>(acc, xp + E, XLO, br, WR_LO, GH16);
+            const int cc = nt * 32 + c31;
+            if (cc < 2 * a.T) {
+                const float bb = a.b_reg[cc];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0p + arow + (i & 3) + 8 * (i >> 2);
+                    if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][i] + bb); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
+#endif
+}
+
+static size_t iocx3_lds(const IocArgs& a) {
+    const int H = a.H, TM = 32, KX = 16 + 32 + 2 * H, B = a.G * a.G, NT = H / 32;
+    size_t b = 2 * ((size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2);
+    b += (size_t)((TM * (B + 1) + 1) & ~1) * 4 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 16;
+    return b;
+}
+bool ioc_x3_supported(int mno, int H, int bins) { return mno >= 1 && mno <= 32 && 32 % mno == 0 && (H == 64 || H == 128) && bins <= 64; }
+template <int H>
+static void launch_x3(const IocArgs& a, hipStream_t s) {
+    allow_big_lds(k_ioc_x3<H, 16, 32>);
+    hipLaunchKernelGGL((k_ioc_x3<H, 16, 32>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), iocx3_lds(a), s, a);
+}
+void launch_ioc_x3(const IocArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_x3<128>(a, s); else launch_x3<64>(a, s);
+}

@@ -81,6 +81,26 @@ __global__ void k_repack(const Seg* __restrict__ segs, const uint32_t* __restric
     }
 }
 
+// split [hi | lo] bf16 packs of kernels_x3.hip (dims.bf16 = 2): dst[i] = bf16(w), dst[n + i] = bf16(w - hi), w = Wflat[idx[i]-1]
+struct Seg16 { uint16_t* dst; unsigned long long idx_off; unsigned long long n; };
+__device__ __forceinline__ uint16_t bf16_rne_dev(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__global__ void k_repack_split(const Seg16* __restrict__ segs, const uint32_t* __restrict__ idx, const float* __restrict__ w) {
+    const Seg16 sg = segs[blockIdx.y];
+    const uint32_t* ix = idx + sg.idx_off;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t j = ix[i];
+        const float v = j ? w[j - 1] : 0.f;
+        const uint16_t hi = bf16_rne_dev(v);
+        sg.dst[i] = hi;
+        sg.dst[sg.n + i] = bf16_rne_dev(v - __uint_as_float((uint32_t)hi << 16));
+    }
+}
+
 // folded batch-norm shift follows the (trainable) conv bias: shift = beta + scale * (b - mean); scale is frozen
 __global__ void k_refold(const float* __restrict__ w, float* __restrict__ shift, const float* __restrict__ scale, size_t off_b,
                          size_t off_beta, size_t off_mean, int C) {
@@ -193,10 +213,32 @@ int build_repack_maps(desire_ctx* h) {
     HIPCHK(hipMemcpy(W(h, "Wflat"), flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(W(h, "Mflat"), 0, h->n_params * sizeof(float)));
     HIPCHK(hipMemset(W(h, "Vflat"), 0, h->n_params * sizeof(float)));
-    std::vector<uint32_t> all_idx; std::vector<Seg> segs;
+    std::vector<uint32_t> all_idx; std::vector<Seg> segs; std::vector<Seg16> segs16;
     std::vector<float> devcopy;
     for (auto& kv : h->captured) {
         const std::string& name = kv.first; const auto& v = kv.second;
+        if (name.size() > 3 && name.compare(name.size() - 3, 3, "#x3") == 0) {      // split [hi | lo] pack: v = index code per bf16 slot
+            const std::string real_name = name.substr(0, name.size() - 3);
+            auto it = h->dev.find(real_name);
+            if (it == h->dev.end() || it->second.bytes != v.size() * 4)
+                return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " changed shape");
+            std::vector<uint16_t> dev16(2 * v.size());
+            HIPCHK(hipMemcpy(dev16.data(), it->second.p, it->second.bytes, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> ix(v.size());
+            for (size_t i = 0; i < v.size(); ++i) {
+                uint32_t u; std::memcpy(&u, &v[i], 4);
+                if (u > h->n_params) return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " is not a gather of the weights");
+                ix[i] = u;
+                const float want = u ? flat[u - 1] : 0.f;
+                const uint16_t hi = bf16_rne(want);
+                if (dev16[i] != hi || dev16[v.size() + i] != bf16_rne(want - bf16_to_f32(hi)))
+                    return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " does not match its map");
+            }
+            segs16.push_back(Seg16{static_cast<uint16_t*>(it->second.p), (unsigned long long)all_idx.size(), (unsigned long long)v.size()});
+            all_idx.insert(all_idx.end(), ix.begin(), ix.end());
+            while (all_idx.size() % 4) all_idx.push_back(0);
+            continue;
+        }
         auto it = h->dev.find(name);
         if (it == h->dev.end() || it->second.bytes != v.size() * sizeof(float))
             return fail(DESIRE_ERR_STATE, "repack map: operand " + name + " changed shape");
@@ -222,8 +264,11 @@ int build_repack_maps(desire_ctx* h) {
         while (all_idx.size() % 4) all_idx.push_back(0);
     }
     h->captured.clear();
-    if (ensure(h, "repack_idx", all_idx.size() * sizeof(uint32_t)) || ensure(h, "repack_segs", segs.size() * sizeof(Seg)))
+    if (ensure(h, "repack_idx", all_idx.size() * sizeof(uint32_t)) || ensure(h, "repack_segs", segs.size() * sizeof(Seg)) ||
+        ensure(h, "repack_segs16", std::max<size_t>(1, segs16.size()) * sizeof(Seg16)))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the repack maps");
+    if (!segs16.empty()) HIPCHK(hipMemcpy(h->ws["repack_segs16"].p, segs16.data(), segs16.size() * sizeof(Seg16), hipMemcpyHostToDevice));
+    h->n_seg16 = (int)segs16.size();
     HIPCHK(hipMemcpy(h->ws["repack_idx"].p, all_idx.data(), all_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->ws["repack_segs"].p, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     h->n_seg = (int)segs.size();
@@ -233,6 +278,9 @@ int build_repack_maps(desire_ctx* h) {
 int repack(desire_ctx* h, hipStream_t s) {
     hipLaunchKernelGGL(k_repack, dim3(64, h->n_seg), dim3(256), 0, s, static_cast<const Seg*>(h->ws["repack_segs"].p),
                        static_cast<const uint32_t*>(h->ws["repack_idx"].p), W(h, "Wflat"));
+    if (h->n_seg16)
+        hipLaunchKernelGGL(k_repack_split, dim3(64, h->n_seg16), dim3(256), 0, s, static_cast<const Seg16*>(h->ws["repack_segs16"].p),
+                           static_cast<const uint32_t*>(h->ws["repack_idx"].p), W(h, "Wflat"));
     for (const char* n : {"vae_enc/conv1", "vae_enc/conv2", "vae_enc/conv3", "vae_dec/deconv1", "vae_dec/deconv2",
                           "vae_dec/deconv3", "vae_dec/deconv4"}) {
         const std::string p(n);
@@ -249,10 +297,19 @@ int repack(desire_ctx* h, hipStream_t s) {
 
 extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (int rc = desire_ready(h)) return rc;
-    if (!enable) { h->training = false; return DESIRE_OK; }
+    if (!enable) {
+        if (h->training) {          // the trained master copy becomes the handle's weights: desire_get_weight and a later
+            std::vector<float> flat(h->n_params);          // desire_set_training(h, 1) start from it (Adam moments restart at zero)
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(flat.data(), W(h, "Wflat"), flat.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (auto& kv : h->slots) h->host_w[kv.first].assign(flat.begin() + kv.second.off, flat.begin() + kv.second.off + kv.second.n);
+        }
+        h->training = false;
+        return DESIRE_OK;
+    }
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
-    if (d.bf16) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0)");
+    if (d.bf16 == 1) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0 or 2; 2 trains with the fp32 kernels)");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
     if (d.bn_mode == 2) return fail(DESIRE_ERR_STATE, "training runs with frozen (bn_mode 0) or per-object (bn_mode 1) batch-norm; whole-batch statistics are forward-only");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))

@@ -10,7 +10,7 @@ Kept from the reference:
     (model/model.py:613-688).
 
 New (the reference has one seq_length, K hard-coded to 7, no IOC): args.pred_length, args.num_samples,
-args.ioc_iters, args.img_width/img_height, args.bf16 (bf16 matrix operands, inference only), and forward() that returns
+args.ioc_iters, args.img_width/img_height, args.bf16 (True/1: bf16 matrix operands, inference only; 2 or "x3": split-bf16 operands, fp32-equivalent), and forward() that returns
 all K refined samples + scores.
 
 PyTorch is used for device memory and streams only.
@@ -56,7 +56,14 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
         posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img,
         bin_mode=int(getattr(args, "social_layout", "rect") == "logpolar"),
         bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")],
-        bf16=int(bool(getattr(args, "bf16", False))))
+        bf16=_operand_mode(getattr(args, "bf16", False)))
+
+
+def _operand_mode(v) -> int:
+    """args.bf16 -> dims.bf16: False/0 fp32 operands, True/1 bf16 operands, 2 / "x3" / "split" split-bf16 operands."""
+    if isinstance(v, str):
+        return {"": 0, "0": 0, "f32": 0, "1": 1, "bf16": 1, "2": 2, "x3": 2, "split": 2}[v.lower()]
+    return int(v) if int(v) in (0, 1, 2) else 1
 
 
 class DESIREModel(object):

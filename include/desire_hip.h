@@ -55,7 +55,11 @@ typedef struct desire_dims {
                               batched.  Modes 1 and 2: fp32 operands; mode 1 also trains (desire_backward goes through the per-sample
                               normalisation), mode 2 is forward-only. */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
-                              for the recurrent IOC kernel (BASELINE configs[2]); inference only */
+                              for the recurrent IOC kernel (BASELINE configs[2]); inference only.  2: SPLIT bf16 operands --
+                              every fp32 operand enters the bf16 matrix pipe as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and a
+                              product is three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 accumulate): results agree with the fp32
+                              kernels to ~1e-5 relative at 3/16 of their matrix time.  Kernels without that form (and training)
+                              run the fp32 kernels, so 2 is always at least as accurate as it claims. */
     int32_t ref_compat;    /* 1: the reference graph AS WRITTEN (model/model.py:116-311) instead of the frozen spec: the GRU
                               decoder runs n_dec steps (7, :280) and every output state [H] is re-read as T_obs (x, y) points
                               (:286-289, needs H == 2*T_obs); one eps per object (K = 1, :262-263); target window = input
@@ -208,7 +212,9 @@ int desire_ioc_finish(desire_handle* h, const float* dev_h_state, const float* d
  * desire_set_training(h,1) allocates the activation-save and gradient buffers; a desire_forward made afterwards keeps
  * what backward needs.  desire_backward computes d(loss)/d(weight) for the loss of DESIGN.md section 8 into ONE flat
  * fp32 device buffer (natural TF layouts; desire_grad_buffer exposes it so a multi-GPU caller can all-reduce it).
- * Frozen batch-norm parameters are constants (no gradient). */
+ * Frozen batch-norm parameters are constants (no gradient).  desire_set_training(h,0) hands the trained master weights back to
+ * the handle (desire_get_weight returns them, inference keeps using the device operands the last desire_adam_step rebuilt);
+ * enabling training again starts from them with the Adam moments at zero (desire_adam_state to carry moments across). */
 int desire_set_training(desire_handle* h, int enable);
 int desire_backward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps, void* stream);
 int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
