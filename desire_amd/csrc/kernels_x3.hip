@@ -36,7 +36,9 @@ __device__ __forceinline__ f32x16 mfma_x3(uint4 ah, uint4 al, uint4 bh, uint4 bl
 // acc[nb] += A[32 x 16G] . B_nb[16G x 32]: A = hi image at ap, lo image at ap + alo (bf16 elements); B = hi pack at bl[nb]
 // (already + lane), lo pack blo uint4 further on.  Chunks of CHX groups, next chunk's B fragments in flight.
 #define CHX 2
-#define RD4 3                                                       // ring depth (k-groups) of the gate contraction
+#ifndef RD4
+#define RD4 2                                                       // ring depth (k-groups) of the gate contraction
+#endif
 template <int NB>
 __device__ __forceinline__ void load_bx(uint4 (&bh)[NB][CHX], uint4 (&bo)[NB][CHX], const uint4* const (&bl)[NB], size_t blo, int g) {
 #pragma unroll
@@ -265,22 +267,16 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                         const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
                         mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                     }
-                    // software pipeline over the hidden blocks: link 1 of block hb+1 is issued before block hb's result is split
-                    // and consumed, so the split never waits on the matrix pipe
-                    auto link1 = [&](int hb) {
-                        f32x16 d1 = zero16();
+#pragma unroll
+                    for (int hb = 0; hb < NT; ++hb) {
+                        // link 1: P_b^T[hidden block hb] = (h_hi + h_lo)^T . M_b^T  (the 0/1 mask is exact in bf16: two MFMAs per chunk)
+                        f32x16 da = zero16();
                         const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
 #pragma unroll
                         for (int jg = 0; jg < 2; ++jg) {
-                            d1 = mfma16(*reinterpret_cast<const uint4*>(hp + TLO + 16 * jg), mf[jg], d1);
-                            d1 = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], d1);
+                            da = mfma16(*reinterpret_cast<const uint4*>(hp + TLO + 16 * jg), mf[jg], da);
+                            da = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], da);
                         }
-                        return d1;
-                    };
-                    f32x16 da = link1(0), dn;
-#pragma unroll
-                    for (int hb = 0; hb < NT; ++hb) {
-                        if (hb + 1 < NT) dn = link1(hb + 1);
                         const Frag2 p0 = split8(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
                         const Frag2 p1 = split8(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
 #pragma unroll
@@ -290,8 +286,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                             const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
                             wh[2 * k] = p[0]; wh[2 * k + 1] = p[64]; wl[2 * k] = p[WS_LO]; wl[2 * k + 1] = p[WS_LO + 64];
                         }
-                        if (hb + 1 < NT) da = dn;
-                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);         // one hidden block at a time: keeps the live set to one chain result
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -30,6 +30,8 @@ pmc   bench_w128_bf16 --bf16
 stats bench_bf16_mno64 --bf16 --mno 64 --windows 64 --steps 5 --warmup 2 --no-cpu-baseline
 stats bench_bf16_mno128 --bf16 --mno 128 --windows 32 --steps 5 --warmup 2 --no-cpu-baseline
 pmc   bench_bf16_mno128 --bf16 --mno 128 --windows 32
+stats bench_w512_split --split --steps 5 --warmup 2 --no-cpu-baseline      # split-bf16 operands in the IOC kernel (dims.bf16 = 2)
+pmc   bench_w512_split --split
 stats train --train --steps 5 --warmup 2
 stats bench_w2 --windows 2 --steps 20 --warmup 5 --no-cpu-baseline
 stats bench_w2_bf16 --bf16 --windows 2 --steps 20 --warmup 5 --no-cpu-baseline
