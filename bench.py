@@ -218,6 +218,8 @@ def main():
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
     a = ap.parse_args()
+    if a.split and (a.bf16 or a.train or a.compact or a.shard == "agents"):
+        raise SystemExit("--split (split-bf16 operands in the IOC kernel) is an inference form of its own: not with --bf16 / --train / --compact / --shard agents")
     if a.windows is None:
         # inference saturates around 512 windows; a training step keeps ~0.5 GB of activations per window (27 GB of it the
         # pooled operand at 128 windows), so it stays at the size its profile was taken at

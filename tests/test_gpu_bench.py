@@ -40,6 +40,10 @@ def test_default_contract_fields():
     assert 0 < r["whole_path_frac_executed"] < r["whole_path_frac"] < 1
     assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
     assert c["host_cores"] >= c["threads"] >= 1
+    # the opt-in forms measured beside the headline: row-compacted pooling, split-bf16 IOC (same results to ~1e-5)
+    sp = o["alt"]["split_bf16x3_ioc"]
+    assert sp["value"] > 0 and sp["ioc_ms"] > 0 and 0 < sp["max_abs_diff_vs_fp32_kernel"] < 1e-4
+    assert o["alt"]["row_compacted_pooling"]["value"] > 0
 
 
 @pytest.mark.parametrize("extra", [[], ["--train"], ["--shard", "agents", "--mno", "16"]])
@@ -68,3 +72,18 @@ def test_compact_flag_is_labelled():
     assert p.returncode == 0, p.stderr[-2000:]
     o = _last_json(p.stdout)
     assert "row-compacted" in o["config"]["workload"] and "note" in o["roofline"] and o["value"] > 0
+
+
+def test_split_flag_is_labelled_and_gated():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--windows", "16", "--split"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = _last_json(p.stdout)
+    assert "split" in o["metric"] and o["dtype"].startswith("bf16x3") and "k_ioc_x3" in o["roofline"]["kernel"]
+    assert abs(o["roofline"]["peak"] - 2500.0 / 3) < 1e-6 and 0 < o["roofline"]["frac"] < 1
+    assert o["accuracy"]["max_abs_err_Y"] < 1e-4          # the HIP path with split operands against the fp32 oracle (gate 1e-3)
+    p = subprocess.run([sys.executable, "bench.py", "--split", "--bf16"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
