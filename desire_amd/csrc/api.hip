@@ -571,16 +571,23 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
     e.out = W(h, "HxHy"); e.ldo = 2 * H; e.p_last = W(h, "p_last"); e.valid = static_cast<uint8_t*>(h->ws["valid"].p);
     if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
-    if (d.bf16 == 1) { e.Whg = D4(h, "enc_x/Whg16"); e.Whc = D4(h, "enc_x/Whc16"); Timer t(h, s, "encoder_x"); launch_encoder_bf16(e, s); }
-    else { Timer t(h, s, "encoder_x"); launch_encoder(e, s); }
+    const EncArgs ex = e;
     if (d.posterior) {
         e.frames = dev_fut; e.T = d.T_pred;
         e.wx_g = D(h, "enc_y/gk"); e.b_g = D(h, "enc_y/gb"); e.wx_c = D(h, "enc_y/ck"); e.b_c = D(h, "enc_y/cb");
         e.Whg = D4(h, "enc_y/Whg"); e.Whc = D4(h, "enc_y/Whc");
         e.out = W(h, "HxHy") + H; e.p_last = nullptr; e.valid = nullptr;
         if (h->training) { e.sv_r = W(h, "ey_sv_r"); e.sv_u = W(h, "ey_sv_u"); e.sv_c = W(h, "ey_sv_c"); e.sv_h = W(h, "ey_sv_h"); e.sv_x = W(h, "ey_sv_x"); }
-        if (d.bf16 == 1) { e.Whg = D4(h, "enc_y/Whg16"); e.Whc = D4(h, "enc_y/Whc16"); Timer t(h, s, "encoder_y"); launch_encoder_bf16(e, s); }
-        else { Timer t(h, s, "encoder_y"); launch_encoder(e, s); }
+    }
+    if (d.bf16 == 1) {
+        EncArgs e16 = ex;
+        e16.Whg = D4(h, "enc_x/Whg16"); e16.Whc = D4(h, "enc_x/Whc16");
+        { Timer t(h, s, "encoder_x"); launch_encoder_bf16(e16, s); }
+        if (d.posterior) { e.Whg = D4(h, "enc_y/Whg16"); e.Whc = D4(h, "enc_y/Whc16"); Timer t(h, s, "encoder_y"); launch_encoder_bf16(e, s); }
+    } else if (d.posterior) {      // the two encoders are independent and latency-bound: one launch
+        Timer t(h, s, "encoder_xy"); launch_encoder_pair(ex, e, s);
+    } else { Timer t(h, s, "encoder_x"); launch_encoder(ex, s); }
+    if (d.posterior) {
         GemmArgs g{};
         g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
         g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");

@@ -68,6 +68,7 @@ struct EncArgs {
     const float* normals; float* roll_out;                 // [n_roll, A, 2] N(0,1) draws in, sampled positions (clipped <= 1) out
 };
 void launch_encoder(const EncArgs& a, hipStream_t s);
+void launch_encoder_pair(const EncArgs& past, const EncArgs& fut, hipStream_t s);   // both encoders, one launch (same H)
 void launch_encoder_bf16(const EncArgs& a, hipStream_t s);    // kernels_bf16.hip; Whg / Whc = bf16 packs
 
 struct DecArgs {

@@ -11,20 +11,23 @@
 #define KC 256            // K-chunk staged in LDS per pass
 #define LDA_C (KC + 4)    // 260 = 4*65: ds_read_b128 conflict-free
 
-template <int EPI, int NTW>
+template <int EPI, int NTW, int MT = 2>      // MT 32-row tiles per workgroup
 __global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
+    constexpr int TMR = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int row0 = blockIdx.x * DS_TM;
-    f32x16 acc[NTW][2];
+    const int row0 = blockIdx.x * TMR;
+    f32x16 acc[NTW][MT];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) { acc[j][0] = zero16(); acc[j][1] = zero16(); }
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = zero16();
     const float* a_lane = smem + (lane & 31) * LDA_C + 4 * (lane >> 5);
 
     for (int k0 = 0; k0 < a.K; k0 += KC) {
         const int kc = min(KC, a.K - k0);
         const int q = kc >> 2;                      // float4 per row
-        for (int i = tid; i < DS_TM * q; i += DS_WG) {
+        for (int i = tid; i < TMR * q; i += DS_WG) {
             const int r = i / q, c4 = i - r * q;
             const int row = row0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
         for (int j = 0; j < NTW; ++j) {
             const int nt = (blockIdx.y * NTW + j) * 4 + w;
             if (nt < a.NT)
-                mma_groups<2>(acc[j], a_lane, LDA_C, a.Bp + ((size_t)nt * a.G + (k0 >> 3)) * 64 + lane, kc >> 3);
+                mma_groups<MT>(acc[j], a_lane, LDA_C, a.Bp + ((size_t)nt * a.G + (k0 >> 3)) * 64 + lane, kc >> 3);
         }
         __syncthreads();
     }
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
         else if (EPI == EPI_ELUGRAD || EPI == EPI_SIGGRAD) p0 = a.p0[col % a.chmod];
         else if (EPI != EPI_NONE) p0 = a.p0[col];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = row0 + m * 32 + acc_row(i);
@@ -67,19 +70,27 @@ __global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
     }
 }
 
+template <int NTW, int MT>
+static void launch_gemm_rows_n(const GemmArgs& a, int epi, hipStream_t s) {
+    constexpr int TMR = 32 * MT;
+    dim3 grid((a.M + TMR - 1) / TMR, (a.NT + 4 * NTW - 1) / (4 * NTW));
+    const size_t lds = TMR * LDA_C * sizeof(float);
+    allow_big_lds(k_gemm_rows<EPI_BIAS, NTW, MT>); allow_big_lds(k_gemm_rows<EPI_BIAS_RELU, NTW, MT>);
+    allow_big_lds(k_gemm_rows<EPI_SCALE_SHIFT_ELU, NTW, MT>); allow_big_lds(k_gemm_rows<EPI_NONE, NTW, MT>);
+    allow_big_lds(k_gemm_rows<EPI_ELUGRAD, NTW, MT>); allow_big_lds(k_gemm_rows<EPI_SIGGRAD, NTW, MT>);
+    if (epi == EPI_NONE) hipLaunchKernelGGL((k_gemm_rows<EPI_NONE, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_ELUGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_ELUGRAD, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_SIGGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_SIGGRAD, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS_RELU, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+    else hipLaunchKernelGGL((k_gemm_rows<EPI_SCALE_SHIFT_ELU, NTW, MT>), grid, dim3(DS_WG), lds, s, a);
+}
+// A workgroup normally holds a 64-row A tile and each wave runs four column tiles over it.  With few row tiles (a handful of
+// windows per call) that leaves most CUs idle behind one long dependent MFMA chain, so small launches give every wave ONE
+// 32 x 32 output tile instead (same k order per output: the results are bit-identical either way).
 void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s) {
-    const int NTW = 4;
-    dim3 grid((a.M + DS_TM - 1) / DS_TM, (a.NT + 4 * NTW - 1) / (4 * NTW));
-    const size_t lds = DS_TM * LDA_C * sizeof(float);
-    allow_big_lds(k_gemm_rows<EPI_BIAS, 4>); allow_big_lds(k_gemm_rows<EPI_BIAS_RELU, 4>);
-    allow_big_lds(k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>); allow_big_lds(k_gemm_rows<EPI_NONE, 4>);
-    allow_big_lds(k_gemm_rows<EPI_ELUGRAD, 4>); allow_big_lds(k_gemm_rows<EPI_SIGGRAD, 4>);
-    if (epi == EPI_NONE) hipLaunchKernelGGL((k_gemm_rows<EPI_NONE, 4>), grid, dim3(DS_WG), lds, s, a);
-    else if (epi == EPI_ELUGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_ELUGRAD, 4>), grid, dim3(DS_WG), lds, s, a);
-    else if (epi == EPI_SIGGRAD) hipLaunchKernelGGL((k_gemm_rows<EPI_SIGGRAD, 4>), grid, dim3(DS_WG), lds, s, a);
-    else if (epi == EPI_BIAS) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS, 4>), grid, dim3(DS_WG), lds, s, a);
-    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL((k_gemm_rows<EPI_BIAS_RELU, 4>), grid, dim3(DS_WG), lds, s, a);
-    else hipLaunchKernelGGL((k_gemm_rows<EPI_SCALE_SHIFT_ELU, 4>), grid, dim3(DS_WG), lds, s, a);
+    const long wgs = (long)((a.M + DS_TM - 1) / DS_TM) * ((a.NT + 15) / 16);
+    if (wgs < 128) launch_gemm_rows_n<1, 1>(a, epi, s); else launch_gemm_rows_n<4, 2>(a, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,8 +33,8 @@ __device__ __forceinline__ void mma1(f32x16& acc, const float* a_lane, const flo
 // ------------------------------------------------------------------------------------------------
 // Encoder: tile = 64 agents, T steps, input (x,y) normalised in-kernel: one fp32 multiply each.
 // ------------------------------------------------------------------------------------------------
-template <int H, int TM, bool ROLL = false>
-__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) {
+template <int H, int TM, bool ROLL>
+__device__ __forceinline__ void encoder_tile(const EncArgs& a, int blk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = H + 4, NT = H >> 5, G = H >> 3, NTHR = NT * (TM / 32) * 64;
     float* hs = smem;                      // [64][LDH]
@@ -42,7 +42,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
     const int A = a.n_scenes * a.mno;
-    const int a0 = blockIdx.x * TM;
+    const int a0 = blk * TM;
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
     float wr0 = 0, wr1 = 0, wu0 = 0, wu1 = 0, wc0 = 0, wc1 = 0, br = 0, bu = 0, bc = 0;
@@ -155,6 +155,24 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
             if (ag < A) a.out[(size_t)ag * a.ldo + col] = h[i];
         }
     }
+}
+template <int H, int TM, bool ROLL = false>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) { encoder_tile<H, TM, ROLL>(a, blockIdx.x); }
+// past and future encoders in ONE launch (they are independent and each is latency-bound: A/32 workgroups stepping through T
+// dependent GRU steps): the first nb0 workgroups run a0, the rest a1
+template <int H, int TM>
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder_pair(EncArgs a0, EncArgs a1, int nb0) {
+    if ((int)blockIdx.x < nb0) encoder_tile<H, TM, false>(a0, blockIdx.x);
+    else encoder_tile<H, TM, false>(a1, blockIdx.x - nb0);
+}
+void launch_encoder_pair(const EncArgs& a0, const EncArgs& a1, hipStream_t s) {
+    constexpr int TM = 32;
+    const int nb0 = (a0.n_scenes * a0.mno + TM - 1) / TM, nb1 = (a1.n_scenes * a1.mno + TM - 1) / TM;
+    const size_t lds = (TM * (a0.H + 4) + TM * 2) * sizeof(float);
+    const dim3 grid(nb0 + nb1);
+    if (a0.H == 256) hipLaunchKernelGGL((k_encoder_pair<256, TM>), grid, dim3(512), lds, s, a0, a1, nb0);
+    else if (a0.H == 128) hipLaunchKernelGGL((k_encoder_pair<128, TM>), grid, dim3(256), lds, s, a0, a1, nb0);
+    else hipLaunchKernelGGL((k_encoder_pair<64, TM>), grid, dim3(128), lds, s, a0, a1, nb0);
 }
 void launch_encoder(const EncArgs& a, hipStream_t s) {
     // 32-agent tiles: the encoders are latency-bound (A/32 workgroups of H/32 waves), smaller tiles = more CUs busy
