@@ -33,6 +33,9 @@ __device__ __forceinline__ f32x16 splat16h(float v) {
 #ifndef IOC16_SPLIT
 #define IOC16_SPLIT 1
 #endif
+#ifndef IOC16_RD
+#define IOC16_RD 4                                                   // gate-contraction ring depth (k-groups in flight)
+#endif
 #ifndef IOC16_TWO_SETS
 #define IOC16_TWO_SETS 1
 #endif
@@ -85,4 +88,5 @@ __device__ __forceinline__ void mma16_groups(f32x16 (&acc)[NB][MT], const u16* c
         }
     }
 }
+
 

@@ -311,32 +311,64 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
             TICK16(3)
             __syncthreads();
             TICK16(4)
-            // ---- P4: gates over [x | h] ----
-            f32x16 u;
+            // ---- P4: gates over [x | h], and the candidate's x part (same A fragments: three n-tiles per LDS read) ----
+            // B fragments run through a ring of RD k-groups requested that many groups before their use; their addresses are formed per
+            // step from wave-uniform bases (the opaque zero keeps ~60 of them from being hoisted out of the time loop into spilled
+            // registers).  (Kept inline in both bf16 IOC kernels: as a shared helper the same code spills three times as much.)
+            f32x16 u, ac = zero16();
             {
-                f32x16 g2[2][1] = {{zero16()}, {zero16()}};
-                const uint4* bl[2] = {Wg + ((size_t)cb * G16) * 64 + lane, Wg + ((size_t)(cb + NT) * G16) * 64 + lane};
-                mma16_groups<1, 2>(g2, xp, bl, G16);
+                f32x16 g0 = zero16(), g1 = zero16();
+                int z4;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z4));
+                const uint4* wg0 = Wg + ((size_t)cb * G16) * 64 + z4;
+                const uint4* wg1 = Wg + ((size_t)(cb + NT) * G16) * 64 + z4;
+                const uint4* wcx = Wc + ((size_t)cb * G16) * 64 + z4;
+                const unsigned ul = (unsigned)lane;
+                constexpr int RD = (NT * WM > 8) ? 2 : IOC16_RD;
+                uint4 rb[RD][3];
+                auto req = [&](int g) {                            // (g is a compile-time constant after unrolling)
+                    const int sl = g % RD;
+                    rb[sl][0] = (wg0 + g * 64)[ul]; rb[sl][1] = (wg1 + g * 64)[ul];
+                    if (g < GX16) rb[sl][2] = (wcx + g * 64)[ul];
+                };
+#pragma unroll
+                for (int g = 0; g < RD && g < G16; ++g) req(g);
+#pragma unroll
+                for (int g = 0; g < G16; ++g) {
+                    const int sl = g % RD;
+                    const uint4 av = *reinterpret_cast<const uint4*>(xp[0] + g * 16);
+                    g0 = mfma16(av, rb[sl][0], g0); g1 = mfma16(av, rb[sl][1], g1);
+                    if (g < GX16) ac = mfma16(av, rb[sl][2], ac);
+                    if (g + RD < G16) req(g + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float r = sigmoidf_(g2[0][0][i] + bgr);
+                    const float r = sigmoidf_(g0[i] + bgr);
                     RHb[(arow + (i & 3) + 8 * (i >> 2)) * LDRB + col] = bf16_of(r * h[i]);
-                    u[i] = sigmoidf_(g2[1][0][i] + bgu);
+                    u[i] = sigmoidf_(g1[i] + bgu);
                 }
+            }
+            // the candidate's r*h part: all of its B fragments are requested before the barrier
+            uint4 ch[GH16];
+            {
+                int z5;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z5));
+                const uint4* wch = Wc + ((size_t)cb * G16 + GX16) * 64 + z5;
+                const unsigned ul = (unsigned)lane;
+#pragma unroll
+                for (int g = 0; g < GH16; ++g) ch[g] = (wch + g * 64)[ul];
             }
             TICK16(5)
             __syncthreads();
             TICK16(6)
-            // ---- P5: candidate over [x | r*h], blend, score; publish h_t ----
+            // ---- P5: candidate += (r*h) part, blend, score; publish h_t ----
             {
-                f32x16 ac[1][1] = {{zero16()}};
-                const uint4* bx[1] = {Wc + ((size_t)cb * G16) * 64 + lane};
-                mma16_groups<1, 1>(ac, xp, bx, GX16);
-                const uint4* bh[1] = {Wc + ((size_t)cb * G16 + GX16) * 64 + lane};
-                mma16_groups<1, 1>(ac, rp, bh, GH16);
+#pragma unroll
+                for (int g = 0; g < GH16; ++g) ac = mfma16(*reinterpret_cast<const uint4*>(rp[0] + g * 16), ch[g], ac);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float c = tanhf_(ac[0][0][i] + bcc);
+                    const float c = tanhf_(ac[i] + bcc);
                     h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
                 }
