@@ -159,3 +159,29 @@ def test_model_surface_selects_split_operands(torch_cuda):
         outs.append(Y.cpu().numpy())
     err = np.abs(outs[0] - outs[1]).max()
     assert 0 < err < TOL_Y, err
+
+
+def test_split_path_is_window_independent_and_deterministic(torch_cuda):
+    """BASELINE configs[1] shapes, 16 windows through the split-operand IOC kernel: together or in two halves, and run twice, the
+    refined trajectories and scores are bit-identical (what scene-sharding over GPUs relies on) -- and within 1e-4 of the fp32
+    kernels' END-TO-END output, because sample generation is the same fp32 code on both sides (same cells, same bins)."""
+    from desire_amd.spec import Dims
+    from desire_amd.synth import make_case as mk
+    n = 16
+    d = Dims(n_scenes=n, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4, nb_w=0.15, nb_h=0.15,
+             sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1, bf16=2)
+    w = init_weights(d, 0)
+    past, fut, eps, grids, gos = mk(d, seed=1, n_absent=0)
+    _, Y, s = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    _, Yr, sr = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    np.testing.assert_array_equal(Y, Yr)
+    np.testing.assert_array_equal(s, sr)
+    rows = d.K * d.mno
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        dd = d.replace(n_scenes=hi - lo)
+        _, Yh, sh = run_gpu(torch_cuda, dd, w, past[lo:hi], fut[lo:hi], eps[lo * rows:hi * rows], grids, gos[lo:hi])
+        np.testing.assert_array_equal(Yh, Y[lo * rows:hi * rows])
+        np.testing.assert_array_equal(sh, s[lo * rows:hi * rows])
+    _, Yf, sf = run_gpu(torch_cuda, d.replace(bf16=0), w, past, fut, eps, grids, gos)
+    assert 0 < np.abs(Y - Yf).max() < TOL_Y
+    assert np.abs(s - sf).max() < 1e-4 * max(1.0, np.abs(sf).max())
