@@ -218,8 +218,8 @@ def main():
                     help="time a TRAINING step instead (forward + backward + gradient all-reduce + clip + Adam + device repack); "
                          "not the BASELINE metric -- the default run is")
     a = ap.parse_args()
-    if a.split and (a.bf16 or a.train or a.compact or a.shard == "agents"):
-        raise SystemExit("--split (split-bf16 operands in the IOC kernel) is an inference form of its own: not with --bf16 / --train / --compact / --shard agents")
+    if a.split and (a.bf16 or a.compact or a.shard == "agents"):
+        raise SystemExit("--split (split-bf16 operands in the IOC kernel) is a form of its own: not with --bf16 / --compact / --shard agents")
     if a.windows is None:
         # inference saturates around 512 windows; a training step keeps ~0.5 GB of activations per window (27 GB of it the
         # pooled operand at 128 windows), so it stays at the size its profile was taken at
@@ -507,8 +507,9 @@ def main():
             "metric": "TRAINING agent-trajectory-samples/sec (K=20, T_pred=40; fwd+bwd+allreduce+clip+Adam+repack)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU%s" % (a.windows, "; launch sequence replayed from a hipGraph" if a.graph else ""),
+            "dtype": "f32; IOC forward with split-bf16 (3-product) operands" if a.split else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU%s%s" % (a.windows, "; launch sequence replayed from a hipGraph" if a.graph else "",
+                                   "; dims.bf16 = 2: the training-mode IOC forward runs k_ioc_x3 (fp32 saves, fp32 backward)" if a.split else ""),
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
             "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
             "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))

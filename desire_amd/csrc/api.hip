@@ -724,7 +724,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
-    const bool x3 = d.bf16 == 2 && !h->training && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);
+    const bool x3 = d.bf16 == 2 && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);     // (also the training-mode forward)
     const bool cluster = d.bf16 == 1 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
                                 : ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
@@ -754,6 +754,10 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
             a.sv_u = W(h, "ioc_sv_u") + (size_t)p * RT * d.H; a.sv_c = W(h, "ioc_sv_c") + (size_t)p * RT * d.H;
             a.sv_h = W(h, "ioc_sv_h") + (size_t)p * RT * d.H;
             if (cluster && p > 0) HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, ((size_t)h->R / d.mno) * sizeof(int), s));
+            if (x3) {       // split-bf16 operands; the saves are fp32 and the backward pass is the fp32 one
+                a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+                Timer t(h, s, "ioc"); launch_ioc_x3(a, s);
+            } else
             { Timer t(h, s, "ioc"); launch_ioc(a, s); }
         }
         launch_copy_f32(W(h, "Y_ref"), dev_Yhat, RT * 2, s);

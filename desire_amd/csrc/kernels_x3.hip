@@ -98,7 +98,7 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
 #else
 #define TICKX(k)
 #endif
-template <int H, int EV, int C>
+template <int H, int EV, int C, bool TRAIN>      // TRAIN: keep x_t = [e_v | e_s | e_r], r, u, c, h_t of every step (fp32) for the backward pass
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -155,6 +155,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
     const u16* xp = Xb + c31 * LDXB + 8 * hi;
     const u16* rp = RHb + c31 * LDRB + 8 * hi;
     const int arow = 4 * hi;                                          // + (i&3) + 8(i>>2): local row of accumulator element i
+    // training-mode saves: (uniform tile base) + (32-bit offset inside the tile) keeps the addresses out of the register budget
+    const size_t sv_tb = TRAIN ? (size_t)row0 * a.T * H : 0;
+    float* sv_r_t = TRAIN ? a.sv_r + sv_tb : nullptr; float* sv_u_t = TRAIN ? a.sv_u + sv_tb : nullptr;
+    float* sv_c_t = TRAIN ? a.sv_c + sv_tb : nullptr; float* sv_h_t = TRAIN ? a.sv_h + sv_tb : nullptr;
+    float* sv_x_t = TRAIN ? a.sv_x + (size_t)row0 * a.T * E : nullptr;
+    auto sv_off = [&](int i, int t) { return (unsigned)(((arow + (i & 3) + 8 * (i >> 2)) * a.T + t) * H + col); };
+    auto sv_ok = [&](int i) { return row0 + arow + (i & 3) + 8 * (i >> 2) < a.R; };
     // h (fp32, accumulator layout) -> hi / lo images of both operand tiles
     auto publish_h = [&](const f32x16& h) {
 #pragma unroll
@@ -208,6 +215,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     split2(e0, e1, eh, el);
                     *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = eh;
                     *reinterpret_cast<unsigned*>(Xb + XLO + r8 * LDXB + j) = el;
+                    if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float2*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + j)) = make_float2(e0, e1);
                 }
                 int cy, cx;
                 scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
@@ -218,6 +226,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     split2(g4.x, g4.y, h0, l0); split2(g4.z, g4.w, h1, l1);
                     *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(h0, h1);
                     *reinterpret_cast<uint2*>(Xb + XLO + r8 * LDXB + EV + j) = make_uint2(l0, l1);
+                    if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + EV + j)) = g4;
                 }
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
@@ -316,6 +325,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     unsigned h0, l0, h1, l1;
                     split2(fmaxf(soc[0][4 * q] + bso, 0.f), fmaxf(soc[0][4 * q + 1] + bso, 0.f), h0, l0);
                     split2(fmaxf(soc[0][4 * q + 2] + bso, 0.f), fmaxf(soc[0][4 * q + 3] + bso, 0.f), h1, l1);
+                    if (TRAIN) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (sv_ok(4 * q + e))
+                                sv_x_t[(unsigned)(((arow + e + 8 * q) * a.T + t) * E + EV + C + col)] = fmaxf(soc[0][4 * q + e] + bso, 0.f);
+                    }
                     u16* x = Xb + (arow + 8 * q) * LDXB + EV + C + col;
                     x[0] = (u16)h0; x[LDXB] = (u16)(h0 >> 16); x[2 * LDXB] = (u16)h1; x[3 * LDXB] = (u16)(h1 >> 16);
                     x[XLO] = (u16)l0; x[XLO + LDXB] = (u16)(l0 >> 16); x[XLO + 2 * LDXB] = (u16)l1; x[XLO + 3 * LDXB] = (u16)(l1 >> 16);
@@ -366,8 +381,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     float rhv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        rhv[e] = sigmoidf_(g0[4 * q + e] + bgr) * h[4 * q + e];
+                        const float r = sigmoidf_(g0[4 * q + e] + bgr);
+                        rhv[e] = r * h[4 * q + e];
                         u[4 * q + e] = sigmoidf_(g1[4 * q + e] + bgu);
+                        if (TRAIN && sv_ok(4 * q + e)) { sv_r_t[sv_off(4 * q + e, t)] = r; sv_u_t[sv_off(4 * q + e, t)] = u[4 * q + e]; }
                     }
                     unsigned h0, l0, h1, l1;
                     split2(rhv[0], rhv[1], h0, l0); split2(rhv[2], rhv[3], h1, l1);
@@ -402,6 +419,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     const float c = tanhf_(ac[i] + bcc);
                     h[i] = gru_blend(u[i], h[i], c);
                     sp[i] = fmaf(h[i], wsc, sp[i]);
+                    if (TRAIN && sv_ok(i)) { sv_c_t[sv_off(i, t)] = c; sv_h_t[sv_off(i, t)] = h[i]; }
                 }
                 publish_h(h);                              // h slots of Xb / Ht were last read before the previous barrier
             }
@@ -462,8 +480,14 @@ static size_t iocx3_lds(const IocArgs& a) {
 bool ioc_x3_supported(int mno, int H, int bins) { return mno >= 1 && mno <= 32 && 32 % mno == 0 && (H == 64 || H == 128) && bins <= 64; }
 template <int H>
 static void launch_x3(const IocArgs& a, hipStream_t s) {
-    allow_big_lds(k_ioc_x3<H, 16, 32>);
-    hipLaunchKernelGGL((k_ioc_x3<H, 16, 32>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), iocx3_lds(a), s, a);
+    const dim3 grid((a.R + 31) / 32), block((H / 32) * 64);
+    if (a.sv_h) {                                              // training-mode forward
+        allow_big_lds(k_ioc_x3<H, 16, 32, true>);
+        hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, true>), grid, block, iocx3_lds(a), s, a);
+    } else {
+        allow_big_lds(k_ioc_x3<H, 16, 32, false>);
+        hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, false>), grid, block, iocx3_lds(a), s, a);
+    }
 }
 void launch_ioc_x3(const IocArgs& a, hipStream_t s) {
     if (a.H == 128) launch_x3<128>(a, s); else launch_x3<64>(a, s);

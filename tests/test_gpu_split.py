@@ -85,7 +85,7 @@ def test_split_operands_reproduce_goldens(tag):
 
 
 def test_shapes_without_a_split_kernel_run_the_fp32_kernels(torch_cuda):
-    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 64 agents (no split form yet) and training run the fp32 kernels,
+    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 64 agents (no split form yet) run the fp32 kernels,
     bit-identically to dims.bf16 = 0."""
     d = small_dims(mno=64, n_scenes=1, K=2, n_grids=1)
     w = init_weights(d, 7)
@@ -95,17 +95,30 @@ def test_shapes_without_a_split_kernel_run_the_fp32_kernels(torch_cuda):
     assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)
 
 
-def test_split_mode_trains_with_the_fp32_kernels(torch_cuda):
+def test_split_mode_training(torch_cuda):
+    """dims.bf16 = 2 while training: the IOC forward runs with split operands and keeps fp32 activations, the backward pass is the
+    fp32 one.  Gradients: against float64 autograd inside the training tests' own 2e-4, and within 1e-4 (relative, whole
+    gradient vector) of the all-fp32 step; an optimiser step refreshes the split packs on the device."""
     from desire_amd import _lib
+    from desire_amd.spec import weight_shapes
+    from oracle import desire_torch as OT
+    from tests.helpers import to_oracle_layout
     torch = torch_cuda
-    d = small_dims(K=2, T_pred=6)
-    w = init_weights(d, 9)
-    past, fut, eps, grids, gos = make_case(d, seed=10, n_absent=2)
+    d = small_dims(n_scenes=2, mno=32, K=3, T_obs=6, T_pred=7, n_grids=1)
+    w = init_weights(d, 41)
+    for k in w:                                   # (as tests/test_gpu_train.py: spread the K samples so ranking gradients exist)
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    past, fut, eps, grids, gos = make_case(d, seed=42, n_absent=4)
+    _, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
     grads = []
     for mode in (0, 2):
         h = _lib.Handle(d.replace(bf16=mode)); h.set_weights(w)
-        p, f, e, g = t(past), t(fut), t(eps), t(grids)
         h.set_scene_grids(g.data_ptr(), gos)
         h.set_training(True)
         Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
@@ -114,6 +127,12 @@ def test_split_mode_trains_with_the_fp32_kernels(torch_cuda):
         torch.cuda.synchronize()
         grads.append(h.grad_tensor().clone())
         if mode == 2:
+            worst = 0.0
+            for name in ("ioc/gates/kernel", "ioc/candidate/kernel", "ioc/social_fc/w", "ioc/reg/w", "ioc/vel_fc/w", "ioc/score/w",
+                         "dec/gates/kernel", "head/w", "vae_dec/deconv2/w", "enc_x/gates/kernel"):
+                got = h.get_grad(name, w[name].shape)
+                worst = max(worst, float(np.abs(got - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12)))
+            assert worst < 2e-4, worst
             # an optimiser step refreshes the split packs on the device (train.hip: k_repack_split): inference after training
             # must equal a fresh handle built from the trained weights
             h.adam_step(lr=1e-3)
@@ -123,7 +142,6 @@ def test_split_mode_trains_with_the_fp32_kernels(torch_cuda):
             h.sample(e.data_ptr(), Y0.data_ptr())
             Ya = Y0.clone(); h.ioc_refine(Ya.data_ptr(), sc.data_ptr())
             torch.cuda.synchronize()
-            from desire_amd.spec import weight_shapes
             w2 = {k: h.get_weight(k, tuple(shp)) for k, shp in weight_shapes(d).items()}
             h2 = _lib.Handle(d.replace(bf16=2)); h2.set_weights(w2)
             h2.set_scene_grids(g.data_ptr(), gos)
@@ -134,7 +152,8 @@ def test_split_mode_trains_with_the_fp32_kernels(torch_cuda):
             assert torch.equal(Ya, Yb)
             h2.close()
         h.close()
-    assert torch.equal(grads[0], grads[1])
+    rel = float((grads[0] - grads[1]).double().norm() / grads[0].double().norm())
+    assert 0 < rel < 1e-4, rel
 
 
 def test_model_surface_selects_split_operands(torch_cuda):
