@@ -17,6 +17,7 @@ def main():
     from oracle import desire_torch as OT
     from tests.helpers import make_case, small_dims, to_oracle_layout
     n, seed = int(sys.argv[1]), int(sys.argv[2])
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0       # dims.bf16: 0 fp32, 2 split-bf16 IOC forward (fp32 saves / backward)
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(n):
@@ -43,7 +44,7 @@ def main():
             for k in ("ioc/vel_fc/b", "ioc/social_fc/b", "fc_c/b", "mask_fc/b"):
                 w[k] = (w[k] + rng.uniform(0.02, 0.1, w[k].shape) * rng.choice([-1.0, 1.0], w[k].shape)).astype(np.float32)
             past, fut, eps, grids, gos = make_case(d, seed=400 + it, n_absent=min(int(rng.integers(0, 4)), d.mno - 1))
-            h = _lib.Handle(d)
+            h = _lib.Handle(d.replace(bf16=mode))
             h.set_weights(w)
             h.set_training(True)
             tab = h.bin_table() if d.bin_mode == 1 else None
