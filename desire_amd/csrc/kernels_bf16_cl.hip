@@ -354,6 +354,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                 a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
             }
             // ---- regression: Y += h_T W_r + b_r ----
+            // (every member has published step T-1, i.e. is past its own load of the group's positions Y[.][T-1]: only now may my rows
+            // of Y be updated in place)
+            group_wait_wt(cnt, tpg * (it * (a.T + 1) + a.T), a.err);
             for (int nt = cb; nt < a.NTreg; nt += NT) {
                 f32x16 acc[1][1] = {{zero16()}};
                 const u16* hp2[1] = {xp[0] + E};

@@ -1025,6 +1025,9 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
                 for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
                 a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
             }
+            // every member has published step T-1, i.e. is past its own load of the group's positions Y[.][T-1]: only now may my rows of
+            // Y be updated in place (a peer that only waited for the T-2 publishes could otherwise read next-pass positions)
+            group_wait_wt(cnt, tpg * (base + it * (a.T + 1) + a.T), a.err);
             for (int nt = cb; nt < a.NTreg; nt += NT) {
                 f32x16 acc = zero16();
                 mma1(acc, x_lane + E, a.Wreg + ((size_t)nt * GH) * 64 + lane, GH);

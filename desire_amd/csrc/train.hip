@@ -406,6 +406,8 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     }
     const int V = h->V, L = d.L, A = h->A;
     const bool bn1 = d.bn_mode == 1;                       // per-object batch-norm (the reference graph's batch of one): DESIGN.md section 8
+    // (under per-object statistics a conv bias cancels against the mean: its gradient is exactly zero, so the column sums of the
+    //  post-norm gradients -- pure rounding noise -- are NOT fed to Adam; the Gflat slots of vae_*/b stay at the fill value 0)
     // ---- ranking / refinement module (trajectories detached: its only path into the rest is dHx) ----
     {
         Timer t(h, s, "bwd_ioc");
@@ -484,7 +486,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         Timer t(h, s, "bwd_cvae_dec");
         const int NSL = 78;
         launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)R, R < 2048 ? (int)R : 2048, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
-        colsum(h, W(h, "dconv4"), 1, R * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv4"), 1, R * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
         ConvArgs c{};
         c.n = (int)R;
         c.in = W(h, "dconv4"); c.out = W(h, "dconv3"); c.w_raw = D(h, "vae_dec/deconv4/raw");
@@ -495,20 +497,20 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
-        colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
         c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
         launch_conv2(c, s);
         if (bn1) launch_instnorm_act_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)R, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0, s);
         wg.S = W(h, "d1"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "dconv2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv2/w"), s);
-        colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
         c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, "vae_dec/deconv2/Wbwd");
         c.scale = D(h, "vae_dec/deconv1/scale"); c.shift = c.scale; c.yprev = W(h, "d1");
         launch_conv3(c, s);
         if (bn1) launch_instnorm_act_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)R, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0, s);
         tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, R, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
-        colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
         GemmArgs g{};
         g.A = W(h, "dconv1"); g.lda = 2048; g.M = (int)R; g.K = 2048; g.Bp = D4(h, "vae_dec/deconv1/WT"); g.G = 2048 / 8;
         g.NT = (L + 31) / 32; g.out = W(h, "dz"); g.ldo = L; g.N = L;
@@ -533,7 +535,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         wg.n = A; wg.partial = W(h, "tn_partial");
         wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv3/w"), s);
-        colsum(h, W(h, "dconvE3"), 128, (long)A * 16, 128, G(h, "vae_enc/conv3/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconvE3"), 128, (long)A * 16, 128, G(h, "vae_enc/conv3/b"), 0, s);
         ConvArgs c{};
         c.n = A; c.mode = bn1 ? 3 : 1;
         c.in = W(h, "dconvE3"); c.out = W(h, "dconvE2"); c.Wp = D4(h, "vae_enc/conv3/Wbwd");
@@ -542,13 +544,13 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         if (bn1) launch_instnorm_act_bwd(W(h, "dconvE2"), W(h, "conv2_pre"), W(h, "c2"), A, 64, 64, D(h, "vae_enc/conv2/gamma"), 0, s);
         wg.S = W(h, "dconvE2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "c1"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv2/w"), s);
-        colsum(h, W(h, "dconvE2"), 64, (long)A * 64, 64, G(h, "vae_enc/conv2/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconvE2"), 64, (long)A * 64, 64, G(h, "vae_enc/conv2/b"), 0, s);
         c.in = W(h, "dconvE2"); c.out = W(h, "dconvE1"); c.Wp = D4(h, "vae_enc/conv2/Wbwd");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = c.scale; c.yprev = W(h, "c1");
         launch_deconv3(c, s);
         if (bn1) launch_instnorm_act_bwd(W(h, "dconvE1"), W(h, "conv1_pre"), W(h, "c1"), A, 256, 32, D(h, "vae_enc/conv1/gamma"), 0, s);
         launch_w1ch_grad(W(h, "vae_in"), W(h, "dconvE1"), A, A < 1024 ? A : 1024, W(h, "tn_partial"), G(h, "vae_enc/conv1/w"), s);
-        colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
         c.in = W(h, "dconvE1"); c.out = W(h, "dq_c"); c.w_raw = D(h, "vae_enc/conv1/raw"); c.mode = 2; c.yprev = W(h, "vae_in");
         launch_deconv4(c, s);
         tn(h, W(h, "HxHy"), 2 * H, W(h, "dq_c"), V, A, 2 * H, V, G(h, "fc_c/w"), V, 0, s);

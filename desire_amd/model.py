@@ -23,7 +23,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .spec import Dims, init_weights
+from .spec import Dims, init_weights, weight_shapes
 
 
 def _next_divisor_of_64(n: int) -> int:
@@ -81,6 +81,7 @@ class DESIREModel(object):
         self.seq_length = int(args.seq_length)
         self.batch_size = int(getattr(args, "batch_size", 1))
         self._weights = weights
+        self._head_given = bool(weights) and "gauss_head/w" in weights      # (restore() clears it when it had to fill the head in)
         self._seed = seed
         self._handles: Dict[Tuple[int, int, int], _lib.Handle] = {}
         self._trained = None                 # the handle train_step updates (weights + Adam moments live on the device)
@@ -97,14 +98,34 @@ class DESIREModel(object):
         self.final_output = None
 
     # ---- plumbing -------------------------------------------------------------------------------
+    def _weights_for(self, d: Dims) -> Dict[str, np.ndarray]:
+        """self._weights in the shapes `d` wants.  Only ref_compat handles can differ from the model's own dims (they force K = 1 and
+        T_pred = T_obs, so the IOC regression head [H, 2*T_pred] -- which ref_compat never runs -- is cut / zero-padded)."""
+        want = weight_shapes(d)
+        out = {}
+        for k, v in self._weights.items():
+            shp = want.get(k)
+            v = np.asarray(v)
+            if shp is None or tuple(v.shape) == tuple(shp):
+                out[k] = v
+                continue
+            if not d.ref_compat or v.ndim != len(shp):
+                raise ValueError("weight %s has shape %s, this call needs %s" % (k, v.shape, shp))
+            fit = np.zeros(shp, np.float32)
+            sl = tuple(slice(0, min(a, b)) for a, b in zip(v.shape, shp))
+            fit[sl] = v[sl]
+            out[k] = fit
+        return out
+
     def _handle(self, n_scenes: int, posterior: bool, ref_compat: bool = False) -> _lib.Handle:
         key = (n_scenes, int(posterior), int(ref_compat))
         if key not in self._handles:
             d = dims_from_args(self.args, n_scenes, posterior, ref_compat)
             h = _lib.Handle(d)
             if self._weights is None:
-                self._weights = init_weights(d, self._seed)
-            h.set_weights(self._weights)
+                # always drawn for the model's OWN dims (a first call through forward_ref_compat must not size them for its T_pred = T_obs)
+                self._weights = init_weights(dims_from_args(self.args, n_scenes, posterior, False), self._seed)
+            h.set_weights(self._weights_for(d) if ref_compat else self._weights)
             h._wver = getattr(self, "_version", 0) if getattr(self, "_weights_ver", 0) == getattr(self, "_version", 0) else -1
             self._handles[key] = h
         h = self._handles[key]
@@ -112,7 +133,7 @@ class DESIREModel(object):
         if trained is not None and h is not trained and getattr(h, "_wver", 0) != self._version:
             # the optimiser updates the weights inside the handle it trains on; any other handle (another batch size, the
             # prior path) gets the current values before it runs
-            h.set_weights(self.sync_weights())
+            h.set_weights(self._weights_for(h.dims) if h.dims.ref_compat else self.sync_weights())
             h._wver = self._version
         return h
 
@@ -309,7 +330,22 @@ class DESIREModel(object):
         from .formats import load_weights
         blob = load_weights(path)
         opt = {k[4:]: blob.pop(k) for k in list(blob) if k.startswith("opt/")}
+        # archives written before an auxiliary weight existed (the sample() head "gauss_head/*" came with round 2): complete them
+        # with the values init_weights draws, so an older checkpoint still loads
+        d0 = dims_from_args(args, 1, True)
+        missing = [k for k in weight_shapes(d0) if k not in blob]
+        if missing:
+            fresh = init_weights(d0, 0)
+            unknown = [k for k in missing if not k.startswith("gauss_head/")]
+            if unknown:
+                raise ValueError("checkpoint %s lacks weights %s" % (path, unknown))
+            for k in missing:
+                blob[k] = fresh[k]
+            if opt:                                   # moments of the flat buffer no longer line up: Adam restarts from zero
+                opt = {}
         m = cls(args, weights=blob)
+        if missing:
+            m._head_given = False
         if opt:
             m._opt_pending = opt                      # applied when training starts (the moments live in the training handle)
         return m
@@ -348,12 +384,18 @@ class DESIREModel(object):
             cache[key] = (sub, self._version)
         return sub
 
-    def sample(self, sess, traj, grid, dimensions, true_traj, num=10, mode: str = "rollout", normals=None, seed: int = 0):
+    def sample(self, sess, traj, grid, dimensions, true_traj, num=10, mode: Optional[str] = None, normals=None, seed: int = 0):
         """traj [obs, MNO, 3] observed frames; returns [obs+num, MNO, 3]: the observed frames followed by `num` predicted
         frames in pixel units, ids carried over from the last observed frame (model/model.py:680-688).  `sess` is ignored;
         `dimensions` = (width, height) of the frame in pixels (default: args.img_width / img_height).
 
-        mode "rollout" (default) is the reference's loop (:623-688) on the device in one launch: warm-up over the observed
+        mode None (default) = "ioc", the path train_step trains (decoder + ranking / refinement) -- or "rollout" when `normals` are
+        passed.  The rollout reads every
+        prediction from the 5-wide head "gauss_head/w|b", which no loss term of DESIGN.md section 8 touches (train_step leaves it at
+        the values it was given): pass mode="rollout" for the reference's loop; it warns when the head still holds the values
+        init_weights drew for it (i.e. it was neither supplied by the caller nor restored from a checkpoint).
+
+        mode "rollout" is the reference's loop (:623-688) on the device in one launch: warm-up over the observed
         frames, then per step the 5-wide Gaussian head "gauss_head/w|b" -> a draw (`normals` [num, MNO, 2] ~ N(0,1), or
         torch's generator seeded with `seed`) -> clip to <= 1.0 in normalised units (:666-669) -> fed back as the next input.
         Like the reference, objects with id 0 are stepped too and keep id 0.  `true_traj` only feeds the reference's cost
@@ -367,7 +409,13 @@ class DESIREModel(object):
         out[: traj.shape[0]] = traj
         m = traj.shape[1]
         out[traj.shape[0]:, :, 0] = traj[-1, :, 0]
+        if mode is None:                                  # (normals only mean something to the rollout: passing them selects it)
+            mode = "rollout" if normals is not None else "ioc"
         if mode == "rollout":
+            if not getattr(self, "_head_given", False):
+                import warnings
+                warnings.warn("sample(mode='rollout') reads gauss_head/w|b, which train_step does not train; this model's head holds "
+                              "its random initial values (pass weights= with a trained head, or use the default mode='ioc')", stacklevel=2)
             h = sub._handle(1, False)
             d = h.dims
             past = sub._pad_windows([traj], d.mno)

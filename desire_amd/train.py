@@ -57,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimiser steps (0 = all epochs)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--fix_id0", action="store_true", help="keep SDD track id 0 (the reference drops it)")
+    p.add_argument("--ioc_iters", type=int, default=1, help="IOC refinement passes")
+    p.add_argument("--report_ade", action="store_true",
+                   help="after every epoch: ADE / FDE (mean-of-K and best-of-K, normalised units) of PRIOR samples on the epoch's last batch")
     return p
 
 
@@ -129,6 +132,19 @@ def train(args, data_loader=None, model=None, log: Callable[[str], None] = print
                 log("model saved to {}".format(path))
             if args.max_steps and steps >= args.max_steps:
                 return losses
+        if getattr(args, "report_ade", False) and data_loader.num_batches > 0:
+            # the evaluation harness the reference never had: prior sampling (no future given) on this rank's share of the
+            # epoch's last batch, masked like the loss (present at the last observed frame and in every future frame)
+            Y, _ = model.forward(past, None, seed=args.seed)
+            ev = model.evaluate(Y, fut)
+            pw, fw = np.stack([np.asarray(p) for p in past]), np.stack([np.asarray(f) for f in fut])
+            there = np.zeros(ev.shape[0], bool)
+            m = pw.shape[2]
+            there.reshape(len(past), -1)[:, :m] = (pw[:, -1, :, 0] != 0) & (fw[:, :, :, 0] != 0).all(1)
+            if there.any():
+                e = ev[there].mean(0)
+                log("epoch {} rank {}: ADE/FDE mean-of-K = {:.5f} / {:.5f}, best-of-K = {:.5f} / {:.5f} ({} agents)".format(
+                    epoch, rank, e[0], e[1], e[2], e[3], int(there.sum())))
     return losses
 
 
@@ -137,12 +153,26 @@ def main(argv=None) -> None:
     import torch
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # DESIRE_DIST_BACKEND=gloo + DESIRE_ONE_GPU=1: the multi-rank path on a box with a single GPU (all ranks share cuda:0 and the
+        # flat-gradient all-reduce runs over gloo, because RCCL refuses two ranks on one device); a test switch, never a deployment
+        backend = os.environ.get("DESIRE_DIST_BACKEND", "nccl")
+        local = 0 if os.environ.get("DESIRE_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     try:
-        train(args)
+        from .model import DESIREModel
+        model = DESIREModel(args, seed=args.seed)
+        train(args, model=model)
+        if dist.is_initialized():
+            # data-parallel invariant: every rank applied the same averaged gradient, so every rank holds the same weights
+            w = model.sync_weights()
+            chk = float(sum(float(np.abs(np.asarray(v, np.float64)).sum()) for v in w.values()))
+            print("rank {} weights_checksum = {:.9e}".format(dist.get_rank(), chk))
+            sys.stdout.flush()
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

@@ -69,3 +69,37 @@ def test_hip_reproduces_goldens(tag):
     torch.cuda.synchronize()
     assert np.abs(Y.cpu().numpy() - g["Y"]).max() < 1e-3
     assert np.abs(score.cpu().numpy() - g["score"]).max() < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cfg0", "cfg1"])
+def test_unanchored_end_to_end_statistic_on_the_sdd_goldens(tag):
+    """every IOC parity check above re-anchors on the oracle's Y0, and the un-anchored compare is asserted only
+    when no pair sits near a bin edge.  This bounds, by a TEST, how often the full HIP chain (its own Y0 -> its own IOC pass) lands a
+    row elsewhere than the oracle's chain on the real-SDD goldens: the fraction of present rows whose refined trajectory differs by
+    more than 1e-3 anywhere must stay under 1 % (a 1e-7 difference in Y0 can move a neighbour across a bin edge or a position
+    across a scene cell; DESIGN.md 4-split measured 0.3 % of rows for 1e-7 perturbations on the dense bench batch), and the rows
+    that do NOT flip agree to the usual 1e-3."""
+    import torch
+    from desire_amd import _lib
+    d, g, eps, grids, gos, w = load_case(tag)
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past, fut, eps_t, grids_t = t(g["past"]), t(g["fut"]), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    h.forward(past.data_ptr(), fut.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    valid = np.repeat((g["past"][:, -1, :, 0] != 0)[:, None, :], d.K, axis=1).reshape(-1)
+    err = np.abs(Y.cpu().numpy() - g["Y"]).reshape(d.R, -1).max(1)[valid]
+    flipped = err > 1e-3
+    frac = float(flipped.mean())
+    print("%s: %d present rows, %d differ by > 1e-3 un-anchored (%.3f %%); others max %.2e" % (tag, valid.sum(), flipped.sum(), 100 * frac,
+                                                                                                 err[~flipped].max() if (~flipped).any() else 0.0))
+    assert frac < 0.01, (tag, frac)
+    assert err[~flipped].max() < 1e-3
+    serr = np.abs(score.cpu().numpy() - g["score"])[valid][~flipped]
+    assert serr.max() < 5e-3

@@ -44,6 +44,14 @@ def test_default_contract_fields():
     sp = o["alt"]["split_bf16x3_ioc"]
     assert sp["value"] > 0 and sp["ioc_ms"] > 0 and 0 < sp["max_abs_diff_vs_fp32_kernel"] < 1e-4
     assert o["alt"]["row_compacted_pooling"]["value"] > 0
+    # round 3: BASELINE configs[2] (128 agents per scene, bf16 operands) is measured by the default command, with its own roofline
+    # fraction and its accuracy against the rounding oracle
+    c2 = o["alt"]["bf16_config2"]
+    for tag, mno in (("mno128", 128), ("mno32", 32)):
+        assert c2[tag]["agents_per_scene"] == mno and c2[tag]["samples_per_step"] == 81920
+        assert c2[tag]["value"] > 0 and 0 < c2[tag]["ioc_frac_of_bf16_peak"] < 1 and 0 < c2[tag]["whole_path_frac_of_bf16_peak"] < 1
+    assert c2["accuracy"]["decoder_max_abs_err_vs_fp32_oracle"] < 1e-3
+    assert c2["accuracy"]["ioc_max_abs_err_vs_rounding_oracle"] < 7e-3 * c2["accuracy"]["refinement_scale"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--train"], ["--shard", "agents", "--mno", "16"]])
@@ -61,6 +69,30 @@ def test_two_ranks_on_one_gpu(extra):
     if not extra:
         assert o["config"]["rows_per_gpu"] == 8 * 32 * 20
         assert abs(o["value"] - 2 * o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must not die on plumbing -- it re-executes
+    itself under torch.distributed.run, keeps the one-JSON-line contract, reports the rank count the collective library saw and
+    carries the agent-sharded leg (per-step neighbour all-gather) in the same line."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DESIRE_BENCH_ONE_GPU"] = "1"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "8"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    o = _last_json(p.stdout)
+    assert o["n_gpus"] == 2 and o["value"] > 0 and o["config"]["rows_per_gpu"] == 8 * 32 * 20
+    leg = o["agent_sharded"]
+    assert "error" not in leg, leg
+    assert leg["finite"] and leg["agents_per_scene_over_all_ranks"] == 64 and leg["bytes_received_per_rank_per_ioc_step"] == 2 * leg["bytes_sent_per_rank_per_ioc_step"]
+    assert leg["ioc_ms_with_collectives"] > 0 and leg["exposed_comm_ms"] >= 0
+    # asking for more GPUs than the node has is an error message, not a hang (without the one-GPU test switch)
+    env.pop("DESIRE_BENCH_ONE_GPU")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "64"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "visible" in (p.stdout + p.stderr)
 
 
 def test_compact_flag_is_labelled():

@@ -131,3 +131,65 @@ def test_checkpoint_keeps_the_optimiser_state():
     for k in ("dec/gates/kernel", "ioc/social_fc/w", "vae_dec/deconv2/w", "enc_x/candidate/bias"):
         assert np.abs(wa[k] - wb[k]).max() < 1e-7, k
     assert m2._trained.opt_state()["t"][0] == 4
+
+
+def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
+    """(medium) train_step never touches gauss_head/*, so the DEFAULT sample() must not read it -- mode None is the
+    IOC path unless normals are passed; an explicit rollout on a head nobody supplied warns.  (low) an archive written before
+    gauss_head/* existed still restores (the head is filled with its initial values, the optimiser state is dropped)."""
+    import os
+    import tempfile
+    import warnings
+    from desire_amd.formats import load_weights, save_weights
+    from desire_amd.model import DESIREModel
+    args = _args()
+    m = DESIREModel(args, seed=7)
+    d = small_dims(n_scenes=1, mno=16, K=3, H=64, L=64, T_obs=8, T_pred=12, posterior=0, n_grids=1)
+    past, fut, _, _, _ = make_case(d, seed=79, n_absent=3)
+    traj = past[0].astype(np.float64)
+    truth = np.concatenate([past[0], fut[0]]).astype(np.float64)
+    a = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+    b = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=3)
+    np.testing.assert_array_equal(a, b)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
+    assert any("gauss_head" in str(r.message) for r in rec)
+    with tempfile.TemporaryDirectory() as td:
+        m.save(os.path.join(td, "new.npz"))
+        blob = load_weights(os.path.join(td, "new.npz"))
+        old = {k: v for k, v in blob.items() if not k.startswith("gauss_head/")}
+        save_weights(os.path.join(td, "old.npz"), old)
+        m2 = DESIREModel.restore(args, os.path.join(td, "old.npz"))
+        c = m2.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+        np.testing.assert_allclose(c, a, atol=1e-3)
+        m3 = DESIREModel.restore(args, os.path.join(td, "new.npz"))          # a head that came with the weights: no warning
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
+        assert not any("gauss_head" in str(r.message) for r in rec)
+
+
+def test_ref_compat_handle_with_its_own_prediction_length():
+    """forward_ref_compat forces T_pred = T_obs; the model's own pred_length may differ and either call may
+    come first -- the T_pred-sized IOC regression head is re-fitted per shape instead of failing in set_weights."""
+    import torch
+    from desire_amd.model import DESIREModel
+    args = _args()
+    args.d_dim, args.seq_length, args.pred_length = 16, 8, 12
+    for first in ("ref", "normal"):
+        m = DESIREModel(args, seed=8)
+        d = small_dims(n_scenes=2, mno=16, K=3, H=16, L=64, T_obs=8, T_pred=12, n_grids=1)
+        past, fut, _, _, _ = make_case(d, seed=80, n_absent=3)
+        x = [p.astype(np.float64) for p in past]
+        y8 = [f[:8].astype(np.float64) for f in fut]
+        y12 = [f.astype(np.float64) for f in fut]
+        if first == "ref":
+            out = m.forward_ref_compat(x, y8, seed=1)
+            Y, _ = m.forward(x, y12, seed=1)
+        else:
+            Y, _ = m.forward(x, y12, seed=1)
+            out = m.forward_ref_compat(x, y8, seed=1)
+        assert Y.shape[-2] == 12 and bool(torch.isfinite(Y).all())
+        assert out["output_states"].shape[-2] == 8 and bool(torch.isfinite(out["output_states"]).all())
+        assert m._weights["ioc/reg/w"].shape == (16, 24)

@@ -154,3 +154,39 @@ def test_command_line_entry_on_a_csv_directory(tmp_path, golden_dir):
     assert p.stdout.count("train_loss") == 6 and "model saved to" in p.stdout      # 160 frames -> 2 batches per epoch (:175-184)
     assert os.path.exists(tmp_path / "save" / "config.pkl") and os.path.exists(tmp_path / "save" / "social_model-4.npz")
     assert os.path.exists(tmp_path / "data" / "trajectories.cpkl")       # the reference's preprocessed pickle, written on first use
+
+
+@pytest.mark.gpu
+def test_config4_shape_two_ranks_mixed_sdd_scenes(tmp_path, golden_dir):
+    """BASELINE configs[4] at its stated shape: "full SDD mixed-scene training loop (fwd+bwd), 512 agents/step,
+    K=20, IOC refinement on" -- `python -m desire_amd.train` over the eight-scene mix (one slice of every SDD scene, the CSVs the
+    reference loader read for tests/golden/loader_mixed8_T20.npz), --num_samples 20 --d_dim 128, batch 8 windows x 64 slots (the
+    reference's --max_num_obj 40 padded to the 64-row tile) = 512 agent slots per step, data-parallel over TWO ranks (4 windows each,
+    gradients averaged by the flat all-reduce; gloo, because both ranks share the one GPU of the test box): the loss goes down,
+    both ranks end with the same weights, ADE / FDE are reported."""
+    import re
+    import subprocess
+    import sys
+    g = np.load(os.path.join(golden_dir, "loader_mixed8_T20.npz"))
+    for i, name in enumerate(g["order"]):
+        scene, video = str(name).split("/") if "/" in str(name) else (str(name), "video0")
+        vid = tmp_path / "data" / scene / video
+        vid.mkdir(parents=True)
+        np.savetxt(vid / "annotations_processed.csv", g["csv%d" % i].astype(np.float64), delimiter=",", fmt="%.1f")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DESIRE_DIST_BACKEND="gloo", DESIRE_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", "-m", "desire_amd.train", "--data_dir", str(tmp_path / "data") + "/", "--save_dir", str(tmp_path / "save"),
+           "--batch_size", "8", "--seq_length", "8", "--pred_length", "12", "--max_num_obj", "40", "--d_dim", "128", "--latent_size", "128",
+           "--num_samples", "20", "--num_epochs", "5", "--learning_rate", "0.0005", "--neighborhood_size", "160", "--leave_dataset", "99",
+           "--report_ade"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    losses = [float(m) for m in re.findall(r"train_loss = ([-0-9.eE+]+)", p.stdout)]
+    assert len(losses) >= 10 and np.isfinite(losses).all(), p.stdout[-2000:]
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    chk = dict(re.findall(r"rank (\d) weights_checksum = ([-0-9.eE+]+)", p.stdout))
+    assert set(chk) == {"0", "1"} and chk["0"] == chk["1"], chk            # same averaged gradient on both ranks, every step
+    ade = re.findall(r"ADE/FDE mean-of-K = ([0-9.]+) / ([0-9.]+), best-of-K = ([0-9.]+) / ([0-9.]+)", p.stdout)
+    assert len(ade) >= 5 and all(float(b[2]) <= float(b[0]) + 1e-9 for b in ade)      # best-of-K never worse than mean-of-K
