@@ -186,7 +186,9 @@ int check_dims(const desire_dims& d) {
         return fail(DESIRE_ERR_ARG, "sizes must be >= 1");
     if (d.grid_size < 1 || d.grid_size > 6) return fail(DESIRE_ERR_ARG, "grid_size must be 1..6 (6 x 6 = the paper's 36 bins)");
     if (d.grid_size > 4 && d.H == 256) return fail(DESIRE_ERR_ARG, "grid_size 5..6 needs H <= 128 (LDS budget of the IOC tile)");
-    if (d.bf16 < 0 || d.bf16 > 2) return fail(DESIRE_ERR_ARG, "bf16 must be 0 (fp32 operands), 1 (bf16 operands) or 2 (split-bf16 operands, fp32-equivalent)");
+    if (d.bf16 < 0 || d.bf16 > 3)
+        return fail(DESIRE_ERR_ARG, "bf16 must be 0 (fp32 operands), 1 (bf16 operands), 2 (split-bf16 operands: hi + lo, three products) or 3 (three "
+                                    "bf16 pieces, six products: fp32-class accuracy)");
     if (d.bn_mode < 0 || d.bn_mode > 2) return fail(DESIRE_ERR_ARG, "bn_mode must be 0 (frozen statistics), 1 (per-object statistics) or 2 (whole-batch statistics)");
     if (d.bn_mode && d.bf16 == 1) return fail(DESIRE_ERR_ARG, "batch statistics (bn_mode 1 / 2) run on fp32 operands (bf16 = 0 or 2)");
     if (d.bin_mode != 0 && d.bin_mode != 1) return fail(DESIRE_ERR_ARG, "bin_mode must be 0 (rectangular) or 1 (log-polar)");
@@ -372,7 +374,9 @@ int desire_pack_all(desire_ctx* h) {
             bad |= up("ioc/WsT_c", tc);
         }
     }
-    if (d.bf16 == 2) {   // split-bf16 packs [hi | lo] of the IOC kernel (kernels_x3.hip): hi = bf16(w), lo = bf16(w - hi)
+    if (d.bf16 == 2 || d.bf16 == 3) {   // split-bf16 packs of the IOC kernel (kernels_x3.hip): [hi | lo], hi = bf16(w), lo = bf16(w - hi);
+                                         // dims.bf16 = 3: [hi | mid | lo], one more piece of the remainder (w = hi + mid + lo exactly)
+        const size_t np = d.bf16 == 3 ? 3 : 2;
         const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
         const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
         auto lin = [](int g, int hi, int e) { return 16 * g + 8 * hi + e; };
@@ -382,13 +386,16 @@ int desire_pack_all(desire_ctx* h) {
         auto up_split = [&](const std::string& name, const std::vector<float>& vals) {
             if (h->pack_mode == 1) { h->captured[name + "#x3"] = vals; return 0; }
             const size_t n = vals.size();
-            std::vector<uint16_t> o(2 * n);
+            std::vector<uint16_t> o(np * n + (np * n & 1));
             for (size_t i = 0; i < n; ++i) {
-                o[i] = bf16_rne(vals[i]);
-                o[n + i] = bf16_rne(vals[i] - bf16_to_f32(o[i]));
+                float r = vals[i];
+                for (size_t pc = 0; pc < np; ++pc) {
+                    o[pc * n + i] = bf16_rne(r);
+                    r -= bf16_to_f32(o[pc * n + i]);              // exact in fp32
+                }
             }
-            std::vector<float> out(n);
-            std::memcpy(out.data(), o.data(), n * 4);
+            std::vector<float> out(o.size() / 2);
+            std::memcpy(out.data(), o.data(), out.size() * 4);
             return up(name, out);
         };
         bad |= up_split("ioc/Wg16", pack_vals16(E + H, 2 * H, lin, [&](int k, int n) { return gk[(size_t)k * 2 * H + n]; }));
@@ -725,6 +732,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
     const bool x3 = d.bf16 == 2 && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);     // (also the training-mode forward)
+    const bool x6 = d.bf16 == 3 && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);     // six-product form: inference only
     const bool cluster = d.bf16 == 1 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
                                 : ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
@@ -763,9 +771,10 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         launch_copy_f32(W(h, "Y_ref"), dev_Yhat, RT * 2, s);
         launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
     } else
-    if (x3) {   // split-bf16 operands: fp32-equivalent results on the bf16 matrix pipe (shapes without that form run the fp32 kernels)
+    if (x3 || x6) {   // split-bf16 operands: fp32-equivalent results on the bf16 matrix pipe (shapes without that form run the fp32 kernels)
         a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
-        Timer t(h, s, "ioc"); launch_ioc_x3(a, s);
+        Timer t(h, s, "ioc");
+        if (x6) launch_ioc_x6(a, s); else launch_ioc_x3(a, s);
     } else
     if (d.bf16 == 1) {
         if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
@@ -786,8 +795,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                                "barrier 3", "P5 cand + publish", "barrier 4", ""};
         const char* nx3[10] = {"step top (bar 4 wait)", "P1 ev/es/masks", "barrier 1", "P2 pooling chain", "exchange + e_r", "barrier 2",
                                "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
-        const char** names = x3 ? nx3 : d.bf16 == 1 ? n16 : n32;
-        const int nk = x3 ? 10 : 9;
+        const char** names = (x3 || x6) ? nx3 : d.bf16 == 1 ? n16 : n32;
+        const int nk = (x3 || x6) ? 10 : 9;
         long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
         for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
     }

@@ -20,73 +20,79 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     hi = pk_bf16(a, b);
     lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
-struct Frag2 { uint4 h, l; };
-__device__ __forceinline__ Frag2 split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-    Frag2 f;
-    split2(v0, v1, f.h.x, f.l.x); split2(v2, v3, f.h.y, f.l.y); split2(v4, v5, f.h.z, f.l.z); split2(v6, v7, f.h.w, f.l.w);
+// NP bf16 pieces of a pair of fp32 values: x = p0 + p1 (+ p2) with p_{i} = bf16(x - p_0 - .. - p_{i-1}); every subtraction is exact.
+// NP = 2 leaves |r| <= 2^-17 |x| (three products per fp32 product, ~2^-16 relative); NP = 3 represents an fp32 value EXACTLY
+// (8 + 8 + 8 significant bits) and six products -- every term down to 2^-16 |a b| -- leave an error of <= 2^-23 |a b| per product,
+// the class of the fp32 fmaf chain's own accumulation rounding (dims.bf16 = 3, "x6").
+template <int NP>
+__device__ __forceinline__ void splitp(float a, float b, unsigned (&p)[NP]) {
+    p[0] = pk_bf16(a, b);
+    float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
+    p[1] = pk_bf16(ra, rb);
+    if constexpr (NP == 3) {
+        ra -= __uint_as_float(p[1] << 16); rb -= __uint_as_float(p[1] & 0xffff0000u);
+        p[2] = pk_bf16(ra, rb);
+    }
+}
+template <int NP> struct FragP { uint4 p[NP]; };
+template <int NP>
+__device__ __forceinline__ FragP<NP> split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    FragP<NP> f;
+    unsigned a[NP], b[NP], c[NP], d[NP];
+    splitp<NP>(v0, v1, a); splitp<NP>(v2, v3, b); splitp<NP>(v4, v5, c); splitp<NP>(v6, v7, d);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) f.p[i] = make_uint4(a[i], b[i], c[i], d[i]);
     return f;
 }
-// acc += a . b with split operands (small terms first)
-__device__ __forceinline__ f32x16 mfma_x3(uint4 ah, uint4 al, uint4 bh, uint4 bl, f32x16 c) {
-    c = mfma16(al, bh, c);
-    c = mfma16(ah, bl, c);
-    return mfma16(ah, bh, c);
+// the (piece of A, piece of B) products of one fp32 product, smallest terms first: NP = 2 -> lo.hi, hi.lo, hi.hi;
+// NP = 3 -> (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+template <int NP> struct Pairs;
+template <> struct Pairs<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+template <> struct Pairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
+// acc += a . b with split operands
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_xp(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 c) {
+#pragma unroll
+    for (int i = 0; i < Pairs<NP>::N; ++i) c = mfma16(a[Pairs<NP>::A[i]], b[Pairs<NP>::B[i]], c);
+    return c;
 }
 
-// acc[nb] += A[32 x 16G] . B_nb[16G x 32]: A = hi image at ap, lo image at ap + alo (bf16 elements); B = hi pack at bl[nb]
-// (already + lane), lo pack blo uint4 further on.  Chunks of CHX groups, next chunk's B fragments in flight.
-#define CHX 2
+// acc[nb] += A[32 x 16G] . B_nb[16G x 32]: piece i of A = the image at ap + i * alo (bf16 elements); piece i of B = the pack at
+// bl[nb] + i * blo (uint4 units; bl already + lane).  One k-group at a time, the next group's fragments in flight (used by the
+// regression head only: G = H/16 groups once per pass).
 #ifndef RD4
 #define RD4 2                                                       // ring depth (k-groups) of the gate contraction
 #endif
-template <int NB>
-__device__ __forceinline__ void load_bx(uint4 (&bh)[NB][CHX], uint4 (&bo)[NB][CHX], const uint4* const (&bl)[NB], size_t blo, int g) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int j = 0; j < CHX; ++j) { bh[nb][j] = bl[nb][(g + j) * 64]; bo[nb][j] = bl[nb][blo + (g + j) * 64]; }
-}
-template <int NB>
-__device__ __forceinline__ void mmax_chunk(f32x16 (&acc)[NB], const u16* ap, int alo, int g, const uint4 (&bh)[NB][CHX], const uint4 (&bo)[NB][CHX]) {
-#pragma unroll
-    for (int j = 0; j < CHX; ++j) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(ap + (g + j) * 16);
-        const uint4 al = *reinterpret_cast<const uint4*>(ap + alo + (g + j) * 16);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(al, bh[nb][j], acc[nb]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(ah, bo[nb][j], acc[nb]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(ah, bh[nb][j], acc[nb]);
-    }
-}
-template <int NB>
+template <int NB, int NP>
 __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
-    const int nch = G / CHX;
-    int c = 0;
-    if (nch > 0) {
-        uint4 h0[NB][CHX], l0[NB][CHX], h1[NB][CHX], l1[NB][CHX];
-        load_bx<NB>(h0, l0, bl, blo, 0);
-#pragma clang loop unroll(disable)
-        for (; c + 2 <= nch; c += 2) {
-            load_bx<NB>(h1, l1, bl, blo, CHX * (c + 1));
-            __builtin_amdgcn_sched_barrier(0);
-            mmax_chunk<NB>(acc, ap, alo, CHX * c, h0, l0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 2 < nch) load_bx<NB>(h0, l0, bl, blo, CHX * (c + 2));
-            __builtin_amdgcn_sched_barrier(0);
-            mmax_chunk<NB>(acc, ap, alo, CHX * (c + 1), h1, l1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c < nch) { mmax_chunk<NB>(acc, ap, alo, CHX * c, h0, l0); ++c; }
-    }
-#pragma clang loop unroll(disable)
-    for (int g = CHX * c; g < G; ++g) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(ap + g * 16);
-        const uint4 al = *reinterpret_cast<const uint4*>(ap + alo + g * 16);
+    uint4 b0[NB][NP], b1[NB][NP];
+    auto ld = [&](uint4 (&b)[NB][NP], int g) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_x3(ah, al, bl[nb][g * 64], bl[nb][blo + g * 64], acc[nb]);
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) b[nb][i] = bl[nb][i * blo + (size_t)g * 64];
+    };
+    auto run = [&](const uint4 (&b)[NB][NP], int g) {
+        uint4 av[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + g * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_xp<NP>(av, b[nb], acc[nb]);
+    };
+    ld(b0, 0);
+    int g = 0;
+#pragma clang loop unroll(disable)
+    for (; g + 2 <= G; g += 2) {
+        ld(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G) ld(b0, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (g < G) run(b0, g);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -98,8 +104,10 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
 #else
 #define TICKX(k)
 #endif
-template <int H, int EV, int C, bool TRAIN>      // TRAIN: keep x_t = [e_v | e_s | e_r], r, u, c, h_t of every step (fp32) for the backward pass
-__global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
+// NP = bf16 pieces per fp32 operand: 2 (dims.bf16 = 2, three products per fp32 product, two workgroups per CU) or 3 (dims.bf16 = 3,
+// six products, fp32-class accuracy; three operand images = 120 KB of LDS, one workgroup per CU with the whole register file).
+template <int H, int EV, int C, bool TRAIN, int NP = 2>      // TRAIN: keep x_t = [e_v | e_s | e_r], r, u, c, h_t of every step (fp32) for the backward pass
+__global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
@@ -110,12 +118,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
     constexpr int XLO = TM * LDXB, RLO = TM * LDRB, TLO = H * LDT;    // element offset of an operand tile's lo image
     constexpr int NTHR = NT * 64, TPR = NTHR / TM;
     constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
-    static_assert(2 * TLO * 2 >= NT * 4096 && 2 * RLO * 2 >= NT * 4096, "exchange slots must fit the tiles they alias");
+    static_assert(NP * TLO * 2 >= NT * 4096 && NP * RLO * 2 >= NT * 4096, "exchange slots must fit the tiles they alias");
+    static_assert(NP == 2 || !TRAIN, "the six-product form is inference only");
     const int B = a.G * a.G, LDM = B + 1;
-    u16* Xb = reinterpret_cast<u16*>(smem_raw);                       // [2][TM][LDXB]  e_v | e_s | e_r | h   (hi image, lo image)
-    u16* RHb = Xb + 2 * XLO;                                          // [2][TM][LDRB]  r * h
-    u16* Ht = RHb + 2 * RLO;                                          // [2][H][LDT]    h transposed (pooling operand)
-    unsigned* masks = reinterpret_cast<unsigned*>(Ht + 2 * TLO);      // [TM][B+1], bit = local row
+    u16* Xb = reinterpret_cast<u16*>(smem_raw);                       // [NP][TM][LDXB]  e_v | e_s | e_r | h   (one image per piece)
+    u16* RHb = Xb + NP * XLO;                                         // [NP][TM][LDRB]  r * h
+    u16* Ht = RHb + NP * RLO;                                         // [NP][H][LDT]    h transposed (pooling operand)
+    unsigned* masks = reinterpret_cast<unsigned*>(Ht + NP * TLO);     // [TM][B+1], bit = local row
     uint2* lut = reinterpret_cast<uint2*>(masks + ((TM * LDM + 1) & ~1));   // [16] nibble -> 4 bf16 (0.0 / 1.0)
     float* pc = reinterpret_cast<float*>(lut + 16);                   // [TM][2]
     float* pp = pc + TM * 2;                                          // [TM][2]
@@ -149,7 +158,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
     const uint4* Wc = reinterpret_cast<const uint4*>(a.Wc);
     const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
     const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
-    constexpr size_t WG_LO = (size_t)2 * NT * G16 * 64, WC_LO = (size_t)NT * G16 * 64;   // uint4 offset of a pack's lo half
+    constexpr size_t WG_LO = (size_t)2 * NT * G16 * 64, WC_LO = (size_t)NT * G16 * 64;   // uint4 offset from one piece's pack to the next
     const size_t WS_LO = (size_t)B * NT * GH16 * 64, WR_LO = (size_t)a.NTreg * GH16 * 64;
 
     const u16* xp = Xb + c31 * LDXB + 8 * hi;
@@ -163,17 +172,22 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
     auto sv_off = [&](int i, int t) { return (unsigned)(((arow + (i & 3) + 8 * (i >> 2)) * a.T + t) * H + col); };
     auto sv_ok = [&](int i) { return row0 + arow + (i & 3) + 8 * (i >> 2) < a.R; };
     // h (fp32, accumulator layout) -> hi / lo images of both operand tiles
+    // four values of one accumulator column run (rows arow + 8q + 0..3) -> every piece's image of a row-major tile
+    auto put4 = [&](u16* x, int ld, int lo, float v0, float v1, float v2, float v3, unsigned (&pa)[NP], unsigned (&pb)[NP]) {
+        splitp<NP>(v0, v1, pa);
+        splitp<NP>(v2, v3, pb);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            x[i * lo] = (u16)pa[i]; x[i * lo + ld] = (u16)(pa[i] >> 16); x[i * lo + 2 * ld] = (u16)pb[i]; x[i * lo + 3 * ld] = (u16)(pb[i] >> 16);
+        }
+    };
     auto publish_h = [&](const f32x16& h) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned h0, l0, h1, l1;
-            split2(h[4 * q], h[4 * q + 1], h0, l0);
-            split2(h[4 * q + 2], h[4 * q + 3], h1, l1);
-            u16* x = Xb + (arow + 8 * q) * LDXB + E + col;
-            x[0] = (u16)h0; x[LDXB] = (u16)(h0 >> 16); x[2 * LDXB] = (u16)h1; x[3 * LDXB] = (u16)(h1 >> 16);
-            x[XLO] = (u16)l0; x[XLO + LDXB] = (u16)(l0 >> 16); x[XLO + 2 * LDXB] = (u16)l1; x[XLO + 3 * LDXB] = (u16)(l1 >> 16);
-            *reinterpret_cast<uint2*>(Ht + col * LDT + arow + 8 * q) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(Ht + TLO + col * LDT + arow + 8 * q) = make_uint2(l0, l1);
+            unsigned pa[NP], pb[NP];
+            put4(Xb + (arow + 8 * q) * LDXB + E + col, LDXB, XLO, h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3], pa, pb);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(Ht + i * TLO + col * LDT + arow + 8 * q) = make_uint2(pa[i], pb[i]);
         }
     };
 
@@ -211,10 +225,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                 for (int j = 2 * q8; j < EV; j += 2 * TPR) {
                     const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
                     const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
-                    unsigned eh, el;
-                    split2(e0, e1, eh, el);
-                    *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = eh;
-                    *reinterpret_cast<unsigned*>(Xb + XLO + r8 * LDXB + j) = el;
+                    unsigned ep[NP];
+                    splitp<NP>(e0, e1, ep);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) *reinterpret_cast<unsigned*>(Xb + i * XLO + r8 * LDXB + j) = ep[i];
                     if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float2*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + j)) = make_float2(e0, e1);
                 }
                 int cy, cx;
@@ -222,10 +236,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                 const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
                 for (int j = 4 * q8; j < C; j += 4 * TPR) {
                     const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
-                    unsigned h0, l0, h1, l1;
-                    split2(g4.x, g4.y, h0, l0); split2(g4.z, g4.w, h1, l1);
-                    *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(Xb + XLO + r8 * LDXB + EV + j) = make_uint2(l0, l1);
+                    unsigned ga[NP], gb[NP];
+                    splitp<NP>(g4.x, g4.y, ga); splitp<NP>(g4.z, g4.w, gb);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(Xb + i * XLO + r8 * LDXB + EV + j) = make_uint2(ga[i], gb[i]);
                     if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + EV + j)) = g4;
                 }
                 for (int j = q8; j < a.mno; j += TPR) {
@@ -254,13 +268,14 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     const int cbo = (cb + k) % NT;
                     return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
                 };
-                uint4 wh[2 * NT], wl[2 * NT];                      // W fragments of one hidden block (hi, lo), refreshed in place
+                uint4 wf[2 * NT][NP];                              // W fragments of one hidden block (every piece), refreshed in place
                 if (mine) {
                     const int b0 = __ffsll((long long)mine) - 1;
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         const uint4* p = wptr(b0, 0, k);
-                        wh[2 * k] = p[0]; wh[2 * k + 1] = p[64]; wl[2 * k] = p[WS_LO]; wl[2 * k + 1] = p[WS_LO + 64];
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
                     }
                 }
 #pragma clang loop unroll(disable)
@@ -278,22 +293,24 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                     }
 #pragma unroll
                     for (int hb = 0; hb < NT; ++hb) {
-                        // link 1: P_b^T[hidden block hb] = (h_hi + h_lo)^T . M_b^T  (the 0/1 mask is exact in bf16: two MFMAs per chunk)
+                        // link 1: P_b^T[hidden block hb] = (sum of h's pieces)^T . M_b^T  (the 0/1 mask is exact in bf16: NP MFMAs per
+                        // chunk, smallest piece first)
                         f32x16 da = zero16();
                         const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
 #pragma unroll
                         for (int jg = 0; jg < 2; ++jg) {
-                            da = mfma16(*reinterpret_cast<const uint4*>(hp + TLO + 16 * jg), mf[jg], da);
-                            da = mfma16(*reinterpret_cast<const uint4*>(hp + 16 * jg), mf[jg], da);
+#pragma unroll
+                            for (int i = NP - 1; i >= 0; --i) da = mfma16(*reinterpret_cast<const uint4*>(hp + i * TLO + 16 * jg), mf[jg], da);
                         }
-                        const Frag2 p0 = split8(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
-                        const Frag2 p1 = split8(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+                        const FragP<NP> p0 = split8<NP>(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
+                        const FragP<NP> p1 = split8<NP>(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
 #pragma unroll
                         for (int k = 0; k < NT; ++k) {            // slot k's fragments are re-requested right after their last use
-                            soc[k] = mfma_x3(p0.h, p0.l, wh[2 * k], wl[2 * k], soc[k]);
-                            soc[k] = mfma_x3(p1.h, p1.l, wh[2 * k + 1], wl[2 * k + 1], soc[k]);
+                            soc[k] = mfma_xp<NP>(p0.p, wf[2 * k], soc[k]);
+                            soc[k] = mfma_xp<NP>(p1.p, wf[2 * k + 1], soc[k]);
                             const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
-                            wh[2 * k] = p[0]; wh[2 * k + 1] = p[64]; wl[2 * k] = p[WS_LO]; wl[2 * k + 1] = p[WS_LO + 64];
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
                         }
                         __builtin_amdgcn_sched_barrier(0);         // one hidden block at a time: keeps the live set to one chain result
                     }
@@ -322,18 +339,15 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    unsigned h0, l0, h1, l1;
-                    split2(fmaxf(soc[0][4 * q] + bso, 0.f), fmaxf(soc[0][4 * q + 1] + bso, 0.f), h0, l0);
-                    split2(fmaxf(soc[0][4 * q + 2] + bso, 0.f), fmaxf(soc[0][4 * q + 3] + bso, 0.f), h1, l1);
                     if (TRAIN) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (sv_ok(4 * q + e))
                                 sv_x_t[(unsigned)(((arow + e + 8 * q) * a.T + t) * E + EV + C + col)] = fmaxf(soc[0][4 * q + e] + bso, 0.f);
                     }
-                    u16* x = Xb + (arow + 8 * q) * LDXB + EV + C + col;
-                    x[0] = (u16)h0; x[LDXB] = (u16)(h0 >> 16); x[2 * LDXB] = (u16)h1; x[3 * LDXB] = (u16)(h1 >> 16);
-                    x[XLO] = (u16)l0; x[XLO + LDXB] = (u16)(l0 >> 16); x[XLO + 2 * LDXB] = (u16)l1; x[XLO + 3 * LDXB] = (u16)(l1 >> 16);
+                    unsigned pa[NP], pb[NP];
+                    put4(Xb + (arow + 8 * q) * LDXB + EV + C + col, LDXB, XLO, fmaxf(soc[0][4 * q] + bso, 0.f), fmaxf(soc[0][4 * q + 1] + bso, 0.f),
+                         fmaxf(soc[0][4 * q + 2] + bso, 0.f), fmaxf(soc[0][4 * q + 3] + bso, 0.f), pa, pb);
                 }
             }
             TICKX(4)
@@ -353,26 +367,30 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                 const uint4* wg1 = Wg + ((size_t)(cb + NT) * G16) * 64 + z4;
                 const uint4* wcx = Wc + ((size_t)cb * G16) * 64 + z4;
                 const unsigned ul = (unsigned)lane;
-                uint4 rh[RD4][3], rl[RD4][3];
+                uint4 rb[RD4][3][NP];
                 auto req = [&](int g) {                            // (g is a compile-time constant after unrolling)
                     const int sl = g % RD4;
-                    rh[sl][0] = (wg0 + g * 64)[ul]; rl[sl][0] = (wg0 + WG_LO + g * 64)[ul];
-                    rh[sl][1] = (wg1 + g * 64)[ul]; rl[sl][1] = (wg1 + WG_LO + g * 64)[ul];
-                    if (g < GX16) { rh[sl][2] = (wcx + g * 64)[ul]; rl[sl][2] = (wcx + WC_LO + g * 64)[ul]; }
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        rb[sl][0][i] = (wg0 + i * WG_LO + g * 64)[ul];
+                        rb[sl][1][i] = (wg1 + i * WG_LO + g * 64)[ul];
+                        if (g < GX16) rb[sl][2][i] = (wcx + i * WC_LO + g * 64)[ul];
+                    }
                 };
 #pragma unroll
                 for (int g = 0; g < RD4; ++g) req(g);
 #pragma unroll
                 for (int g = 0; g < G16; ++g) {
                     const int sl = g % RD4;
-                    const uint4 ah = *reinterpret_cast<const uint4*>(xp + g * 16);
-                    const uint4 al = *reinterpret_cast<const uint4*>(xp + XLO + g * 16);
-                    g0 = mfma16(al, rh[sl][0], g0); g1 = mfma16(al, rh[sl][1], g1);
-                    if (g < GX16) ac = mfma16(al, rh[sl][2], ac);
-                    g0 = mfma16(ah, rl[sl][0], g0); g1 = mfma16(ah, rl[sl][1], g1);
-                    if (g < GX16) ac = mfma16(ah, rl[sl][2], ac);
-                    g0 = mfma16(ah, rh[sl][0], g0); g1 = mfma16(ah, rh[sl][1], g1);
-                    if (g < GX16) ac = mfma16(ah, rh[sl][2], ac);
+                    uint4 av[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(xp + i * XLO + g * 16);
+#pragma unroll
+                    for (int pr = 0; pr < Pairs<NP>::N; ++pr) {     // smallest products first, the three n-tiles side by side
+                        const int pa = Pairs<NP>::A[pr], pb = Pairs<NP>::B[pr];
+                        g0 = mfma16(av[pa], rb[sl][0][pb], g0); g1 = mfma16(av[pa], rb[sl][1][pb], g1);
+                        if (g < GX16) ac = mfma16(av[pa], rb[sl][2][pb], ac);
+                    }
                     if (g + RD4 < G16) req(g + RD4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -386,22 +404,21 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
                         u[4 * q + e] = sigmoidf_(g1[4 * q + e] + bgu);
                         if (TRAIN && sv_ok(4 * q + e)) { sv_r_t[sv_off(4 * q + e, t)] = r; sv_u_t[sv_off(4 * q + e, t)] = u[4 * q + e]; }
                     }
-                    unsigned h0, l0, h1, l1;
-                    split2(rhv[0], rhv[1], h0, l0); split2(rhv[2], rhv[3], h1, l1);
-                    u16* x = RHb + (arow + 8 * q) * LDRB + col;
-                    x[0] = (u16)h0; x[LDRB] = (u16)(h0 >> 16); x[2 * LDRB] = (u16)h1; x[3 * LDRB] = (u16)(h1 >> 16);
-                    x[RLO] = (u16)l0; x[RLO + LDRB] = (u16)(l0 >> 16); x[RLO + 2 * LDRB] = (u16)l1; x[RLO + 3 * LDRB] = (u16)(l1 >> 16);
+                    unsigned pa[NP], pb[NP];
+                    put4(RHb + (arow + 8 * q) * LDRB + col, LDRB, RLO, rhv[0], rhv[1], rhv[2], rhv[3], pa, pb);
                 }
             }
             // the candidate's r*h part: all of its B fragments are requested before the barrier
-            uint4 ch[GH16], cl[GH16];
+            uint4 chp[GH16][NP];
             {
                 int z5;
                 asm volatile("s_mov_b32 %0, 0" : "=s"(z5));
                 const uint4* wch = Wc + ((size_t)cb * G16 + GX16) * 64 + z5;
                 const unsigned ul = (unsigned)lane;
 #pragma unroll
-                for (int g = 0; g < GH16; ++g) { ch[g] = (wch + g * 64)[ul]; cl[g] = (wch + WC_LO + g * 64)[ul]; }
+                for (int g = 0; g < GH16; ++g)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) chp[g][i] = (wch + i * WC_LO + g * 64)[ul];
             }
             TICKX(6)
             __syncthreads();
@@ -410,9 +427,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
             {
 #pragma unroll
                 for (int g = 0; g < GH16; ++g) {
-                    const uint4 ah = *reinterpret_cast<const uint4*>(rp + g * 16);
-                    const uint4 al = *reinterpret_cast<const uint4*>(rp + RLO + g * 16);
-                    ac = mfma_x3(ah, al, ch[g], cl[g], ac);
+                    uint4 av[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(rp + i * RLO + g * 16);
+                    ac = mfma_xp<NP>(av, chp[g], ac);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -452,7 +470,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
         for (int nt = cb; nt < a.NTreg; nt += NT) {
             f32x16 acc[1] = {zero16()};
             const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
-            mmax_groups<1>(acc, xp + E, XLO, br, WR_LO, GH16);
+            mmax_groups<1, NP>(acc, xp + E, XLO, br, WR_LO, GH16);
             const int cc = nt * 32 + c31;
             if (cc < 2 * a.T) {
                 const float bb = a.b_reg[cc];
@@ -471,9 +489,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_x3(IocArgs a) {
 #endif
 }
 
-static size_t iocx3_lds(const IocArgs& a) {
+static size_t iocx3_lds(const IocArgs& a, int np = 2) {
     const int H = a.H, TM = 32, KX = 16 + 32 + 2 * H, B = a.G * a.G, NT = H / 32;
-    size_t b = 2 * ((size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2);
+    size_t b = np * ((size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (TM + 8) * 2);
     b += (size_t)((TM * (B + 1) + 1) & ~1) * 4 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 16;
     return b;
 }
@@ -491,4 +509,14 @@ static void launch_x3(const IocArgs& a, hipStream_t s) {
 }
 void launch_ioc_x3(const IocArgs& a, hipStream_t s) {
     if (a.H == 128) launch_x3<128>(a, s); else launch_x3<64>(a, s);
+}
+// three pieces per operand, six products per fp32 product (dims.bf16 = 3): same shapes, inference only
+template <int H>
+static void launch_x6(const IocArgs& a, hipStream_t s) {
+    const dim3 grid((a.R + 31) / 32), block((H / 32) * 64);
+    allow_big_lds(k_ioc_x3<H, 16, 32, false, 3>);
+    hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, false, 3>), grid, block, iocx3_lds(a, 3), s, a);
+}
+void launch_ioc_x6(const IocArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_x6<128>(a, s); else launch_x6<64>(a, s);
 }

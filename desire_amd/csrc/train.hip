@@ -309,7 +309,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     }
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
-    if (d.bf16 == 1) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0 or 2; 2 trains with the fp32 kernels)");
+    if (d.bf16 == 1 || d.bf16 == 3) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0 or 2; 2 trains with the fp32 kernels)");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
     if (d.bn_mode == 2) return fail(DESIRE_ERR_STATE, "training runs with frozen (bn_mode 0) or per-object (bn_mode 1) batch-norm; whole-batch statistics are forward-only");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))

@@ -60,10 +60,11 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
 
 
 def _operand_mode(v) -> int:
-    """args.bf16 -> dims.bf16: False/0 fp32 operands, True/1 bf16 operands, 2 / "x3" / "split" split-bf16 operands."""
+    """args.bf16 -> dims.bf16: False/0 fp32 operands, True/1 bf16 operands, 2 / "x3" / "split" split-bf16 operands (three products),
+    3 / "x6" three bf16 pieces (six products, fp32-class accuracy)."""
     if isinstance(v, str):
-        return {"": 0, "0": 0, "f32": 0, "1": 1, "bf16": 1, "2": 2, "x3": 2, "split": 2}[v.lower()]
-    return int(v) if int(v) in (0, 1, 2) else 1
+        return {"": 0, "0": 0, "f32": 0, "1": 1, "bf16": 1, "2": 2, "x3": 2, "split": 2, "3": 3, "x6": 3}[v.lower()]
+    return int(v) if int(v) in (0, 1, 2, 3) else 1
 
 
 class DESIREModel(object):

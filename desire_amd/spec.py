@@ -52,7 +52,8 @@ class Dims:
     bin_mode: int = 0      # social bins: 0 rectangular window nb_w x nb_h; 1 log-polar (rings nb_h .. nb_w x sectors)
     bn_mode: int = 0       # CVAE batch-norm: 0 frozen moving statistics; 1 per-object statistics (the reference's batch of one); 2 whole-batch statistics
     bf16: int = 0          # 1: bf16 MFMA operands (fp32 accumulate / state), inference only; 2: split-bf16 operands (hi + lo, three bf16
-                           #    MFMAs per product): fp32-equivalent results (~1e-5) from the bf16 matrix pipe where a kernel has that form
+                           #    MFMAs per product): fp32-equivalent results (~1e-5) from the bf16 matrix pipe where a kernel has that form;
+                           #    3: three bf16 pieces, six MFMAs per product: fp32-class accuracy (inference only)
     ref_compat: int = 0    # 1: the reference graph as written (model/model.py:116-311): n_dec decoder states re-read as T_obs points
     n_dec: int = 0         # ref_compat only: decoder steps (the reference hard-codes 7, model/model.py:280)
 

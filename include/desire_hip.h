@@ -59,7 +59,10 @@ typedef struct desire_dims {
                               every fp32 operand enters the bf16 matrix pipe as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and a
                               product is three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 accumulate): results agree with the fp32
                               kernels to ~1e-5 relative at 3/16 of their matrix time.  Kernels without that form (and training)
-                              run the fp32 kernels, so 2 is always at least as accurate as it claims. */
+                              run the fp32 kernels, so 2 is always at least as accurate as it claims.  3: THREE bf16 pieces per operand
+                              (x = hi + mid + lo exactly) and six products per fp32 product -- every term down to 2^-16 |a b| -- i.e.
+                              the accuracy class of the fp32 fmaf chain itself at 6/16 of its matrix time; inference only, same
+                              shapes as 2 (others run the fp32 kernels). */
     int32_t ref_compat;    /* 1: the reference graph AS WRITTEN (model/model.py:116-311) instead of the frozen spec: the GRU
                               decoder runs n_dec steps (7, :280) and every output state [H] is re-read as T_obs (x, y) points
                               (:286-289, needs H == 2*T_obs); one eps per object (K = 1, :262-263); target window = input
