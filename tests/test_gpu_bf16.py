@@ -106,7 +106,7 @@ def test_bf16_is_inference_only_and_validated(torch_cuda):
     with pytest.raises(_lib.DesireError):
         h.set_training(True)
     with pytest.raises(_lib.DesireError):
-        _lib.Handle(small_dims(bf16=3))                   # (2 = split operands: tests/test_gpu_split.py)
+        _lib.Handle(small_dims(bf16=4))                   # (2 / 3 = split operands, three / six products: tests/test_gpu_split.py)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64)])

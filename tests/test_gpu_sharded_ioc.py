@@ -26,7 +26,11 @@ def _setup_rank(torch, d_loc, w, past, fut, eps, grids, gos):
 
 @pytest.mark.parametrize("kw,nranks", [(dict(), 2), (dict(), 4), (dict(mno=64, n_scenes=1, K=2, n_grids=1), 2),
                                        (dict(H=64, T_pred=7, K=3), 2), (dict(iters=2, K=2), 2),
-                                       (dict(nb_w=0.04, nb_h=0.04, K=2), 2)])
+                                       (dict(nb_w=0.04, nb_h=0.04, K=2), 2),
+                                       # BASELINE configs[3] ("2048 agents, K=50, hidden=256, agents sharded 8 x MI355X with RCCL neighbour
+                                       # all-gather") at its per-scene shape: 64-agent scenes split over EIGHT ranks (8 slots each), K = 50,
+                                       # H = 256, T_pred = 40; two of its 32 scenes (untested above 4 ranks / H = 128)
+                                       (dict(mno=64, n_scenes=2, K=50, H=256, L=128, T_obs=8, T_pred=40, n_grids=1, nb_w=0.3, nb_h=0.3), 8)])
 def test_virtual_ranks_reproduce_the_unsharded_ioc(kw, nranks):
     import torch
     from desire_amd import _lib
