@@ -344,6 +344,9 @@ def main():
     ap.add_argument("--split", action="store_true",
                     help="split-bf16 operands (dims.bf16 = 2): every fp32 product runs as three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 "
                          "accumulate) in the kernels that have that form; fp32-equivalent results (~1e-5), NOT the headline line")
+    ap.add_argument("--x6", action="store_true",
+                    help="three bf16 pieces per fp32 operand, six bf16 MFMAs per product (dims.bf16 = 3) in the IOC kernel: fp32-class accuracy "
+                         "from the bf16 matrix pipe; NOT the headline line")
     ap.add_argument("--mno", type=int, default=32, help="agent slots per window (configs[2]/[3]: 64)")
     ap.add_argument("--H", type=int, default=128, help="hidden width (configs[3]: 256)")
     ap.add_argument("--K", type=int, default=20, help="samples per agent (configs[3]: 50)")
@@ -374,8 +377,9 @@ def main():
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(a.gpus)
-    if a.split and (a.bf16 or a.compact or a.shard == "agents"):
-        raise SystemExit("--split (split-bf16 operands in the IOC kernel) is a form of its own: not with --bf16 / --compact / --shard agents")
+    if (a.split or a.x6) and (a.bf16 or a.compact or a.shard == "agents" or (a.split and a.x6) or (a.x6 and a.train)):
+        raise SystemExit("--split / --x6 (split-bf16 operands in the IOC kernel) are forms of their own: not with --bf16 / --compact / --shard agents "
+                         "/ each other (and --x6 is inference only)")
     if a.windows is None:
         # inference saturates around 512 windows; a training step keeps ~0.5 GB of activations per window (27 GB of it the
         # pooled operand at 128 windows), so it stays at the size its profile was taken at
@@ -411,7 +415,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=2 if a.split else int(a.bf16), bn_mode=int(a.bn == "per_object"), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
+    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=3 if a.x6 else 2 if a.split else int(a.bf16), bn_mode=int(a.bn == "per_object"), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
              nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
@@ -521,7 +525,7 @@ def main():
         comm = agent_sharded_comm(sharded, halves, fence, max(2, a.steps // 2), world, d.T_pred)
     # outside the timed region: the same steps through the opt-in row-compacted pooling, reported next to the headline
     alt = None
-    if world == 1 and not (a.train or a.bf16 or a.split or a.graph or a.compact) and a.shard == "scenes" and a.mno <= 32 and a.H <= 128:
+    if world == 1 and not (a.train or a.bf16 or a.split or a.x6 or a.graph or a.compact) and a.shard == "scenes" and a.mno <= 32 and a.H <= 128:
         os.environ["DESIRE_IOC_VARIANT"] = "8"                # read by the library at every launch
         try:
             step(); torch.cuda.synchronize()
@@ -710,6 +714,17 @@ def main():
             out["config"]["workload"] += "; social window %.3g (non-default: sparse bins)" % a.nb
             out["roofline"]["note"] = ("achieved / frac credit the dense algorithm's flops; with --nb below 0.15 part of the social "
                                        "contraction is skipped (exact zeros), so frac can exceed 1 and is not a utilisation figure")
+        if a.x6:
+            out["metric"] += " -- split-bf16 (3 pieces, 6 products) operands in the IOC kernel"
+            out["dtype"] = "bf16x6 (three bf16 pieces per fp32 operand, six bf16 MFMAs per product, f32 accumulate/state) in the IOC kernel; other kernels f32"
+            out["config"]["workload"] += "; IOC contractions on the bf16 matrix pipe with three-piece operands (dims.bf16 = 3)"
+            out["roofline"].update({"kernel": "k_ioc_x3<%d,16,32,false,3>" % d.H, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
+                                    "frac": (ioc_tflops / (BF16_MFMA_PEAK_TFLOPS / 6.0)) if ioc_tflops else None, "traffic": None,
+                                    "traffic_source": "not collected for this form",
+                                    "note": "achieved = fp32-equivalent (algorithmic) flops / kernel time; peak = dense bf16 MFMA peak / 6 "
+                                            "(six bf16 products per fp32 product)"})
+            out["roofline"]["whole_path_frac"] = whole_tflops / (BF16_MFMA_PEAK_TFLOPS / 6.0)
+            out["roofline"]["whole_path_frac_executed"] = whole_exec_tflops / (BF16_MFMA_PEAK_TFLOPS / 6.0)
         if a.split:
             out["metric"] += " -- split-bf16 (3-product) operands in the IOC kernel"
             out["dtype"] = "bf16x3 (hi+lo split of fp32 operands, three bf16 MFMAs per product, f32 accumulate/state) in the IOC kernel; other kernels f32"

@@ -795,8 +795,11 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                                "barrier 3", "P5 cand + publish", "barrier 4", ""};
         const char* nx3[10] = {"step top (bar 4 wait)", "P1 ev/es/masks", "barrier 1", "P2 pooling chain", "exchange + e_r", "barrier 2",
                                "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
-        const char** names = (x3 || x6) ? nx3 : d.bf16 == 1 ? n16 : n32;
-        const int nk = (x3 || x6) ? 10 : 9;
+        const char* ncl[10] = {"step top: positions + clear + bar", "P1 ev/es/masks", "wait for the peers", "copy peers' Ht + bar", "P2 pooling chains",
+                               "exchange + e_r", "barrier 2", "P4 gates + r*h + cand frags", "bar 3 + P5 cand + publish stores", "drain + arrive + bar"};
+        const bool r2 = d.bf16 == 1 && !cluster && a.variant == 12 && ioc_bf16_r2_supported(d.mno, d.H, d.grid_size * d.grid_size);
+        const char** names = (x3 || x6 || r2) ? nx3 : d.bf16 == 1 ? (cluster ? ncl : n16) : n32;
+        const int nk = (x3 || x6 || r2 || (d.bf16 == 1 && cluster)) ? 10 : 9;
         long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
         for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
     }

@@ -121,7 +121,9 @@ int launch_ioc_bf16_cluster(const IocArgs& a, hipStream_t s);
 // split-bf16 form (kernels_x3.hip): fp32-equivalent results from three bf16 MFMAs per product; weight pointers = [hi | lo] packs
 bool ioc_x3_supported(int mno, int H, int bins);
 void launch_ioc_x3(const IocArgs& a, hipStream_t s);
-void launch_ioc_x6(const IocArgs& a, hipStream_t s);            // three bf16 pieces per operand, six products (dims.bf16 = 3)
+void launch_ioc_x6(const IocArgs& a, hipStream_t s);
+bool ioc_bf16_r2_supported(int mno, int H, int bins);          // 64-row tiles, two row blocks per wave (kernels_bf16_r2.hip)
+void launch_ioc_bf16_r2(const IocArgs& a, hipStream_t s);            // three bf16 pieces per operand, six products (dims.bf16 = 3)
 // agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
 struct IocStepArgs {
     int t; int rank; int nranks; int m_loc; int n_scenes; int K; int R;       // R = local rows = n_scenes * K * m_loc

@@ -439,6 +439,10 @@ static void launch16(const IocArgs& a, hipStream_t s) {
 // mno must divide 32 (32-row tiles, two workgroups per CU at H <= 128) or be 64 (64-row tiles, twice the waves);
 // a.variant == 2 forces 64-row tiles (A/B)
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
+    // a.variant == 12: 64-row tiles with two row blocks per wave (half the weight bytes per row, one workgroup per CU:
+    // kernels_bf16_r2.hip) -- bit-identical results, measured SLOWER (4.26 vs 3.16 ms per 81 920 rows: one wave per SIMD leaves the
+    // position-only phase, the exchange and the epilogues uncovered), so it stays an A/B form
+    if (a.variant == 12 && ioc_bf16_r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_bf16_r2(a, s); return; }
     const bool two = a.mno > 32 || a.variant == 2;
     if (a.H == 128) { if (two) launch16<128, 2>(a, s); else launch16<128, 1>(a, s); }
     else if (a.H == 64) { if (two) launch16<64, 2>(a, s); else launch16<64, 1>(a, s); }

@@ -19,8 +19,17 @@
 
 #define CLMAXM 128
 
+#ifdef DESIRE_IOC_TIMING
+#define TICKC(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICKC(k)
+#endif
 template <int H, int EV, int C, bool SPLIT>
 __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_bf16_cl(IocArgs a, u16* __restrict__ hex16) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = H >> 5, TM = 32, E = EV + C + H, KX = E + H;
     constexpr int LDXB = KX + 8, LDRB = H + 8, LDT = CLMAXM + 8;      // bf16 elements; (ld/2) = 4 mod 8 dwords: conflict-free b128
@@ -119,6 +128,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                 for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
                 if (tid < 2) occ[tid] = 0;
                 __syncthreads();
+                TICKC(0)
                 // ---- P1: e_v, e_s, neighbour bits of my rows against the whole group (positions only: no hidden state needed) ----
                 {
                     const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
@@ -141,9 +151,11 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                         if (b >= 0) { atomicOr(&masks[(r8 * LDM + b) * 2 + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
                     }
                 }
+                TICKC(1)
                 // ---- neighbours' h_{t-1}: published by their tiles at the end of step t-1 (parity (t-1)&1) ----
                 if (t > 0) {
                     group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
+                    TICKC(2)
                     const u16* src0 = hex16 + (size_t)((t + 1) & 1) * n_tiles * H * TM;
                     // ALL of a thread's loads first (up to three other members x four 8-byte words: [H][32] bf16 = H * 8 words per
                     // tile over 2H threads), one wait, then the LDS stores.  Written as a load -> wait -> store loop these twelve
@@ -172,6 +184,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                     }
                 }
                 __syncthreads();
+                TICKC(3)
                 // ---- P2: social pooling chain -> e_r ----
                 unsigned long long om_all = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
                 om_all |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
@@ -240,6 +253,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    TICKC(4)
                     if (om) {                                          // (workgroup-uniform)
                         __syncthreads();                               // every wave is done reading Ht: it now carries the exchange slots
 #pragma unroll
@@ -293,7 +307,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                     for (int i = 0; i < 16; ++i)
                         Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + EV + C + col] = bf16_of(fmaxf(soc[i] + bso, 0.f));
                 }
+                TICKC(5)
                 __syncthreads();
+                TICKC(6)
                 // ---- P4: gates over [x | h], and the candidate's x part (same A fragments: three n-tiles per LDS read) ----
                 // B fragments run through a ring of RD k-groups requested that many groups before their use; their addresses are formed per
                 // step from wave-uniform bases (the opaque zero keeps ~60 of them from being hoisted out of the time loop into spilled
@@ -342,6 +358,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
 #pragma unroll
                     for (int g = 0; g < GH16; ++g) ch[g] = (wch + g * 64)[ul];
                 }
+                TICKC(7)
                 __syncthreads();
                 // ---- P5: candidate += (r*h) part, blend, score; publish h_t ----
                 {
@@ -356,7 +373,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                     publish_h(h, hex16 + ((size_t)(t & 1) * n_tiles + tile) * H * TM);       // LDS images + exchange buffer, parity t & 1
                 }
                 if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
+                TICKC(8)
                 group_publish_wt(cnt);                       // includes the end-of-step __syncthreads
+                TICKC(9)
             }
             // ---- score ----
 #pragma unroll
@@ -394,6 +413,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
             group_publish(cnt);                              // pass end: my rows of Y are final for this pass
         }
     }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
+#endif
 }
 
 static size_t ioc16_cl_lds(const IocArgs& a, bool split) {

@@ -256,3 +256,21 @@ def test_ioc_bf16_error_budget_per_pass(torch_cuda, kw):
         assert e16 < 7e-3 * scale and e32 < 3e-2 * scale, (p, e16, e32)
         assert np.abs(score - r16["score"]).max() < 2e-2 * max(1.0, np.abs(r16["score"]).max())
         Yin = r32["Y"].astype(np.float32)              # the next pass starts from the exact first-pass result
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(mno=64, n_scenes=2, K=3, n_grids=1),
+                                dict(mno=8, n_scenes=5, K=3), dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2), dict(nb_w=0.04, nb_h=0.04, K=2),
+                                dict(iters=2, K=2), dict(mno=1, n_scenes=3, K=2), dict(H=32, T_pred=9, K=2, mno=8)])
+def test_two_row_blocks_per_wave_is_bit_identical_to_the_32_row_tiles(torch_cuda, kw, monkeypatch):
+    """kernels_bf16_r2.hip (64-row tiles, every weight fragment used for two row blocks, one workgroup per CU; the A/B form
+    DESIRE_IOC_VARIANT=12) keeps k_ioc_bf16's rounding points AND its per-row summation order: trajectories and scores equal the
+    default 32-row / 8-wave forms' bit for bit, ragged last tiles and 64-agent groups included."""
+    d = small_dims(bf16=1, **kw)
+    w = init_weights(d, 31)
+    past, fut, eps, grids, gos = make_case(d, seed=32, n_absent=min(2, d.mno - 1))
+    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    monkeypatch.setenv("DESIRE_IOC_VARIANT", "12")
+    _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    assert np.isfinite(Ya).all() and np.abs(Ya).max() > 0
+    np.testing.assert_array_equal(Ya, Yb)
+    np.testing.assert_array_equal(sa, sb)
