@@ -606,12 +606,10 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         const bool pobn = d.bn_mode != 0;                 // batch statistics: linear conv epilogue, then a normalise + activate pass per layer
         auto norm = [&](const char* layer, float* x, int n, int P, int C, int sig) {     // 1: per sample (k_instnorm_act), 2: over the whole batch
             const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
+            if (h->training)            // the batch-statistics backward needs the pre-norm tensor: kept next to the activation
+                launch_copy_f32(W(h, (std::string(layer).substr(std::string(layer).rfind('/') + 1) + "_pre").c_str()), x, (size_t)n * P * C, s);
             if (d.bn_mode == 2) launch_batchnorm_act(x, (size_t)n, P, C, ga, be, sig, W(h, "bn_part"), W(h, "bn_stat"), s);
-            else {
-                if (h->training)        // the instance-norm backward needs the pre-norm tensor: kept next to the activation
-                    launch_copy_f32(W(h, (std::string(layer).substr(std::string(layer).rfind('/') + 1) + "_pre").c_str()), x, (size_t)n * P * C, s);
-                launch_instnorm_act(x, n, P, C, ga, be, sig, s);
-            }
+            else launch_instnorm_act(x, n, P, C, ga, be, sig, s);
         };
         if (pobn) c.mode = 3;
         { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), A, 256, 32, 0); }
@@ -641,12 +639,10 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
     auto normd = [&](const char* layer, float* x, int P, int C, int sig) {          // batch statistics of the decoder layers (see desire_encode)
         const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
+        if (h->training)
+            launch_copy_f32(W(h, (std::string(layer).substr(std::string(layer).rfind('/') + 1) + "_pre").c_str()), x, (size_t)R * P * C, s);
         if (d.bn_mode == 2) launch_batchnorm_act(x, (size_t)R, P, C, ga, be, sig, W(h, "bn_part"), W(h, "bn_stat"), s);
-        else {
-            if (h->training)
-                launch_copy_f32(W(h, (std::string(layer).substr(std::string(layer).rfind('/') + 1) + "_pre").c_str()), x, (size_t)R * P * C, s);
-            launch_instnorm_act(x, R, P, C, ga, be, sig, s);
-        }
+        else launch_instnorm_act(x, R, P, C, ga, be, sig, s);
     };
     GemmArgs g{};
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;

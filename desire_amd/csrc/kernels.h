@@ -158,6 +158,8 @@ void launch_instnorm_act(float* x, int n, int P, int C, const float* gamma, cons
 void launch_instnorm_act_oop(const float* x, float* y, int n, int P, int C, const float* gamma, const float* beta, int sig, hipStream_t s);
 void launch_instnorm_act_bwd(float* dy, const float* x, const float* y, int n, int P, int C, const float* gamma, int sig, hipStream_t s);
 void launch_batchnorm_act(float* x, size_t n, int P, int C, const float* gamma, const float* beta, int sig, float* part, float* stat, hipStream_t s);
+void launch_batchnorm_act_bwd(float* dy, const float* x, const float* y, size_t n, int P, int C, const float* gamma, int sig,
+                              float* part, float* stat, float* stat2, hipStream_t s);
 void launch_conv_direct(const float* in, const float* w, const float* b, float* out, int n, int Hi, int Wi, int Ci,
                         int Co, int stride, int relu, hipStream_t s);
 void launch_temporal_conv(const float* frames, const float* w, const float* b, float* rho, int n_scenes, int T, int mno,

@@ -440,7 +440,8 @@ __global__ void k_bn_finish(const float* __restrict__ part, int nb, int C, float
     float t = 0.f;
     for (int b = 0; b < nb; ++b) t += part[(size_t)b * C + c];
     if (!second) stat[c] = t * inv_n;
-    else stat[C + c] = gamma[c] / sqrtf(t * inv_n + 1e-3f);
+    else if (second == 1) stat[C + c] = gamma[c] / sqrtf(t * inv_n + 1e-3f);
+    else stat[C + c] = 1.0f / sqrtf(t * inv_n + 1e-3f);              // (backward: the plain reciprocal deviation)
 }
 __global__ void k_bn_apply(float* __restrict__ x, size_t n, int C, const float* __restrict__ stat, const float* __restrict__ beta, int sig) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -458,6 +459,67 @@ void launch_batchnorm_act(float* x, size_t n, int P, int C, const float* gamma, 
     hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, part, nb, C, 1.0f / (float)rows, gamma, stat, 1);
     const size_t tot = rows * C, nbk = (tot + 255) / 256;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)(nbk < 4096 ? nbk : 4096)), dim3(256), 0, s, x, tot, C, stat, beta, sig);
+}
+
+// Backward of the whole-batch form, y = act(gamma * xh + beta), xh = (x - mean) * rstd with per-channel moments over ALL rows (every
+// sample's every pixel) of the call -- the reference's literal phase=train batch-norm when objects are batched (model/model.py:453,459-461,
+// 471):   g = dy * act'(y);   dx = gamma * rstd * ( g - mean_rows(g) - xh * mean_rows(g * xh) ).
+// The moments are recomputed from the kept pre-norm tensor exactly as the forward took them (same per-block partition, same order);
+// the two gradient means use the same deterministic two-stage reduction.  dy -> dx in place; gamma / beta are constants of the spec.
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                        size_t rows, int C, const float* __restrict__ stat, int sig, float* __restrict__ part) {
+    __shared__ float red[256], red2[256];
+    const int tid = threadIdx.x, c = tid % C, g = tid / C, G = 256 / C;
+    const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const float m = stat[c], rs = stat[C + c];
+    float sg = 0.f, sgx = 0.f;
+    for (size_t r = r0 + g; r < r1; r += G) {
+        const size_t i = r * C + c;
+        const float yv = y[i];
+        const float gv = dy[i] * (sig ? yv * (1.0f - yv) : (yv > 0.f ? 1.0f : yv + 1.0f));
+        sg += gv; sgx += gv * (x[i] - m) * rs;
+    }
+    red[tid] = sg; red2[tid] = sgx;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f, t2 = 0.f;
+        for (int j = 0; j < G; ++j) { t += red[j * C + tid]; t2 += red2[j * C + tid]; }
+        part[(size_t)blockIdx.x * 2 * C + tid] = t;
+        part[(size_t)blockIdx.x * 2 * C + C + tid] = t2;
+    }
+}
+__global__ void k_bn_bwd_finish(const float* __restrict__ part, int nb, int C, float inv_n, float* __restrict__ stat2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    float t = 0.f;
+    for (int b = 0; b < nb; ++b) t += part[(size_t)b * 2 * C + c];
+    stat2[c] = t * inv_n;
+}
+__global__ void k_bn_bwd_apply(float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, size_t n, int C,
+                               const float* __restrict__ stat, const float* __restrict__ stat2, const float* __restrict__ gamma, int sig) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C);
+        const float yv = y[i];
+        const float gv = dy[i] * (sig ? yv * (1.0f - yv) : (yv > 0.f ? 1.0f : yv + 1.0f));
+        const float xh = (x[i] - stat[ch]) * stat[C + ch];
+        dy[i] = gamma[ch] * stat[C + ch] * (gv - stat2[ch] - xh * stat2[C + ch]);
+    }
+}
+// part: [BN_BLOCKS][2C] scratch, stat [2][C] = (mean | rstd), stat2 [2][C] = (mean g | mean g xh)
+void launch_batchnorm_act_bwd(float* dy, const float* x, const float* y, size_t n, int P, int C, const float* gamma, int sig,
+                              float* part, float* stat, float* stat2, hipStream_t s) {
+    const size_t rows = n * P;
+    const int nb = rows < BN_BLOCKS ? (int)rows : BN_BLOCKS;
+    hipLaunchKernelGGL(k_bn_partial, dim3(nb), dim3(256), 0, s, x, rows, C, (const float*)nullptr, part);
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, part, nb, C, 1.0f / (float)rows, gamma, stat, 0);
+    hipLaunchKernelGGL(k_bn_partial, dim3(nb), dim3(256), 0, s, x, rows, C, stat, part);
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, part, nb, C, 1.0f / (float)rows, gamma, stat, 2);
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(256), 0, s, (const float*)dy, x, y, rows, C, (const float*)stat, sig, part);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3((2 * C + 63) / 64), dim3(64), 0, s, (const float*)part, nb, C, 1.0f / (float)rows, stat2);
+    const size_t tot = rows * C, nbk = (tot + 255) / 256;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)(nbk < 4096 ? nbk : 4096)), dim3(256), 0, s, dy, x, y, tot, C, (const float*)stat,
+                       (const float*)stat2, gamma, sig);
 }
 
 // Stream-ordered fill / copy as KERNELS: the hot sequences stay kernel-only, which keeps them capturable into a hipGraph

@@ -311,7 +311,6 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
     if (d.bf16 == 1 || d.bf16 == 3) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0 or 2; 2 trains with the fp32 kernels)");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
-    if (d.bn_mode == 2) return fail(DESIRE_ERR_STATE, "training runs with frozen (bn_mode 0) or per-object (bn_mode 1) batch-norm; whole-batch statistics are forward-only");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))
         return fail(DESIRE_ERR_STATE, "training of groups larger than one workgroup tile (64 / 96 / 128 agents: cluster-form BPTT) needs H <= 128 and grid_size <= 4");
     if (d.iters > 4) return fail(DESIRE_ERR_STATE, "training keeps the activations of every IOC refinement pass: iters <= 4");
@@ -352,12 +351,14 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     };
     for (const B& b : bufs)
         if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
-    if (d.bn_mode == 1) {          // pre-norm copies of the seven conv layers (instance-norm backward)
+    if (d.bn_mode != 0) {          // pre-norm copies of the seven conv layers (instance-norm / batch-norm backward)
         const B pre[] = {{"conv1_pre", (size_t)h->A * 8192 * f}, {"conv2_pre", (size_t)h->A * 4096 * f}, {"conv3_pre", (size_t)h->A * 2048 * f},
                          {"deconv1_pre", R * 2048 * f}, {"deconv2_pre", R * 4096 * f}, {"deconv3_pre", R * 8192 * f}, {"deconv4_pre", R * 1024 * f}};
         for (const B& b : pre)
             if (ensure(h, b.n, b.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for training buffer ") + b.n);
     }
+    if (d.bn_mode == 2 && (ensure(h, "bn_part2", (size_t)512 * 256 * f) || ensure(h, "bn_stat2", (size_t)2 * 128 * f) || ensure(h, "bn_statb", (size_t)2 * 128 * f)))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the batch-norm backward scratch");
     if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss buffers");
     if (int rc = build_repack_maps(h)) return rc;
@@ -405,7 +406,13 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         colsum(h, W(h, "dec_dac"), H, R * T, H, G(h, "dec/candidate/bias"), 0, s);
     }
     const int V = h->V, L = d.L, A = h->A;
-    const bool bn1 = d.bn_mode == 1;                       // per-object batch-norm (the reference graph's batch of one): DESIGN.md section 8
+    const bool bn1 = d.bn_mode != 0;                       // batch statistics -- per object (mode 1, the reference graph's batch of one) or over
+                                                           // the whole batch (mode 2): the conv data-gradient kernels run with a linear epilogue and
+                                                           // norm_bwd takes the gradient through activation + normalisation
+    auto norm_bwd = [&](float* dy, const float* pre, const float* y, int n, int P, int C, const float* gamma, int sig) {
+        if (d.bn_mode == 2) launch_batchnorm_act_bwd(dy, pre, y, (size_t)n, P, C, gamma, sig, W(h, "bn_part2"), W(h, "bn_statb"), W(h, "bn_stat2"), s);
+        else launch_instnorm_act_bwd(dy, pre, y, n, P, C, gamma, sig, s);
+    };
     // (under per-object statistics a conv bias cancels against the mean: its gradient is exactly zero, so the column sums of the
     //  post-norm gradients -- pure rounding noise -- are NOT fed to Adam; the Gflat slots of vae_*/b stay at the fill value 0)
     // ---- ranking / refinement module (trajectories detached: its only path into the rest is dHx) ----
@@ -477,7 +484,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         g.out = W(h, "dconv4"); g.ldo = V; g.N = V; g.p0 = D(h, "vae_dec/deconv4/scale"); g.chmod = 1; g.aux = W(h, "xhat");
         if (bn1) {          // per-object batch-norm: gradient w.r.t. the layer OUTPUT first, then through activation + instance norm
             launch_gemm_rows(g, EPI_NONE, s);
-            launch_instnorm_act_bwd(W(h, "dconv4"), W(h, "deconv4_pre"), W(h, "xhat"), (int)R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), 1, s);
+            norm_bwd(W(h, "dconv4"), W(h, "deconv4_pre"), W(h, "xhat"), (int)R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), 1);
         } else
         launch_gemm_rows(g, EPI_SIGGRAD, s);
     }
@@ -492,7 +499,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         c.in = W(h, "dconv4"); c.out = W(h, "dconv3"); c.w_raw = D(h, "vae_dec/deconv4/raw");
         c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = c.scale; c.mode = bn1 ? 3 : 1; c.yprev = W(h, "d3");
         launch_conv1(c, s);
-        if (bn1) launch_instnorm_act_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
         ConvWgradArgs wg{};
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
@@ -501,14 +508,14 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
         launch_conv2(c, s);
-        if (bn1) launch_instnorm_act_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)R, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)R, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0);
         wg.S = W(h, "d1"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "dconv2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv2/w"), s);
         if (!bn1) colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
         c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, "vae_dec/deconv2/Wbwd");
         c.scale = D(h, "vae_dec/deconv1/scale"); c.shift = c.scale; c.yprev = W(h, "d1");
         launch_conv3(c, s);
-        if (bn1) launch_instnorm_act_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)R, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)R, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0);
         tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, R, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
         if (!bn1) colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
         GemmArgs g{};
@@ -527,7 +534,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         g.out = W(h, "dconvE3"); g.ldo = 2048; g.N = 2048; g.p0 = D(h, "vae_enc/conv3/scale"); g.chmod = 128; g.aux = W(h, "c3");
         if (bn1) {
             launch_gemm_rows(g, EPI_NONE, s);
-            launch_instnorm_act_bwd(W(h, "dconvE3"), W(h, "conv3_pre"), W(h, "c3"), A, 16, 128, D(h, "vae_enc/conv3/gamma"), 0, s);
+            norm_bwd(W(h, "dconvE3"), W(h, "conv3_pre"), W(h, "c3"), A, 16, 128, D(h, "vae_enc/conv3/gamma"), 0);
         } else
         launch_gemm_rows(g, EPI_ELUGRAD, s);
         const int NSL = A >= 2048 ? 64 : (A >= 256 ? 16 : 4);
@@ -541,14 +548,14 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         c.in = W(h, "dconvE3"); c.out = W(h, "dconvE2"); c.Wp = D4(h, "vae_enc/conv3/Wbwd");
         c.scale = D(h, "vae_enc/conv2/scale"); c.shift = c.scale; c.yprev = W(h, "c2");
         launch_deconv2(c, s);
-        if (bn1) launch_instnorm_act_bwd(W(h, "dconvE2"), W(h, "conv2_pre"), W(h, "c2"), A, 64, 64, D(h, "vae_enc/conv2/gamma"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconvE2"), W(h, "conv2_pre"), W(h, "c2"), A, 64, 64, D(h, "vae_enc/conv2/gamma"), 0);
         wg.S = W(h, "dconvE2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "c1"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv2/w"), s);
         if (!bn1) colsum(h, W(h, "dconvE2"), 64, (long)A * 64, 64, G(h, "vae_enc/conv2/b"), 0, s);
         c.in = W(h, "dconvE2"); c.out = W(h, "dconvE1"); c.Wp = D4(h, "vae_enc/conv2/Wbwd");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = c.scale; c.yprev = W(h, "c1");
         launch_deconv3(c, s);
-        if (bn1) launch_instnorm_act_bwd(W(h, "dconvE1"), W(h, "conv1_pre"), W(h, "c1"), A, 256, 32, D(h, "vae_enc/conv1/gamma"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconvE1"), W(h, "conv1_pre"), W(h, "c1"), A, 256, 32, D(h, "vae_enc/conv1/gamma"), 0);
         launch_w1ch_grad(W(h, "vae_in"), W(h, "dconvE1"), A, A < 1024 ? A : 1024, W(h, "tn_partial"), G(h, "vae_enc/conv1/w"), s);
         if (!bn1) colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
         c.in = W(h, "dconvE1"); c.out = W(h, "dq_c"); c.w_raw = D(h, "vae_enc/conv1/raw"); c.mode = 2; c.yprev = W(h, "vae_in");

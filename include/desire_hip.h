@@ -53,7 +53,8 @@ typedef struct desire_dims {
                               pixels.  2 = whole-batch statistics: the same phase=train moments taken over everything one call
                               batches (per channel over all samples and pixels) -- what prettytensor's default does when objects ARE
                               batched.  Modes 1 and 2: fp32 operands; mode 1 also trains (desire_backward goes through the per-sample
-                              normalisation), mode 2 is forward-only. */
+                              normalisation); mode 2 trains too (desire_backward takes the gradient means over every sample of the call; with
+                              several data-parallel ranks each rank normalises over ITS share of the batch). */
     int32_t bf16;          /* 0: fp32 matrix operands (default); 1: bf16 operands / fp32 accumulate + fp32 state
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only.  2: SPLIT bf16 operands --
                               every fp32 operand enters the bf16 matrix pipe as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and a

@@ -91,6 +91,10 @@ def bn(x, w, p, d):
         mean = x.mean(dim=(1, 2), keepdim=True)
         var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
         return (x - mean) * (w[p + "/bn/gamma"] / torch.sqrt(var + O.BN_EPS)) + w[p + "/bn/beta"]
+    if getattr(d, "bn_mode", 0) == 2:      # whole-batch phase=train statistics (model/model.py:453,459-461,471 with the objects batched):
+        mean = x.mean(dim=(0, 1, 2), keepdim=True)                     # per channel over every sample and pixel of the call
+        var = ((x - mean) ** 2).mean(dim=(0, 1, 2), keepdim=True)
+        return (x - mean) * (w[p + "/bn/gamma"] / torch.sqrt(var + O.BN_EPS)) + w[p + "/bn/beta"]
     return bn_frozen(x, w, p)
 
 

@@ -142,15 +142,19 @@ def test_training_through_several_refinement_passes(kw):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, H=64, L=64), dict(H=16, K=2)])
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, H=64, L=64), dict(H=16, K=2),
+                                dict(bn_mode=2), dict(bn_mode=2, mno=16, n_scenes=3, H=64, L=64), dict(bn_mode=2, H=16, K=2)])
 def test_training_through_per_object_batch_norm(kw):
     """dims.bn_mode = 1 in training (frozen statistics only): the backward goes through the reference graph's
     batch-of-one batch-norm -- per-sample, per-channel moments of every CVAE conv layer -- against autograd of the same graph.
-    gamma / beta stay constants of the training spec; the conv biases cancel against the mean (their gradient is exactly 0)."""
+    gamma / beta stay constants of the training spec; the conv biases cancel against the mean (their gradient is exactly 0).
+    bn_mode = 2 (VERDICT r02 missing 4 / item 8): the same through WHOLE-BATCH statistics -- the reference's literal phase=train
+    batch-norm with the objects batched (model/model.py:453-462): the gradient means run over every sample of the call."""
     import torch
     from desire_amd import _lib
     from oracle import desire_torch as OT
-    d = small_dims(T_obs=5, T_pred=6, n_grids=1, K=kw.pop("K", 3), bn_mode=1, **kw)
+    kw = dict(kw)
+    d = small_dims(T_obs=5, T_pred=6, n_grids=1, K=kw.pop("K", 3), bn_mode=kw.pop("bn_mode", 1), **kw)
     w = init_weights(d, 65)
     rng = np.random.default_rng(66)
     for k in list(w):
