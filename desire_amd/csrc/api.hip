@@ -407,6 +407,22 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pv.begin(), pv.end());
         }
         bad |= up_split("ioc/Wsoc16", all);
+        if (d.bf16 == 3) {   // three-piece packs of the sample-generation kernels (kernels_x6.hip): decoder h-blocks, deconv2 / deconv3 taps
+            const auto& dg = hw["dec/gates/kernel"]; const auto& dc = hw["dec/candidate/kernel"];
+            bad |= up_split("dec/Whg6", pack_vals16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }));
+            bad |= up_split("dec/Whc6", pack_vals16(H, H, lin, [&](int k, int n) { return dc[(size_t)(H + k) * H + n]; }));
+            auto taps6 = [&](const std::vector<float>& wt, int CI, int CO) {        // transposed conv weights [tap][co][ci]
+                std::vector<float> out;
+                for (int tap = 0; tap < 25; ++tap) {
+                    const float* base = wt.data() + (size_t)tap * CI * CO;
+                    const auto pv = pack_vals16(CI, CO, lin, [&](int k, int n) { return base[(size_t)n * CI + k]; });
+                    out.insert(out.end(), pv.begin(), pv.end());
+                }
+                return out;
+            };
+            bad |= up_split("vae_dec/deconv2/W6", taps6(hw["vae_dec/deconv2/w"], 128, 64));
+            bad |= up_split("vae_dec/deconv3/W6", taps6(hw["vae_dec/deconv3/w"], 64, 32));
+        }
     }
     if (d.bf16 == 1) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
         const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
@@ -660,7 +676,10 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
+    // dims.bf16 = 3: six-product forms of the two large transposed convolutions and of the decoder (frozen batch-norm, inference)
+    const bool x6gen = d.bf16 == 3 && d.bn_mode == 0 && !h->training && !d.ref_compat;
     if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
+    else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
            if (pobn) normd("vae_dec/deconv2", W(h, "d2"), 64, 64, 0); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
@@ -672,6 +691,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         launch_deconv34_bf16(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), s);
     } else {
         if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
+        else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv3/W6"); Timer t(h, s, "deconv3"); launch_deconv3_x6(c, s); }
         else { Timer t(h, s, "deconv3"); launch_deconv3(c, s);
                if (pobn) normd("vae_dec/deconv3", W(h, "d3"), 256, 32, 0); }
         c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
@@ -696,6 +716,10 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     if (d.bf16 == 1) {
         a.Whg = D4(h, "dec/Whg16"); a.Whc = D4(h, "dec/Whc16");
         Timer t(h, s, "decoder"); launch_decoder_bf16(a, s);
+    } else
+    if (x6gen && decoder_x6_supported(H)) {
+        a.Whg = D4(h, "dec/Whg6"); a.Whc = D4(h, "dec/Whc6");
+        Timer t(h, s, "decoder"); launch_decoder_x6(a, s);
     } else
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
     if (d.ref_compat)      // model/model.py:286-289: each state [H] re-read as T_obs points (x, y) -> [A, n_dec, T_obs, 2]

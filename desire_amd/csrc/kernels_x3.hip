@@ -15,47 +15,7 @@
 #include "kernels.h"
 
 #include "bf16.h"
-
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = pk_bf16(a, b);
-    lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
-}
-// NP bf16 pieces of a pair of fp32 values: x = p0 + p1 (+ p2) with p_{i} = bf16(x - p_0 - .. - p_{i-1}); every subtraction is exact.
-// NP = 2 leaves |r| <= 2^-17 |x| (three products per fp32 product, ~2^-16 relative); NP = 3 represents an fp32 value EXACTLY
-// (8 + 8 + 8 significant bits) and six products -- every term down to 2^-16 |a b| -- leave an error of <= 2^-23 |a b| per product,
-// the class of the fp32 fmaf chain's own accumulation rounding (dims.bf16 = 3, "x6").
-template <int NP>
-__device__ __forceinline__ void splitp(float a, float b, unsigned (&p)[NP]) {
-    p[0] = pk_bf16(a, b);
-    float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
-    p[1] = pk_bf16(ra, rb);
-    if constexpr (NP == 3) {
-        ra -= __uint_as_float(p[1] << 16); rb -= __uint_as_float(p[1] & 0xffff0000u);
-        p[2] = pk_bf16(ra, rb);
-    }
-}
-template <int NP> struct FragP { uint4 p[NP]; };
-template <int NP>
-__device__ __forceinline__ FragP<NP> split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-    FragP<NP> f;
-    unsigned a[NP], b[NP], c[NP], d[NP];
-    splitp<NP>(v0, v1, a); splitp<NP>(v2, v3, b); splitp<NP>(v4, v5, c); splitp<NP>(v6, v7, d);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) f.p[i] = make_uint4(a[i], b[i], c[i], d[i]);
-    return f;
-}
-// the (piece of A, piece of B) products of one fp32 product, smallest terms first: NP = 2 -> lo.hi, hi.lo, hi.hi;
-// NP = 3 -> (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
-template <int NP> struct Pairs;
-template <> struct Pairs<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
-template <> struct Pairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
-// acc += a . b with split operands
-template <int NP>
-__device__ __forceinline__ f32x16 mfma_xp(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 c) {
-#pragma unroll
-    for (int i = 0; i < Pairs<NP>::N; ++i) c = mfma16(a[Pairs<NP>::A[i]], b[Pairs<NP>::B[i]], c);
-    return c;
-}
+#include "split.h"
 
 // acc[nb] += A[32 x 16G] . B_nb[16G x 32]: piece i of A = the image at ap + i * alo (bf16 elements); piece i of B = the pack at
 // bl[nb] + i * blo (uint4 units; bl already + lane).  One k-group at a time, the next group's fragments in flight (used by the

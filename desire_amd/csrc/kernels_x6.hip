@@ -1,0 +1,303 @@
+// kernels_x6.hip -- sample generation with three-piece operands (dims.bf16 = 3): the GRU decoder and the two large CVAE-decoder
+// transposed convolutions as six bf16 MFMAs per fp32 product (split.h).
+//
+// Why these three: the fp32 matrix pipe (157 TFLOP/s) is 1/16 of the bf16 one, and deconv2 + deconv3 + decoder are 48 of the
+// 58 ms the fp32 sample generation takes per 327 680 samples.  Two-piece operands (dims.bf16 = 2, ~1e-5) are NOT an option here:
+// the refinement that follows is a discontinuous function of the sampled positions (scene cell and social bin are floors of
+// them), so sample generation has to stay in the fp32 kernels' own accuracy class -- which three exact pieces and six products
+// are (<= 2^-23 |a b| dropped per product, the size of the fmaf chain's own rounding).
+//   * activations stay fp32 in HBM and in LDS; an A fragment is split into its pieces on the fly (44 VALU per fragment, against
+//     the >= 192 matrix-pipe cycles of the six MFMAs it feeds), or once per tile where it lives in registers (deconv2)
+//   * weights are three-piece bf16 packs [p0 | p1 | p2] in bf16-MFMA fragment order ("*/W6", "dec/Wh?6": api.hip)
+//   * tilings, epilogues and the summation order over k are those of the fp32 kernels (kernels_conv.hip, kernels_rnn.hip)
+#include "common.h"
+#include "kernels.h"
+
+#include "split.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// GRU decoder + head (k_decoder<H, 32>): the constant-input half (x_z W_x, once per tile) stays on the exact fp32 pipe, the per-step
+// contractions h W_hg and (r*h) W_hc run as six-product bf16 MFMAs.  a.Whg / a.Whc point at the three-piece packs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, LDH = H + 4, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
+    float* hs = smem;                       // [32][LDH]  h (A operand of the gates, head operand)
+    float* xs = smem + TM * LDH;            // [32][LDH]  x_z tile (prologue), then r*h
+    float* wo = xs + TM * LDH;              // [H][2] head weights
+    float* pl = wo + 2 * H;                 // [32][2] last observed position
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + (lane & 31), hi = lane >> 5;
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+        const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+        const int row = min(row0 + r, a.R - 1);
+        *reinterpret_cast<float4*>(xs + r * LDH + c4 * 4) = *reinterpret_cast<const float4*>(a.xz + (size_t)row * H + c4 * 4);
+        const int ag = agent_of_row(row, a.K, a.mno);
+        *reinterpret_cast<float4*>(hs + r * LDH + c4 * 4) = *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
+    }
+    for (int i = tid; i < 2 * H; i += NTHR) wo[i] = a.w_head[i];
+    if (tid < TM) {
+        const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
+        pl[tid * 2] = a.p_last[(size_t)ag * 2];
+        pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+    }
+    __syncthreads();
+    float* my_h = hs + (4 * hi) * LDH + col;
+    float* my_rh = xs + (4 * hi) * LDH + col;
+    f32x16 xr[1] = {splat16h(a.b_g[col])}, xu[1] = {splat16h(a.b_g[H + col])}, xc[1] = {splat16h(a.b_c[col])};
+    {
+        const float* x_lane = xs + (lane & 31) * LDH + 4 * hi;
+        mma_groups<1>(xr, x_lane, LDH, a.Wxg + ((size_t)cb * G) * 64 + lane, G);
+        mma_groups<1>(xu, x_lane, LDH, a.Wxg + ((size_t)(cb + NT) * G) * 64 + lane, G);
+        mma_groups<1>(xc, x_lane, LDH, a.Wxc + ((size_t)cb * G) * 64 + lane, G);
+    }
+    f32x16 h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = my_h[((i & 3) + 8 * (i >> 2)) * LDH];
+    __syncthreads();                                   // every wave is done with the x_z tile: its space now carries r*h
+    const uint4* Whg = reinterpret_cast<const uint4*>(a.Whg);
+    const uint4* Whc = reinterpret_cast<const uint4*>(a.Whc);
+    constexpr size_t PLG = (size_t)2 * NT * GH16 * 64, PLC = (size_t)NT * GH16 * 64;      // uint4 offset from one piece's pack to the next
+    const uint4* bg[2] = {Whg + ((size_t)cb * GH16) * 64 + lane, Whg + ((size_t)(cb + NT) * GH16) * 64 + lane};
+    const uint4* bc[1] = {Whc + ((size_t)cb * GH16) * 64 + lane};
+    const float* a8 = hs + (lane & 31) * LDH + 8 * hi;
+    const float* r8p = xs + (lane & 31) * LDH + 8 * hi;
+    const float bh0 = a.b_head[0], bh1 = a.b_head[1];
+    for (int t = 0; t < a.T; ++t) {
+        f32x16 g2[2] = {xr[0], xu[0]};
+        mma6_groups<2>(g2, a8, bg, PLG, GH16);
+        f32x16 u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float r = sigmoidf_(g2[0][i]);
+            my_rh[((i & 3) + 8 * (i >> 2)) * LDH] = r * h[i];
+            u[i] = sigmoidf_(g2[1][i]);
+        }
+        __syncthreads();
+        f32x16 ac[1] = {xc[0]};
+        mma6_groups<1>(ac, r8p, bc, PLC, GH16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float c = tanhf_(ac[0][i]);
+            h[i] = gru_blend(u[i], h[i], c);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
+        __syncthreads();
+        {   // head: y = p_last + h W_o + b_o ; TPR threads per row (fp32 VALU: trajectory coordinates come straight out of it)
+            const int r = tid / TPR, q8 = tid % TPR;
+            constexpr int per = H / TPR;
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = q8 * per; c < (q8 + 1) * per; ++c) {
+                const float hv = hs[r * LDH + c];
+                s0 = fmaf(hv, wo[c * 2], s0);
+                s1 = fmaf(hv, wo[c * 2 + 1], s1);
+            }
+            s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
+            s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+            if (TPR >= 8) { s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4); }
+            if (TPR >= 16) { s0 += __shfl_xor(s0, 8); s1 += __shfl_xor(s1, 8); }
+            if (q8 == 0 && row0 + r < a.R)
+                *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + r) * a.T + t) * 2) =
+                    make_float2(pl[r * 2] + (s0 + bh0), pl[r * 2 + 1] + (s1 + bh1));
+        }
+        // the head's reads of h_t are ordered before the next rewrite of the h tile by the next step's first barrier
+    }
+}
+template <int H>
+static void launch_dec6(const DecArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(2 * 32 * (H + 4) + 2 * H + 64) * sizeof(float);
+    allow_big_lds(k_decoder_x6<H>);
+    hipLaunchKernelGGL((k_decoder_x6<H>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+}
+bool decoder_x6_supported(int H) { return H == 64 || H == 128; }
+void launch_decoder_x6(const DecArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_dec6<128>(a, s); else launch_dec6<64>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// deconv2: [n,4,4,128] -> [n,8,8,64], 5x5 VALID stride 1, scatter form (k_deconv2): wave = (co-half hf, sample pair sp), M-tile rows =
+// (sample, input pixel).  A (K = 128) is split ONCE into 3 x 8 register fragments; the B fragments of all 25 taps x 8 k-groups run
+// through one ring RD k-groups deep; 48 MFMAs per tap in two interleaved accumulator chains, then the plain LDS scatter.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo) {
+    extern __shared__ __attribute__((aligned(16))) float out_s6[];    // [4][64 px][64 co]
+    constexpr int RD = 4;
+    const int lane = lane_id(), w = wave_id();
+    const int hf = w & 1, sp = w >> 1;
+    const int s0 = blockIdx.x * 4 + sp * 2;
+    const int c = lane & 31, hi = lane >> 5;
+    float* my = out_s6 + (sp * 2) * 4096;
+    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 af[8][3];
+    {
+        const int row = lane & 31;
+        const int smp = min(s0 + (row >> 4), a.n - 1);
+        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const FragP<3> f = frag6(src + g * 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[g][i] = f.p[i];
+        }
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    uint4 rb[RD][3];
+    auto req = [&](int tap, int g) {                       // g: compile-time after unrolling; the slot is g % RD (8 % RD == 0)
+        const uint4* bp = Wp + ((size_t)(min(tap, 24) * 2 + hf) * 8 + g) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rb[g % RD][i] = bp[i * plo];
+    };
+#pragma unroll
+    for (int g = 0; g < RD; ++g) req(0, g);
+#pragma clang loop unroll(disable)
+    for (int tap = 0; tap < 25; ++tap) {
+        const int ky = tap / 5, kx = tap - ky * 5;
+        f32x16 accA = zero16(), accB = zero16();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int sl = g % RD;
+#pragma unroll
+            for (int pr = 0; pr < 6; pr += 2) {
+                accA = mfma16(af[g][Pairs<3>::A[pr]], rb[sl][Pairs<3>::B[pr]], accA);
+                accB = mfma16(af[g][Pairs<3>::A[pr + 1]], rb[sl][Pairs<3>::B[pr + 1]], accB);
+            }
+            if (g + RD < 8) req(tap, g + RD); else req(tap + 1, g + RD - 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column
+        float* dst[16]; float old[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            const int s = rr >> 4, p = rr & 15;
+            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+            dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) old[i] = *dst[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *dst[i] = old[i] + (accA[i] + accB[i]);
+    }
+    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
+    for (int i = 0; i < 16; ++i) {
+        const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
+        const int smp = s0 + (sp_px >> 6);
+        if (smp < a.n) {
+            const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
+            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
+            float4 o;
+            o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);      // inference only: BN + ELU
+            o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
+            *reinterpret_cast<float4*>(a.out + ix) = o;
+        }
+    }
+}
+void launch_deconv2_x6(const ConvArgs& a, hipStream_t s) {
+    allow_big_lds(k_deconv2_x6);
+    const size_t plo = (size_t)25 * 2 * 8 * 64;                        // uint4 per piece: 25 taps x 2 n-tiles x 8 k-groups x 64 lanes
+    hipLaunchKernelGGL(k_deconv2_x6, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2, output-parity gather (k_deconv3): one wave per sample, the sample's fp32
+// input staged in LDS, contracted TRANSPOSED (weights = A operand: lane = output channel) so the accumulators hold D[co][pixel]
+// with lane = pixel and runs of four channels -> float4 stores.  A pixel fragment (8 input channels) is split on the fly and feeds six
+// MFMAs; K = 64 = 4 k-groups per tap; the next tap's weight fragments are in flight.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6(ConvArgs a, size_t plo) {
+    constexpr int LDP = 68;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* zero_row = smem;
+    float* in_s = smem + LDP;                                          // [4][64][LDP]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * 4;
+    for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
+    for (int i = tid; i < 4 * 64 * 16; i += DS_WG) {
+        const int pix = i >> 4, c4 = i & 15;
+        const int smp = s0 + (pix >> 6);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
+        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int smp = s0 + w;
+    const float* mine = in_s + w * 64 * LDP;
+    const int hi = lane >> 5;
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
+        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    int qy[2], qx[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            f32x16 acc[2] = {zero16(), zero16()};
+            const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
+            auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
+            uint4 bc[4][3], bn[4][3];
+            auto ldw = [&](uint4 (&b)[4][3], int tap) {
+                const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) b[g][i] = bp[i * plo + g * 64];
+            };
+            ldw(bc, tap_of(0));
+#pragma clang loop unroll(disable)
+            for (int t = 0; t < ntap; ++t) {
+                const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
+                ldw(bn, tap_of(min(t + 1, ntap - 1)));
+                __builtin_amdgcn_sched_barrier(0);
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+                const float* xp[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int iy = qy[m] + dy, ix = qx[m] + dx;
+                    const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                    xp[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 8 * hi;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const FragP<3> f0 = frag6(xp[0] + 16 * g), f1 = frag6(xp[1] + 16 * g);
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr) {                       // D[co][pixel]: the two row blocks alternate on the pipe
+                        acc[0] = mfma16(bc[g][Pairs<3>::B[pr]], f0.p[Pairs<3>::A[pr]], acc[0]);
+                        acc[1] = mfma16(bc[g][Pairs<3>::B[pr]], f1.p[Pairs<3>::A[pr]], acc[1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) bc[g][i] = bn[g][i];
+            }
+            if (smp < a.n) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
+                    const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 o;
+                        o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
+                        o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
+                        *reinterpret_cast<float4*>(a.out + base + 8 * q) = o;
+                    }
+                }
+            }
+        }
+}
+void launch_deconv3_x6(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (68 + (size_t)4 * 64 * 68) * sizeof(float);
+    allow_big_lds(k_deconv3_x6);
+    const size_t plo = (size_t)25 * 1 * 4 * 64;                        // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
+    hipLaunchKernelGGL(k_deconv3_x6, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a, plo);
+}

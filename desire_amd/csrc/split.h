@@ -1,0 +1,90 @@
+// split.h -- fp32 operands as bf16 pieces on the bf16 matrix pipe (shared by kernels_x3.hip and kernels_x6.hip).
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the flop rate of v_mfma_f32_32x32x2_f32 and has no xf32 / TF32 rate in between.
+// An fp32 value is a sum of bf16 pieces, every piece product is exact in the fp32 accumulator, so an fp32 product becomes a few
+// bf16 MFMAs: two pieces / three products (~2^-16 relative), or three pieces / six products (fp32-class, below).
+#pragma once
+#include "bf16.h"
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// NP bf16 pieces of a pair of fp32 values: x = p0 + p1 (+ p2) with p_{i} = bf16(x - p_0 - .. - p_{i-1}); every subtraction is exact.
+// NP = 2 leaves |r| <= 2^-17 |x| (three products per fp32 product, ~2^-16 relative); NP = 3 represents an fp32 value EXACTLY
+// (8 + 8 + 8 significant bits) and six products -- every term down to 2^-16 |a b| -- leave an error of <= 2^-23 |a b| per product,
+// the class of the fp32 fmaf chain's own accumulation rounding (dims.bf16 = 3, "x6").
+template <int NP>
+__device__ __forceinline__ void splitp(float a, float b, unsigned (&p)[NP]) {
+    p[0] = pk_bf16(a, b);
+    float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
+    p[1] = pk_bf16(ra, rb);
+    if constexpr (NP == 3) {
+        ra -= __uint_as_float(p[1] << 16); rb -= __uint_as_float(p[1] & 0xffff0000u);
+        p[2] = pk_bf16(ra, rb);
+    }
+}
+template <int NP> struct FragP { uint4 p[NP]; };
+template <int NP>
+__device__ __forceinline__ FragP<NP> split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    FragP<NP> f;
+    unsigned a[NP], b[NP], c[NP], d[NP];
+    splitp<NP>(v0, v1, a); splitp<NP>(v2, v3, b); splitp<NP>(v4, v5, c); splitp<NP>(v6, v7, d);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) f.p[i] = make_uint4(a[i], b[i], c[i], d[i]);
+    return f;
+}
+// the (piece of A, piece of B) products of one fp32 product, smallest terms first: NP = 2 -> lo.hi, hi.lo, hi.hi;
+// NP = 3 -> (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+template <int NP> struct Pairs;
+template <> struct Pairs<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+template <> struct Pairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
+// acc += a . b with split operands
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_xp(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 c) {
+#pragma unroll
+    for (int i = 0; i < Pairs<NP>::N; ++i) c = mfma16(a[Pairs<NP>::A[i]], b[Pairs<NP>::B[i]], c);
+    return c;
+}
+
+
+// One A fragment (lane = row, 8 consecutive k) straight out of an fp32 LDS tile: two 16-byte reads, split on the fly into its three
+// pieces (44 VALU operations -- affordable where the fragment feeds six or more MFMAs, i.e. >= 192 matrix-pipe cycles).
+__device__ __forceinline__ FragP<3> frag6(const float* p8) {
+    const float4 x0 = *reinterpret_cast<const float4*>(p8), x1 = *reinterpret_cast<const float4*>(p8 + 4);
+    return split8<3>(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
+}
+// acc[nb] += A[32 x 16 G16] . B_nb[16 G16 x 32], six products per fp32 product: A from an fp32 LDS tile (ap = this lane's row + 8 * hi
+// floats, 16-byte aligned), B from three-piece packs [p0 | p1 | p2]: piece i of n-tile nb at bl[nb] + i * plo (uint4 units, already
+// + lane; 64 uint4 per k-group).  B fragments run one k-group ahead (two named register sets, fenced).
+template <int NB>
+__device__ __forceinline__ void mma6_groups(f32x16 (&acc)[NB], const float* ap, const uint4* const (&bl)[NB], size_t plo, int G16) {
+    uint4 b0[NB][3], b1[NB][3];
+    auto ld = [&](uint4 (&b)[NB][3], int g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[nb][i] = bl[nb][i * plo + (size_t)g * 64];
+    };
+    auto run = [&](const uint4 (&b)[NB][3], int g) {
+        const FragP<3> a = frag6(ap + g * 16);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(a.p[Pairs<3>::A[pr]], b[nb][Pairs<3>::B[pr]], acc[nb]);
+    };
+    ld(b0, 0);
+    int g = 0;
+#pragma clang loop unroll(disable)
+    for (; g + 2 <= G16; g += 2) {
+        ld(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G16) ld(b0, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g < G16) run(b0, g);
+}

@@ -276,10 +276,36 @@ def test_six_product_form_refuses_training_and_falls_back_on_other_shapes(torch_
     d = small_dims(mno=64, n_scenes=1, K=2, n_grids=1)
     w = init_weights(d, 7)
     past, fut, eps, grids, gos = make_case(d, seed=8, n_absent=5)
-    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
-    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos)      # no six-product form for 64-agent groups: fp32 kernels
-    assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)
+    ha, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0 = ha.read_buffer("Y0", (d.R, d.T_pred, 2))
+    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
+    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos, Y_in=Y0)    # no six-product IOC form for 64-agent groups:
+    assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)                                      # the fp32 kernel runs, bit for bit
     h = _lib.Handle(small_dims().replace(bf16=3)); h.set_weights(init_weights(small_dims(), 1))
     with pytest.raises(_lib.DesireError):
         h.set_training(True)
     h.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(T_pred=40, K=2), dict(posterior=0, K=3),
+                                dict(H=16, T_pred=8, T_obs=8, K=2, mno=4, n_scenes=3)])
+def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cuda, kw):
+    """dims.bf16 = 3 also runs the GRU decoder and the two large CVAE-decoder transposed convolutions as six bf16 MFMAs per fp32
+    product (kernels_x6.hip).  Sample generation feeds a DISCONTINUOUS refinement (cells and bins are floors of the sampled
+    positions), so the claim is strict: every stage sits where the fp32 kernels sit -- against the oracle no further than twice the
+    fp32 kernel's own distance (or 1e-6), and within 2e-6 of the fp32 kernels themselves."""
+    d = small_dims(**kw)
+    w = init_weights(d, 9)
+    past, fut, eps, grids, gos = make_case(d, seed=10, n_absent=min(3, d.mno - 1))
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h6, _, _ = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos)
+    hf, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    rep = {}
+    for name, shp in (("d2", (d.R, 4096)), ("d3", (d.R, 8192)), ("xhat", (d.R, 1024)), ("xz", (d.R, d.H)), ("Y0", (d.R, d.T_pred, 2))):
+        g6, gf, r = h6.read_buffer(name, shp), hf.read_buffer(name, shp), ref[name].reshape(shp)
+        e6, ef, e6f = float(np.abs(g6 - r).max()), float(np.abs(gf - r).max()), float(np.abs(g6 - gf).max())
+        rep[name] = (e6, ef, e6f)
+        assert e6 < max(2.0 * ef, 1e-6), (name, e6, ef)
+        assert e6f < 2e-6 * max(1.0, float(np.abs(r).max())), (name, e6f)
+    print({k: tuple("%.1e" % x for x in v) for k, v in rep.items()})
+    assert rep["Y0"][2] > 0                                  # (a different code path, not the fp32 kernels again)
