@@ -611,15 +611,16 @@ def test_whole_batch_batch_norm_mode(torch_cuda, kw):
     assert np.abs(ref_po["xhat"] - ref["xhat"]).max() > 1e-3           # not the per-object function
 
 
-def test_batch_statistics_modes_are_fp32_and_batch_mode_is_forward_only(torch_cuda):
+def test_batch_statistics_modes_are_fp32_and_both_train(torch_cuda):
     from desire_amd import _lib
     with pytest.raises(_lib.DesireError):
         _lib.Handle(small_dims(bn_mode=1, bf16=1))
-    d = small_dims(bn_mode=2)
-    h = _lib.Handle(d)
-    h.set_weights(init_weights(d, 0))
-    with pytest.raises(_lib.DesireError):                 # whole-batch statistics: forward only (per-object ones train, test_gpu_train_cluster.py)
+    for mode in (1, 2):                                   # per-object AND whole-batch statistics train (gradients: test_gpu_train_cluster.py)
+        d = small_dims(bn_mode=mode)
+        h = _lib.Handle(d)
+        h.set_weights(init_weights(d, 0))
         h.set_training(True)
+        h.close()
 
 
 @pytest.mark.parametrize("kw", [
