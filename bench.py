@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
                          "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")
-    ap.add_argument("--bn", choices=["frozen", "per_object"], default="frozen",
+    ap.add_argument("--bn", choices=["frozen", "per_object", "batch"], default="frozen",
                     help="CVAE batch-norm: 'frozen' moving statistics (default, the headline) or 'per_object' = the reference graph's literal "
                          "phase=train on a batch of one object (dims.bn_mode = 1: per-sample moments, model/model.py:453-462,471-481)")
     ap.add_argument("--data", choices=["both", "synthetic"], default="both",
@@ -415,7 +415,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=3 if a.x6 else 2 if a.split else int(a.bf16), bn_mode=int(a.bn == "per_object"), K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
+    d = Dims(n_scenes=a.windows, mno=a.mno, bf16=3 if a.x6 else 2 if a.split else int(a.bf16), bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[a.bn], K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
              nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
@@ -764,6 +764,8 @@ def main():
             out["comm"] = comm
         if a.bn == "per_object":
             out["config"]["workload"] += "; CVAE batch-norm with per-object statistics (the reference's batch-of-one phase=train)"
+        if a.bn == "batch":
+            out["config"]["workload"] += "; CVAE batch-norm with whole-batch statistics (phase=train over everything the call batches)"
         if alt:
             out["alt"] = alt
         if sdd:
