@@ -157,30 +157,13 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
                     group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
                     TICKC(2)
                     const u16* src0 = hex16 + (size_t)((t + 1) & 1) * n_tiles * H * TM;
-                    // ALL of a thread's loads first (up to three other members x four 8-byte words: [H][32] bf16 = H * 8 words per
-                    // tile over 2H threads), one wait, then the LDS stores.  Written as a load -> wait -> store loop these twelve
-                    // past-L1 (sc1) loads ran strictly one after the other -- twelve fabric round trips per step.
-                    constexpr int WPT = (H * 8) / NTHR;
-                    uint2 xb[3][WPT];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int tp = k + (k >= tile_pos ? 1 : 0);                  // the k-th OTHER member (workgroup-uniform)
-                        if (tp < tpg) {
-                            const u16* src = src0 + (size_t)(tile - tile_pos + tp) * H * TM;
-#pragma unroll
-                            for (int u = 0; u < WPT; ++u) xb[k][u] = ld_agent_u64(src + (size_t)(tid + u * NTHR) * 4);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int tp = k + (k >= tile_pos ? 1 : 0);
-                        if (tp < tpg) {
-#pragma unroll
-                            for (int u = 0; u < WPT; ++u) {
-                                const int i = tid + u * NTHR;
-                                *reinterpret_cast<uint2*>(Ht + (i >> 3) * LDT + tp * TM + 4 * (i & 7)) = xb[k][u];
-                            }
-                        }
+                    // (one load -> wait -> LDS store at a time ON PURPOSE: with all twelve loads of a thread in flight first -- 24 more live
+                    //  registers in a kernel that already sits at 256 -- the pass measured 7.33 instead of 6.62 ms, same box)
+                    for (int tp = 0; tp < tpg; ++tp) {
+                        if (tp == tile_pos) continue;
+                        const u16* src = src0 + (size_t)(tile - tile_pos + tp) * H * TM;
+                        for (int i = tid; i < H * 8; i += NTHR)                   // 8-byte words: [H][32] bf16 = H * 8 of them
+                            *reinterpret_cast<uint2*>(Ht + (i >> 3) * LDT + tp * TM + 4 * (i & 7)) = ld_agent_u64(src + (size_t)i * 4);
                     }
                 }
                 __syncthreads();
