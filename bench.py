@@ -46,7 +46,8 @@ def committed_traffic(windows, bf16=False):
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
     name = {(128, False): "r01_final_bench_pmc_per_kernel.json", (128, True): "r01_bf16_bench_pmc_per_kernel.json",
             (512, False): "r01_final_bench_w512_pmc_per_kernel.json"}.get((windows, bool(bf16)))
-    for newer in ("r02_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else ""),):
+    for newer in ("r02_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else ""),
+                  "r03_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else "")):
         if os.path.exists(os.path.join(ROOT, "profiles", newer)):
             name = newer
     path = os.path.join(ROOT, "profiles", name) if name else None
