@@ -228,53 +228,121 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                     const int cbo = (cb + k) % NT;
                     return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
                 };
-                uint4 wf[2 * NT][NP];                              // W fragments of one hidden block (every piece), refreshed in place
-                if (mine) {
-                    const int b0 = __ffsll((long long)mine) - 1;
+                if constexpr (NP == 3) {
+                    // one wave per SIMD (the whole register file, nobody else to cover a stall): two fragment sets, set (hb & 1), each
+                    // refreshed right after its last use with the fragments of the iteration AFTER next; the first link of hidden block
+                    // hb + 1 is issued before hb's accumulators are split and consumed; the second link's MFMAs walk the NT partial
+                    // tiles round-robin, so an accumulator is revisited NT MFMAs later (per accumulator the order of the products is
+                    // unchanged: results are bit-identical to the straight form)
+                    uint4 wf[2][2 * NT][NP];
+                    if (mine) {
+                        const int b0 = __ffsll((long long)mine) - 1;
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) {
-                        const uint4* p = wptr(b0, 0, k);
+                        for (int st = 0; st < 2; ++st)
 #pragma unroll
-                        for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
+                            for (int k = 0; k < NT; ++k) {
+                                const uint4* p = wptr(b0, st % NT, k);
+#pragma unroll
+                                for (int i = 0; i < NP; ++i) { wf[st][2 * k][i] = p[i * WS_LO]; wf[st][2 * k + 1][i] = p[i * WS_LO + 64]; }
+                            }
                     }
-                }
 #pragma clang loop unroll(disable)
-                while (mine) {
-                    const int b = __ffsll((long long)mine) - 1;
-                    mine &= mine - 1;
-                    const int nb = mine ? __ffsll((long long)mine) - 1 : b;
-                    uint4 mf[2];
-                    const unsigned m32 = masks[c31 * LDM + b];
-#pragma unroll
-                    for (int jg = 0; jg < 2; ++jg) {
-                        const unsigned bits = (m32 >> (16 * jg + 8 * hi)) & 0xffu;
-                        const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
-                        mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                    }
-#pragma unroll
-                    for (int hb = 0; hb < NT; ++hb) {
-                        // link 1: P_b^T[hidden block hb] = (sum of h's pieces)^T . M_b^T  (the 0/1 mask is exact in bf16: NP MFMAs per
-                        // chunk, smallest piece first)
-                        f32x16 da = zero16();
-                        const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
+                    while (mine) {
+                        const int b = __ffsll((long long)mine) - 1;
+                        mine &= mine - 1;
+                        const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                        uint4 mf[2];
+                        const unsigned m32 = masks[c31 * LDM + b];
 #pragma unroll
                         for (int jg = 0; jg < 2; ++jg) {
-#pragma unroll
-                            for (int i = NP - 1; i >= 0; --i) da = mfma16(*reinterpret_cast<const uint4*>(hp + i * TLO + 16 * jg), mf[jg], da);
+                            const unsigned bits = (m32 >> (16 * jg + 8 * hi)) & 0xffu;
+                            const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                            mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                         }
-                        const FragP<NP> p0 = split8<NP>(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
-                        const FragP<NP> p1 = split8<NP>(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+                        auto chain = [&](int hb) {
+                            f32x16 d1 = zero16();
+                            const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
 #pragma unroll
-                        for (int k = 0; k < NT; ++k) {            // slot k's fragments are re-requested right after their last use
-                            soc[k] = mfma_xp<NP>(p0.p, wf[2 * k], soc[k]);
-                            soc[k] = mfma_xp<NP>(p1.p, wf[2 * k + 1], soc[k]);
-                            const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+                            for (int jg = 0; jg < 2; ++jg)
 #pragma unroll
+                                for (int i = NP - 1; i >= 0; --i) d1 = mfma16(*reinterpret_cast<const uint4*>(hp + i * TLO + 16 * jg), mf[jg], d1);
+                            return d1;
+                        };
+                        f32x16 da = chain(0), dn;
+#pragma unroll
+                        for (int hb = 0; hb < NT; ++hb) {
+                            const int st = hb & 1;
+                            if (hb + 1 < NT) dn = chain(hb + 1);
+                            const FragP<NP> p0 = split8<NP>(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
+                            const FragP<NP> p1 = split8<NP>(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+#pragma unroll
+                            for (int pr = 0; pr < Pairs<NP>::N; ++pr)
+#pragma unroll
+                                for (int k = 0; k < NT; ++k) soc[k] = mfma16(p0.p[Pairs<NP>::A[pr]], wf[st][2 * k][Pairs<NP>::B[pr]], soc[k]);
+#pragma unroll
+                            for (int pr = 0; pr < Pairs<NP>::N; ++pr)
+#pragma unroll
+                                for (int k = 0; k < NT; ++k) soc[k] = mfma16(p1.p[Pairs<NP>::A[pr]], wf[st][2 * k + 1][Pairs<NP>::B[pr]], soc[k]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < NT; ++k) {            // refresh set st: (b, hb + 2), or (next bin, hb + 2 - NT)
+                                const uint4* p = (hb + 2 < NT) ? wptr(b, hb + 2, k) : wptr(nb, (hb + 2 - NT) % NT, k);
+#pragma unroll
+                                for (int i = 0; i < NP; ++i) { wf[st][2 * k][i] = p[i * WS_LO]; wf[st][2 * k + 1][i] = p[i * WS_LO + 64]; }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (hb + 1 < NT) da = dn;
+                        }
+                    }
+                } else {
+                uint4 wf[2 * NT][NP];                              // W fragments of one hidden block (every piece), refreshed in place
+                    if (mine) {
+                        const int b0 = __ffsll((long long)mine) - 1;
+    #pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            const uint4* p = wptr(b0, 0, k);
+    #pragma unroll
                             for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
                         }
-                        __builtin_amdgcn_sched_barrier(0);         // one hidden block at a time: keeps the live set to one chain result
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+    #pragma clang loop unroll(disable)
+                    while (mine) {
+                        const int b = __ffsll((long long)mine) - 1;
+                        mine &= mine - 1;
+                        const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                        uint4 mf[2];
+                        const unsigned m32 = masks[c31 * LDM + b];
+    #pragma unroll
+                        for (int jg = 0; jg < 2; ++jg) {
+                            const unsigned bits = (m32 >> (16 * jg + 8 * hi)) & 0xffu;
+                            const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                            mf[jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        }
+    #pragma unroll
+                        for (int hb = 0; hb < NT; ++hb) {
+                            // link 1: P_b^T[hidden block hb] = (sum of h's pieces)^T . M_b^T  (the 0/1 mask is exact in bf16: NP MFMAs per
+                            // chunk, smallest piece first)
+                            f32x16 da = zero16();
+                            const u16* hp = Ht + (hb * 32 + c31) * LDT + 8 * hi;
+    #pragma unroll
+                            for (int jg = 0; jg < 2; ++jg) {
+    #pragma unroll
+                                for (int i = NP - 1; i >= 0; --i) da = mfma16(*reinterpret_cast<const uint4*>(hp + i * TLO + 16 * jg), mf[jg], da);
+                            }
+                            const FragP<NP> p0 = split8<NP>(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
+                            const FragP<NP> p1 = split8<NP>(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+    #pragma unroll
+                            for (int k = 0; k < NT; ++k) {            // slot k's fragments are re-requested right after their last use
+                                soc[k] = mfma_xp<NP>(p0.p, wf[2 * k], soc[k]);
+                                soc[k] = mfma_xp<NP>(p1.p, wf[2 * k + 1], soc[k]);
+                                const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+    #pragma unroll
+                                for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);         // one hidden block at a time: keeps the live set to one chain result
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 // fixed-order sum of the partial tiles: round s hands slot s to the wave s column blocks further on; rounds
                 // alternate between the two slot sets, one barrier per round
