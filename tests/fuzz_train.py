@@ -30,6 +30,8 @@ def main():
                   nb_w=float(rng.choice([0.05, 0.2, 0.5])), nb_h=float(rng.choice([0.05, 0.25, 0.5])))
         if rng.random() < 0.25 and gs >= 3:
             kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04)
+        if rng.random() < 0.3:
+            kw["bn_mode"] = int(rng.choice([1, 2]))          # per-object / whole-batch batch-norm statistics in the training graph
         try:
             d = small_dims(**kw)
             w = init_weights(d, 300 + it)
