@@ -1,0 +1,444 @@
+// kernels_x6r2.hip -- six-product IOC kernel (dims.bf16 = 3) on 64-row tiles: two row blocks per wave, fp32 operand tiles in LDS.
+//
+// k_ioc_x3<NP = 3> (kernels_x3.hip) keeps three bf16 images of every operand tile: 120 KB of LDS, i.e. one workgroup per CU with one
+// wave per SIMD -- and is bound by its weight stream (three-piece packs: 1.5 MB of W_soc fragments + 0.7 MB of gate / candidate
+// fragments per 32-row tile-step through the CU's ~64 B/clk vector-memory path, against 40 k cycles of MFMA work).  Since that form
+// already pays for one wave per SIMD, the lever kernels_bf16_r2.hip could not use is free here: give the wave a SECOND row block, so
+// that every weight fragment it fetches is used twice -- half the weight bytes per row, twice the MFMAs per fragment.
+// What makes 64 rows fit the 160 KB of LDS: the operand tiles stay fp32 (one image, 4 bytes per element instead of 3 x 2) and an
+// A fragment is split into its three pieces ON THE FLY (split.h: frag6, 44 VALU operations against the six or more MFMAs it feeds;
+// one wave per SIMD issues them in the shadow of its own MFMAs).
+//   LDS:  XH [64][308] fp32  e_v | e_s | e_r | h     RH [64][132] fp32  r*h     HtT [128][68] fp32  h transposed (pooling operand)
+// Same products in the same per-accumulator order as k_ioc_x3<NP = 3>; results agree with it to an ulp or two (that form splits r*h where
+// it is computed, and the compiler contracts the product into the split's subtraction).
+// Tile = 64 rows = whole (scene, k) groups: mno divides 32, or mno = 64.  Weight pointers of IocArgs = the three-piece packs.
+#include "common.h"
+#include "kernels.h"
+
+#include "split.h"
+
+#ifdef DESIRE_IOC_TIMING
+#define TICK6(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICK6(k)
+#endif
+
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NP = 3, NT = H >> 5, RB = 2, TM = 32 * RB, E = EV + C + H, KX = E + H;
+    constexpr int LDX = KX + 4, LDB = H + 4, LDT = TM + 4;            // fp32 elements; row strides = 4 mod 8 dwords: conflict-free b128
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
+    constexpr int JGM = TM / 16;
+    constexpr int RD = 2;                                             // gate ring depth (k-groups in flight; 36 MFMAs per group)
+    static_assert(H * LDT * 4 >= 2 * NT * 4096, "both exchange sets live inside the h^T tile");
+    const int B = a.G * a.G, LDM = B + 1;
+    float* XH = reinterpret_cast<float*>(smem_raw);                   // [TM][LDX]  e_v | e_s | e_r | h
+    float* RH = XH + TM * LDX;                                        // [TM][LDB]  r * h
+    float* HtT = RH + TM * LDB;                                       // [H][LDT]   h transposed
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(HtT + H * LDT);   // [TM][B+1], bit = tile-local row
+    uint2* lut = reinterpret_cast<uint2*>(masks + TM * LDM);          // [16] nibble -> 4 bf16 (0.0 / 1.0)
+    float* pc = reinterpret_cast<float*>(lut + 16);                   // [TM][2]
+    float* pp = pc + TM * 2;                                          // [TM][2]
+    float* wv = pp + TM * 2;                                          // [3][EV]
+    float* red = wv + 3 * EV;                                         // [NT][TM]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);                  // [2]
+    float* EX0 = HtT;                                                       // exchange sets: inside the h^T tile (dead between the pooling
+    float* EX1 = HtT + NT * 1024;                                           // chains and the end of the step)
+
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int hi = lane >> 5, c31 = lane & 31;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + c31;
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int my_scene = my_row / (a.K * a.mno);
+    const int grp_base = (r8 / a.mno) * a.mno;
+    const int my_slot = r8 - grp_base;
+    const bool wide = a.mno > 32;
+    const int JG = wide ? JGM : 2;
+
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    if (tid < 16) {
+        const unsigned lo = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        lut[tid] = make_uint2(lo, hi2);
+    }
+    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
+    const uint4* Wg = reinterpret_cast<const uint4*>(a.Wg);
+    const uint4* Wc = reinterpret_cast<const uint4*>(a.Wc);
+    const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
+    const uint4* Wreg = reinterpret_cast<const uint4*>(a.Wreg);
+    constexpr size_t WG_LO = (size_t)2 * NT * G16 * 64, WC_LO = (size_t)NT * G16 * 64;   // uint4 offset from one piece's pack to the next
+    const size_t WS_LO = (size_t)B * NT * GH16 * 64, WR_LO = (size_t)a.NTreg * GH16 * 64;
+
+    const int arow = 4 * hi;                                          // + 32m + (i&3) + 8(i>>2): tile-local row of accumulator element i of block m
+    // h (fp32, accumulator layout) of row block m -> the row-major operand tile and the transposed pooling operand
+    auto publish_h = [&](const f32x16& h, int m) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) XH[(32 * m + arow + (i & 3) + 8 * (i >> 2)) * LDX + E + col] = h[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(HtT + col * LDT + 32 * m + arow + 8 * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    };
+
+    for (int it = 0; it < a.iters; ++it) {
+        int row0p;                                                    // opaque copy: keeps the prologue's address math out of the time loop's registers
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
+        f32x16 h[RB], sp[RB];
+#pragma unroll
+        for (int m = 0; m < RB; ++m) {
+            sp[m] = zero16();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = min(row0p + 32 * m + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
+                h[m][i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
+            }
+        }
+        __syncthreads();                                  // previous pass's readers of XH / HtT are done
+#pragma unroll
+        for (int m = 0; m < RB; ++m) publish_h(h[m], m);
+        float2 ynext = make_float2(0.f, 0.f);
+        if (tid < TM) {
+            const int row = min(row0 + tid, a.R - 1);
+            const int ag = agent_of_row(row, a.K, a.mno);
+            pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)row * a.T) * 2);
+            pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
+        }
+        for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+        if (tid < 2) occ[tid] = 0;
+        __syncthreads();
+
+        for (int t = 0; t < a.T; ++t) {
+            TICK6(0)
+            if (tid < TM && t + 1 < a.T)
+                ynext = *reinterpret_cast<const float2*>(a.Y + ((size_t)min(row0 + tid, a.R - 1) * a.T + t + 1) * 2);
+            // ---- P1: e_v, e_s, neighbour bits (row threads) ----
+            {
+                const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+                int cy, cx;
+                scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                constexpr int NG4 = (C + 4 * TPR - 1) / (4 * TPR);
+                float4 g4[NG4];                                       // the scene gather first: its L2 latency hides under the neighbour search
+#pragma unroll
+                for (int u = 0; u < NG4; ++u)
+                    if (4 * q8 + 4 * TPR * u < C) g4[u] = *reinterpret_cast<const float4*>(gsrc + 4 * q8 + 4 * TPR * u);
+                const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                for (int j = 2 * q8; j < EV; j += 2 * TPR) {
+                    const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
+                    const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
+                    *reinterpret_cast<float2*>(XH + r8 * LDX + j) = make_float2(e0, e1);
+                }
+                for (int j = q8; j < a.mno; j += TPR) {
+                    if (j == my_slot || !vld[grp_base + j]) continue;
+                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
+                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
+                }
+#pragma unroll
+                for (int u = 0; u < NG4; ++u)
+                    if (4 * q8 + 4 * TPR * u < C) *reinterpret_cast<float4*>(XH + r8 * LDX + EV + 4 * q8 + 4 * TPR * u) = g4[u];
+            }
+            TICK6(1)
+            __syncthreads();
+            TICK6(2)
+            // ---- P2: social pooling chain -> e_r (occupied bins dealt round-robin to the waves; both row blocks per weight fragment) ----
+            unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+            om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+            {
+                unsigned long long mine = 0ull;
+                {
+                    int k = 0;
+                    for (unsigned long long tmp = om; tmp; tmp &= tmp - 1, ++k)
+                        if (k % NT == cb) mine |= tmp & (0ull - tmp);
+                }
+                f32x16 soc[RB][NT];
+#pragma unroll
+                for (int m = 0; m < RB; ++m)
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) soc[m][k] = zero16();
+                auto wptr = [&](int b, int hb, int k) {           // piece-0 fragments of W_b[hidden block hb][column block (cb+k)%NT], 2 k-groups
+                    const int cbo = (cb + k) % NT;
+                    return Wsoc + ((size_t)(b * NT + cbo) * GH16 + 2 * hb) * 64 + lane;
+                };
+                uint4 wf[2 * NT][NP];                              // W fragments of one hidden block (every piece), refreshed in place: a load
+                if (mine) {                                        // is in flight for a whole (bin, hidden block) iteration = 108 MFMAs
+                    const int b0 = __ffsll((long long)mine) - 1;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const uint4* p = wptr(b0, 0, k);
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
+                    }
+                }
+                // (measured and not kept: the first link + splits of iteration n + 1 issued inside iteration n's second link, fragments
+                //  re-requested half by half -- 41 spilled registers, 51.0 instead of 49.7 ms at 512 windows)
+#pragma clang loop unroll(disable)
+                while (mine) {
+                    const int b = __ffsll((long long)mine) - 1;
+                    mine &= mine - 1;
+                    const int nb = mine ? __ffsll((long long)mine) - 1 : b;
+                    uint4 mf[RB][JGM];                                  // neighbour bits -> bf16 B fragments (exact in one piece)
+#pragma unroll
+                    for (int m = 0; m < RB; ++m) {
+                        const unsigned long long m64 = masks[(32 * m + c31) * LDM + b];
+                        const int jb = wide ? 0 : 32 * m;
+#pragma unroll
+                        for (int jg = 0; jg < JGM; ++jg) {
+                            if (jg < JG) {
+                                const unsigned bits = (unsigned)(m64 >> (jb + 16 * jg + 8 * hi)) & 0xffu;
+                                const uint2 l0 = lut[bits & 15u], l1 = lut[bits >> 4];
+                                mf[m][jg] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int hb = 0; hb < NT; ++hb) {
+                        FragP<NP> p0[RB], p1[RB];
+#pragma unroll
+                        for (int m = 0; m < RB; ++m) {
+                            // link 1: P_b^T[hidden block hb] = (h's pieces)^T . M_b^T: the h^T fragment is split on the fly, smallest piece first
+                            f32x16 da = zero16();
+                            const float* hp = HtT + (hb * 32 + c31) * LDT + (wide ? 0 : 32 * m) + 8 * hi;
+#pragma unroll
+                            for (int jg = 0; jg < JGM; ++jg) {
+                                if (jg < JG) {
+                                    const FragP<NP> hf = frag6(hp + 16 * jg);
+#pragma unroll
+                                    for (int i = NP - 1; i >= 0; --i) da = mfma16(hf.p[i], mf[m][jg], da);
+                                }
+                            }
+                            p0[m] = split8<NP>(da[0], da[1], da[2], da[3], da[4], da[5], da[6], da[7]);
+                            p1[m] = split8<NP>(da[8], da[9], da[10], da[11], da[12], da[13], da[14], da[15]);
+                        }
+                        // link 2 into all NT column blocks, both row blocks per fragment; the accumulators are walked round-robin
+#pragma unroll
+                        for (int pr = 0; pr < Pairs<NP>::N; ++pr)
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int m = 0; m < RB; ++m)
+                                    soc[m][k] = mfma16(p0[m].p[Pairs<NP>::A[pr]], wf[2 * k][Pairs<NP>::B[pr]], soc[m][k]);
+#pragma unroll
+                        for (int pr = 0; pr < Pairs<NP>::N; ++pr)
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int m = 0; m < RB; ++m)
+                                    soc[m][k] = mfma16(p1[m].p[Pairs<NP>::A[pr]], wf[2 * k + 1][Pairs<NP>::B[pr]], soc[m][k]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {            // re-request right after the last use: next hidden block, or block 0 of my next bin
+                            const uint4* p = (hb + 1 < NT) ? wptr(b, hb + 1, k) : wptr(nb, 0, k);
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) { wf[2 * k][i] = p[i * WS_LO]; wf[2 * k + 1][i] = p[i * WS_LO + 64]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                TICK6(3)
+                // fixed-order sum of the partial tiles: round (sft, m) hands slot sft of block m to the wave sft column blocks further on;
+                // rounds alternate between the two slot sets, one barrier per round
+                if (om) {                                          // (workgroup-uniform)
+                    __syncthreads();                               // every wave is done reading HtT: it now carries the exchange sets
+#pragma unroll
+                    for (int sft = 1; sft < NT; ++sft) {
+#pragma unroll
+                        for (int m = 0; m < RB; ++m) {
+                            float* ex = (((sft - 1) * RB + m) & 1) ? EX1 : EX0;
+                            float4* dst = reinterpret_cast<float4*>(ex + (size_t)cb * 1024) + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                dst[q * 64] = make_float4(soc[m][sft][4 * q], soc[m][sft][4 * q + 1], soc[m][sft][4 * q + 2], soc[m][sft][4 * q + 3]);
+                            __syncthreads();
+                            const float4* src = reinterpret_cast<const float4*>(ex + (size_t)((cb + NT - sft) % NT) * 1024) + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 v = src[q * 64];
+                                soc[m][0][4 * q] += v.x; soc[m][0][4 * q + 1] += v.y; soc[m][0][4 * q + 2] += v.z; soc[m][0][4 * q + 3] += v.w;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < RB; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        XH[(32 * m + arow + (i & 3) + 8 * (i >> 2)) * LDX + EV + C + col] = fmaxf(soc[m][0][i] + bso, 0.f);
+            }
+            TICK6(4)
+            __syncthreads();
+            TICK6(5)
+            // ---- P4: gates over [x | h], and the candidate's x part (three n-tiles and both row blocks per weight fragment) ----
+            f32x16 u[RB], ac[RB];
+            {
+                f32x16 g0[RB], g1[RB];
+#pragma unroll
+                for (int m = 0; m < RB; ++m) { g0[m] = zero16(); g1[m] = zero16(); ac[m] = zero16(); }
+                int z4;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z4));
+                const uint4* wg0 = Wg + ((size_t)cb * G16) * 64 + z4;
+                const uint4* wg1 = Wg + ((size_t)(cb + NT) * G16) * 64 + z4;
+                const uint4* wcx = Wc + ((size_t)cb * G16) * 64 + z4;
+                const unsigned ul = (unsigned)lane;
+                uint4 rb[RD][3][NP];
+                auto req = [&](int g) {                            // (g is a compile-time constant after unrolling)
+                    const int sl = g % RD;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        rb[sl][0][i] = (wg0 + i * WG_LO + g * 64)[ul];
+                        rb[sl][1][i] = (wg1 + i * WG_LO + g * 64)[ul];
+                        if (g < GX16) rb[sl][2][i] = (wcx + i * WC_LO + g * 64)[ul];
+                    }
+                };
+#pragma unroll
+                for (int g = 0; g < RD; ++g) req(g);
+                const float* xp0 = XH + c31 * LDX + 8 * hi;
+#pragma unroll
+                for (int g = 0; g < G16; ++g) {
+                    const int sl = g % RD;
+                    FragP<NP> av[RB];
+#pragma unroll
+                    for (int m = 0; m < RB; ++m) av[m] = frag6(xp0 + 32 * m * LDX + g * 16);
+#pragma unroll
+                    for (int pr = 0; pr < Pairs<NP>::N; ++pr) {     // smallest products first; six / four accumulators side by side
+                        const int pa = Pairs<NP>::A[pr], pb = Pairs<NP>::B[pr];
+#pragma unroll
+                        for (int m = 0; m < RB; ++m) {
+                            g0[m] = mfma16(av[m].p[pa], rb[sl][0][pb], g0[m]); g1[m] = mfma16(av[m].p[pa], rb[sl][1][pb], g1[m]);
+                            if (g < GX16) ac[m] = mfma16(av[m].p[pa], rb[sl][2][pb], ac[m]);
+                        }
+                    }
+                    if (g + RD < G16) req(g + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 0; m < RB; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float r = sigmoidf_(g0[m][i] + bgr);
+                        RH[(32 * m + arow + (i & 3) + 8 * (i >> 2)) * LDB + col] = r * h[m][i];
+                        u[m][i] = sigmoidf_(g1[m][i] + bgu);
+                    }
+            }
+            // the candidate's r*h part: all of its B fragments are requested before the barrier
+            uint4 chp[GH16][NP];
+            {
+                int z5;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z5));
+                const uint4* wch = Wc + ((size_t)cb * G16 + GX16) * 64 + z5;
+                const unsigned ul = (unsigned)lane;
+#pragma unroll
+                for (int g = 0; g < GH16; ++g)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) chp[g][i] = (wch + i * WC_LO + g * 64)[ul];
+            }
+            TICK6(6)
+            __syncthreads();
+            TICK6(7)
+            // ---- P5: candidate += (r*h) part, blend, score; publish h_t ----
+            {
+                const float* rp0 = RH + c31 * LDB + 8 * hi;
+#pragma unroll
+                for (int g = 0; g < GH16; ++g) {
+                    FragP<NP> av[RB];
+#pragma unroll
+                    for (int m = 0; m < RB; ++m) av[m] = frag6(rp0 + 32 * m * LDB + g * 16);
+#pragma unroll
+                    for (int pr = 0; pr < Pairs<NP>::N; ++pr)
+#pragma unroll
+                        for (int m = 0; m < RB; ++m) ac[m] = mfma16(av[m].p[Pairs<NP>::A[pr]], chp[g][Pairs<NP>::B[pr]], ac[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < RB; ++m) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float c = tanhf_(ac[m][i] + bcc);
+                        h[m][i] = gru_blend(u[m][i], h[m][i], c);
+                        sp[m][i] = fmaf(h[m][i], wsc, sp[m][i]);
+                    }
+                    publish_h(h[m], m);                    // h slots of XH / HtT were last read before the previous barrier
+                }
+            }
+            if (tid < TM) {
+                pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
+                pc[tid * 2] = ynext.x; pc[tid * 2 + 1] = ynext.y;
+            }
+            for (int i = tid; i < TM * LDM; i += NTHR) masks[i] = 0ull;
+            if (tid < 2) occ[tid] = 0;
+            TICK6(8)
+            __syncthreads();
+            TICK6(9)
+        }
+        // ---- score ----
+#pragma unroll
+        for (int m = 0; m < RB; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sp[m][i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+                if (c31 == 0) red[cb * TM + 32 * m + arow + (i & 3) + 8 * (i >> 2)] = v;
+            }
+        __syncthreads();
+        asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));
+        if (tid < TM && row0p + tid < a.R && it == a.iters - 1) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+            a.score[row0p + tid] = sc + (float)a.T * a.b_score[0];
+        }
+        // ---- regression: Y += h_T W_r + b_r ----
+        for (int nt = cb; nt < a.NTreg; nt += NT) {
+            const int cc = nt * 32 + c31;
+            const float bb = cc < 2 * a.T ? a.b_reg[cc] : 0.f;
+#pragma unroll
+            for (int m = 0; m < RB; ++m) {
+                f32x16 acc[1] = {zero16()};
+                const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
+                mma6_groups<1>(acc, XH + (32 * m + c31) * LDX + E + 8 * hi, br, WR_LO, GH16);
+                if (cc < 2 * a.T) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = row0p + 32 * m + arow + (i & 3) + 8 * (i >> 2);
+                        if (row < a.R) { float* y = a.Y + (size_t)row * 2 * a.T + cc; *y = *y + (acc[0][i] + bb); }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
+#endif
+}
+
+static size_t iocx6r2_lds(const IocArgs& a) {
+    const int H = a.H, TM = 64, KX = 16 + 32 + 2 * H, B = a.G * a.G, NT = H / 32;
+    size_t b = ((size_t)TM * (KX + 4) + (size_t)TM * (H + 4) + (size_t)H * (TM + 4)) * 4;
+    b += (size_t)TM * (B + 1) * 8 + 16 * 8 + (size_t)TM * 4 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + TM + 64;
+    return b;
+}
+bool ioc_x6r2_supported(int mno, int H, int bins) {
+    if (!((H == 64 || H == 128) && mno >= 1 && ((mno <= 32 && 32 % mno == 0) || mno == 64))) return false;
+    const int KX = 16 + 32 + 2 * H, NT = H / 32;
+    const size_t lds = ((size_t)64 * (KX + 4) + (size_t)64 * (H + 4) + (size_t)H * 68) * 4 + (size_t)64 * (bins + 1) * 8 + 128 + 1024 + 192 + (size_t)NT * 256 + 128;
+    return lds <= 160 * 1024;
+}
+template <int H>
+static void launch_x6r2(const IocArgs& a, hipStream_t s) {
+    allow_big_lds(k_ioc_x6r2<H, 16, 32>);
+    hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32>), dim3((a.R + 63) / 64), dim3((H / 32) * 64), iocx6r2_lds(a), s, a);
+}
+void launch_ioc_x6r2(const IocArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_x6r2<128>(a, s); else launch_x6r2<64>(a, s);
+}
