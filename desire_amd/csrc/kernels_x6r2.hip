@@ -23,7 +23,7 @@
 #define TICK6(k)
 #endif
 
-template <int H, int EV, int C>
+template <int H, int EV, int C, bool WIDE>          // WIDE: one 64-agent group spans both row blocks (compile-time: keeps the chains branch-free)
 __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -61,8 +61,8 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
     const int my_scene = my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;
     const int my_slot = r8 - grp_base;
-    const bool wide = a.mno > 32;
-    const int JG = wide ? JGM : 2;
+    constexpr bool wide = WIDE;
+    constexpr int JG = WIDE ? JGM : 2;
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     if (tid < 16) {
@@ -436,8 +436,14 @@ bool ioc_x6r2_supported(int mno, int H, int bins) {
 }
 template <int H>
 static void launch_x6r2(const IocArgs& a, hipStream_t s) {
-    allow_big_lds(k_ioc_x6r2<H, 16, 32>);
-    hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32>), dim3((a.R + 63) / 64), dim3((H / 32) * 64), iocx6r2_lds(a), s, a);
+    const dim3 grid((a.R + 63) / 64), block((H / 32) * 64);
+    if (a.mno > 32) {
+        allow_big_lds(k_ioc_x6r2<H, 16, 32, true>);
+        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, true>), grid, block, iocx6r2_lds(a), s, a);
+    } else {
+        allow_big_lds(k_ioc_x6r2<H, 16, 32, false>);
+        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, false>), grid, block, iocx6r2_lds(a), s, a);
+    }
 }
 void launch_ioc_x6r2(const IocArgs& a, hipStream_t s) {
     if (a.H == 128) launch_x6r2<128>(a, s); else launch_x6r2<64>(a, s);
