@@ -440,7 +440,7 @@ static void launch16(const IocArgs& a, hipStream_t s) {
 // a.variant == 2 forces 64-row tiles (A/B)
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
     // a.variant == 12: 64-row tiles with two row blocks per wave (half the weight bytes per row, one workgroup per CU:
-    // kernels_bf16_r2.hip) -- bit-identical results, measured SLOWER (4.26 vs 3.16 ms per 81 920 rows: one wave per SIMD leaves the
+    // kernels_bf16_r2.hip) -- bit-identical results, measured SLOWER (3.67 vs 3.20 ms per 81 920 rows: one wave per SIMD leaves the
     // position-only phase, the exchange and the epilogues uncovered), so it stays an A/B form
     if (a.variant == 12 && ioc_bf16_r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_bf16_r2(a, s); return; }
     const bool two = a.mno > 32 || a.variant == 2;

@@ -26,7 +26,7 @@
 #define TICKR(k)
 #endif
 
-template <int H, int EV, int C>
+template <int H, int EV, int C, bool WIDE>          // WIDE: one 64-agent group spans both row blocks (compile-time: keeps the chains branch-free)
 __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_bf16_r2(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -64,8 +64,8 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_bf16_r2(IocArgs a) {
     const int my_scene = my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;
     const int my_slot = r8 - grp_base;
-    const bool wide = a.mno > 32;                                     // one group spans both row blocks
-    const int JG = wide ? JGM : 2;                                    // 16-wide neighbour chunks of a row block
+    constexpr bool wide = WIDE;                                       // one group spans both row blocks
+    constexpr int JG = WIDE ? JGM : 2;                                // 16-wide neighbour chunks of a row block
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     if (tid < 16) {
@@ -417,8 +417,14 @@ bool ioc_bf16_r2_supported(int mno, int H, int bins) {
 }
 template <int H>
 static void launch_r2(const IocArgs& a, hipStream_t s) {
-    allow_big_lds(k_ioc_bf16_r2<H, 16, 32>);
-    hipLaunchKernelGGL((k_ioc_bf16_r2<H, 16, 32>), dim3((a.R + 63) / 64), dim3((H / 32) * 64), ioc16_r2_lds(a), s, a);
+    const dim3 grid((a.R + 63) / 64), block((H / 32) * 64);
+    if (a.mno > 32) {
+        allow_big_lds(k_ioc_bf16_r2<H, 16, 32, true>);
+        hipLaunchKernelGGL((k_ioc_bf16_r2<H, 16, 32, true>), grid, block, ioc16_r2_lds(a), s, a);
+    } else {
+        allow_big_lds(k_ioc_bf16_r2<H, 16, 32, false>);
+        hipLaunchKernelGGL((k_ioc_bf16_r2<H, 16, 32, false>), grid, block, ioc16_r2_lds(a), s, a);
+    }
 }
 void launch_ioc_bf16_r2(const IocArgs& a, hipStream_t s) {
     if (a.H == 128) launch_r2<128>(a, s); else launch_r2<64>(a, s);
