@@ -30,7 +30,7 @@
 #else
 #define TICK16(k)
 #endif
-template <int H, int EV, int C, int WM>
+template <int H, int EV, int C, int WM, bool WIDE = (WM > 1)>      // WIDE: one 64-agent group spans both row blocks (compile-time: branch-free chains)
 __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OCC : 1) void k_ioc_bf16(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -68,8 +68,8 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
     const int my_scene = my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;
     const int my_slot = r8 - grp_base;
-    const bool wide = a.mno > 32;                                     // one group spans both row blocks
-    const int JG = wide ? JGM : 2;                                    // 16-wide neighbour chunks of this wave's rows
+    constexpr bool wide = WIDE;                                       // one group spans both row blocks
+    constexpr int JG = wide ? JGM : 2;                                // 16-wide neighbour chunks of this wave's rows
     const int jbase = wide ? 0 : mt * 32;                             // first local row its neighbours can have
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
@@ -433,8 +433,14 @@ static size_t ioc16_lds(const IocArgs& a, int WM) {
 template <int H, int WM>
 static void launch16(const IocArgs& a, hipStream_t s) {
     const int TM = 32 * WM;
-    allow_big_lds(k_ioc_bf16<H, 16, 32, WM>);
-    hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, WM>), dim3((a.R + TM - 1) / TM), dim3((H / 32) * WM * 64), ioc16_lds(a, WM), s, a);
+    const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * WM * 64);
+    if (WM > 1 && a.mno <= 32) {                              // (64-row tiles forced onto small groups: a.variant == 2)
+        allow_big_lds(k_ioc_bf16<H, 16, 32, WM, false>);
+        hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, WM, false>), grid, block, ioc16_lds(a, WM), s, a);
+    } else {
+        allow_big_lds(k_ioc_bf16<H, 16, 32, WM>);
+        hipLaunchKernelGGL((k_ioc_bf16<H, 16, 32, WM>), grid, block, ioc16_lds(a, WM), s, a);
+    }
 }
 // mno must divide 32 (32-row tiles, two workgroups per CU at H <= 128) or be 64 (64-row tiles, twice the waves);
 // a.variant == 2 forces 64-row tiles (A/B)

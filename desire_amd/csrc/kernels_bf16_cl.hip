@@ -24,7 +24,9 @@
 #else
 #define TICKC(k)
 #endif
-template <int H, int EV, int C, bool SPLIT>
+// TPGT: tiles per group as a compile-time constant (2, 3, 4: the neighbour-chunk loops of the pooling chains are then branch-free), or 0 = read
+// it from the arguments
+template <int H, int EV, int C, bool SPLIT, int TPGT = 0>
 __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_bf16_cl(IocArgs a, u16* __restrict__ hex16) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -37,8 +39,8 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_
     constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
     constexpr int JGM = CLMAXM / 16;                                   // most 16-neighbour chunks a row can have
     const int B = a.G * a.G, LDM = B + 1;
-    const int tpg = a.mno / 32;                                        // tiles (workgroups) per group
-    const int JG = a.mno / 16;
+    const int tpg = TPGT ? TPGT : a.mno / 32;                          // tiles (workgroups) per group
+    const int JG = TPGT ? 2 * TPGT : a.mno / 16;
     u16* Xb = reinterpret_cast<u16*>(smem_raw);                        // [TM][LDXB]  e_v | e_s | e_r | h   (my rows)
     u16* RHb = Xb + TM * LDXB;                                         // [TM][LDRB]  r * h
     u16* Ht = RHb + TM * LDRB;                                         // [H][LDT]    h transposed, the WHOLE group
@@ -409,9 +411,9 @@ static size_t ioc16_cl_lds(const IocArgs& a, bool split) {
     (void)split;                                           // the bin-split exchange lives inside the Ht tile
     return b;
 }
-template <int H, bool SPLIT>
+template <int H, bool SPLIT, int TPGT = 0>
 static int launch16_cl(const IocArgs& a, u16* hex16, hipStream_t s) {
-    auto kern = k_ioc_bf16_cl<H, 16, 32, SPLIT>;
+    auto kern = k_ioc_bf16_cl<H, 16, 32, SPLIT, TPGT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const size_t lds = ioc16_cl_lds(a, SPLIT);
     const int threads = (H / 32) * 64;
@@ -433,6 +435,9 @@ static int launch16_cl(const IocArgs& a, u16* hex16, hipStream_t s) {
 int launch_ioc_bf16_cluster(const IocArgs& a, hipStream_t s) {
     u16* hex16 = reinterpret_cast<u16*>(a.hex);
     const bool split = a.variant != 4 && a.H <= 128;
+    if (a.H == 128 && split && a.mno == 128) return launch16_cl<128, true, 4>(a, hex16, s);
+    if (a.H == 128 && split && a.mno == 96) return launch16_cl<128, true, 3>(a, hex16, s);
+    if (a.H == 128 && split && a.mno == 64) return launch16_cl<128, true, 2>(a, hex16, s);
     if (a.H == 128) return split ? launch16_cl<128, true>(a, hex16, s) : launch16_cl<128, false>(a, hex16, s);
     if (a.H == 64) return split ? launch16_cl<64, true>(a, hex16, s) : launch16_cl<64, false>(a, hex16, s);
     return launch16_cl<256, false>(a, hex16, s);
