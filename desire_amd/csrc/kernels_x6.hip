@@ -17,16 +17,21 @@
 
 // ------------------------------------------------------------------------------------------------------------------
 // GRU decoder + head (k_decoder<H, 32>): the constant-input half (x_z W_x, once per tile) stays on the exact fp32 pipe, the per-step
-// contractions h W_hg and (r*h) W_hc run as six-product bf16 MFMAs.  a.Whg / a.Whc point at the three-piece packs.
+// contractions h W_hg and (r*h) W_hc run as six-product bf16 MFMAs over three bf16 images of h and of r*h, written once per step by the
+// wave that owns the columns (splitting the fp32 tile on the fly in every wave: 8.9 ms per 327 680 samples; the images: 8.6 ms).  a.Whg / a.Whc point at the
+// three-piece packs.
 // ------------------------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 32, LDH = H + 4, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
-    float* hs = smem;                       // [32][LDH]  h (A operand of the gates, head operand)
-    float* xs = smem + TM * LDH;            // [32][LDH]  x_z tile (prologue), then r*h
-    float* wo = xs + TM * LDH;              // [H][2] head weights
+    constexpr int TM = 32, LDH = H + 4, LDB = H + 8, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int ILO = TM * LDB;                                      // bf16 elements from one piece's image to the next
+    float* hs = smem;                       // [32][LDH]  fp32 h (head operand); initial state in the prologue
+    float* wo = hs + TM * LDH;              // [H][2] head weights
     float* pl = wo + 2 * H;                 // [32][2] last observed position
+    u16* hb = reinterpret_cast<u16*>(pl + TM * 2);     // [3][32][LDB]  the three bf16 pieces of h      (A operand of the gates)
+    u16* rb = hb + 3 * ILO;                            // [3][32][LDB]  ... of r*h                        (A operand of the candidate)
+    float* xs = reinterpret_cast<float*>(hb);          // [32][LDH]  x_z tile: prologue only, in the space the images take afterwards
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
     const int col = cb * 32 + (lane & 31), hi = lane >> 5;
@@ -45,7 +50,6 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
     }
     __syncthreads();
     float* my_h = hs + (4 * hi) * LDH + col;
-    float* my_rh = xs + (4 * hi) * LDH + col;
     f32x16 xr[1] = {splat16h(a.b_g[col])}, xu[1] = {splat16h(a.b_g[H + col])}, xc[1] = {splat16h(a.b_c[col])};
     {
         const float* x_lane = xs + (lane & 31) * LDH + 4 * hi;
@@ -56,28 +60,46 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
     f32x16 h;
 #pragma unroll
     for (int i = 0; i < 16; ++i) h[i] = my_h[((i & 3) + 8 * (i >> 2)) * LDH];
-    __syncthreads();                                   // every wave is done with the x_z tile: its space now carries r*h
+    __syncthreads();                                   // every wave is done with the x_z tile: its space now carries the images
+    // four values of one accumulator column run (rows 4hi + 8q + 0..3) -> every piece's image of a row-major bf16 tile
+    auto put4 = [&](u16* img, int q, float v0, float v1, float v2, float v3) {
+        unsigned pa[3], pb[3];
+        splitp<3>(v0, v1, pa);
+        splitp<3>(v2, v3, pb);
+        u16* x = img + (4 * hi + 8 * q) * LDB + col;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            x[i * ILO] = (u16)pa[i]; x[i * ILO + LDB] = (u16)(pa[i] >> 16); x[i * ILO + 2 * LDB] = (u16)pb[i]; x[i * ILO + 3 * LDB] = (u16)(pb[i] >> 16);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) put4(hb, q, h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    __syncthreads();
     const uint4* Whg = reinterpret_cast<const uint4*>(a.Whg);
     const uint4* Whc = reinterpret_cast<const uint4*>(a.Whc);
     constexpr size_t PLG = (size_t)2 * NT * GH16 * 64, PLC = (size_t)NT * GH16 * 64;      // uint4 offset from one piece's pack to the next
     const uint4* bg[2] = {Whg + ((size_t)cb * GH16) * 64 + lane, Whg + ((size_t)(cb + NT) * GH16) * 64 + lane};
     const uint4* bc[1] = {Whc + ((size_t)cb * GH16) * 64 + lane};
-    const float* a8 = hs + (lane & 31) * LDH + 8 * hi;
-    const float* r8p = xs + (lane & 31) * LDH + 8 * hi;
+    const u16* a8 = hb + (lane & 31) * LDB + 8 * hi;
+    const u16* r8p = rb + (lane & 31) * LDB + 8 * hi;
     const float bh0 = a.b_head[0], bh1 = a.b_head[1];
     for (int t = 0; t < a.T; ++t) {
         f32x16 g2[2] = {xr[0], xu[0]};
-        mma6_groups<2>(g2, a8, bg, PLG, GH16);
+        mmax_groups<2, 3>(g2, a8, ILO, bg, PLG, GH16);
         f32x16 u;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float r = sigmoidf_(g2[0][i]);
-            my_rh[((i & 3) + 8 * (i >> 2)) * LDH] = r * h[i];
-            u[i] = sigmoidf_(g2[1][i]);
+        for (int q = 0; q < 4; ++q) {
+            float rh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rh[e] = sigmoidf_(g2[0][4 * q + e]) * h[4 * q + e];
+                u[4 * q + e] = sigmoidf_(g2[1][4 * q + e]);
+            }
+            put4(rb, q, rh[0], rh[1], rh[2], rh[3]);
         }
         __syncthreads();
         f32x16 ac[1] = {xc[0]};
-        mma6_groups<1>(ac, r8p, bc, PLC, GH16);
+        mmax_groups<1, 3>(ac, r8p, ILO, bc, PLC, GH16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float c = tanhf_(ac[0][i]);
@@ -85,6 +107,8 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put4(hb, q, h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
         __syncthreads();
         {   // head: y = p_last + h W_o + b_o ; TPR threads per row (fp32 VALU: trajectory coordinates come straight out of it)
             const int r = tid / TPR, q8 = tid % TPR;
@@ -103,12 +127,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
                 *reinterpret_cast<float2*>(a.Y + ((size_t)(row0 + r) * a.T + t) * 2) =
                     make_float2(pl[r * 2] + (s0 + bh0), pl[r * 2 + 1] + (s1 + bh1));
         }
-        // the head's reads of h_t are ordered before the next rewrite of the h tile by the next step's first barrier
+        // the head's reads of h_t (and the gates' of its images) are ordered before the next rewrite by the next step's first barrier
     }
 }
 template <int H>
 static void launch_dec6(const DecArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(2 * 32 * (H + 4) + 2 * H + 64) * sizeof(float);
+    const size_t lds = (size_t)(32 * (H + 4) + 2 * H + 64) * sizeof(float) + (size_t)6 * 32 * (H + 8) * sizeof(u16);
     allow_big_lds(k_decoder_x6<H>);
     hipLaunchKernelGGL((k_decoder_x6<H>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }

@@ -88,3 +88,42 @@ __device__ __forceinline__ void mma6_groups(f32x16 (&acc)[NB], const float* ap, 
     }
     if (g < G16) run(b0, g);
 }
+
+// acc[nb] += A[32 x 16G] . B_nb[16G x 32]: piece i of A = the image at ap + i * alo (bf16 elements); piece i of B = the pack at
+// bl[nb] + i * blo (uint4 units; bl already + lane).  One k-group at a time, the next group's fragments in flight (used by the
+// regression head only: G = H/16 groups once per pass).
+#ifndef RD4
+#define RD4 2                                                       // ring depth (k-groups) of the gate contraction
+#endif
+template <int NB, int NP>
+__device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
+    uint4 b0[NB][NP], b1[NB][NP];
+    auto ld = [&](uint4 (&b)[NB][NP], int g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) b[nb][i] = bl[nb][i * blo + (size_t)g * 64];
+    };
+    auto run = [&](const uint4 (&b)[NB][NP], int g) {
+        uint4 av[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + g * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_xp<NP>(av, b[nb], acc[nb]);
+    };
+    ld(b0, 0);
+    int g = 0;
+#pragma clang loop unroll(disable)
+    for (; g + 2 <= G; g += 2) {
+        ld(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G) ld(b0, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        run(b1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g < G) run(b0, g);
+}
+
