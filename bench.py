@@ -140,11 +140,13 @@ def cpu_baseline(d_full, seed):
     hh.encode(p_t.data_ptr(), f_t.data_ptr())
     hh.sample(e_t.data_ptr(), Yg.data_ptr())
     torch.cuda.synchronize()
-    e_y0 = float(np.abs(Yg.cpu().numpy() - ref["Y0"]).max())
+    Y0f = Yg.cpu().numpy()
+    e_y0 = float(np.abs(Y0f - ref["Y0"]).max())
     Yg.copy_(tt_(ref["Y0"].astype(np.float32)))
     hh.ioc_refine(Yg.data_ptr(), sg.data_ptr())
     torch.cuda.synchronize()
-    dY = Yg.cpu().numpy() - ref["Y"]
+    Yf = Yg.cpu().numpy()
+    dY = Yf - ref["Y"]
     accuracy = {"max_abs_err_Y0": e_y0, "max_abs_err_Y": float(np.abs(dY).max()), "ade_vs_oracle": float(np.sqrt((dY ** 2).sum(-1)).mean()),
                 "gate": 1e-3, "units": "normalised frame coordinates", "sample": "%d samples (4 windows), HIP path vs oracle/desire_oracle.py" % d.R}
     hh.close()
@@ -157,12 +159,22 @@ def cpu_baseline(d_full, seed):
         h6.encode(p_t.data_ptr(), f_t.data_ptr())
         h6.sample(e_t.data_ptr(), Yg.data_ptr())
         torch.cuda.synchronize()
-        accuracy["x6_max_abs_err_Y0"] = float(np.abs(Yg.cpu().numpy() - ref["Y0"]).max())
+        Y06 = Yg.cpu().numpy()
+        accuracy["x6_max_abs_err_Y0"] = float(np.abs(Y06 - ref["Y0"]).max())
         Yg.copy_(tt_(ref["Y0"].astype(np.float32)))
         h6.ioc_refine(Yg.data_ptr(), sg.data_ptr())
         torch.cuda.synchronize()
-        accuracy["x6_max_abs_err_Y"] = float(np.abs(Yg.cpu().numpy() - ref["Y"]).max())
+        Y6 = Yg.cpu().numpy()
+        accuracy["x6_max_abs_err_Y"] = float(np.abs(Y6 - ref["Y"]).max())
         h6.close()
+        # ... and all three fp32 roundings (numpy oracle, fp32 MFMA kernels, six-product kernels) against the oracle evaluated in
+        # float64 on the same inputs: which of them is closer to exact arithmetic (IOC pass from the same fp32 Y0 everywhere)
+        ref64 = O.forward(tr(past), tr(fut), eps, grids, gos, w, d, dt=np.float64, Y_override=ref["Y0"])
+        e64 = lambda Y, key: np.abs(np.asarray(Y, np.float64) - ref64[key])
+        st = lambda e: {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean()))}
+        accuracy["vs_float64_oracle"] = {
+            "Y0": {"six_products": st(e64(Y06, "Y0")), "fp32_kernels": st(e64(Y0f, "Y0")), "fp32_numpy_oracle": st(e64(ref["Y0"], "Y0"))},
+            "Y": {"six_products": st(e64(Y6, "Y")), "fp32_kernels": st(e64(Yf, "Y")), "fp32_numpy_oracle": st(e64(ref["Y"], "Y"))}}
     # the reference's own structure (model/model.py:211): one object at a time, batch dimension 1, for the
     # sample-generation stages (the IOC stage needs the whole group and stays batched above)
     d1 = d.replace(n_scenes=1, mno=1, iters=1)

@@ -46,6 +46,10 @@ def test_default_contract_fields():
     assert o["alt"]["row_compacted_pooling"]["value"] > 0
     assert o["alt"]["reference_defaults"]["batch_size_10"]["value"] > 0 and o["alt"]["reference_defaults"]["windows_128"]["value"] > 0
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class
+    v64 = o["accuracy"]["vs_float64_oracle"]                  # against exact (float64) arithmetic: not further than the fp32 implementations
+    for key in ("Y0", "Y"):
+        worst32 = max(v64[key]["fp32_kernels"]["max"], v64[key]["fp32_numpy_oracle"]["max"])
+        assert v64[key]["six_products"]["max"] < max(1.5 * worst32, 5e-7), v64[key]
     s6 = o["alt"]["split_bf16x6_ioc"]
     assert s6["value"] > 0 and s6["ioc_ms"] > 0 and s6["max_abs_diff_vs_fp32_kernel"] < 2e-6 and s6["max_abs_diff_vs_fp32_kernel"] < sp["max_abs_diff_vs_fp32_kernel"]
     # round 3: BASELINE configs[2] (128 agents per scene, bf16 operands) is measured by the default command, with its own roofline

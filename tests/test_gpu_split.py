@@ -245,6 +245,28 @@ def test_six_product_form_is_as_close_to_the_oracle_as_the_fp32_kernel(torch_cud
     assert np.abs(s6 - ref["score"]).max() < max(2.0 * np.abs(sf - ref["score"]).max(), 2e-5 * max(1.0, np.abs(ref["score"]).max()))
 
 
+@pytest.mark.parametrize("kw", [dict(T_pred=40, K=4, n_scenes=3), dict(grid_size=2, nb_w=0.6, nb_h=0.6, K=2), dict(H=64, T_pred=12, K=3)])
+def test_six_product_form_against_float64(torch_cuda, kw):
+    """Which fp32 implementation is closer to EXACT arithmetic?  The oracle evaluated in float64 on the same inputs (the IOC pass from
+    the same fp32 Y0, so cells and bins are shared) is the yardstick; the fp32 numpy oracle, the fp32 MFMA kernel and the six-product
+    kernel are three roundings of it.  Claim: the six-product form is not further from exact than the fp32 implementations are
+    (what it drops per product, <= 2^-26 |a b| with round-to-nearest pieces, is below one fp32 accumulation rounding)."""
+    d = small_dims(**kw)
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos = make_case(d, seed=4, n_absent=min(3, d.mno - 1))
+    ref32 = oracle_forward(d, w, past, fut, eps, grids, gos)
+    ref64 = oracle_forward(d, w, past, fut, eps, grids, gos, dt=np.float64, Y_override=ref32["Y0"])
+    _, Y6, _ = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
+    _, Yf, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
+    err = lambda Y: np.abs(np.asarray(Y, np.float64) - ref64["Y"])
+    e6, ef, eo = err(Y6), err(Yf), err(ref32["Y"])
+    print("vs float64: six products max %.2e rms %.2e | fp32 kernel max %.2e rms %.2e | fp32 numpy oracle max %.2e rms %.2e"
+          % (e6.max(), np.sqrt((e6 ** 2).mean()), ef.max(), np.sqrt((ef ** 2).mean()), eo.max(), np.sqrt((eo ** 2).mean())))
+    worst32 = max(ef.max(), eo.max())
+    assert e6.max() < max(1.5 * worst32, 5e-7), (e6.max(), ef.max(), eo.max())
+    assert np.sqrt((e6 ** 2).mean()) < 1.5 * max(np.sqrt((ef ** 2).mean()), np.sqrt((eo ** 2).mean()))
+
+
 @pytest.mark.parametrize("tag", ["cfg0", "cfg1"])
 def test_six_product_form_reproduces_goldens(tag):
     """Both real-SDD goldens through dims.bf16 = 3, IOC on the golden decoder output (so cells and bins are the golden's): the
