@@ -199,12 +199,16 @@ void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
 struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial;
                 // optional block-sparsity of A: flags[m] bit b set <=> columns [b*fcols, (b+1)*fcols) of row m can be non-zero.  A 32-row
                 // chunk whose flags are clear over the workgroup's whole k-block is skipped (no loads, no MFMAs).
-                const unsigned long long* flags; int fcols; };
+                const unsigned long long* flags; int fcols;
+                int np; };                                  // 2: split-bf16 operands (hi + lo, three bf16 MFMAs per product) in the large forms; 0: fp32
+// im2col view of a convolution's large-grid tensor as the A operand: column = tap*Cl + cl, row m = (sample, small-grid pixel)
+struct ConvGather { int Cl, Pl, Ps, stride, pad; };
+void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n, hipStream_t s);       // kernels_bwd_x3.hip
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
                      int Hl, int K, int mno, hipStream_t s);
-struct ConvWgradArgs { const float* S; int Cs; int Ps; const float* Lg; int Cl; int Pl; int stride; int pad; int n; float* partial; };
+struct ConvWgradArgs { const float* S; int Cs; int Ps; const float* Lg; int Cl; int Pl; int stride; int pad; int n; float* partial; int np; };
 void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s);
 void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s);
 void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,

@@ -248,7 +248,6 @@ __global__ void k_reduce_slices(const float* __restrict__ partial, int nslices, 
 // (the output index map absorbs the interleave).  Needs 16-byte aligned rows (lda, ldg, Kd, N multiples of 4).
 // CONV: the A operand is the im2col view of a convolution's large-grid tensor (ConvGather), column = tap*Cl + cl,
 // row m = (sample, small-grid pixel) -- the weight gradient of a (transposed) convolution as ONE [25*Cl] x [Cs] GEMM.
-struct ConvGather { int Cl, Pl, Ps, stride, pad; };
 template <int WK, int WN, bool CONV>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     constexpr int BK = WK * 64, BN = WN * 64, QA = BK / 4, QG = BN / 4, PA = 32 / (256 / QA), PG = 32 / (256 / QG);
@@ -258,8 +257,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int nbn = (a.N + BN - 1) / BN;
     const int bk = (blockIdx.x / nbn) * BK, bn = (blockIdx.x % nbn) * BN;
     const int wk = w / WN, wn = w % WN;
-    const long mper = ((a.M + a.nslices - 1) / a.nslices + 31) / 32 * 32;
-    const long m_lo = (long)blockIdx.y * mper, m_hi = min(a.M, m_lo + mper);
+    // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
+    // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channels at the same time)
+    const long m_hi = a.M, step = (long)a.nslices * 32;
+    const long m_lo = (long)blockIdx.y * 32;
     const int hi = lane >> 5, c = lane & 31;
     f32x16 acc[2][2];
 #pragma unroll
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     }
     auto next_live = [&](long m0) {                       // first chunk start >= m0 that has something in the k-block (uniform)
         if (!a.flags) return m0;
-        for (; m0 < m_hi; m0 += 32) {                    // one flag word per lane, OR-reduced over the wave (same value in every wave)
+        for (; m0 < m_hi; m0 += step) {                  // one flag word per lane, OR-reduced over the wave (same value in every wave)
             unsigned long long f = (c < 32 && hi == 0 && m0 + c < m_hi) ? a.flags[m0 + c] & kmask : 0ull;
             unsigned lo32 = (unsigned)f | (unsigned)(f >> 32);
             const unsigned long long any = __ballot(lo32 != 0u);
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     __syncthreads();
     int buf = 0;
     while (m0 < m_hi) {
-        const long m1 = next_live(m0 + 32);
+        const long m1 = next_live(m0 + step);
         const bool more = m1 < m_hi;
         if (more) gload(m1);
         const float* ap = &As[buf][hi * BK + wk * 64 + 2 * c];
@@ -458,7 +459,8 @@ void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStr
     const bool big = a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
                      !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);
     if (big) {
-        if (a.N <= 64) {
+        if (a.np == 2) launch_gemm_tn2_split(a, nullptr, a.N <= 64, s);
+        else if (a.N <= 64) {
             const int nb = (a.Kd + 255) / 256;
             hipLaunchKernelGGL((k_gemm_tn2<4, 1, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
         } else {
@@ -676,7 +678,9 @@ void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStrea
         }
         t.nslices = nslices; t.partial = a.partial;
         const ConvGather cg{a.Cl, a.Pl, a.Ps, a.stride, a.pad};
-        if (a.Cs <= 64) hipLaunchKernelGGL((k_gemm_tn2<4, 1, true>), dim3((t.Kd + 255) / 256, nslices), dim3(256), 0, s, t, cg);
+        t.np = a.np;
+        if (a.np == 2) launch_gemm_tn2_split(t, &cg, a.Cs <= 64, s);
+        else if (a.Cs <= 64) hipLaunchKernelGGL((k_gemm_tn2<4, 1, true>), dim3((t.Kd + 255) / 256, nslices), dim3(256), 0, s, t, cg);
         else hipLaunchKernelGGL((k_gemm_tn2<2, 2, true>), dim3(((t.Kd + 127) / 128) * ((t.N + 127) / 128), nslices), dim3(256), 0, s, t, cg);
         const int n = 25 * a.Cl * a.Cs;
         reduce_slices(a.partial, nslices, 25 * a.Cl, a.Cs, out, a.Cs, 0, s);

@@ -1,0 +1,231 @@
+// kernels_bwd_x3.hip -- weight-gradient reductions with split-bf16 operands (dims.bf16 = 2 while training).
+//
+// Every weight gradient of the model is one A^T.G reduction over all rows and steps (kernels_bwd.hip: k_gemm_tn2), on the fp32
+// matrix pipe 37 of the training step's 126 ms.  The same reduction with every fp32 product as three bf16 MFMAs (split.h:
+// x = hi + lo, hi.hi + lo.hi + hi.lo, fp32 accumulation, ~2^-16 relative per product) costs 3/16 of the matrix time.
+//
+// Layout: the contraction runs over m (rows x steps), which is the SLOW index of both operands in HBM, while a bf16 MFMA lane
+// wants 8 consecutive contraction indices of one output row.  The staging through LDS does the transposition: a thread loads
+// the SAME four columns of P consecutive m-rows (coalesced float4 per row), splits them, and writes per column one P-element run
+// of the [column][32 m] bf16 image of each piece -- so fragments are single 16-byte LDS reads.  Rows of the image are 64 bytes:
+// the four 16-byte slots of a row are XOR-swizzled and the row order is column-major over the thread's four columns, which keeps
+// both the 8-byte writes (lanes = consecutive float4 columns) and the 16-byte fragment reads (lanes = consecutive columns) spread
+// over all banks.
+#include "common.h"
+#include "kernels.h"
+
+#include "split.h"
+
+namespace {
+
+template <int BC> __device__ __forceinline__ int img_row(int col) { return (col & 3) * (BC / 4) + (col >> 2); }
+__device__ __forceinline__ int img_swz(int col) { return ((col >> 3) ^ col) & 3; }
+
+// P rows x 4 columns (r[j] = columns col0..col0+3 of chunk row P*r0 + j) -> the NP piece images
+template <int BC, int P, int NP>
+__device__ __forceinline__ void put_rows(u16* img, int piece_stride, int col0, int r0, const float4 (&r)[P]) {
+    const int slot = (P * r0) >> 3, sub = ((P * r0) & 7) * 2;
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp) {
+        unsigned pc[NP][P / 2];
+#pragma unroll
+        for (int jj = 0; jj < P / 2; ++jj) {
+            const float4 x0 = r[2 * jj], x1 = r[2 * jj + 1];
+            const float v0 = comp == 0 ? x0.x : comp == 1 ? x0.y : comp == 2 ? x0.z : x0.w;
+            const float v1 = comp == 0 ? x1.x : comp == 1 ? x1.y : comp == 2 ? x1.z : x1.w;
+            unsigned t[NP];
+            splitp<NP>(v0, v1, t);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) pc[i][jj] = t[i];
+        }
+        const int col = col0 + comp;
+        char* dst = reinterpret_cast<char*>(img) + img_row<BC>(col) * 64 + ((slot ^ img_swz(col)) << 4) + sub;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            char* d = dst + (size_t)i * piece_stride * 2;
+            if (P == 8) *reinterpret_cast<uint4*>(d) = make_uint4(pc[i][0], pc[i][1], pc[i][2], pc[i][3]);
+            else if (P == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pc[i][0], pc[i][1]);
+            else *reinterpret_cast<unsigned*>(d) = pc[i][0];
+        }
+    }
+}
+template <int BC>
+__device__ __forceinline__ uint4 get_frag(const u16* img, int col, int slot) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + img_row<BC>(col) * 64 + ((slot ^ img_swz(col)) << 4));
+}
+
+// (WK*64) x (WN*64) output tile per workgroup, wave = 2x2 tiles of 32x32, 32-row chunks of m double-buffered in LDS as piece images
+template <int WK, int WN, bool CONV, int NP>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg) {
+    constexpr int BK = WK * 64, BN = WN * 64, QA = BK / 4, QG = BN / 4, PA = 32 / (256 / QA), PG = 32 / (256 / QG);
+    constexpr int IA = BK * 32, IG = BN * 32;                       // bf16 elements of one piece image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
+    u16* As = reinterpret_cast<u16*>(smem_x);                       // [2][NP][BK][32]
+    u16* Gs = As + 2 * NP * IA;                                     // [2][NP][BN][32]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int nbn = (a.N + BN - 1) / BN;
+    const int bk = (blockIdx.x / nbn) * BK, bn = (blockIdx.x % nbn) * BN;
+    const int wk = w / WN, wn = w % WN;
+    // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
+    // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channel at the same time)
+    const long m_hi = a.M, step = (long)a.nslices * 32;
+    const long m_lo = (long)blockIdx.y * 32;
+    const int hi = lane >> 5, c = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = zero16();
+    const int qa = tid % QA, ra0 = tid / QA, qg = tid % QG, rg0 = tid / QG;
+    const int kcol = bk + 4 * qa;
+    const bool ka = kcol < a.Kd, na = bn + 4 * qg < a.N;
+    int ky = 0, kx = 0, cl = 0;
+    if (CONV) { const int tap = kcol / cg.Cl; cl = kcol - tap * cg.Cl; ky = tap / 5; kx = tap - ky * 5; }
+    const int PP = cg.Ps * cg.Ps;
+    const int ps_sh = (CONV && cg.Ps > 0 && (cg.Ps & (cg.Ps - 1)) == 0) ? __ffs(cg.Ps) - 1 : -1;
+    // two register stages: the chunk after next is already in flight while the current one is multiplied (the contraction is short
+    // now -- 24 bf16 MFMAs per wave and chunk -- so one chunk in flight per workgroup left the kernel waiting on HBM latency)
+    float4 raA[PA], rgA[PG], raB[PA], rgB[PG];
+    auto gload = [&](float4 (&ra)[PA], float4 (&rg)[PG], long m0) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const long m = m0 + PA * ra0 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi && ka) {
+                if (CONV) {
+                    long n; int p, py, px;                       // (sample, small-grid pixel) of row m
+                    if (ps_sh >= 0) { n = m >> (2 * ps_sh); p = (int)(m & (PP - 1)); py = p >> ps_sh; px = p & (cg.Ps - 1); }
+                    else { n = m / PP; p = (int)(m - n * PP); py = p / cg.Ps; px = p - py * cg.Ps; }
+                    const int qy = cg.stride * py + ky - cg.pad, qx = cg.stride * px + kx - cg.pad;
+                    if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
+                        v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
+                } else {
+                    v = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + kcol);
+                    if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const long m = m0 + PG * rg0 + j;
+            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)m * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf, const float4 (&ra)[PA], const float4 (&rg)[PG]) {
+        put_rows<BK, PA, NP>(As + buf * NP * IA, IA, 4 * qa, ra0, ra);
+        put_rows<BN, PG, NP>(Gs + buf * NP * IG, IG, 4 * qg, rg0, rg);
+    };
+    // block-sparse A (a.flags): only chunks with a set flag bit inside this workgroup's k-block are visited.  The scan looks 64 chunks
+    // ahead at a time (lane = chunk: the OR of its 32 flag words), so its memory latency is paid once per 2 MB of operands
+    unsigned long long kmask = ~0ull;
+    if (a.flags) {
+        const int b_lo = bk / a.fcols, b_hi = min((bk + BK - 1) / a.fcols, 63);
+        kmask = (b_hi - b_lo >= 63) ? ~0ull : (((1ull << (b_hi - b_lo + 1)) - 1ull) << b_lo);
+    }
+    long grp = -1;                                         // 64-chunk group (of this slice's sequence) the live mask belongs to
+    unsigned long long live = 0ull;
+    auto next_live = [&](long m0) {                        // first chunk of this slice at or after m0 with something in the k-block
+        if (!a.flags) return m0;
+        while (m0 < m_hi) {
+            const long q = (m0 - m_lo) / step;             // position in the slice's sequence
+            if ((q >> 6) != grp) {
+                grp = q >> 6;
+                const long mb = m_lo + ((grp << 6) + lane) * step;
+                unsigned long long f = 0ull;
+                if (mb + 32 <= a.M) {
+                    const uint4* fp = reinterpret_cast<const uint4*>(a.flags + mb);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const uint4 v = fp[i]; f |= ((unsigned long long)(v.y | v.w) << 32) | (v.x | v.z); }
+                } else {
+                    for (long m = mb; m < a.M; ++m) f |= a.flags[m];
+                }
+                f &= kmask;
+                live = __ballot(((unsigned)f | (unsigned)(f >> 32)) != 0u);
+            }
+            const unsigned long long rest = live >> (q & 63);
+            if (rest) return m0 + step * (long)(__ffsll((long long)rest) - 1);
+            m0 = m_lo + ((grp + 1) << 6) * step;
+        }
+        return m0;
+    };
+    const bool mine = bk + wk * 64 < a.Kd && bn + wn * 64 < a.N;       // a wave whose whole strip lies past Kd / N has only zeros to multiply
+    auto compute = [&](int buf) {
+        if (!mine) return;
+        const u16* ab = As + buf * NP * IA;
+        const u16* gb = Gs + buf * NP * IG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 af[2][NP], gf[2][NP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    af[u][i] = get_frag<BK>(ab + i * IA, wk * 64 + 32 * u + c, 2 * kb + hi);
+                    gf[u][i] = get_frag<BN>(gb + i * IG, wn * 64 + 32 * u + c, 2 * kb + hi);
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) acc[u][v] = mfma_xp<NP>(af[u], gf[v], acc[u][v]);
+        }
+    };
+    // at the loop top: LDS[buf] holds chunk mA, stage B holds chunk mB, stage A holds chunk mC (each only if < m_hi)
+    long mA = next_live(m_lo);
+    if (mA < m_hi) gload(raA, rgA, mA);
+    long mB = mA < m_hi ? next_live(mA + step) : m_hi;
+    if (mB < m_hi) gload(raB, rgB, mB);
+    if (mA < m_hi) lstore(0, raA, rgA);
+    long mC = mB < m_hi ? next_live(mB + step) : m_hi;
+    if (mC < m_hi) gload(raA, rgA, mC);
+    __syncthreads();
+    int buf = 0;
+    while (mA < m_hi) {
+        compute(buf);
+        if (mB < m_hi) lstore(buf ^ 1, raB, rgB);
+        __syncthreads();
+        buf ^= 1;
+        long mD = mC < m_hi ? next_live(mC + step) : m_hi;
+        if (mD < m_hi) gload(raB, rgB, mD);
+        mA = mB; mB = mC; mC = mD;
+        if (!(mA < m_hi)) break;
+        compute(buf);
+        if (mB < m_hi) lstore(buf ^ 1, raA, rgA);
+        __syncthreads();
+        buf ^= 1;
+        mD = mC < m_hi ? next_live(mC + step) : m_hi;
+        if (mD < m_hi) gload(raA, rgA, mD);
+        mA = mB; mB = mC; mC = mD;
+    }
+    float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = bk + wk * 64 + 32 * u + acc_row(i), n = bn + wn * 64 + 32 * v + c;
+                if (k < a.Kd && n < a.N) out[(size_t)k * a.N + n] = acc[u][v][i];
+            }
+}
+
+template <int WK, int WN, bool CONV>
+void launch_t(const TnArgs& a, const ConvGather& cg, int nblocks, hipStream_t s) {
+    constexpr int NP = 2;
+    const size_t lds = (size_t)2 * NP * (WK + WN) * 64 * 32 * sizeof(u16);
+    allow_big_lds(k_gemm_tn2_xp<WK, WN, CONV, NP>);
+    hipLaunchKernelGGL((k_gemm_tn2_xp<WK, WN, CONV, NP>), dim3(nblocks, a.nslices), dim3(256), lds, s, a, cg);
+}
+
+}  // namespace
+
+// the partial-tile stage of launch_gemm_tn / launch_conv_wgrad's "big" forms with split operands (the slice reduction stays the caller's)
+void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n, hipStream_t s) {
+    if (narrow_n) {
+        const int nb = (a.Kd + 255) / 256;
+        if (cg) launch_t<4, 1, true>(a, *cg, nb, s); else launch_t<4, 1, false>(a, ConvGather{}, nb, s);
+    } else {
+        const int nb = ((a.Kd + 127) / 128) * ((a.N + 127) / 128);
+        if (cg) launch_t<2, 2, true>(a, *cg, nb, s); else launch_t<2, 2, false>(a, ConvGather{}, nb, s);
+    }
+}

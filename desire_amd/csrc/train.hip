@@ -22,6 +22,7 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
         int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0) {
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
+    a.np = h->d.bf16 == 2 ? 2 : 0;
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
     long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
@@ -501,6 +502,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_conv1(c, s);
         if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
         ConvWgradArgs wg{};
+        wg.np = h->d.bf16 == 2 ? 2 : 0;
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
@@ -539,6 +541,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_gemm_rows(g, EPI_ELUGRAD, s);
         const int NSL = A >= 2048 ? 64 : (A >= 256 ? 16 : 4);
         ConvWgradArgs wg{};
+        wg.np = h->d.bf16 == 2 ? 2 : 0;
         wg.n = A; wg.partial = W(h, "tn_partial");
         wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv3/w"), s);
