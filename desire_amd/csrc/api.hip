@@ -407,6 +407,19 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pv.begin(), pv.end());
         }
         bad |= up_split("ioc/Wsoc16", all);
+        if (d.bf16 == 2) {   // training under dims.bf16 = 2: the two large data-gradient convolutions of the CVAE decoder (kernels_bwd_x3.hip)
+            auto taps16 = [&](const std::vector<float>& wt, int CI, int CO) {       // as pack_taps(.., false): w[tap][ci][co]
+                std::vector<float> out;
+                for (int tap = 0; tap < 25; ++tap) {
+                    const float* base = wt.data() + (size_t)tap * CI * CO;
+                    const auto pv = pack_vals16(CI, CO, lin, [&](int k, int n) { return base[(size_t)k * CO + n]; });
+                    out.insert(out.end(), pv.begin(), pv.end());
+                }
+                return out;
+            };
+            bad |= up_split("vae_dec/deconv3/Wbwd16", taps16(hw["vae_dec/deconv3/w"], 32, 64));
+            bad |= up_split("vae_dec/deconv2/Wbwd16", taps16(hw["vae_dec/deconv2/w"], 64, 128));
+        }
         if (d.bf16 == 3) {   // three-piece packs of the sample-generation kernels (kernels_x6.hip): decoder h-blocks, deconv2 / deconv3 taps
             const auto& dg = hw["dec/gates/kernel"]; const auto& dc = hw["dec/candidate/kernel"];
             bad |= up_split("dec/Whg6", pack_vals16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }));

@@ -46,6 +46,8 @@ struct ConvArgs {
 };
 void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
 void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
+void launch_conv2_x3(const ConvArgs& a, hipStream_t s);  // same with split-bf16 operands (kernels_bwd_x3.hip; a.Wp = [hi | lo] pack)
+void launch_conv3_x3(const ConvArgs& a, hipStream_t s);  // [n,8,8,64] -> [n,4,4,128]
 void launch_conv3(const ConvArgs& a, hipStream_t s);     // [n,8,8,64]   -> [n,4,4,128]
 void launch_deconv2(const ConvArgs& a, hipStream_t s);   // [n,4,4,128]  -> [n,8,8,64]
 void launch_deconv3(const ConvArgs& a, hipStream_t s);   // [n,8,8,64]   -> [n,16,16,32]

@@ -492,12 +492,13 @@ __global__ __launch_bounds__(256) void k_colsum4(const float* __restrict__ G, in
     __shared__ float4 red[256];
     const int VN = N >> 2, RP = 256 / VN;
     const int cv = threadIdx.x % VN, ro = threadIdx.x / VN;
-    const long mper = (M + nslices - 1) / nslices;
-    const long lo = (long)blockIdx.x * mper, hi = min(M, lo + mper);
+    // slice = every nslices-th group of 4 RP rows (neighbouring workgroups read neighbouring rows: contiguous ranges per slice start
+    // megabytes apart and meet in the same HBM channels)
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     const float* base = G + 4 * cv;
-    long m = lo + ro;
-    for (; m + 3 * RP < hi; m += 4 * RP) {
+    const long stride = (long)nslices * 4 * RP;
+    long m = (long)blockIdx.x * 4 * RP + ro;
+    for (; m + 3 * RP < M; m += stride) {
         const float4 x0 = *reinterpret_cast<const float4*>(base + (size_t)m * ldg);
         const float4 x1 = *reinterpret_cast<const float4*>(base + (size_t)(m + RP) * ldg);
         const float4 x2 = *reinterpret_cast<const float4*>(base + (size_t)(m + 2 * RP) * ldg);
@@ -507,10 +508,11 @@ __global__ __launch_bounds__(256) void k_colsum4(const float* __restrict__ G, in
         s2.x += x2.x; s2.y += x2.y; s2.z += x2.z; s2.w += x2.w;
         s3.x += x3.x; s3.y += x3.y; s3.z += x3.z; s3.w += x3.w;
     }
-    for (; m < hi; m += RP) {
-        const float4 x0 = *reinterpret_cast<const float4*>(base + (size_t)m * ldg);
-        s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
-    }
+    for (int j = 0; j < 3; ++j)                                       // the ragged last group (at most one slice reaches it)
+        if (m + j * RP < M) {
+            const float4 x0 = *reinterpret_cast<const float4*>(base + (size_t)(m + j * RP) * ldg);
+            s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+        }
     s0.x = (s0.x + s1.x) + (s2.x + s3.x); s0.y = (s0.y + s1.y) + (s2.y + s3.y);
     s0.z = (s0.z + s1.z) + (s2.z + s3.z); s0.w = (s0.w + s1.w) + (s2.w + s3.w);
     red[threadIdx.x] = s0;

@@ -229,3 +229,109 @@ void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n,
         if (cg) launch_t<2, 2, true>(a, *cg, nb, s); else launch_t<2, 2, false>(a, ConvGather{}, nb, s);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Data-gradient convolutions of the CVAE decoder (k_conv_gather with the layers' roles swapped) with split operands: the
+// input image is split ONCE when it is staged ([pixel][CI] bf16 images of hi and lo in LDS), so every A fragment is a single
+// 16-byte LDS read per piece; weights are [hi | lo] packs in bf16-MFMA fragment order per tap ("*/Wbwd16").  A wave owns MT
+// row blocks of 32 output pixels x one 32-channel n-tile; every weight fragment feeds all MT blocks.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int CI, int IW, int OW, int STRIDE, int PAD, int CO, int SPW>
+__global__ __launch_bounds__(256, 2) void k_conv_gather_x3(ConvArgs a) {
+    constexpr int PIX = OW * OW, ROWS = SPW * PIX, LDB = CI + 8, NT = CO / 32, G16 = CI / 16;
+    constexpr int WM = 4 / NT, MT = ROWS / (32 * WM);                 // waves along m; row blocks per wave
+    static_assert(NT == 2 || NT == 4, "n-tiles per workgroup");
+    static_assert(ROWS % (32 * WM) == 0, "rows per workgroup");
+    constexpr int NPX = SPW * IW * IW, IMG = (NPX + 1) * LDB;         // + one zero pixel for taps outside the image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+    u16* img = reinterpret_cast<u16*>(smem_c);                        // [2 pieces][NPX + 1][LDB]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * SPW;
+    // position of pixel (y, x) of a sample's image.  Stride 2: the four parity classes are stored as separate (IW/2)^2 sub-images -- a tap
+    // reads ONE class, so the lanes of a fragment read (ox, oy)-consecutive pixels LDB apart (80 / 144 bytes: conflict-free 16-byte
+    // reads) instead of every second pixel (160 bytes apart: 8 lanes per bank group)
+    auto pos = [](int y, int x) {
+        if (STRIDE == 2) return (((y & 1) * 2 + (x & 1)) * (IW / 2) + (y >> 1)) * (IW / 2) + (x >> 1);
+        return y * IW + x;
+    };
+    for (int i = tid; i < LDB; i += 256) { img[NPX * LDB + i] = 0; img[IMG + NPX * LDB + i] = 0; }
+    constexpr int Q = CI / 4;
+    for (int i = tid; i < NPX * Q; i += 256) {
+        const int pix = i / Q, c4 = i - pix * Q;
+        const int ls = pix / (IW * IW), pp = pix - ls * IW * IW;
+        const int smp = s0 + ls;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * IW * IW + pix) * CI + c4 * 4);
+        unsigned p0[2], p1[2];
+        splitp<2>(v.x, v.y, p0); splitp<2>(v.z, v.w, p1);
+        const int at = (ls * IW * IW + pos(pp / IW, pp % IW)) * LDB + c4 * 4;
+        *reinterpret_cast<uint2*>(img + at) = make_uint2(p0[0], p1[0]);
+        *reinterpret_cast<uint2*>(img + IMG + at) = make_uint2(p0[1], p1[1]);
+    }
+    __syncthreads();
+    const int nt = w % NT, mt0 = (w / NT) * MT;
+    const int hi = lane >> 5;
+    f32x16 acc[MT];
+    int oy[MT], ox[MT], sm[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc[m] = zero16();
+        const int r = (mt0 + m) * 32 + (lane & 31);
+        sm[m] = r / PIX;
+        const int q = r - sm[m] * PIX;
+        oy[m] = q / OW;
+        ox[m] = q - oy[m] * OW;
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    constexpr size_t PLO = (size_t)25 * NT * G16 * 64;                 // uint4 from the hi pack to the lo pack
+    const uint4* bl = Wp + ((size_t)nt * G16) * 64 + lane;
+    uint4 b[2][2];
+    b[0][0] = bl[0]; b[0][1] = bl[PLO];
+#pragma unroll 1
+    for (int tap = 0; tap < 25; ++tap) {
+        const int ky = tap / 5, kx = tap - ky * 5;
+        const u16* ap[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
+            const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
+            ap[m] = img + (ok ? sm[m] * IW * IW + pos(iy, ix) : NPX) * LDB + 8 * hi;
+        }
+#pragma unroll
+        for (int g = 0; g < G16; ++g) {
+            // next fragment pair in flight (the last one re-reads the first: harmless)
+            const int nx = (tap * G16 + g + 1 < 25 * G16) ? tap * G16 + g + 1 : 0;
+            const int ntap = nx / G16, ng = nx - ntap * G16;
+            const uint4* nb = bl + ((size_t)ntap * NT * G16 + ng) * 64;
+            b[(g + 1) & 1][0] = nb[0]; b[(g + 1) & 1][1] = nb[PLO];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint4 av[2];
+                av[0] = *reinterpret_cast<const uint4*>(ap[m] + g * 16);
+                av[1] = *reinterpret_cast<const uint4*>(ap[m] + IMG + g * 16);
+                acc[m] = mfma_xp<2>(av, b[g & 1], acc[m]);
+            }
+        }
+    }
+    const int co = nt * 32 + (lane & 31);
+    const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (mt0 + m) * 32 + acc_row(i);
+            const int smp = s0 + r / PIX;
+            if (smp < a.n) { const size_t ix = ((size_t)s0 * PIX + r) * CO + co; a.out[ix] = conv_epilogue(acc[m][i], sc, sh, a.mode, false, a.yprev, ix); }
+        }
+}
+template <int CI, int IW, int OW, int STRIDE, int PAD, int CO, int SPW>
+void launch_cg(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * (SPW * IW * IW + 1) * (CI + 8) * sizeof(u16);
+    allow_big_lds(k_conv_gather_x3<CI, IW, OW, STRIDE, PAD, CO, SPW>);
+    hipLaunchKernelGGL((k_conv_gather_x3<CI, IW, OW, STRIDE, PAD, CO, SPW>), dim3((a.n + SPW - 1) / SPW), dim3(256), lds, s, a);
+}
+}  // namespace
+// a.Wp = the [hi | lo] pack ("vae_dec/deconv3/Wbwd16", "vae_dec/deconv2/Wbwd16")
+void launch_conv2_x3(const ConvArgs& a, hipStream_t s) { launch_cg<32, 16, 8, 2, 1, 64, 1>(a, s); }     // [n,16,16,32] -> [n,8,8,64]
+void launch_conv3_x3(const ConvArgs& a, hipStream_t s) { launch_cg<64, 8, 4, 1, 0, 128, 4>(a, s); }     // [n,8,8,64]  -> [n,4,4,128]

@@ -74,12 +74,20 @@ __global__ __launch_bounds__(DS_WG) void k_conv_gather(ConvArgs a) {
     const int s0 = blockIdx.x * SPW;
     for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
     constexpr int Q = CI / 4;
+    // position of pixel (y, x) in a sample's LDS image.  Stride 2: the four parity classes are kept as separate (IW/2)^2 sub-images -- a tap
+    // reads ONE class, so the lanes of a fragment read neighbouring pixels LDP floats apart (conflict-free 16-byte reads) instead of
+    // every second pixel (2 LDP = 288 bytes apart: eight lanes per bank group, half of the LDS cycles were conflicts)
+    auto pos = [](int y, int x) {
+        if (STRIDE == 2) return (((y & 1) * 2 + (x & 1)) * (IW / 2) + (y >> 1)) * (IW / 2) + (x >> 1);
+        return y * IW + x;
+    };
     for (int i = tid; i < SPW * IW * IW * Q; i += DS_WG) {
         const int pix = i / Q, c4 = i - pix * Q;
-        const int smp = s0 + pix / (IW * IW);
+        const int ls = pix / (IW * IW), pp = pix - ls * IW * IW;
+        const int smp = s0 + ls;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * IW * IW + pix) * CI + c4 * 4);
-        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
+        *reinterpret_cast<float4*>(in_s + (ls * IW * IW + pos(pp / IW, pp % IW)) * LDP + c4 * 4) = v;
     }
     __syncthreads();
     const int nt = (NT == 4) ? w : (w & 1);
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv_gather(ConvArgs a) {
             for (int m = 0; m < MT; ++m) {
                 const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
                 const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
-                ap[m] = (ok ? in_s + ((sm[m] * IW + iy) * IW + ix) * LDP : zero_row) + 4 * (lane >> 5);
+                ap[m] = (ok ? in_s + (sm[m] * IW * IW + pos(iy, ix)) * LDP : zero_row) + 4 * (lane >> 5);
             }
             mma_groups_ptr<MT>(acc, ap, a.Wp + ((size_t)((ky * 5 + kx) * NT + nt) * G) * 64 + lane, G);
         }

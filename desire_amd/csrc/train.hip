@@ -507,16 +507,17 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
         if (!bn1) colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
-        c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, "vae_dec/deconv3/Wbwd");
+        const bool x3 = h->d.bf16 == 2;                  // split-bf16 operands in the two large data-gradient convolutions
+        c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, x3 ? "vae_dec/deconv3/Wbwd16" : "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
-        launch_conv2(c, s);
+        if (x3) launch_conv2_x3(c, s); else launch_conv2(c, s);
         if (bn1) norm_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)R, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0);
         wg.S = W(h, "d1"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "dconv2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv2/w"), s);
         if (!bn1) colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
-        c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, "vae_dec/deconv2/Wbwd");
+        c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, x3 ? "vae_dec/deconv2/Wbwd16" : "vae_dec/deconv2/Wbwd");
         c.scale = D(h, "vae_dec/deconv1/scale"); c.shift = c.scale; c.yprev = W(h, "d1");
-        launch_conv3(c, s);
+        if (x3) launch_conv3_x3(c, s); else launch_conv3(c, s);
         if (bn1) norm_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)R, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0);
         tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, R, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
         if (!bn1) colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
