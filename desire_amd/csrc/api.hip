@@ -417,6 +417,19 @@ int desire_pack_all(desire_ctx* h) {
                 }
                 return out;
             };
+            {   // transposed blocks of the IOC BPTT (k_ioc_bwd_x3): n-tiles [h columns | e_r columns | one e_v tile], B(k', n') = W[row0 + n'][k']
+                const int xr = d.E_v + d.C;
+                bad |= up_split("ioc/WcT16", pack_vals16(H, 2 * H + 32, lin, [&](int k, int n) {
+                    return n < H ? ck[(size_t)(E + n) * H + k] : n < 2 * H ? ck[(size_t)(xr + n - H) * H + k] : (n - 2 * H < d.E_v ? ck[(size_t)(n - 2 * H) * H + k] : 0.f); }));
+                bad |= up_split("ioc/WgT16", pack_vals16(2 * H, 2 * H + 32, lin, [&](int k, int n) {
+                    return n < H ? gk[(size_t)(E + n) * 2 * H + k] : n < 2 * H ? gk[(size_t)(xr + n - H) * 2 * H + k] : (n - 2 * H < d.E_v ? gk[(size_t)(n - 2 * H) * 2 * H + k] : 0.f); }));
+                std::vector<float> allT;
+                for (int b = 0; b < B; ++b) {
+                    const auto pv = pack_vals16(H, H, lin, [&](int k, int n) { return ws[((size_t)b * H + n) * H + k]; });
+                    allT.insert(allT.end(), pv.begin(), pv.end());
+                }
+                bad |= up_split("ioc/WsT16", allT);
+            }
             bad |= up_split("vae_dec/deconv3/Wbwd16", taps16(hw["vae_dec/deconv3/w"], 32, 64));
             bad |= up_split("vae_dec/deconv2/Wbwd16", taps16(hw["vae_dec/deconv2/w"], 64, 128));
         }

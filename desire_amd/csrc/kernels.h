@@ -233,5 +233,7 @@ struct IocBwdArgs {
     const float* bin_tab;
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);
+bool ioc_bwd_x3_supported(int mno, int H);                       // kernels_bwd_x3.hip: groups of up to 32 agents, H = 64 / 128
+void launch_ioc_bwd_x3(const IocBwdArgs& a, hipStream_t s);      // a.WcT_h / a.WgT_h / a.WsT = the [hi | lo] packs "ioc/W?T16"
 // cluster form (kernels_bwd_cl.hip): groups of 64 / 96 / 128 agents, H <= 128, <= 16 bins; grp_cnt zeroed per launch; != 0: shape not served
 int launch_ioc_bwd_cluster(const IocBwdArgs& a, int* grp_cnt, int* err, hipStream_t s);

@@ -335,3 +335,306 @@ void launch_cg(const ConvArgs& a, hipStream_t s) {
 // a.Wp = the [hi | lo] pack ("vae_dec/deconv3/Wbwd16", "vae_dec/deconv2/Wbwd16")
 void launch_conv2_x3(const ConvArgs& a, hipStream_t s) { launch_cg<32, 16, 8, 2, 1, 64, 1>(a, s); }     // [n,16,16,32] -> [n,8,8,64]
 void launch_conv3_x3(const ConvArgs& a, hipStream_t s) { launch_cg<64, 8, 4, 1, 0, 128, 4>(a, s); }     // [n,8,8,64]  -> [n,4,4,128]
+
+// ------------------------------------------------------------------------------------------------------------------
+// IOC BPTT with split operands (k_ioc_bwd of kernels_bwd.hip, groups of up to 32 agents): the gate-gradient tiles da_c, da_r | da_u and
+// dpre_r are written as [hi | lo] bf16 images by the lanes that produce them (same LDS bytes as the fp32 tiles they replace), so every
+// data-gradient contraction reads single 16-byte fragments per piece and runs as three bf16 MFMAs per fp32 product.  The row-compacted
+// dpool of the fp32 kernel is gone: the dense 32-row contraction per bin costs 24 bf16 MFMAs per wave, less than one packed chunk did.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4v_x __attribute__((ext_vector_type(4)));
+template <int TM> struct BwdMask { typedef unsigned long long type; };
+template <> struct BwdMask<32> { typedef unsigned type; };
+__device__ __forceinline__ int ffsm(unsigned m) { return __ffs((int)m); }
+__device__ __forceinline__ void mma1b(f32x16& acc, const float* a_lane, const float4* __restrict__ b_lane, int G) {
+    f32x16 t[1] = {acc};
+    mma_groups<1>(t, a_lane, 0, b_lane, G);
+    acc = t[0];
+}
+namespace {
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32;
+    constexpr int NT = H / 32, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
+    typedef typename BwdMask<TM>::type mask_t;
+    constexpr int E = EV + C + H, LD1 = H + 4, LDB1 = H + 8, LDB2 = 2 * H + 8, G16 = H / 16, G32 = 2 * H / 16;
+    constexpr int ILO1 = TM * LDB1, ILO2 = TM * LDB2;                      // bf16 elements from the hi image to the lo image
+    const int B = a.G * a.G;
+    const int KR = (2 * a.T + 7) / 8 * 8, LDR = KR + 4;                   // regression-head operand width
+    // LDS (73 KB at H = 128, so two workgroups share a CU).  The MFMA operands live as [hi | lo] bf16 images (same bytes as an fp32 tile):
+    float* A1 = smem;                         // [32][LD1]  fp32: h_{t-1} (part 1, pooled rebuild);  then the neighbour gradient
+    float* A2 = A1 + TM * LD1;                // images [2][32][LDB2] of da_r | da_u;  then dpool_b (fp32 [32][LD1]), double buffered
+    u16* I2 = reinterpret_cast<u16*>(A2);
+    u16* I3 = reinterpret_cast<u16*>(A2 + 2 * TM * LD1);              // images [2][32][LDB1]: da_c (part 1), then dpre_r (part 2, bins)
+    float* DP = A2, *HP = A1, *NB = A1;
+    mask_t* masks = reinterpret_cast<mask_t*>(I3 + 2 * ILO1);         // [TM][B] neighbours of i in bin b (bit = slot)
+    mask_t* obs = masks + TM * B;                                     // [TM][B] observers of j in bin b
+    float* pc = reinterpret_cast<float*>(obs + TM * B);   // [32][2]
+    float* dsc = pc + TM * 2;                 // [32]
+    float* wsc = dsc + TM;                    // [H]
+    unsigned char* vld = reinterpret_cast<unsigned char*>(wsc + H);   // [32]
+    unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);            // [2] bins that hold a neighbour anywhere in the tile
+    float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
+
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int cb = w % NT, mt = w / NT;
+    const int row0 = blockIdx.x * TM;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
+    const u16* a2_lane = I2 + (lane & 31) * LDB2 + 8 * (lane >> 5);
+    const u16* a3_lane = I3 + (lane & 31) * LDB1 + 8 * (lane >> 5);
+    // four values of one accumulator column run (rows rofs + 8q + 0..3 of column c) -> both piece images of a row-major bf16 tile
+    auto put4 = [&](u16* img, int ld, int ilo, int c, int q, float v0, float v1, float v2, float v3) {
+        unsigned pa[2], pb[2];
+        splitp<2>(v0, v1, pa);
+        splitp<2>(v2, v3, pb);
+        u16* x = img + (4 * (lane >> 5) + 8 * q) * ld + c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            x[i * ilo] = (u16)pa[i]; x[i * ilo + ld] = (u16)(pa[i] >> 16); x[i * ilo + 2 * ld] = (u16)pb[i]; x[i * ilo + 3 * ld] = (u16)(pb[i] >> 16);
+        }
+    };
+    // weight packs: [hi | lo], n-tiles [h columns | e_r columns | e_v tile] (api.hip: "ioc/WcT16", "ioc/WgT16"), per-bin blocks ("ioc/WsT16")
+    const uint4* WcT = reinterpret_cast<const uint4*>(a.WcT_h);
+    const uint4* WgT = reinterpret_cast<const uint4*>(a.WgT_h);
+    const uint4* WsT = reinterpret_cast<const uint4*>(a.WsT);
+    constexpr size_t PLC = (size_t)(2 * NT + 1) * G16 * 64, PLG = (size_t)(2 * NT + 1) * G32 * 64;
+    const size_t PLS = (size_t)B * NT * G16 * 64;
+    const uint4* bc2[2] = {WcT + ((size_t)cb * G16) * 64 + lane, WcT + ((size_t)(NT + cb) * G16) * 64 + lane};
+    const uint4* bcv[1] = {WcT + ((size_t)(2 * NT) * G16) * 64 + lane};
+    const uint4* bg2[2] = {WgT + ((size_t)cb * G32) * 64 + lane, WgT + ((size_t)(NT + cb) * G32) * 64 + lane};
+    const uint4* bgv[1] = {WgT + ((size_t)(2 * NT) * G32) * 64 + lane};
+    const int rofs = mt * 32 + 4 * (lane >> 5);   // + (i&3) + 8*(i>>2) = local row of accumulator element i
+    auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
+    // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
+    const int nloc = min(TM, a.R - row0);
+    int nlv = nloc;                                        // re-defined opaquely per step (see k_decoder_bwd)
+    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nlv - 1) * a.T + t); };   // (local row, t) index
+    const size_t tb = (size_t)row0 * a.T;
+    const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
+    const float* svx = a.sv_x + tb * E;
+    float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
+    float* o_dpr = a.dpre_r + tb * H; float* o_dpv = a.dpre_v + tb * EV;
+
+    for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
+    if (tid < TM) {
+        const int row = min(row0 + tid, a.R - 1);
+        vld[tid] = a.valid[agent_of_row(row, a.K, a.mno)];
+        dsc[tid] = (row0 + tid < a.R) ? a.dscore[row] : 0.f;
+    }
+    for (int i = tid; i < TM * KR; i += NTHR) {
+        const int r = i / KR, c = i - r * KR;
+        DR[r * LDR + c] = (c < 2 * a.T && row0 + r < a.R) ? a.dYr[(size_t)(row0 + r) * 2 * a.T + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 dh = zero16();
+    mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
+        __syncthreads();
+        // ---- P0: positions, cleared masks, h_{t-1} tile ----
+        if (tid < TM) {
+            const int row = min(row0 + tid, a.R - 1);
+            const float2 y = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t) * 2);
+            pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
+            float2 pv;
+            if (t > 0) pv = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t - 1) * 2);
+            else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
+            if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
+        }
+        for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
+        if (tid < 2) occ[tid] = 0;
+        auto load_hprev = [&]() {                                              // h_{t-1} tile -> A1's space
+            for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+                const int row = min(row0 + r, a.R - 1);
+                const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
+                                           : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
+                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+            }
+        };
+        load_hprev();                                    // part 1 reads each element, then overwrites it with da_c
+        __syncthreads();
+        // ---- P1: neighbour / observer masks ----
+        {
+            const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
+            for (int j = q8; j < a.mno; j += TPR) {
+                if (j == my_slot || !vld[grp_base + j]) continue;
+                const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
+                if (b >= 0) {
+                    atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
+                    atomicOr(&obs[(grp_base + j) * B + b], (mask_t)1 << my_slot);
+                    atomicOr(&occ[b >> 5], 1u << (b & 31));
+                }
+            }
+        }
+        // ---- GRU cell backward, part 1 ----
+        if (a.pool_flags && q8 == 0 && row0 + r8 < a.R) {      // which bins of this (row, t) hold a neighbour: the weight-gradient
+            unsigned long long fl = 0ull;                       // GEMM skips the all-zero blocks of the pooled operand
+            for (int b = 0; b < B; ++b) fl |= (unsigned long long)(masks[r8 * B + b] != 0) << b;
+            a.pool_flags[(size_t)my_row * a.T + t] = fl;
+        }
+        f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dacv[4], dauv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e;
+                const int rl = rofs + (i & 3) + 8 * (i >> 2);
+                const unsigned ix = tl(i, t) * H + col;
+                const float u = svu[ix], c = svc[ix], r = svr[ix];
+                const float hprev = A1[rl * LD1 + col];
+                const float dht = dh[i] + dsc[rl] * wsc[col];
+                const float dau = dht * (hprev - c) * u * (1.0f - u);
+                const float dc = dht * (1.0f - u);
+                dhp[i] = dht * u;
+                const float dac = dc * (1.0f - c * c);
+                dacv[e] = dac; dauv[e] = dau;
+                if (row0 + rl < a.R) {
+                    o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
+                    o_dag[tl(i, t) * 2 * H + H + col] = dau;
+                }
+                rr[i] = r; hp[i] = hprev;
+            }
+            put4(I3, LDB1, ILO1, col, q, dacv[0], dacv[1], dacv[2], dacv[3]);
+            put4(I2, LDB2, ILO2, H + col, q, dauv[0], dauv[1], dauv[2], dauv[3]);      // (the dpool tiles that share A2 were last read before the step's barrier)
+        }
+        __syncthreads();
+        f32x16 dev = zero16(), der;
+        {
+            f32x16 t2[2] = {zero16(), zero16()};                  // drh | de_r, one pass over the da_c fragments
+            mmax_groups<2, 2>(t2, a3_lane, ILO1, bc2, PLC, G16);
+            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2>(tv, a3_lane, ILO1, bcv, PLC, G16); dev = tv[0]; }
+            der = t2[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float darv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    const int rl = rofs + (i & 3) + 8 * (i >> 2);
+                    const float dr = t2[0][i] * hp[i];
+                    dhp[i] += t2[0][i] * rr[i];
+                    const float dar = dr * rr[i] * (1.0f - rr[i]);
+                    darv[e] = dar;
+                    if (row0 + rl < a.R) o_dag[tl(i, t) * 2 * H + col] = dar;
+                }
+                put4(I2, LDB2, ILO2, col, q, darv[0], darv[1], darv[2], darv[3]);
+            }
+        }
+        __syncthreads();
+        // part 1 has read h_{t-1}: reload it for the pooled rebuild (visible after the next barrier); da_c is consumed, its images take dpre_r
+        load_hprev();
+        {
+            f32x16 t2[2] = {zero16(), der};                       // dh (gates) | de_r
+            mmax_groups<2, 2>(t2, a2_lane, ILO2, bg2, PLG, G32);
+            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2>(tv, a2_lane, ILO2, bgv, PLG, G32); dev = tv[0]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dprv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    const int rl = rofs + (i & 3) + 8 * (i >> 2);
+                    dhp[i] += t2[0][i];
+                    const unsigned ixx = tl(i, t) * E;
+                    const float er = svx[ixx + EV + C + col];
+                    const float dpr = er > 0.f ? t2[1][i] : 0.f;
+                    dprv[e] = dpr;
+                    if (row0 + rl < a.R) {
+                        o_dpr[tl(i, t) * H + col] = dpr;
+                        if (cb == 0 && (lane & 31) < EV) {
+                            const float ev = svx[ixx + (lane & 31)];
+                            o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
+                        }
+                    }
+                }
+                put4(I3, LDB1, ILO1, col, q, dprv[0], dprv[1], dprv[2], dprv[3]);
+            }
+        }
+        __syncthreads();
+        // ---- social pooling backward ----
+        float4 nb[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) nb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // bins without a neighbour anywhere in the tile have dpool_b gathered by nobody: only their (zero) pooled rows are written
+        unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+        om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+        int buf = 0;
+        for (int b = 0; b < B; ++b) {
+            const bool live = (om >> b) & 1ull;
+            {   // pooled_b[i] = sum_{j in bin b of i} h_{t-1}[j]  -> HBM (operand of the social-fc weight gradient)
+                float4 s[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                mask_t m2 = masks[r8 * B + b];
+                while (m2) {
+                    const int j = ffsm(m2) - 1;
+                    m2 &= m2 - 1;
+                    const float* src = HP + (grp_base + j) * LD1 + q8 * 4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
+                        s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                    }
+                }
+                if (row0 + r8 < a.R && (!a.pool_flags || masks[r8 * B + b] != 0)) {     // (flagged-empty blocks are never read)
+                    float* dst = a.pooled + (((size_t)my_row * a.T + t) * B + b) * H + q8 * 4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
+                }
+            }
+            if (!live) continue;
+            float* dp = DP + buf * TM * LD1;
+            buf ^= 1;
+            {
+                f32x16 dpl[1] = {zero16()};
+                const uint4* bs[1] = {WsT + ((size_t)(b * NT + cb) * G16) * 64 + lane};
+                mmax_groups<1, 2>(dpl, a3_lane, ILO1, bs, PLS, G16);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[0][i];
+            }
+            __syncthreads();
+            mask_t m2 = obs[r8 * B + b];
+            while (m2) {
+                const int i2 = ffsm(m2) - 1;
+                m2 &= m2 - 1;
+                const int srow = grp_base + i2;
+                const float* src = dp + srow * LD1 + q8 * 4;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
+                    nb[c].x += v.x; nb[c].y += v.y; nb[c].z += v.z; nb[c].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(NB + r8 * LD1 + q8 * 4 + c * 4 * TPR) = nb[c];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (row0 + rofs + (i & 3) + 8 * (i >> 2) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
+}
+
+template <int H>
+void launch_ioc_bwd_x3_t(const IocBwdArgs& a, hipStream_t s) {
+    const int B = a.G * a.G;
+    const size_t lds = (size_t)(32 * (H + 4) * 3) * sizeof(float) + (size_t)2 * 32 * (H + 8) * sizeof(u16) + (size_t)2 * 32 * B * sizeof(unsigned)
+                       + (size_t)(32 * 2 + 32 + H) * sizeof(float) + 32 + 64;
+    allow_big_lds(k_ioc_bwd_x3<H, 16, 32>);
+    hipLaunchKernelGGL((k_ioc_bwd_x3<H, 16, 32>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+}
+}  // namespace
+bool ioc_bwd_x3_supported(int mno, int H) { return mno <= 32 && (H == 128 || H == 64); }
+// a.WcT_h / a.WgT_h / a.WsT = the [hi | lo] packs "ioc/WcT16" / "ioc/WgT16" / "ioc/WsT16"; a.WrT stays the fp32 pack (prologue)
+void launch_ioc_bwd_x3(const IocBwdArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_ioc_bwd_x3_t<128>(a, s); else launch_ioc_bwd_x3_t<64>(a, s);
+}

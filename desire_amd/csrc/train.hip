@@ -451,6 +451,9 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                 if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
                 if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
                     return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
+            } else if (d.bf16 == 2 && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
+                q.WcT_h = D4(h, "ioc/WcT16"); q.WgT_h = D4(h, "ioc/WgT16"); q.WsT = D4(h, "ioc/WsT16");
+                launch_ioc_bwd_x3(q, s);
             } else
             launch_ioc_bwd(q, s);
             tn(h, sv_h + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, acc, s);
