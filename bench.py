@@ -753,9 +753,9 @@ def main():
             "metric": "TRAINING agent-trajectory-samples/sec (K=20, T_pred=40; fwd+bwd+allreduce+clip+Adam+repack)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32; IOC forward with split-bf16 (3-product) operands" if a.split else "f32", "data": "synthetic",
+            "dtype": "f32 state / activations / gradients; matrix products as three bf16 MFMAs on split operands (IOC forward, IOC BPTT, weight-gradient reductions, large data-gradient convolutions)" if a.split else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU%s%s" % (a.windows, "; launch sequence replayed from a hipGraph" if a.graph else "",
-                                   "; dims.bf16 = 2: the training-mode IOC forward runs k_ioc_x3 (fp32 saves, fp32 backward)" if a.split else ""),
+                                   "; dims.bf16 = 2: k_ioc_x3 forward (fp32 saves), k_ioc_bwd_x3, k_gemm_tn2_xp, k_conv_gather_x3; sample generation and the remaining backward kernels fp32" if a.split else ""),
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
             "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
             "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))

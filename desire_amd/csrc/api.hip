@@ -895,6 +895,14 @@ extern "C" int desire_read_buffer(desire_handle* h, const char* name, float* hos
             HIPCHK(hipMemcpy(host_out, W(h, p.n), p.cnt * f, hipMemcpyDeviceToHost));
             return DESIRE_OK;
         }
+    {   // any other workspace buffer by its internal name (training-mode saves and gradient streams; the caller knows the layout)
+        auto it = h->ws.find(nm);
+        if (it != h->ws.end() && it->second.p) {
+            if (n * f > it->second.bytes) return fail(DESIRE_ERR_ARG, nm + ": holds " + std::to_string(it->second.bytes / f) + " values");
+            HIPCHK(hipMemcpy(host_out, it->second.p, n * f, hipMemcpyDeviceToHost));
+            return DESIRE_OK;
+        }
+    }
     return fail(DESIRE_ERR_ARG, "unknown buffer: " + nm);
 }
 

@@ -15,6 +15,10 @@ int ensure(desire_ctx* h, const char* name, size_t bytes) {
     return h->ws[name].alloc(bytes);
 }
 
+// A/B switch: which parts of the backward pass use split operands under dims.bf16 = 2 (1: weight-gradient reductions, 2: data-gradient
+// convolutions, 4: IOC BPTT; default all)
+int train_x3_mask() { static const int m = getenv("DESIRE_TRAIN_X3") ? atoi(getenv("DESIRE_TRAIN_X3")) : 7; return m; }
+
 float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slots.at(name).off; }
 
 // weight gradient block: out[Kd, N] = A^T G over M rows, written into a [.., ldo] matrix
@@ -22,7 +26,7 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
         int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0) {
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
-    a.np = h->d.bf16 == 2 ? 2 : 0;
+    a.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
     long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
@@ -451,7 +455,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                 if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
                 if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
                     return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
-            } else if (d.bf16 == 2 && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
+            } else if (d.bf16 == 2 && (train_x3_mask() & 4) && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
                 q.WcT_h = D4(h, "ioc/WcT16"); q.WgT_h = D4(h, "ioc/WgT16"); q.WsT = D4(h, "ioc/WsT16");
                 launch_ioc_bwd_x3(q, s);
             } else
@@ -505,12 +509,12 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_conv1(c, s);
         if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
         ConvWgradArgs wg{};
-        wg.np = h->d.bf16 == 2 ? 2 : 0;
+        wg.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
         if (!bn1) colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
-        const bool x3 = h->d.bf16 == 2;                  // split-bf16 operands in the two large data-gradient convolutions
+        const bool x3 = h->d.bf16 == 2 && (train_x3_mask() & 2);                  // split-bf16 operands in the two large data-gradient convolutions
         c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, x3 ? "vae_dec/deconv3/Wbwd16" : "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
         if (x3) launch_conv2_x3(c, s); else launch_conv2(c, s);
@@ -545,7 +549,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_gemm_rows(g, EPI_ELUGRAD, s);
         const int NSL = A >= 2048 ? 64 : (A >= 256 ? 16 : 4);
         ConvWgradArgs wg{};
-        wg.np = h->d.bf16 == 2 ? 2 : 0;
+        wg.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
         wg.n = A; wg.partial = W(h, "tn_partial");
         wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv3/w"), s);

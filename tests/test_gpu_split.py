@@ -95,9 +95,63 @@ def test_shapes_without_a_split_kernel_run_the_fp32_kernels(torch_cuda):
     assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_scenes=2, mno=32, K=3, T_obs=6, T_pred=7, n_grids=1),                       # the fixture of tests/test_gpu_train.py
+    dict(n_scenes=3, mno=16, K=5, T_obs=6, T_pred=7, n_grids=1),                       # two groups per tile, ragged last tile
+    dict(n_scenes=2, mno=32, K=2, T_obs=6, T_pred=6, n_grids=1, H=64, case_seed=44),   # the 64-wide instantiations
+    dict(n_scenes=2, mno=32, K=2, T_obs=6, T_pred=6, n_grids=1, grid_size=6, nb_w=0.5, nb_h=0.5),    # 36 bins
+    dict(n_scenes=2, mno=32, K=2, T_obs=6, T_pred=6, n_grids=1, iters=2),              # two refinement passes accumulate
+])
+def test_every_weight_gradient_under_split_operands(torch_cuda, kw):
+    """the training step under dims.bf16 = 2 -- IOC forward, IOC BPTT (k_ioc_bwd_x3), every large weight-gradient
+    reduction (k_gemm_tn2_xp) and the two large data-gradient convolutions (k_conv_gather_x3) with split-bf16 operands -- against
+    float64 autograd of the oracle, every one of the 46 weight gradients inside the fp32 training tests' own 2e-4.
+    (The loss is only piecewise smooth: an e_r pre-activation within the split forward's ~3e-6 of the ReLU kink takes the other branch
+    than float64 does and changes dpre_r by a whole term -- seed 42 of the 64-wide case has one such element at (row 17, t 3, column 42),
+    with the backward pass entirely fp32 as well; its case uses another seed.  tests/fuzz_train.py moves such points off the kink.)"""
+    kw = dict(kw)
+    case_seed = kw.pop("case_seed", 42)
+    from desire_amd import _lib
+    from oracle import desire_torch as OT
+    from tests.helpers import to_oracle_layout
+    from tests.test_gpu_train import DONE, rel_err
+    torch = torch_cuda
+    d = small_dims(**kw)
+    w = init_weights(d, 41)
+    for k in w:
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    past, fut, eps, grids, gos = make_case(d, seed=case_seed, n_absent=min(4, d.mno - 1))
+    _, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
+    h = _lib.Handle(d.replace(bf16=2)); h.set_weights(w)
+    h.set_scene_grids(g.data_ptr(), gos)
+    h.set_training(True)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+    h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr())
+    h.backward(p.data_ptr(), f.data_ptr(), e.data_ptr())
+    torch.cuda.synchronize()
+    bad = {}
+    for name in DONE:
+        got = h.get_grad(name, w[name].shape)
+        assert np.isfinite(got).all(), name
+        if name == "ioc/score/b":
+            assert np.abs(got).max() < 1e-6
+            continue
+        r = rel_err(got, ref[name])
+        if not r < 2e-4:
+            bad[name] = r
+    h.close()
+    assert not bad, bad
+
+
 def test_split_mode_training(torch_cuda):
-    """dims.bf16 = 2 while training: the IOC forward runs with split operands and keeps fp32 activations, the backward pass is the
-    fp32 one.  Gradients: against float64 autograd inside the training tests' own 2e-4, and within 1e-4 (relative, whole
+    """dims.bf16 = 2 while training: the IOC forward, the IOC BPTT, the weight-gradient reductions and the large data-gradient
+    convolutions run with split operands; activations and gradients stay fp32 in HBM.  Gradients: against float64 autograd inside the training tests' own 2e-4, and within 1e-4 (relative, whole
     gradient vector) of the all-fp32 step; an optimiser step refreshes the split packs on the device."""
     from desire_amd import _lib
     from desire_amd.spec import weight_shapes
