@@ -273,6 +273,7 @@ extern "C" int desire_get_bin_table(desire_handle* h, float* host_out20) {
 
 extern "C" int desire_destroy(desire_handle* h) {
     if (!h) return DESIRE_OK;
+    if (h->host_err) { (void)hipHostFree(h->host_err); h->host_err = nullptr; }
     for (auto& kv : h->dev) kv.second.release();
     for (auto& kv : h->ws) kv.second.release();
     for (auto& p : h->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -791,6 +792,31 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
         HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
         a.hex = W(h, "hex"); a.grp_cnt = static_cast<int*>(h->ws["grp_cnt"].p); a.err = static_cast<int*>(h->ws["ioc_err"].p);
+    }
+    // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; DESIRE_IOC_SPLIT=0: off)
+    static const bool no_split = getenv("DESIRE_IOC_SPLIT") && atoi(getenv("DESIRE_IOC_SPLIT")) == 0;
+    if (!cluster && d.bf16 == 0 && !h->training && !no_split && a.variant == 0) {
+        int nspl = ioc_bin_split(h->R, d.mno, d.H, d.grid_size * d.grid_size, d.iters);
+        if (nspl > 1 && getenv("DESIRE_IOC_NSPL")) nspl = std::min(nspl, std::max(1, atoi(getenv("DESIRE_IOC_NSPL"))));    // A/B: cap the split
+        if (nspl > 1) {
+            const size_t tiles = ((size_t)h->R + 31) / 32;
+            if (!h->ws.count("hex_s")) {
+                if (h->ws["hex_s"].alloc(tiles * 2 * 4 * 32 * d.H * sizeof(float)) || h->ws["cnt_s"].alloc(tiles * sizeof(int)))
+                    return fail(DESIRE_ERR_HIP, "hipMalloc failed for the bin-split exchange buffers");
+                // the error word is mapped host memory: no read-back (and no stream synchronisation) per call; a timed-out hand-off is
+                // reported by the NEXT call on this handle
+                if (hipHostMalloc(reinterpret_cast<void**>(&h->host_err), sizeof(int), hipHostMallocMapped) != hipSuccess)
+                    return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the bin-split error word");
+                *h->host_err = 0;
+            }
+            if (*static_cast<volatile int*>(h->host_err)) {
+                *h->host_err = 0;
+                return fail(DESIRE_ERR_HIP, "bin-split IOC hand-off timed out in an earlier call (workgroups of a tile were not co-resident)");
+            }
+            HIPCHK(hipMemsetAsync(h->ws["cnt_s"].p, 0, tiles * sizeof(int), s));
+            a.hex = W(h, "hex_s"); a.grp_cnt = static_cast<int*>(h->ws["cnt_s"].p); a.err = h->host_err;
+            a.nspl = nspl;
+        }
     }
 #ifdef DESIRE_IOC_TIMING
     if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }

@@ -60,6 +60,7 @@ struct desire_ctx {
     const float* grids = nullptr;
     bool grids_set = false;
     bool profiling = false;
+    int* host_err = nullptr;                                 // mapped host word the bin-split IOC's bounded spins report into (checked by the next call)
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;
     // ---- training (train.hip) ----

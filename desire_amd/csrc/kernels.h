@@ -101,6 +101,7 @@ struct IocArgs {
     int variant;                                           // A/B switch, see launch_ioc
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
     float* hex; int* grp_cnt; int* err;                    // cluster form: exchange buffer [2][R][H], group counters, error word
+    int nspl;                                              // > 1: bin-split form of k_ioc (hex = [tiles][2][nspl][32 H], grp_cnt per tile)
     float* sv_x; float* sv_r; float* sv_u; float* sv_c; float* sv_h;   // training saves: [R,T,E], [R,T,H] x4 (32-row form only)
     const float* bin_tab;                                  // log-polar bin table (common.h:neighbor_bin_dev) or nullptr = rectangular grid
 };
@@ -115,6 +116,15 @@ inline bool ioc_uses_cluster(int mno, int H, int bins, int variant) {
         return tile > 160 * 1024;
     }
     return false;
+}
+// Few tiles (a handful of windows): how many workgroups share one 32-row tile's social bins (k_ioc NSPL), so that the launch covers
+// up to 256 CUs instead of one per (scene, k) group.  1 = the plain form.
+inline int ioc_bin_split(int R, int mno, int H, int bins, int iters) {
+    if (mno > 32 || H > 128 || iters != 1) return 1;
+    const int tiles = (R + 31) / 32;
+    for (int n = 4; n >= 2; --n)          // (8 per tile measured no faster than 4: what is left of a step is the part every member repeats)
+        if (tiles * n <= 256 && bins >= n) return n;
+    return 1;
 }
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
 // bf16 cluster form (kernels_bf16_cl.hip): groups of 64 / 96 / 128 agents over mno/32 workgroups; returns != 0 when the

@@ -340,6 +340,7 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 // phases interleave with each other's MFMA phases.
 // neighbour bit-masks: 32 bits are enough when the tile holds 32 rows (mno <= 32), which keeps a 36-bin tile under half
 // the LDS of a CU (two workgroups per CU); 64-row tiles use 64 bits
+#include "cluster.h"
 template <int TM> struct MaskT { typedef unsigned long long type; };
 template <> struct MaskT<32> { typedef unsigned type; };
 __device__ __forceinline__ int ffs_(unsigned m) { return __ffs((int)m); }
@@ -355,7 +356,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // they belong to -- at the bench's density (about a quarter of the rows per bin) that halves the pooling MFMAs and builds a
 // quarter of the operand rows.  Per-bin partial sums are added in ascending bin order (not one running accumulator), so the
 // result differs from the default form by fp32 rounding only.
-template <int H, int EV, int C, int TM, bool TRAIN, bool CP = false>
+// NSPL > 1 ("bin split", few tiles: launch_ioc): NSPL workgroups per tile, on as many CUs.  Member m contracts the social bins b = m
+// (mod NSPL) only, the members add their partial e_r pre-activations through global memory once per step (cluster.h write-through
+// hand-off, fixed member order: every member holds bit-identical state afterwards) and everything else runs redundantly in each of
+// them; member 0 writes the results.  One pass only (a second pass would need member 0's refined Y in every member).
+template <int H, int EV, int C, int TM, bool TRAIN, bool CP = false, int NSPL = 1>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2) ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -383,7 +388,10 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
-    const int row0 = blockIdx.x * TM;
+    const int tile = NSPL > 1 ? (int)blockIdx.x / NSPL : (int)blockIdx.x, member = NSPL > 1 ? (int)blockIdx.x % NSPL : 0;
+    const int row0 = tile * TM;
+    unsigned long long my_bins = ~0ull;
+    if (NSPL > 1) { my_bins = 0ull; for (int b = member; b < 64; b += NSPL) my_bins |= 1ull << b; }
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid / TPR, q8 = tid % TPR;           // TPR threads per row for the VALU phases
@@ -621,6 +629,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 f32x16 soc = zero16();          // biases join after the contraction (a splat start value would pin 16 registers)
                 unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
                 om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+                if (NSPL > 1) om &= my_bins;
                 int buf = 0;
                 if (om) build(ffs_(om) - 1, 0);
                 __syncthreads();
@@ -643,6 +652,32 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     __syncthreads();
                     TICK(5)
                     buf ^= 1;
+                }
+                if constexpr (NSPL > 1) {
+                    // partial sums of this member's bins -> slot [tile][step parity][member]; total = fixed-order sum over the members
+                    const int sidx = it * a.T + t;
+                    float* slot = a.hex + (((size_t)tile * 2 + (sidx & 1)) * NSPL) * (TM * H);
+                    uint2* mine = reinterpret_cast<uint2*>(slot + (size_t)member * TM * H) + (size_t)w * 8 * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) st_agent_u64(mine + q * 64, make_uint2(__float_as_uint(soc[2 * q]), __float_as_uint(soc[2 * q + 1])));
+                    group_publish_wt(a.grp_cnt + tile);
+                    group_wait_wt(a.grp_cnt + tile, NSPL * (sidx + 1), a.err);
+                    f32x16 tot = zero16();
+#pragma unroll
+                    for (int m = 0; m < NSPL; ++m) {
+                        if (m == member) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tot[i] += soc[i];
+                        } else {
+                            const uint2* src = reinterpret_cast<const uint2*>(slot + (size_t)m * TM * H) + (size_t)w * 8 * 64 + lane;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const uint2 v = ld_agent_u64(src + q * 64);
+                                tot[2 * q] += __uint_as_float(v.x); tot[2 * q + 1] += __uint_as_float(v.y);
+                            }
+                        }
+                    }
+                    soc = tot;
                 }
                 if (active) {
 #pragma unroll
@@ -717,7 +752,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             if ((lane & 31) == 0) red[cb * TM + mt * 32 + acc_row(i)] = v;
         }
         __syncthreads();
-        if (tid < TM && row0 + tid < a.R && it == a.iters - 1) {
+        if (tid < TM && row0 + tid < a.R && it == a.iters - 1 && member == 0) {
             float sc = 0.f;
 #pragma unroll
             for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
@@ -733,7 +768,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = row0 + mt * 32 + acc_row(i);
-                    if (row < a.R) {
+                    if (row < a.R && member == 0) {
                         float* y = a.Y + (size_t)row * 2 * a.T + cc;
                         *y = *y + (acc[i] + bb);
                     }
@@ -743,7 +778,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         __syncthreads();
     }
 #ifdef DESIRE_IOC_TIMING
-    if (a.dbg && blockIdx.x == 7 && tid == 0)
+    if (a.dbg && tile == 7 && member == 0 && tid == 0)
         for (int k = 0; k < 10; ++k) a.dbg[k] = tacc[k];
 #endif
 }
@@ -776,6 +811,16 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
             return;
         }
     }
+    if constexpr (TM == 32 && H <= 128) {
+        if (a.nspl > 1) {                                      // few tiles: the social bins of a tile split over nspl workgroups (see k_ioc)
+            const dim3 gs(grid.x * a.nspl);
+            switch (a.nspl) {
+                case 3: allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 3>); hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 3>), gs, block, ioc_lds_bytes(a, TM), s, a); return;
+                case 4: allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 4>); hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 4>), gs, block, ioc_lds_bytes(a, TM), s, a); return;
+                default: allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 2>); hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 2>), gs, block, ioc_lds_bytes(a, TM), s, a); return;
+            }
+        }
+    }
     allow_big_lds(k_ioc<H, 16, 32, TM, false>);
     hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, false>), grid, block, ioc_lds_bytes(a, TM), s, a);
 }
@@ -802,7 +847,6 @@ void launch_ioc(const IocArgs& a, hipStream_t s) {
 // after every group member has published the step in between, i.e. finished reading parity p.
 // Serves mno in {64, 96, 128} (and H = 256 with mno = 64, which does not fit one workgroup's LDS).
 // ------------------------------------------------------------------------------------------------
-#include "cluster.h"
 template <int H, int EV, int C, bool TRAIN = false>      // TRAIN: keeps x_t, r, u, c, h per step for the cluster-form BPTT (k_ioc_bwd_cl)
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl(IocArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

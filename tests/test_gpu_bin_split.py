@@ -1,0 +1,63 @@
+"""Few tiles per launch (a handful of windows): k_ioc's bin-split form -- several workgroups per 32-row tile, each contracting its share
+of the social bins, partial e_r sums exchanged through global memory once per step (kernels_rnn.hip: k_ioc NSPL, api.hip:
+ioc_bin_split).  Checked against the plain form of the same kernel (DESIRE_IOC_NSPL=1 caps the split at one workgroup per tile), against
+the oracle, and for run-to-run determinism."""
+import numpy as np
+import pytest
+
+from desire_amd.spec import Dims, init_weights
+from tests.helpers import make_case, small_dims
+from tests.test_gpu_parity import oracle_forward, run_gpu, torch_cuda  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_scenes=1, mno=32, K=20, T_obs=8, T_pred=40, n_grids=1, nb_w=0.2, nb_h=0.2),     # literal BASELINE configs[1]: one window
+    dict(mno=16, n_scenes=3, K=5),                                                         # ragged last tile
+    dict(H=64, T_pred=7, K=3),
+    dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2),                                            # 36 bins
+    dict(bin_mode=1, grid_size=4, nb_w=0.45, nb_h=0.04, K=2),                              # log-polar bins
+    dict(nb_w=0.04, nb_h=0.04, K=2),                                                       # sparse windows: some members get no bin at all
+])
+def test_bin_split_matches_the_plain_form(torch_cuda, kw, monkeypatch):
+    d = Dims(sx=1 / 1400.0, sy=1 / 1100.0, **kw) if "n_grids" in kw else small_dims(**kw)
+    w = init_weights(d, 5)
+    past, fut, eps, grids, gos = make_case(d, seed=6, n_absent=min(3, d.mno - 1))
+    monkeypatch.setenv("DESIRE_IOC_NSPL", "1")
+    _, Yp, sp = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    outs = {}
+    for cap in (2, 3, 4):
+        monkeypatch.setenv("DESIRE_IOC_NSPL", str(cap))
+        _, Y, s = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+        assert np.abs(Y - Yp).max() < 2e-6, (cap, np.abs(Y - Yp).max())
+        assert np.abs(s - sp).max() < 2e-5 * max(1.0, np.abs(sp).max())
+        _, Y2, s2 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+        np.testing.assert_array_equal(Y, Y2)                 # fixed member order: deterministic
+        np.testing.assert_array_equal(s, s2)
+        outs[cap] = Y
+    assert any(not np.array_equal(outs[c], Yp) for c in outs)         # (the split really ran: partial sums group differently)
+
+
+def test_bin_split_against_the_oracle(torch_cuda, monkeypatch):
+    monkeypatch.delenv("DESIRE_IOC_NSPL", raising=False)
+    d = small_dims(T_pred=40, K=4)
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos = make_case(d, seed=4, n_absent=3)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    _, Y, s = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert np.abs(Y - ref["Y"]).max() < 1e-5
+    assert np.abs(s - ref["score"]).max() < 5e-3
+
+
+def test_two_passes_run_the_plain_form(torch_cuda, monkeypatch):
+    """A second refinement pass reads the first pass's refined positions, which only member 0 of a tile holds: iters > 1 never splits."""
+    d = small_dims(iters=2, K=2)
+    w = init_weights(d, 5)
+    past, fut, eps, grids, gos = make_case(d, seed=6, n_absent=2)
+    monkeypatch.setenv("DESIRE_IOC_NSPL", "1")
+    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    monkeypatch.setenv("DESIRE_IOC_NSPL", "4")
+    _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    np.testing.assert_array_equal(Ya, Yb)
+    np.testing.assert_array_equal(sa, sb)

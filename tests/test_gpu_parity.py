@@ -176,7 +176,10 @@ def test_config1_shape_properties(torch_cuda):
     ref = O.forward(to_oracle_layout(past[:1]), to_oracle_layout(fut[:1]), eps[:r1], grids, gos[:1], w, d1)
     _, Yw, sw = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1], Y_in=ref["Y0"])
     assert np.abs(Yw - ref["Y"]).max() < TOL_Y
-    np.testing.assert_array_equal(Y1[:r1], run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1])[1])
+    # one window on its own: 20 tiles run the bin-split IOC with 8 workgroups per tile, the 4-window batch above with 2 -- the partial sums
+    # of e_r group differently, so the two agree to fp32 rounding (bit-identical under DESIRE_IOC_SPLIT=0, where both run the plain form)
+    Y1w = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1])[1]
+    assert np.abs(Y1[:r1] - Y1w).max() < 2e-6
 
 
 def test_model_api_and_sample_layout(torch_cuda):
