@@ -31,5 +31,8 @@ stats bench_w128_bf16 --bf16 --steps 5 --warmup 2 --no-cpu-baseline
 pmc   bench_w128_bf16 --bf16
 stats bench_w512_split --split --steps 5 --warmup 2 --no-cpu-baseline
 stats train --train --steps 5 --warmup 2
+stats train_split --train --split --steps 5 --warmup 2                      # dims.bf16 = 2: split operands in forward IOC, IOC BPTT, weight-gradient reductions, data-gradient convolutions
 stats train_bn2 --train --bn batch --steps 3 --warmup 1
+# few windows per call (literal configs[1] = one window): per-kernel ms of every form, with and without hipGraph replay
+( cd $R && bash profiles/small_batch.sh > /dev/null 2>&1; cp gpurun_out/sb3/summary.json $O/small_batch_w1_w2_w8.json )
 ls -la $O
