@@ -508,8 +508,10 @@ static void launch_x6(const IocArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, false, 3>), grid, block, iocx3_lds(a, 3), s, a);
 }
 void launch_ioc_x6(const IocArgs& a, hipStream_t s) {
-    // default: 64-row tiles, two row blocks per wave, fp32 operand tiles split on the fly (kernels_x6r2.hip; bit-identical results);
-    // a.variant == 13 keeps the 32-row / three-image form below (A/B), which also serves the shapes whose masks do not fit beside a 64-row tile
-    if (a.variant != 13 && ioc_x6r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_x6r2(a, s); return; }
+    // default: 64-row tiles, two row blocks per wave, fp32 operand tiles split on the fly (kernels_x6r2.hip; results within 1-2 ulp);
+    // a.variant == 13 keeps the 32-row / three-image form below (A/B), which also serves the shapes whose masks do not fit beside a
+    // 64-row tile -- and launches that would leave CUs idle with 64-row tiles (a few windows: one window = 20 tiles of 32 rows on 20 CUs
+    // takes 1.29 ms, 10 tiles of 64 rows 2.39 ms)
+    if (a.variant != 13 && ((a.R + 63) / 64 >= 256 || a.variant == 14) && ioc_x6r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_x6r2(a, s); return; }    // (14: always, A/B and tests)
     if (a.H == 128) launch_x6<128>(a, s); else launch_x6<64>(a, s);
 }

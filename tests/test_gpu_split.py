@@ -400,6 +400,7 @@ def test_six_product_ioc_on_64_row_tiles_matches_the_32_row_form(torch_cuda, kw,
     past, fut, eps, grids, gos = make_case(d, seed=34, n_absent=min(2, d.mno - 1))
     ha, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     Y0 = ha.read_buffer("Y0", (d.R, d.T_pred, 2))
+    monkeypatch.setenv("DESIRE_IOC_VARIANT", "14")       # 64-row tiles whatever the launch size (by default only launches of >= 256 such tiles)
     _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
     monkeypatch.setenv("DESIRE_IOC_VARIANT", "13")
     _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
