@@ -322,6 +322,53 @@ def reference_defaults_leg(seed, dev, steps):
     return out
 
 
+def training_step_leg(d_full, seed, dev, steps):
+    """BASELINE configs[4]'s per-GPU work on configs[1] shapes: one training step (forward with saves, backward, global-norm clip, Adam,
+    device-side repack) over 128 windows = 81 920 samples, outside the timed region -- fp32 operands, and dims.bf16 = 2 (split-bf16
+    operands in the IOC forward, the IOC BPTT, the weight-gradient reductions and the large data-gradient convolutions; every
+    gradient within the fp32 training tests' 2e-4 of float64 autograd: tests/test_gpu_split.py)."""
+    import torch
+    from desire_amd import _lib
+    from desire_amd.spec import init_weights
+    from desire_amd.synth import make_case
+    out = {}
+    dt_ = d_full.replace(n_scenes=128, n_grids=1)
+    w = init_weights(dt_, seed)
+    past, fut, eps, grids, gos = make_case(dt_, seed=seed + 1)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+    p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+    stream = torch.cuda.current_stream().cuda_stream
+    Y = torch.zeros((dt_.R, dt_.T_pred, 2), device=dev); sc = torch.zeros((dt_.R,), device=dev)
+    for tag, mode in (("fp32", 0), ("split_bf16x3", 2)):
+        h = _lib.Handle(dt_.replace(bf16=mode))
+        h.set_weights(w)
+        h.set_scene_grids(g_t.data_ptr(), gos)
+        h.set_training(True)
+
+        def one():
+            h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+            h.backward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), stream)
+            h.clip_grads(10.0, stream=stream)
+            h.adam_step(1e-4, stream=stream)
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        n2 = max(3, min(steps, 8))
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            one()
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / n2
+        terms = h.train_loss(f_t.data_ptr(), stream)
+        assert all(np.isfinite(float(v)) for v in terms.values()), terms
+        out[tag] = {"ms_per_step": dts * 1e3, "value": dt_.R / dts, "unit": "samples/s trained", "samples_per_step": dt_.R, "loss": float(terms["loss"])}
+        h.close()
+        del h
+        torch.cuda.empty_cache()
+    out["note"] = "128 windows per step (a training step keeps ~0.5 GB of activations per window); lr 1e-4, clip 10; synthetic windows"
+    return out
+
+
 def agent_sharded_setup(d, w, grids_t, gos, past_t, fut_t, eps_t, rank, world, dev):
     """SURVEY.md 8(e) E1's prescribed partitioning: the agents of EVERY scene block-sharded over the ranks (d.mno slots per rank).  Two
     micro-batches (half of the rank's windows each, own handle): their IOC steps alternate on the compute stream while the per-step
@@ -695,6 +742,7 @@ def main():
         h6.close()
         alt["bf16_config2"] = bf16_config2_leg(d, w, a.seed, dev, a.steps, with_accuracy=not a.no_cpu_baseline)
         alt["reference_defaults"] = reference_defaults_leg(a.seed, dev, a.steps)
+        alt["training_step"] = training_step_leg(d, a.seed, dev, a.steps)
 
     # outside the timed region: the same path on REAL SDD windows (BASELINE configs[1] names "SDD bookstore"): tiled bookstore/video6
     # windows with their absent slots and the reference's 32-px neighbourhood (train.py:68-70) on the 1424 x 1088 frame
@@ -773,7 +821,7 @@ def main():
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": ("scene-sharded x%d" % world) if a.shard == "scenes" else
                                       ("agent-sharded x%d: %d slots/rank of %d-agent scenes, RCCL all-gather of [R_loc, H] per IOC step" % (world, d.mno, d.mno * world)),
                        "flops_per_sample": flops_per_sample(d)},
-            "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1>" if a.bf16 else "k_ioc<128,16,32>", "achieved": ioc_tflops,
+            "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1,false>" if a.bf16 else "k_ioc<%d,16,32,32,false,%s>" % (d.H, "true" if a.compact else "false"), "achieved": ioc_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": (ioc_tflops / peak) if ioc_tflops else None,
                          "traffic": committed_traffic(a.windows, a.bf16) if a.mno == 32 and a.H == 128 and a.grid == 4 else None,
                          "traffic_unit": "bytes/launch", "traffic_source": "from_profile: %s (rocprofv3 --pmc passes of this command, committed; "
@@ -800,7 +848,7 @@ def main():
             out["metric"] += " -- split-bf16 (3 pieces, 6 products) operands in the IOC kernel"
             out["dtype"] = "bf16x6 (three bf16 pieces per fp32 operand, six bf16 MFMAs per product, f32 accumulate/state) in the IOC kernel; other kernels f32"
             out["config"]["workload"] += "; IOC contractions on the bf16 matrix pipe with three-piece operands (dims.bf16 = 3)"
-            out["roofline"].update({"kernel": "k_ioc_x3<%d,16,32,false,3>" % d.H, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
+            out["roofline"].update({"kernel": ("k_ioc_x6r2<%d,16,32,false>" if d.n_scenes * d.K * d.mno >= 256 * 64 else "k_ioc_x3<%d,16,32,false,3>") % d.H, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
                                     "frac": (ioc_tflops / (BF16_MFMA_PEAK_TFLOPS / 6.0)) if ioc_tflops else None, "traffic": None,
                                     "traffic_source": "not collected for this form",
                                     "note": "achieved = fp32-equivalent (algorithmic) flops / kernel time; peak = dense bf16 MFMA peak / 6 "
@@ -811,7 +859,7 @@ def main():
             out["metric"] += " -- split-bf16 (3-product) operands in the IOC kernel"
             out["dtype"] = "bf16x3 (hi+lo split of fp32 operands, three bf16 MFMAs per product, f32 accumulate/state) in the IOC kernel; other kernels f32"
             out["config"]["workload"] += "; IOC contractions on the bf16 matrix pipe with split operands (dims.bf16 = 2)"
-            out["roofline"].update({"kernel": "k_ioc_x3<%d,16,32>" % d.H, "peak": BF16_MFMA_PEAK_TFLOPS / 3.0,
+            out["roofline"].update({"kernel": "k_ioc_x3<%d,16,32,false,2>" % d.H, "peak": BF16_MFMA_PEAK_TFLOPS / 3.0,
                                     "frac": (ioc_tflops / (BF16_MFMA_PEAK_TFLOPS / 3.0)) if ioc_tflops else None, "traffic": None,
                                     "traffic_source": "not collected for this form",
                                     "note": "achieved = fp32-equivalent (algorithmic) flops / kernel time; peak = dense bf16 MFMA peak / 3 "

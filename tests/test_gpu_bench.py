@@ -2,6 +2,8 @@
 path (barrier / max-over-ranks timing / sharded work) run as two ranks that share the single GPU over gloo."""
 import json
 import os
+
+import numpy as np
 import subprocess
 import sys
 
@@ -45,6 +47,8 @@ def test_default_contract_fields():
     assert sp["value"] > 0 and sp["ioc_ms"] > 0 and 0 < sp["max_abs_diff_vs_fp32_kernel"] < 1e-4
     assert o["alt"]["row_compacted_pooling"]["value"] > 0
     assert o["alt"]["reference_defaults"]["batch_size_10"]["value"] > 0 and o["alt"]["reference_defaults"]["windows_128"]["value"] > 0
+    tr = o["alt"]["training_step"]                            # configs[4]'s per-GPU work, fp32 and split operands
+    assert tr["fp32"]["value"] > 0 and tr["split_bf16x3"]["value"] > tr["fp32"]["value"] and np.isfinite(tr["split_bf16x3"]["loss"])
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class
     v64 = o["accuracy"]["vs_float64_oracle"]                  # against exact (float64) arithmetic: not further than the fp32 implementations
     for key in ("Y0", "Y"):
