@@ -377,15 +377,16 @@ int desire_pack_all(desire_ctx* h) {
     }
     if (d.bf16 == 2 || d.bf16 == 3) {   // split-bf16 packs of the IOC kernel (kernels_x3.hip): [hi | lo], hi = bf16(w), lo = bf16(w - hi);
                                          // dims.bf16 = 3: [hi | mid | lo], one more piece of the remainder (w = hi + mid + lo exactly)
-        const size_t np = d.bf16 == 3 ? 3 : 2;
+        const size_t np_default = d.bf16 == 3 ? 3 : 2;
         const auto& gk = hw["ioc/gates/kernel"]; const auto& ck = hw["ioc/candidate/kernel"];
         const auto& wr = hw["ioc/reg/w"]; const auto& ws = hw["ioc/social_fc/w"];
         auto lin = [](int g, int hi, int e) { return 16 * g + 8 * hi + e; };
         auto chain = [](int g, int hi, int e) { const int hb = g >> 1, r = 8 * (g & 1) + e; return 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi; };
         // vals = one fp32 value per bf16 slot.  While the repack maps are being built (pack_mode 1: values are index codes) the
         // value list itself is captured under "<name>#x3": it IS the gather map of the hi half, and of the lo half
-        auto up_split = [&](const std::string& name, const std::vector<float>& vals) {
-            if (h->pack_mode == 1) { h->captured[name + "#x3"] = vals; return 0; }
+        auto up_split = [&](const std::string& name, const std::vector<float>& vals, size_t np_over = 0) {
+            const size_t np = np_over ? np_over : np_default;
+            if (h->pack_mode == 1) { h->captured[name + (np == 3 ? "#x6" : "#x3")] = vals; return 0; }
             const size_t n = vals.size();
             std::vector<uint16_t> o(np * n + (np * n & 1));
             for (size_t i = 0; i < n; ++i) {
@@ -434,10 +435,11 @@ int desire_pack_all(desire_ctx* h) {
             bad |= up_split("vae_dec/deconv3/Wbwd16", taps16(hw["vae_dec/deconv3/w"], 32, 64));
             bad |= up_split("vae_dec/deconv2/Wbwd16", taps16(hw["vae_dec/deconv2/w"], 64, 128));
         }
-        if (d.bf16 == 3) {   // three-piece packs of the sample-generation kernels (kernels_x6.hip): decoder h-blocks, deconv2 / deconv3 taps
+        {   // three-piece packs of the sample-generation kernels (kernels_x6.hip): decoder h-blocks, deconv2 / deconv3 taps.  dims.bf16 = 3:
+            // inference; dims.bf16 = 2: the training-mode forward (sample generation stays in the fp32 kernels' accuracy class there too)
             const auto& dg = hw["dec/gates/kernel"]; const auto& dc = hw["dec/candidate/kernel"];
-            bad |= up_split("dec/Whg6", pack_vals16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }));
-            bad |= up_split("dec/Whc6", pack_vals16(H, H, lin, [&](int k, int n) { return dc[(size_t)(H + k) * H + n]; }));
+            bad |= up_split("dec/Whg6", pack_vals16(H, 2 * H, lin, [&](int k, int n) { return dg[(size_t)(H + k) * 2 * H + n]; }), 3);
+            bad |= up_split("dec/Whc6", pack_vals16(H, H, lin, [&](int k, int n) { return dc[(size_t)(H + k) * H + n]; }), 3);
             auto taps6 = [&](const std::vector<float>& wt, int CI, int CO) {        // transposed conv weights [tap][co][ci]
                 std::vector<float> out;
                 for (int tap = 0; tap < 25; ++tap) {
@@ -447,8 +449,8 @@ int desire_pack_all(desire_ctx* h) {
                 }
                 return out;
             };
-            bad |= up_split("vae_dec/deconv2/W6", taps6(hw["vae_dec/deconv2/w"], 128, 64));
-            bad |= up_split("vae_dec/deconv3/W6", taps6(hw["vae_dec/deconv3/w"], 64, 32));
+            bad |= up_split("vae_dec/deconv2/W6", taps6(hw["vae_dec/deconv2/w"], 128, 64), 3);
+            bad |= up_split("vae_dec/deconv3/W6", taps6(hw["vae_dec/deconv3/w"], 64, 32), 3);
         }
     }
     if (d.bf16 == 1) {   // bf16 operand packs of the IOC kernel (kernels_bf16.hip)
@@ -704,7 +706,8 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     // dims.bf16 = 3: six-product forms of the two large transposed convolutions and of the decoder (frozen batch-norm, inference)
-    const bool x6gen = d.bf16 == 3 && d.bn_mode == 0 && !h->training && !d.ref_compat;
+    // six-product sample generation: dims.bf16 = 3 (inference), and the training-mode forward under dims.bf16 = 2
+    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && h->training && (train_x3_mask() & 8))) && d.bn_mode == 0 && !d.ref_compat;
     if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
     else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);

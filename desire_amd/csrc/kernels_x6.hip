@@ -21,7 +21,7 @@
 // wave that owns the columns (splitting the fp32 tile on the fly in every wave: 8.9 ms per 327 680 samples; the images: 8.6 ms).  a.Whg / a.Whc point at the
 // three-piece packs.
 // ------------------------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, bool SAVE>           // SAVE: training-mode forward (gates / candidate / hidden states kept for BPTT, fp32)
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, LDH = H + 4, LDB = H + 8, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
@@ -92,8 +92,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
             float rh[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                rh[e] = sigmoidf_(g2[0][4 * q + e]) * h[4 * q + e];
+                const float r = sigmoidf_(g2[0][4 * q + e]);
+                rh[e] = r * h[4 * q + e];
                 u[4 * q + e] = sigmoidf_(g2[1][4 * q + e]);
+                if (SAVE && row0 + 4 * hi + 8 * q + e < a.R) {
+                    const size_t ix = ((size_t)(row0 + 4 * hi + 8 * q + e) * a.T + t) * H + col;
+                    a.sv_r[ix] = r; a.sv_u[ix] = u[4 * q + e];
+                }
             }
             put4(rb, q, rh[0], rh[1], rh[2], rh[3]);
         }
@@ -104,6 +109,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
         for (int i = 0; i < 16; ++i) {
             const float c = tanhf_(ac[0][i]);
             h[i] = gru_blend(u[i], h[i], c);
+            if (SAVE && row0 + 4 * hi + (i & 3) + 8 * (i >> 2) < a.R) {
+                const size_t ix = ((size_t)(row0 + 4 * hi + (i & 3) + 8 * (i >> 2)) * a.T + t) * H + col;
+                a.sv_c[ix] = c; a.hdump[ix] = h[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) my_h[((i & 3) + 8 * (i >> 2)) * LDH] = h[i];
@@ -133,8 +142,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
 template <int H>
 static void launch_dec6(const DecArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(32 * (H + 4) + 2 * H + 64) * sizeof(float) + (size_t)6 * 32 * (H + 8) * sizeof(u16);
-    allow_big_lds(k_decoder_x6<H>);
-    hipLaunchKernelGGL((k_decoder_x6<H>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+    if (a.sv_r) {                                              // training-mode forward (api.hip sets all four save streams together)
+        allow_big_lds(k_decoder_x6<H, true>);
+        hipLaunchKernelGGL((k_decoder_x6<H, true>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+        return;
+    }
+    allow_big_lds(k_decoder_x6<H, false>);
+    hipLaunchKernelGGL((k_decoder_x6<H, false>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }
 bool decoder_x6_supported(int H) { return H == 64 || H == 128; }
 void launch_decoder_x6(const DecArgs& a, hipStream_t s) {

@@ -15,10 +15,6 @@ int ensure(desire_ctx* h, const char* name, size_t bytes) {
     return h->ws[name].alloc(bytes);
 }
 
-// A/B switch: which parts of the backward pass use split operands under dims.bf16 = 2 (1: weight-gradient reductions, 2: data-gradient
-// convolutions, 4: IOC BPTT; default all)
-int train_x3_mask() { static const int m = getenv("DESIRE_TRAIN_X3") ? atoi(getenv("DESIRE_TRAIN_X3")) : 7; return m; }
-
 float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slots.at(name).off; }
 
 // weight gradient block: out[Kd, N] = A^T G over M rows, written into a [.., ldo] matrix
@@ -87,7 +83,7 @@ __global__ void k_repack(const Seg* __restrict__ segs, const uint32_t* __restric
 }
 
 // split [hi | lo] bf16 packs of kernels_x3.hip (dims.bf16 = 2): dst[i] = bf16(w), dst[n + i] = bf16(w - hi), w = Wflat[idx[i]-1]
-struct Seg16 { uint16_t* dst; unsigned long long idx_off; unsigned long long n; };
+struct Seg16 { uint16_t* dst; unsigned long long idx_off; unsigned long long n; unsigned long long np; };     // np = pieces (2: "#x3" packs, 3: "#x6")
 __device__ __forceinline__ uint16_t bf16_rne_dev(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
@@ -99,10 +95,12 @@ __global__ void k_repack_split(const Seg16* __restrict__ segs, const uint32_t* _
     const uint32_t* ix = idx + sg.idx_off;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t j = ix[i];
-        const float v = j ? w[j - 1] : 0.f;
-        const uint16_t hi = bf16_rne_dev(v);
-        sg.dst[i] = hi;
-        sg.dst[sg.n + i] = bf16_rne_dev(v - __uint_as_float((uint32_t)hi << 16));
+        float v = j ? w[j - 1] : 0.f;
+        for (unsigned long long pc = 0; pc < sg.np; ++pc) {               // piece pc = bf16 of what the earlier pieces left (each subtraction exact)
+            const uint16_t b = bf16_rne_dev(v);
+            sg.dst[pc * sg.n + i] = b;
+            v -= __uint_as_float((uint32_t)b << 16);
+        }
     }
 }
 
@@ -222,24 +220,29 @@ int build_repack_maps(desire_ctx* h) {
     std::vector<float> devcopy;
     for (auto& kv : h->captured) {
         const std::string& name = kv.first; const auto& v = kv.second;
-        if (name.size() > 3 && name.compare(name.size() - 3, 3, "#x3") == 0) {      // split [hi | lo] pack: v = index code per bf16 slot
+        const bool is3 = name.size() > 3 && name.compare(name.size() - 3, 3, "#x3") == 0, is6 = name.size() > 3 && name.compare(name.size() - 3, 3, "#x6") == 0;
+        if (is3 || is6) {      // split [hi | lo] (or [p0 | p1 | p2]) pack: v = index code per bf16 slot
+            const size_t np = is6 ? 3 : 2;
             const std::string real_name = name.substr(0, name.size() - 3);
             auto it = h->dev.find(real_name);
-            if (it == h->dev.end() || it->second.bytes != v.size() * 4)
+            if (it == h->dev.end() || it->second.bytes != (np * v.size() + (np * v.size() & 1)) * 2)
                 return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " changed shape");
-            std::vector<uint16_t> dev16(2 * v.size());
+            std::vector<uint16_t> dev16(np * v.size() + (np * v.size() & 1));
             HIPCHK(hipMemcpy(dev16.data(), it->second.p, it->second.bytes, hipMemcpyDeviceToHost));
             std::vector<uint32_t> ix(v.size());
             for (size_t i = 0; i < v.size(); ++i) {
                 uint32_t u; std::memcpy(&u, &v[i], 4);
                 if (u > h->n_params) return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " is not a gather of the weights");
                 ix[i] = u;
-                const float want = u ? flat[u - 1] : 0.f;
-                const uint16_t hi = bf16_rne(want);
-                if (dev16[i] != hi || dev16[v.size() + i] != bf16_rne(want - bf16_to_f32(hi)))
-                    return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " does not match its map");
+                float want = u ? flat[u - 1] : 0.f;
+                for (size_t pc = 0; pc < np; ++pc) {
+                    const uint16_t b = bf16_rne(want);
+                    if (dev16[pc * v.size() + i] != b)
+                        return fail(DESIRE_ERR_STATE, "repack map: split operand " + real_name + " does not match its map");
+                    want -= bf16_to_f32(b);
+                }
             }
-            segs16.push_back(Seg16{static_cast<uint16_t*>(it->second.p), (unsigned long long)all_idx.size(), (unsigned long long)v.size()});
+            segs16.push_back(Seg16{static_cast<uint16_t*>(it->second.p), (unsigned long long)all_idx.size(), (unsigned long long)v.size(), (unsigned long long)np});
             all_idx.insert(all_idx.end(), ix.begin(), ix.end());
             while (all_idx.size() % 4) all_idx.push_back(0);
             continue;
