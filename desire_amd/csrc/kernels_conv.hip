@@ -339,11 +339,15 @@ template <bool FWD, int NS>
 __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
     constexpr int LDP = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* zero_row = smem;
-    float* in_s = smem + LDP;                                          // [NS][64][LDP]
+    // 384 bytes of zeros for the taps outside the image.  A lane whose tap is outside reads them at the byte offset (mod 256) its pixel
+    // WOULD have had: ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row, consecutive pixels (272 bytes apart) fill its
+    // sixteen 16-byte slots exactly once, and ONE shared zero address sits on the slot of some valid lane of the group -- a second LDS
+    // cycle for every group of a border tap (19 % of this kernel's LDS cycles were such conflicts)
+    float* zero_row = smem;                                            // [96] floats, 256-byte aligned (dynamic LDS base)
+    float* in_s = smem + 128;                                          // [NS][64][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * NS;
-    for (int i = tid; i < LDP; i += NS * 64) zero_row[i] = 0.f;
+    for (int i = tid; i < 128; i += NS * 64) zero_row[i] = 0.f;
     for (int i = tid; i < NS * 64 * 16; i += NS * 64) {
         const int pix = i >> 4, c4 = i & 15;
         const int smp = s0 + (pix >> 6);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
                     for (int m = 0; m < 2; ++m) {
                         const int iy = qy[m] + dy, ix = qx[m] + dx;
                         const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
-                        ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 4 * hi;
+                        ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row + ((((w * 64 + iy * 8 + ix + 64) * LDP + 128) & 63))) + 4 * hi;
                     }
                     mma_groups_ptr<2, true>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
                 }
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
 }
 void launch_deconv3(const ConvArgs& a, hipStream_t s) {
     static const int ns = getenv("DESIRE_DECONV3_NS2") ? 2 : 4;       // A/B: four 2-wave workgroups per CU measured 15 % slower
-    const size_t lds = (68 + (size_t)ns * 64 * 68) * sizeof(float);
+    const size_t lds = (128 + (size_t)ns * 64 * 68) * sizeof(float);
     allow_big_lds(k_deconv3<true, 4>); allow_big_lds(k_deconv3<false, 4>);
     if (ns == 4) {
         if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);

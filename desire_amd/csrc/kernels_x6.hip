@@ -333,7 +333,121 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6(ConvArgs a, size_t plo)
             }
         }
 }
+// The same contraction from three pre-split bf16 images of the input (one conversion per element instead of one per fragment use:
+// 25 taps read every pixel ~6 times): two samples per workgroup, two waves per sample -- wave (sample, half) owns the output parity
+// classes {(0,0), (1,1)} (4 + 9 taps) or {(0,1), (1,0)} (6 + 6) -- so that the images (56 KB) still leave two workgroups per CU.
+// Same pieces, same products, same order: bit-identical to k_deconv3_x6.
+__global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo) {
+    // bf16 elements per piece image: 128 pixels, then 384 bytes of zeros for the taps outside.  A lane whose tap is outside reads the
+    // zeros at the byte offset (mod 256) its pixel WOULD have had: ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row,
+    // consecutive pixels (144 bytes apart) fill its sixteen 16-byte slots exactly once, and one shared zero address would sit on the
+    // slot of some valid lane of the group (a second LDS cycle for every group of a border tap: 31 % of this kernel's LDS cycles)
+    constexpr int LDB = 72, NPX = 2 * 64, ZB = NPX * LDB, IMG = ZB + 192;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* img = reinterpret_cast<u16*>(smem);                           // [3][NPX + 1][LDB]
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int s0 = blockIdx.x * 2;
+    for (int i = tid; i < 3 * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
+    for (int i = tid; i < NPX * 16; i += DS_WG) {
+        const int pix = i >> 4, c4 = i & 15;
+        const int smp = s0 + (pix >> 6);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
+        unsigned p0[3], p1[3];
+        splitp<3>(v.x, v.y, p0); splitp<3>(v.z, v.w, p1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
+    }
+    __syncthreads();
+    const int ls = w >> 1, half = w & 1, smp = s0 + ls;
+    const int hi = lane >> 5;
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
+        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
+    }
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    int qy[2], qx[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
+    for (int cls = 0; cls < 2; ++cls) {
+        const int py = cls, px = half ? 1 - cls : cls;                 // half 0: (0,0), (1,1);  half 1: (0,1), (1,0)
+        f32x16 acc[2] = {zero16(), zero16()};
+        const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
+        auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
+        uint4 bc[4][3], bn[4][3];
+        auto ldw = [&](uint4 (&b)[4][3], int tap) {
+            const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) b[g][i] = bp[i * plo + g * 64];
+        };
+        auto run = [&](const uint4 (&b)[4][3], int t) {
+            const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
+            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+            const u16* xp[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int iy = qy[m] + dy, ix = qx[m] + dx;
+                const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                xp[m] = img + (ok ? (ls * 64 + iy * 8 + ix) * LDB : ZB + ((((ls * 64 + iy * 8 + ix + 64) * LDB * 2) & 255) >> 1)) + 8 * hi;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint4 f0[3], f1[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    f0[i] = *reinterpret_cast<const uint4*>(xp[0] + i * IMG + 16 * g);
+                    f1[i] = *reinterpret_cast<const uint4*>(xp[1] + i * IMG + 16 * g);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {                       // D[co][pixel]: the two row blocks alternate on the pipe
+                    acc[0] = mfma16(b[g][Pairs<3>::B[pr]], f0[Pairs<3>::A[pr]], acc[0]);
+                    acc[1] = mfma16(b[g][Pairs<3>::B[pr]], f1[Pairs<3>::A[pr]], acc[1]);
+                }
+            }
+        };
+        // weight fragments of the next tap in flight while this tap's 48 MFMAs run: two named register sets, no copies
+        ldw(bc, tap_of(0));
+        int t = 0;
+#pragma clang loop unroll(disable)
+        for (; t + 2 <= ntap; t += 2) {
+            ldw(bn, tap_of(t + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            run(bc, t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntap) ldw(bc, tap_of(t + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            run(bn, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t < ntap) run(bc, t);
+        if (smp < a.n) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
+                const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
+                    o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
+                    *reinterpret_cast<float4*>(a.out + base + 8 * q) = o;
+                }
+            }
+        }
+    }
+}
 void launch_deconv3_x6(const ConvArgs& a, hipStream_t s) {
+    static const bool fly = getenv("DESIRE_DECONV3_X6_FLY") != nullptr;     // A/B: the form that splits fragments on the fly
+    if (!fly) {
+        const size_t ldsi = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16);
+        allow_big_lds(k_deconv3_x6i);
+        hipLaunchKernelGGL(k_deconv3_x6i, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, (size_t)25 * 1 * 4 * 64);
+        return;
+    }
     const size_t lds = (68 + (size_t)4 * 64 * 68) * sizeof(float);
     allow_big_lds(k_deconv3_x6);
     const size_t plo = (size_t)25 * 1 * 4 * 64;                        // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
