@@ -688,8 +688,9 @@ def main():
             "ioc_frac_of_bf16_peak_over_3": ioc_flops_per_row(d) * d.R / (ioc3 * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0),
             "max_abs_diff_vs_fp32_kernel": float(dlt.max()), "mean_abs_diff_vs_fp32_kernel": float(dlt.mean()),
             "note": "opt-in (dims.bf16 = 2 / --split): the IOC kernel's fp32 operands enter the bf16 matrix pipe as hi + lo and every "
-                    "product is three bf16 MFMAs with fp32 accumulation (k_ioc_x3); all other kernels are the fp32 ones.  Same results as "
-                    "the fp32 kernel to ~1e-5 (north_star's gate is 1e-3); not the headline because its operands are not fp32 words"}
+                    "product is three bf16 MFMAs with fp32 accumulation (k_ioc_x3); the decoder, deconv2 and deconv3 run the six-product kernels "
+                    "of dims.bf16 = 3 (fp32 class), everything else the fp32 ones.  IOC results as the fp32 kernel's to ~1e-5 from the same Y0 "
+                    "(north_star's gate is 1e-3); not the headline because its operands are not fp32 words"}
         h3.close()
         # three bf16 pieces per operand, six products per fp32 product (dims.bf16 = 3): the accuracy class of the fp32 kernel itself from
         # the bf16 matrix pipe.  Evidence asked for by VERDICT r02 item 5: its distance from the fp32 kernel on THIS batch, from the same Y0.
@@ -803,7 +804,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 state / activations / gradients; matrix products as three bf16 MFMAs on split operands (IOC forward, IOC BPTT, weight-gradient reductions, large data-gradient convolutions)" if a.split else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] shapes, training step; %d windows/step/GPU%s%s" % (a.windows, "; launch sequence replayed from a hipGraph" if a.graph else "",
-                                   "; dims.bf16 = 2: k_ioc_x3 forward (fp32 saves), k_ioc_bwd_x3, k_gemm_tn2_xp, k_conv_gather_x3; sample generation and the remaining backward kernels fp32" if a.split else ""),
+                                   "; dims.bf16 = 2: k_ioc_x3 forward (fp32 saves), k_ioc_bwd_x3, k_gemm_tn2_xp, k_conv_gather_x3, six-product sample generation; the remaining backward kernels fp32" if a.split else ""),
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
             "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
             "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))

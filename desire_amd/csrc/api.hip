@@ -706,8 +706,9 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     // dims.bf16 = 3: six-product forms of the two large transposed convolutions and of the decoder (frozen batch-norm, inference)
-    // six-product sample generation: dims.bf16 = 3 (inference), and the training-mode forward under dims.bf16 = 2
-    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && h->training && (train_x3_mask() & 8))) && d.bn_mode == 0 && !d.ref_compat;
+    // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
+    // two-piece operands are an IOC-kernel matter (sample generation must not move Y0 by more than fp32 rounding)
+    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask() & 8)))) && d.bn_mode == 0 && !d.ref_compat;
     if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
     else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);

@@ -85,13 +85,17 @@ def test_split_operands_reproduce_goldens(tag):
 
 
 def test_shapes_without_a_split_kernel_run_the_fp32_kernels(torch_cuda):
-    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 64 agents (no split form yet) run the fp32 kernels,
-    bit-identically to dims.bf16 = 0."""
+    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 64 agents (no split IOC form yet) run the fp32 IOC kernel, bit-identically
+    to dims.bf16 = 0 from the same decoder output; sample generation runs the six-product kernels (fp32 class: Y0 within 1e-6)."""
     d = small_dims(mno=64, n_scenes=1, K=2, n_grids=1)
     w = init_weights(d, 7)
     past, fut, eps, grids, gos = make_case(d, seed=8, n_absent=5)
-    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
-    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=2), w, past, fut, eps, grids, gos)
+    ha, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    hb, _, _ = run_gpu(torch_cuda, d.replace(bf16=2), w, past, fut, eps, grids, gos)
+    Y0a, Y0b = ha.read_buffer("Y0", (d.R, d.T_pred, 2)), hb.read_buffer("Y0", (d.R, d.T_pred, 2))
+    assert np.abs(Y0a - Y0b).max() < 1e-6
+    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0a)
+    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=2), w, past, fut, eps, grids, gos, Y_in=Y0a)
     assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)
 
 
@@ -211,7 +215,7 @@ def test_split_mode_training(torch_cuda):
 
 
 def test_model_surface_selects_split_operands(torch_cuda):
-    """DESIREModel(args.bf16 = "x3") -> dims.bf16 = 2; forward (same fp32 sample generation, split IOC) agrees with the fp32 model
+    """DESIREModel(args.bf16 = "x3") -> dims.bf16 = 2; forward (six-product sample generation, split IOC) agrees with the fp32 model
     far inside the 1e-3 gate."""
     import argparse
     from desire_amd.model import DESIREModel
@@ -236,8 +240,9 @@ def test_model_surface_selects_split_operands(torch_cuda):
 
 def test_split_path_is_window_independent_and_deterministic(torch_cuda):
     """BASELINE configs[1] shapes, 16 windows through the split-operand IOC kernel: together or in two halves, and run twice, the
-    refined trajectories and scores are bit-identical (what scene-sharding over GPUs relies on) -- and within 1e-4 of the fp32
-    kernels' END-TO-END output, because sample generation is the same fp32 code on both sides (same cells, same bins)."""
+    refined trajectories and scores are bit-identical (what scene-sharding over GPUs relies on).  Against the fp32 kernels' END-TO-END
+    output: sample generation runs the six-product kernels here (Y0 within an ulp or two of the fp32 kernels'), so all but a fraction
+    of a percent of the rows keep their cells and bins and agree to 1e-4; a row whose neighbour sat within 1e-7 of a bin edge may not."""
     from desire_amd.spec import Dims
     from desire_amd.synth import make_case as mk
     n = 16
@@ -256,8 +261,9 @@ def test_split_path_is_window_independent_and_deterministic(torch_cuda):
         np.testing.assert_array_equal(Yh, Y[lo * rows:hi * rows])
         np.testing.assert_array_equal(sh, s[lo * rows:hi * rows])
     _, Yf, sf = run_gpu(torch_cuda, d.replace(bf16=0), w, past, fut, eps, grids, gos)
-    assert 0 < np.abs(Y - Yf).max() < TOL_Y
-    assert np.abs(s - sf).max() < 1e-4 * max(1.0, np.abs(sf).max())
+    e = np.abs(Y - Yf).reshape(d.R, -1).max(1)
+    assert 0 < np.median(e) < 2e-5 and (e > TOL_Y).mean() < 0.01, (np.median(e), (e > TOL_Y).mean(), e.max())
+    assert np.median(np.abs(s - sf)) < 1e-4 * max(1.0, np.abs(sf).max())
 
 
 # ---- three bf16 pieces per operand, six products per fp32 product (dims.bf16 = 3) ------------------------------
