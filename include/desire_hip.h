@@ -59,8 +59,11 @@ typedef struct desire_dims {
                               for the recurrent IOC kernel (BASELINE configs[2]); inference only.  2: SPLIT bf16 operands --
                               every fp32 operand enters the bf16 matrix pipe as hi + lo (hi = bf16(x), lo = bf16(x - hi)) and a
                               product is three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 accumulate): results agree with the fp32
-                              kernels to ~1e-5 relative at 3/16 of their matrix time.  Kernels without that form (and training)
-                              run the fp32 kernels, so 2 is always at least as accurate as it claims.  3: THREE bf16 pieces per operand
+                              kernels to ~1e-5 relative at 3/16 of their matrix time: the IOC kernel, and in a training step the IOC
+                              BPTT, the large weight-gradient reductions and data-gradient convolutions (gradients stay within 2e-4 of
+                              float64 autograd); sample generation (decoder, deconv2, deconv3) runs the six-product kernels of mode 3,
+                              because two-piece operands there would move the sampled positions.  Kernels without a split form run the
+                              fp32 kernels, so 2 is always at least as accurate as it claims.  3: THREE bf16 pieces per operand
                               (x = hi + mid + lo exactly) and six products per fp32 product -- every term down to 2^-16 |a b| -- i.e.
                               the accuracy class of the fp32 fmaf chain itself at 6/16 of its matrix time; inference only, same
                               shapes as 2 (others run the fp32 kernels). */
@@ -117,6 +120,8 @@ int desire_forward(desire_handle* h, const float* dev_past, const float* dev_fut
 /* Intermediates kept in the handle's workspace, for parity tests:
  * "Hx" [A,H], "Hy" [A,H], "vae_in" [A,V], "z_mean" [A,L], "z_log_sigma_sq" [A,L], "z" [R,L],
  * "d1" [R,2048], "d2" [R,4096], "d3" [R,8192], "xhat" [R,1024], "xz" [R,H], "Y0" [R,T_pred,2].
+ * Any other name is looked up among the handle's internal workspace buffers (training-mode saves and gradient streams, e.g.
+ * "ioc_sv_h" [R,T_pred,H]; layouts as in csrc/train.hip) -- a debugging aid, not a stable interface.
  * Copies n floats to host_out after synchronising the stream. */
 int desire_read_buffer(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
 
