@@ -752,11 +752,15 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             if ((lane & 31) == 0) red[cb * TM + mt * 32 + acc_row(i)] = v;
         }
         __syncthreads();
+        // bin-split form: a hand-off that timed out (members of a tile not co-resident) has set the error word; its tile's results are
+        // then made NaN instead of silently wrong (the host reports the word on the next call: api.hip)
+        bool poisoned = false;
+        if constexpr (NSPL > 1) poisoned = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         if (tid < TM && row0 + tid < a.R && it == a.iters - 1 && member == 0) {
             float sc = 0.f;
 #pragma unroll
             for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
-            a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+            a.score[row0 + tid] = poisoned ? __builtin_nanf("") : sc + (float)a.T * a.b_score[0];
         }
         // ---- regression: Y += h_T W_r + b_r   (columns = (t, xy) flattened) ----
         for (int nt = cb; nt < a.NTreg; nt += NT) {
@@ -770,7 +774,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     const int row = row0 + mt * 32 + acc_row(i);
                     if (row < a.R && member == 0) {
                         float* y = a.Y + (size_t)row * 2 * a.T + cc;
-                        *y = *y + (acc[i] + bb);
+                        *y = poisoned ? __builtin_nanf("") : *y + (acc[i] + bb);
                     }
                 }
             }
