@@ -224,6 +224,19 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
         pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
     }
     __syncthreads();
+    // head weights of this thread's 16 columns, in the order it walks them.  The walk starts at chunk hrot: ds_read_b128 is serviced in
+    // 16-lane groups over a 256-byte bank row, and with rows (H + 4) floats apart the threads q and q + 4 of a row would meet in one
+    // 16-byte slot (the scalar form this replaces read h and both weights from LDS per column: 4- and 8-way conflicts, a fifth of the
+    // kernel's LDS cycles)
+    const int hq = tid % TPR, hrot = TPR >= 8 ? (hq >> 2) * (TPR == 8 ? 2 : 1) : 0;
+    float hw0[16], hw1[16];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = hq * 16 + 4 * ((jj + hrot) & 3) + e;
+            hw0[4 * jj + e] = wo[c * 2]; hw1[4 * jj + e] = wo[c * 2 + 1];
+        }
     const float* x_lane = xs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
     const float* a_lane = hs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);
     const float* r_lane = xs + (mt * 32 + (lane & 31)) * LDH + 4 * (lane >> 5);     // r*h operand: the x_z tile's space after the prologue
@@ -284,15 +297,18 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
             }
         }
         __syncthreads();
-        {   // head: y = p_last + h W_o + b_o ; TPR threads per row
-            const int r = tid / TPR, q8 = tid % TPR;
-            constexpr int per = H / TPR;
+        {   // head: y = p_last + h W_o + b_o ; TPR threads per row, 16 columns each, their weights in registers (hw0 / hw1)
+            const int r = tid / TPR;
             float s0 = 0.f, s1 = 0.f;
-            for (int c = q8 * per; c < (q8 + 1) * per; ++c) {
-                const float hv = hs[r * LDH + c];
-                s0 = fmaf(hv, wo[c * 2], s0);
-                s1 = fmaf(hv, wo[c * 2 + 1], s1);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 hv = *reinterpret_cast<const float4*>(hs + r * LDH + hq * 16 + 4 * ((jj + hrot) & 3));
+                s0 = fmaf(hv.x, hw0[4 * jj], s0); s1 = fmaf(hv.x, hw1[4 * jj], s1);
+                s0 = fmaf(hv.y, hw0[4 * jj + 1], s0); s1 = fmaf(hv.y, hw1[4 * jj + 1], s1);
+                s0 = fmaf(hv.z, hw0[4 * jj + 2], s0); s1 = fmaf(hv.z, hw1[4 * jj + 2], s1);
+                s0 = fmaf(hv.w, hw0[4 * jj + 3], s0); s1 = fmaf(hv.w, hw1[4 * jj + 3], s1);
             }
+            const int q8 = hq;
             s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
             s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
             if (TPR >= 8) { s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4); }

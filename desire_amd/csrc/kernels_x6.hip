@@ -49,6 +49,16 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
         pl[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
     }
     __syncthreads();
+    // head weights of this thread's 16 columns in registers, walked from chunk hrot on (k_decoder: conflict-free 16-byte reads of h)
+    const int hq = tid % TPR, hrot = TPR >= 8 ? (hq >> 2) * (TPR == 8 ? 2 : 1) : 0;
+    float hw0[16], hw1[16];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = hq * 16 + 4 * ((jj + hrot) & 3) + e;
+            hw0[4 * jj + e] = wo[c * 2]; hw1[4 * jj + e] = wo[c * 2 + 1];
+        }
     float* my_h = hs + (4 * hi) * LDH + col;
     f32x16 xr[1] = {splat16h(a.b_g[col])}, xu[1] = {splat16h(a.b_g[H + col])}, xc[1] = {splat16h(a.b_c[col])};
     {
@@ -119,15 +129,19 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) put4(hb, q, h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
         __syncthreads();
-        {   // head: y = p_last + h W_o + b_o ; TPR threads per row (fp32 VALU: trajectory coordinates come straight out of it)
-            const int r = tid / TPR, q8 = tid % TPR;
-            constexpr int per = H / TPR;
+        {   // head: y = p_last + h W_o + b_o ; TPR threads per row, 16 columns each, their weights in registers (k_decoder: hw0 / hw1;
+            // fp32 VALU: trajectory coordinates come straight out of it)
+            const int r = tid / TPR;
             float s0 = 0.f, s1 = 0.f;
-            for (int c = q8 * per; c < (q8 + 1) * per; ++c) {
-                const float hv = hs[r * LDH + c];
-                s0 = fmaf(hv, wo[c * 2], s0);
-                s1 = fmaf(hv, wo[c * 2 + 1], s1);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 hv = *reinterpret_cast<const float4*>(hs + r * LDH + hq * 16 + 4 * ((jj + hrot) & 3));
+                s0 = fmaf(hv.x, hw0[4 * jj], s0); s1 = fmaf(hv.x, hw1[4 * jj], s1);
+                s0 = fmaf(hv.y, hw0[4 * jj + 1], s0); s1 = fmaf(hv.y, hw1[4 * jj + 1], s1);
+                s0 = fmaf(hv.z, hw0[4 * jj + 2], s0); s1 = fmaf(hv.z, hw1[4 * jj + 2], s1);
+                s0 = fmaf(hv.w, hw0[4 * jj + 3], s0); s1 = fmaf(hv.w, hw1[4 * jj + 3], s1);
             }
+            const int q8 = hq;
             s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
             s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
             if (TPR >= 8) { s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4); }
