@@ -449,6 +449,11 @@ int desire_pack_all(desire_ctx* h) {
                 }
                 return out;
             };
+            {
+                const auto& w1 = hw["vae_dec/deconv1/w"]; const auto& wm = hw["mask_fc/w"];
+                bad |= up_split("vae_dec/deconv1/W6", pack_vals16(L, 2048, lin, [&](int k, int n) { return w1[(size_t)n * L + k]; }), 3);
+                bad |= up_split("mask/W6", pack_vals16(V, H, lin, [&](int k, int n) { return wm[(size_t)k * H + n]; }), 3);
+            }
             bad |= up_split("vae_dec/deconv2/W6", taps6(hw["vae_dec/deconv2/w"], 128, 64), 3);
             bad |= up_split("vae_dec/deconv3/W6", taps6(hw["vae_dec/deconv3/w"], 64, 32), 3);
         }
@@ -693,7 +698,11 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
+    // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
+    // two-piece operands are an IOC-kernel matter (DESIGN.md 4-split: sample generation must not move Y0 by more than fp32 rounding)
+    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask() & 8)))) && d.bn_mode == 0 && !d.ref_compat;
     if (d.bf16 == 1 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
+    else if (x6gen && rows_x6_supported(d.L, 64)) { g.Bp = D4(h, "vae_dec/deconv1/W6"); Timer t(h, s, "deconv1"); launch_deconv1_x6(g, s); }
     else if (d.bn_mode != 0) {
         Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_NONE, s);
         normd("vae_dec/deconv1", W(h, "d1"), 16, 128, 0);
@@ -706,9 +715,6 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     // dims.bf16 = 3: six-product forms of the two large transposed convolutions and of the decoder (frozen batch-norm, inference)
-    // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
-    // two-piece operands are an IOC-kernel matter (DESIGN.md 4-split: sample generation must not move Y0 by more than fp32 rounding)
-    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask() & 8)))) && d.bn_mode == 0 && !d.ref_compat;
     if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
     else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
@@ -735,6 +741,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
     if (h->training) m.sv_p = W(h, "mask_sv_p");
     if (d.bf16 == 1) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
+    else if (x6gen && (H == 64 || H == 128) && h->V % 128 == 0) { m.Wp = D4(h, "mask/W6"); Timer t(h, s, "mask_fc"); launch_mask_x6(m, s); }
     else { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
     DecArgs a{};
     a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");

@@ -35,6 +35,10 @@ struct MaskArgs {
     float* sv_p;                                   // optional [R,H]: relu(xhat W + b) kept for the backward softmax
 };
 void launch_mask(const MaskArgs& a, hipStream_t s);
+// six-product forms of deconv1 and the mask fc (kernels_x6.hip; weight pointers = three-piece packs)
+bool rows_x6_supported(int K, int NT);
+void launch_deconv1_x6(const GemmArgs& a, hipStream_t s);
+void launch_mask_x6(const MaskArgs& a, hipStream_t s);
 
 // ---- CVAE conv / deconv stack (kernels_conv.hip) ----
 struct ConvArgs {

@@ -467,3 +467,133 @@ void launch_deconv3_x6(const ConvArgs& a, hipStream_t s) {
     const size_t plo = (size_t)25 * 1 * 4 * 64;                        // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
     hipLaunchKernelGGL(k_deconv3_x6, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a, plo);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row GEMMs of sample generation in six-product form: deconv1 (k_gemm_rows<EPI_SCALE_SHIFT_ELU>: [R, L] x [L, 2048], folded
+// batch-norm + ELU) and the mask fc (k_mask: softmax(relu(xhat W + b)) * Hx, K = 1024).  The 64-row A tile is split once, when a
+// 128-column chunk of it is staged: three bf16 images [64][136] in LDS (52 KB: two workgroups per CU), every A fragment read feeds
+// all of a wave's n-tiles; weights are [p0 | p1 | p2] packs ("vae_dec/deconv1/W6", "mask/W6").  Same k order as the fp32 kernels.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int KC6 = 128, LDB6 = KC6 + 8, ILO6 = 64 * LDB6;
+// stages columns [k0, k0 + KC6) of 64 rows (row0..) of A [M, lda] into the three images
+__device__ __forceinline__ void stage6(u16* img, const float* __restrict__ A, int lda, int M, int row0, int k0, int kc, int tid) {
+    const int q = kc >> 2;
+    for (int i = tid; i < 64 * q; i += DS_WG) {
+        const int r = i / q, c4 = i - r * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < M) v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + r) * lda + k0 + c4 * 4);
+        unsigned p0[3], p1[3];
+        splitp<3>(v.x, v.y, p0); splitp<3>(v.z, v.w, p1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(img + k * ILO6 + r * LDB6 + c4 * 4) = make_uint2(p0[k], p1[k]);
+    }
+}
+template <int NTW>
+__global__ __launch_bounds__(DS_WG, 2) void k_deconv1_x6(GemmArgs a) {          // K <= KC6: the whole A tile is staged once
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* img = reinterpret_cast<u16*>(smem);
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const uint4* Bp = reinterpret_cast<const uint4*>(a.Bp);
+    const int G16 = a.K >> 4;
+    const size_t plo = (size_t)a.NT * G16 * 64;
+    const u16* a8 = img + (lane & 31) * LDB6 + 8 * (lane >> 5);
+    stage6(img, a.A, a.lda, a.M, row0, 0, a.K, tid);
+    __syncthreads();
+    // one n-tile at a time (two row blocks = two accumulators): eight live accumulators plus two fragment sets would not fit the register file
+#pragma unroll 1
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = (blockIdx.y * NTW + j) * 4 + w;
+        if (nt >= a.NT) continue;
+        f32x16 acc[2][1] = {{zero16()}, {zero16()}};
+        const uint4* bl[1] = {Bp + ((size_t)nt * G16) * 64 + lane};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) mmax_groups<1, 3>(acc[m], a8 + m * 32 * LDB6, ILO6, bl, plo, G16);
+        const int col = nt * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const int ch = col % a.chmod;
+        const float p0 = a.p0[ch], p1 = a.p1[ch];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + m * 32 + acc_row(i);
+                if (row < a.M) a.out[(size_t)row * a.ldo + col] = eluf_(acc[m][0][i] * p0 + p1);
+            }
+    }
+}
+
+__global__ __launch_bounds__(DS_WG, 2) void k_mask_x6(MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* img = reinterpret_cast<u16*>(smem);
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const int NT = a.H >> 5;                                 // 2 or 4 column tiles: wave w takes tile w
+    f32x16 acc[2][1] = {{zero16()}, {zero16()}};
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+    const int G16 = a.V >> 4;
+    const size_t plo = (size_t)NT * G16 * 64;
+    const u16* a8 = img + (lane & 31) * LDB6 + 8 * (lane >> 5);
+    for (int k0 = 0; k0 < a.V; k0 += KC6) {
+        stage6(img, a.xhat, a.V, a.R, row0, k0, KC6, tid);
+        __syncthreads();
+        if (w < NT) {
+            const uint4* bl[1] = {Wp + ((size_t)w * G16 + (k0 >> 4)) * 64 + lane};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) mmax_groups<1, 3>(acc[m], a8 + m * 32 * LDB6, ILO6, bl, plo, KC6 >> 4);
+        }
+        __syncthreads();
+    }
+    // relu(acc + b) -> LDS tile [64][H+4] (the images are dead), then the row softmax of k_mask
+    const int LDT = a.H + 4;
+    if (w < NT) {
+        const int col = w * 32 + (lane & 31);
+        const float b = a.bias[col];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = fmaxf(acc[m][0][i] + b, 0.f);
+                smem[(m * 32 + acc_row(i)) * LDT + col] = pv;
+                if (a.sv_p && row0 + m * 32 + acc_row(i) < a.R) a.sv_p[(size_t)(row0 + m * 32 + acc_row(i)) * a.H + col] = pv;
+            }
+    }
+    __syncthreads();
+    const int r = tid >> 2, q4 = tid & 3;
+    const int row = row0 + r;
+    const int per = a.H >> 2;
+    float mx = -3.0e38f;
+    for (int c = 0; c < per; ++c) mx = fmaxf(mx, smem[r * LDT + q4 * per + c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float sum = 0.f;
+    for (int c = 0; c < per; ++c) {
+        const float e = expf(smem[r * LDT + q4 * per + c] - mx);
+        smem[r * LDT + q4 * per + c] = e;
+        sum += (q4 * per + c < a.Hl) ? e : 0.f;         // padded columns are not in the softmax
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (row < a.R) {
+        const int ag = agent_of_row(row, a.K, a.mno);
+        for (int c = 0; c < per; ++c) {
+            const int col = q4 * per + c;
+            a.xz[(size_t)row * a.H + col] = (smem[r * LDT + col] / sum) * a.Hx[(size_t)ag * a.ldhx + col];
+        }
+    }
+}
+}  // namespace
+bool rows_x6_supported(int K, int NT) { return (K % 16) == 0 && K <= 128 && NT % 16 == 0; }
+// a.Bp = the three-piece pack; a.K a multiple of 16; a.NT a multiple of 16 (deconv1: 64 n-tiles)
+void launch_deconv1_x6(const GemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)3 * ILO6 * sizeof(u16);
+    allow_big_lds(k_deconv1_x6<4>);
+    hipLaunchKernelGGL((k_deconv1_x6<4>), dim3((a.M + 63) / 64, a.NT / 16), dim3(DS_WG), lds, s, a);
+}
+// a.Wp = the three-piece pack "mask/W6"; H = 64 or 128, V a multiple of 128
+void launch_mask_x6(const MaskArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)3 * ILO6 * sizeof(u16);
+    allow_big_lds(k_mask_x6);
+    hipLaunchKernelGGL(k_mask_x6, dim3((a.R + 63) / 64), dim3(DS_WG), lds, s, a);
+}
