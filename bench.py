@@ -730,7 +730,7 @@ def main():
             "max_abs_diff_vs_fp32_kernel": float(dl6.max()), "mean_abs_diff_vs_fp32_kernel": float(dl6.mean()),
             "rows_compared": int(d.R),
             "kernel_ms": {k: float(np.mean(v)) for k, v in k6.items()},
-            "sample_generation": {"kernels": "k_decoder_x6, k_deconv2_x6, k_deconv3_x6 (kernels_x6.hip); everything else the fp32 kernels",
+            "sample_generation": {"kernels": "k_decoder_x6, k_deconv1_x6, k_deconv2_x6, k_deconv3_x6i, k_mask_x6 (kernels_x6.hip); everything else the fp32 kernels",
                                   "max_abs_diff_Y0_vs_fp32_kernels": float(d06.max()), "mean_abs_diff_Y0_vs_fp32_kernels": float(d06.mean()),
                                   "rows_moved_by_more_than_1e-3_end_to_end_vs_fp32_path": float(moved6),
                                   "note": "the refinement is a discontinuous function of the sampled positions (floors): a row whose Y0 differs "
