@@ -789,10 +789,13 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
-    const bool x3 = d.bf16 == 2 && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);     // (also the training-mode forward)
-    const bool x6 = d.bf16 == 3 && ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size);     // six-product form: inference only
+    // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
+    // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
+    const bool wide64 = d.mno == 64 && !h->training && ioc_x6r2_supported(d.mno, d.H, d.grid_size * d.grid_size);
+    const bool x3 = d.bf16 == 2 && (ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size) || wide64);
+    const bool x6 = d.bf16 == 3 && (ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size) || wide64);     // six-product form: inference only
     const bool cluster = d.bf16 == 1 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
-                                : ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
+                                : (!(x3 || x6) || h->training) && ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
     if (cluster) {
         const size_t n_groups = (size_t)h->R / d.mno;
         if (!h->ws.count("hex")) {

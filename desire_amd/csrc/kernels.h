@@ -140,6 +140,7 @@ void launch_ioc_x3(const IocArgs& a, hipStream_t s);
 void launch_ioc_x6(const IocArgs& a, hipStream_t s);
 bool ioc_x6r2_supported(int mno, int H, int bins);             // ... on 64-row tiles, two row blocks per wave (kernels_x6r2.hip)
 void launch_ioc_x6r2(const IocArgs& a, hipStream_t s);
+void launch_ioc_x3r2(const IocArgs& a, hipStream_t s);             // ... with two-piece operands (dims.bf16 = 2)
 // sample generation with three-piece operands (kernels_x6.hip, dims.bf16 = 3)
 bool decoder_x6_supported(int H);
 void launch_decoder_x6(const DecArgs& a, hipStream_t s);

@@ -23,14 +23,15 @@
 #define TICK6(k)
 #endif
 
-template <int H, int EV, int C, bool WIDE>          // WIDE: one 64-agent group spans both row blocks (compile-time: keeps the chains branch-free)
+// NP = 3: six products (dims.bf16 = 3); NP = 2: the same tile with two-piece operands, three products (dims.bf16 = 2).
+template <int H, int EV, int C, bool WIDE, int NP = 3>          // WIDE: one 64-agent group spans both row blocks (compile-time: keeps the chains branch-free)
 __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int NP = 3, NT = H >> 5, RB = 2, TM = 32 * RB, E = EV + C + H, KX = E + H;
+    constexpr int NT = H >> 5, RB = 2, TM = 32 * RB, E = EV + C + H, KX = E + H;
     constexpr int LDX = KX + 4, LDB = H + 4, LDT = TM + 4;            // fp32 elements; row strides = 4 mod 8 dwords: conflict-free b128
     constexpr int NTHR = NT * 64, TPR = NTHR / TM;
     constexpr int G16 = KX >> 4, GX16 = E >> 4, GH16 = H >> 4;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
 #pragma unroll
                             for (int jg = 0; jg < JGM; ++jg) {
                                 if (jg < JG) {
-                                    const FragP<NP> hf = frag6(hp + 16 * jg);
+                                    const FragP<NP> hf = fragp<NP>(hp + 16 * jg);
 #pragma unroll
                                     for (int i = NP - 1; i >= 0; --i) da = mfma16(hf.p[i], mf[m][jg], da);
                                 }
@@ -308,7 +309,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
                     const int sl = g % RD;
                     FragP<NP> av[RB];
 #pragma unroll
-                    for (int m = 0; m < RB; ++m) av[m] = frag6(xp0 + 32 * m * LDX + g * 16);
+                    for (int m = 0; m < RB; ++m) av[m] = fragp<NP>(xp0 + 32 * m * LDX + g * 16);
 #pragma unroll
                     for (int pr = 0; pr < Pairs<NP>::N; ++pr) {     // smallest products first; six / four accumulators side by side
                         const int pa = Pairs<NP>::A[pr], pb = Pairs<NP>::B[pr];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
                 for (int g = 0; g < GH16; ++g) {
                     FragP<NP> av[RB];
 #pragma unroll
-                    for (int m = 0; m < RB; ++m) av[m] = frag6(rp0 + 32 * m * LDB + g * 16);
+                    for (int m = 0; m < RB; ++m) av[m] = fragp<NP>(rp0 + 32 * m * LDB + g * 16);
 #pragma unroll
                     for (int pr = 0; pr < Pairs<NP>::N; ++pr)
 #pragma unroll
@@ -404,7 +405,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
             for (int m = 0; m < RB; ++m) {
                 f32x16 acc[1] = {zero16()};
                 const uint4* br[1] = {Wreg + ((size_t)nt * GH16) * 64 + lane};
-                mma6_groups<1>(acc, XH + (32 * m + c31) * LDX + E + 8 * hi, br, WR_LO, GH16);
+                mma6_groups<1, NP>(acc, XH + (32 * m + c31) * LDX + E + 8 * hi, br, WR_LO, GH16);
                 if (cc < 2 * a.T) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -434,17 +435,21 @@ bool ioc_x6r2_supported(int mno, int H, int bins) {
     const size_t lds = ((size_t)64 * (KX + 4) + (size_t)64 * (H + 4) + (size_t)H * 68) * 4 + (size_t)64 * (bins + 1) * 8 + 128 + 1024 + 192 + (size_t)NT * 256 + 128;
     return lds <= 160 * 1024;
 }
-template <int H>
+template <int H, int NP>
 static void launch_x6r2(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 63) / 64), block((H / 32) * 64);
     if (a.mno > 32) {
-        allow_big_lds(k_ioc_x6r2<H, 16, 32, true>);
-        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, true>), grid, block, iocx6r2_lds(a), s, a);
+        allow_big_lds(k_ioc_x6r2<H, 16, 32, true, NP>);
+        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, true, NP>), grid, block, iocx6r2_lds(a), s, a);
     } else {
-        allow_big_lds(k_ioc_x6r2<H, 16, 32, false>);
-        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, false>), grid, block, iocx6r2_lds(a), s, a);
+        allow_big_lds(k_ioc_x6r2<H, 16, 32, false, NP>);
+        hipLaunchKernelGGL((k_ioc_x6r2<H, 16, 32, false, NP>), grid, block, iocx6r2_lds(a), s, a);
     }
 }
 void launch_ioc_x6r2(const IocArgs& a, hipStream_t s) {
-    if (a.H == 128) launch_x6r2<128>(a, s); else launch_x6r2<64>(a, s);
+    if (a.H == 128) launch_x6r2<128, 3>(a, s); else launch_x6r2<64, 3>(a, s);
+}
+// the same 64-row tile with two-piece operands (dims.bf16 = 2; weight pointers = the [hi | lo] packs)
+void launch_ioc_x3r2(const IocArgs& a, hipStream_t s) {
+    if (a.H == 128) launch_x6r2<128, 2>(a, s); else launch_x6r2<64, 2>(a, s);
 }

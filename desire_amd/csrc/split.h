@@ -50,28 +50,30 @@ __device__ __forceinline__ f32x16 mfma_xp(const uint4 (&a)[NP], const uint4 (&b)
 
 // One A fragment (lane = row, 8 consecutive k) straight out of an fp32 LDS tile: two 16-byte reads, split on the fly into its three
 // pieces (44 VALU operations -- affordable where the fragment feeds six or more MFMAs, i.e. >= 192 matrix-pipe cycles).
-__device__ __forceinline__ FragP<3> frag6(const float* p8) {
+template <int NP>
+__device__ __forceinline__ FragP<NP> fragp(const float* p8) {
     const float4 x0 = *reinterpret_cast<const float4*>(p8), x1 = *reinterpret_cast<const float4*>(p8 + 4);
-    return split8<3>(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
+    return split8<NP>(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
 }
+__device__ __forceinline__ FragP<3> frag6(const float* p8) { return fragp<3>(p8); }
 // acc[nb] += A[32 x 16 G16] . B_nb[16 G16 x 32], six products per fp32 product: A from an fp32 LDS tile (ap = this lane's row + 8 * hi
 // floats, 16-byte aligned), B from three-piece packs [p0 | p1 | p2]: piece i of n-tile nb at bl[nb] + i * plo (uint4 units, already
 // + lane; 64 uint4 per k-group).  B fragments run one k-group ahead (two named register sets, fenced).
-template <int NB>
+template <int NB, int NP = 3>
 __device__ __forceinline__ void mma6_groups(f32x16 (&acc)[NB], const float* ap, const uint4* const (&bl)[NB], size_t plo, int G16) {
-    uint4 b0[NB][3], b1[NB][3];
-    auto ld = [&](uint4 (&b)[NB][3], int g) {
+    uint4 b0[NB][NP], b1[NB][NP];
+    auto ld = [&](uint4 (&b)[NB][NP], int g) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) b[nb][i] = bl[nb][i * plo + (size_t)g * 64];
+            for (int i = 0; i < NP; ++i) b[nb][i] = bl[nb][i * plo + (size_t)g * 64];
     };
-    auto run = [&](const uint4 (&b)[NB][3], int g) {
-        const FragP<3> a = frag6(ap + g * 16);
+    auto run = [&](const uint4 (&b)[NB][NP], int g) {
+        const FragP<NP> a = fragp<NP>(ap + g * 16);
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr)
+        for (int pr = 0; pr < Pairs<NP>::N; ++pr)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(a.p[Pairs<3>::A[pr]], b[nb][Pairs<3>::B[pr]], acc[nb]);
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(a.p[Pairs<NP>::A[pr]], b[nb][Pairs<NP>::B[pr]], acc[nb]);
     };
     ld(b0, 0);
     int g = 0;

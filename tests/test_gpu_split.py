@@ -31,6 +31,8 @@ TOL_Y = 1e-4
     dict(nb_w=0.04, nb_h=0.04, K=2),                     # sparse windows: empty bins skipped per tile
     dict(bin_mode=1, grid_size=4, nb_w=0.45, nb_h=0.04, K=2),       # log-polar bins
     dict(posterior=0, K=3),
+    dict(mno=64, n_scenes=1, K=2, n_grids=1),            # one 64-agent group per 64-row tile (kernels_x6r2.hip with two pieces)
+    dict(mno=64, n_scenes=2, K=3, n_grids=1, H=64),
 ])
 def test_ioc_split_operands_match_fp32_oracle(torch_cuda, kw):
     kw = dict(kw)
@@ -85,9 +87,10 @@ def test_split_operands_reproduce_goldens(tag):
 
 
 def test_shapes_without_a_split_kernel_run_the_fp32_kernels(torch_cuda):
-    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 64 agents (no split IOC form yet) run the fp32 IOC kernel, bit-identically
-    to dims.bf16 = 0 from the same decoder output; sample generation runs the six-product kernels (fp32 class: Y0 within 1e-6)."""
-    d = small_dims(mno=64, n_scenes=1, K=2, n_grids=1)
+    """dims.bf16 = 2 promises AT LEAST split accuracy: groups of 96 agents (the cluster form has no split IOC kernel) run the fp32 IOC
+    kernel, bit-identically to dims.bf16 = 0 from the same decoder output; sample generation runs the six-product kernels (fp32 class:
+    Y0 within 1e-6)."""
+    d = small_dims(mno=96, n_scenes=1, K=2, n_grids=1)
     w = init_weights(d, 7)
     past, fut, eps, grids, gos = make_case(d, seed=8, n_absent=5)
     ha, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
@@ -278,6 +281,7 @@ def test_split_path_is_window_independent_and_deterministic(torch_cuda):
     dict(nb_w=0.04, nb_h=0.04, K=2),
     dict(bin_mode=1, grid_size=4, nb_w=0.45, nb_h=0.04, K=2),
     dict(iters=2, K=2),
+    dict(mno=64, n_scenes=1, K=2, n_grids=1),            # one 64-agent group per 64-row tile
 ])
 def test_six_product_form_is_as_close_to_the_oracle_as_the_fp32_kernel(torch_cuda, kw):
     """dims.bf16 = 3: x = hi + mid + lo EXACTLY (8 + 8 + 8 bits), products (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi): what is
@@ -355,14 +359,14 @@ def test_six_product_form_reproduces_goldens(tag):
 
 def test_six_product_form_refuses_training_and_falls_back_on_other_shapes(torch_cuda):
     from desire_amd import _lib
-    d = small_dims(mno=64, n_scenes=1, K=2, n_grids=1)
+    d = small_dims(mno=96, n_scenes=1, K=2, n_grids=1)
     w = init_weights(d, 7)
     past, fut, eps, grids, gos = make_case(d, seed=8, n_absent=5)
     ha, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     Y0 = ha.read_buffer("Y0", (d.R, d.T_pred, 2))
     _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
-    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos, Y_in=Y0)    # no six-product IOC form for 64-agent groups:
-    assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)                                      # the fp32 kernel runs, bit for bit
+    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3), w, past, fut, eps, grids, gos, Y_in=Y0)    # no six-product IOC form for 96-agent groups (cluster
+    assert np.array_equal(Ya, Yb) and np.array_equal(sa, sb)                                      # form): the fp32 kernel runs, bit for bit
     h = _lib.Handle(small_dims().replace(bf16=3)); h.set_weights(init_weights(small_dims(), 1))
     with pytest.raises(_lib.DesireError):
         h.set_training(True)
@@ -409,7 +413,7 @@ def test_six_product_ioc_on_64_row_tiles_matches_the_32_row_form(torch_cuda, kw,
     monkeypatch.setenv("DESIRE_IOC_VARIANT", "14")       # 64-row tiles whatever the launch size (by default only launches of >= 256 such tiles)
     _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
     monkeypatch.setenv("DESIRE_IOC_VARIANT", "13")
-    _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
+    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3 if d.mno <= 32 else 0), w, past, fut, eps, grids, gos, Y_in=Y0)   # (64-agent groups: the fp32 kernel)
     assert np.isfinite(Ya).all() and np.abs(Ya - Y0).max() > 0
     # same products, same per-accumulator order -- but not the same bits: the 32-row form splits r*h (and friends) where it computes
     # them, and hipcc contracts the product into the split's subtraction (the pieces then carry the UNROUNDED product); a tile's
