@@ -722,6 +722,12 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
     const bool fuse34 = d.bf16 == 1 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
+    if (x6gen && !h->training && getenv("DESIRE_FUSE34_X6")) {             // six-product form, inference: likewise -- opt-in (A/B): 15.4 ms against 11.9 + 2.5 for
+                                                                           // the two kernels: the tap products cost the contracting waves more than the d3 pass did
+        c.Wp = D4(h, "vae_dec/deconv3/W6"); c.w_raw = D(h, "vae_dec/deconv4/raw");
+        Timer t(h, s, "deconv34");
+        launch_deconv34_x6(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), W(h, "xhat"), s);
+    } else
     if (fuse34) {
         c.Wp = D4(h, "vae_dec/deconv3/W16"); c.w_raw = D(h, "vae_dec/deconv4/W16"); c.out = W(h, "xhat");
         Timer t(h, s, "deconv34");

@@ -49,6 +49,7 @@ struct ConvArgs {
                                                    // destination layer for the backward modes
 };
 void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
+void launch_deconv34_x6(const ConvArgs& a, const float* sc4, const float* sh4, float* xhat, hipStream_t s);   // six-product deconv3 + deconv4 fused (kernels_x6.hip, inference)
 void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
 void launch_conv2_x3(const ConvArgs& a, hipStream_t s);  // same with split-bf16 operands (kernels_bwd_x3.hip; a.Wp = [hi | lo] pack)
 void launch_conv3_x3(const ConvArgs& a, hipStream_t s);  // [n,8,8,64] -> [n,4,4,128]
