@@ -322,6 +322,41 @@ def reference_defaults_leg(seed, dev, steps):
     return out
 
 
+def few_windows_leg(d_full, seed, dev):
+    """Literal BASELINE configs[1] (ONE window = 640 samples per call) and its neighbours, fp32, outside the timed region: latency of a whole
+    forward per call.  Up to 6 windows the IOC kernel runs its bin-split form (several workgroups per 32-row tile: DESIGN.md section 11)."""
+    import torch
+    from desire_amd import _lib
+    from desire_amd.spec import init_weights
+    from desire_amd.synth import make_case
+    out = {}
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n_w in (1, 2, 8):
+        dw = d_full.replace(n_scenes=n_w, n_grids=1)
+        w = init_weights(dw, seed)
+        past, fut, eps, grids, gos = make_case(dw, seed=seed + 1)
+        h = _lib.Handle(dw)
+        h.set_weights(w)
+        p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+        h.set_scene_grids(g_t.data_ptr(), gos)
+        Y = torch.zeros((dw.R, dw.T_pred, 2), device=dev); sc = torch.zeros((dw.R,), device=dev)
+        for _ in range(5):
+            h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        n2 = 50
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dtw = (time.perf_counter() - t0) / n2
+        assert bool(torch.isfinite(Y).all())
+        out["windows_%d" % n_w] = {"ms_per_call": dtw * 1e3, "value": dw.R / dtw, "unit": "samples/s", "samples_per_call": dw.R}
+        h.close()
+    out["note"] = "one call = encode + sample + refine for this many 32-agent windows (K = 20), back-to-back launches, no hipGraph"
+    return out
+
+
 def training_step_leg(d_full, seed, dev, steps):
     """BASELINE configs[4]'s per-GPU work on configs[1] shapes: one training step (forward with saves, backward, global-norm clip, Adam,
     device-side repack) over 128 windows = 81 920 samples, outside the timed region -- fp32 operands, and dims.bf16 = 2 (split-bf16
@@ -744,6 +779,7 @@ def main():
         alt["bf16_config2"] = bf16_config2_leg(d, w, a.seed, dev, a.steps, with_accuracy=not a.no_cpu_baseline)
         alt["reference_defaults"] = reference_defaults_leg(a.seed, dev, a.steps)
         alt["training_step"] = training_step_leg(d, a.seed, dev, a.steps)
+        alt["few_windows"] = few_windows_leg(d, a.seed, dev)
 
     # outside the timed region: the same path on REAL SDD windows (BASELINE configs[1] names "SDD bookstore"): tiled bookstore/video6
     # windows with their absent slots and the reference's 32-px neighbourhood (train.py:68-70) on the 1424 x 1088 frame

@@ -47,6 +47,8 @@ def test_default_contract_fields():
     assert sp["value"] > 0 and sp["ioc_ms"] > 0 and 0 < sp["max_abs_diff_vs_fp32_kernel"] < 1e-4
     assert o["alt"]["row_compacted_pooling"]["value"] > 0
     assert o["alt"]["reference_defaults"]["batch_size_10"]["value"] > 0 and o["alt"]["reference_defaults"]["windows_128"]["value"] > 0
+    fw = o["alt"]["few_windows"]                              # literal configs[1]: one window per call
+    assert 0 < fw["windows_1"]["ms_per_call"] <= fw["windows_8"]["ms_per_call"] < 10
     tr = o["alt"]["training_step"]                            # configs[4]'s per-GPU work, fp32 and split operands
     assert tr["fp32"]["value"] > 0 and tr["split_bf16x3"]["value"] > tr["fp32"]["value"] and np.isfinite(tr["split_bf16x3"]["loss"])
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class
