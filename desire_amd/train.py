@@ -58,6 +58,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--fix_id0", action="store_true", help="keep SDD track id 0 (the reference drops it)")
     p.add_argument("--ioc_iters", type=int, default=1, help="IOC refinement passes")
+    p.add_argument("--bf16", type=str, default="", choices=["", "f32", "x3", "split"],
+                   help="matrix operands of the training step: fp32 (default) or x3 = split-bf16 (hi + lo, three bf16 MFMAs per product) in the IOC "
+                        "forward / BPTT, the weight-gradient reductions and the large data-gradient convolutions; gradients stay within the fp32 "
+                        "path's tolerance of float64 autograd")
     p.add_argument("--report_ade", action="store_true",
                    help="after every epoch: ADE / FDE (mean-of-K and best-of-K, normalised units) of PRIOR samples on the epoch's last batch")
     return p
