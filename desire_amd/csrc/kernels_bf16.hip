@@ -944,26 +944,33 @@ __global__ __launch_bounds__(DS_WG) void k_mask_bf16(MaskArgs a) {
             for (int i = 0; i < 16; ++i) tile[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) * LDT + col] = fmaxf(acc[j][0][m][i] + b, 0.f);
     }
     __syncthreads();
+    // softmax over H per row: 4 threads per row, each owning every fourth float4 of it (16-byte accesses to the tile, xz and Hx; as k_mask)
     const int r = tid >> 2, q4 = tid & 3;
     const int row = row0 + r;
-    const int per = a.H >> 2;
+    const int nv = a.H >> 4;
+    float4* trow = reinterpret_cast<float4*>(tile + r * LDT);
     float mx = -3.0e38f;
-    for (int c = 0; c < per; ++c) mx = fmaxf(mx, tile[r * LDT + q4 * per + c]);
+    for (int j = 0; j < nv; ++j) { const float4 v = trow[4 * j + q4]; mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
     mx = fmaxf(mx, __shfl_xor(mx, 1));
     mx = fmaxf(mx, __shfl_xor(mx, 2));
     float sum = 0.f;
-    for (int c = 0; c < per; ++c) {
-        const float e = expf(tile[r * LDT + q4 * per + c] - mx);
-        tile[r * LDT + q4 * per + c] = e;
-        sum += (q4 * per + c < a.Hl) ? e : 0.f;         // padded columns (relu(0) = 0 <= mx) are not in the softmax
+    for (int j = 0; j < nv; ++j) {
+        float4 v = trow[4 * j + q4];
+        v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);
+        trow[4 * j + q4] = v;
+        const int c0 = 16 * j + 4 * q4;         // padded columns (relu(0) = 0 <= mx) are not in the softmax
+        sum += (c0 < a.Hl ? v.x : 0.f) + (c0 + 1 < a.Hl ? v.y : 0.f) + (c0 + 2 < a.Hl ? v.z : 0.f) + (c0 + 3 < a.Hl ? v.w : 0.f);
     }
     sum += __shfl_xor(sum, 1);
     sum += __shfl_xor(sum, 2);
     if (row < a.R) {
         const int ag = agent_of_row(row, a.K, a.mno);
-        for (int c = 0; c < per; ++c) {
-            const int col = q4 * per + c;
-            a.xz[(size_t)row * a.H + col] = (tile[r * LDT + col] / sum) * a.Hx[(size_t)ag * a.ldhx + col];
+        const float inv = 1.0f / sum;
+        const float4* hx = reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx);
+        float4* xz = reinterpret_cast<float4*>(a.xz + (size_t)row * a.H);
+        for (int j = 0; j < nv; ++j) {
+            const float4 e = trow[4 * j + q4], hv = hx[4 * j + q4];
+            xz[4 * j + q4] = make_float4(e.x * inv * hv.x, e.y * inv * hv.y, e.z * inv * hv.z, e.w * inv * hv.w);
         }
     }
 }
