@@ -212,7 +212,10 @@ struct DecBwdArgs {
     float* dag; float* dac; float* rh; float* hprev;       // [R,T,2H], [R,T,H] x3: gate gradients, r*h_{t-1}, h_{t-1}
     float* dxg; float* dxc; float* dxz; float* dHx_rows;   // [R,2H], [R,H], [R,H], [R,H]  (dxz == null: encoder use)
     const float* dh_init; int ld_init;                     // optional gradient w.r.t. the FINAL state (encoders)
-};
+    float* bias_part;                                      // optional [tiles][3H]: per-tile column sums of da_r | da_u | da_c over rows and steps
+};                                                         // (the bias gradients, without another pass over the gate-gradient streams)
+// out[n] (+)= sum_p part[p * ld + off + n], n < N: fixed order over p (deterministic)
+void launch_reduce_parts(const float* part, int nparts, int ld, int off, int N, float* out, int accumulate, hipStream_t s);
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
 struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd; int N; int nslices; float* partial;
                 // optional block-sparsity of A: flags[m] bit b set <=> columns [b*fcols, (b+1)*fcols) of row m can be non-zero.  A 32-row
@@ -247,6 +250,7 @@ struct IocBwdArgs {
     float* dag; float* dac; float* rh; float* hprev; float* dpre_r; float* dpre_v; float* vel; float* pooled;
     float* dHx_rows;
     const float* bin_tab;
+    float* bias_part;                                      // optional [32-row blocks][4H]: column sums of da_r | da_u | da_c | dpre_r (32-row forms only)
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);
 bool ioc_bwd_x3_supported(int mno, int H);                       // kernels_bwd_x3.hip: groups of up to 32 agents, H = 64 / 128

@@ -156,6 +156,17 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
         for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + dhg[i];
     }
     __syncthreads();
+    if (a.bias_part) {                                     // bias gradients: this tile's column sums of the gate gradients (rows < R only)
+        float vr = 0.f, vu = 0.f, vc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (row0 + acc_row(i) < a.R) { vr += sxr[i]; vu += sxu[i]; vc += sxc[i]; }
+        vr += __shfl_xor(vr, 32); vu += __shfl_xor(vu, 32); vc += __shfl_xor(vc, 32);
+        if (lane < 32) {
+            float* part = a.bias_part + (size_t)blockIdx.x * 3 * H;
+            part[col] = vr; part[H + col] = vu; part[2 * H + col] = vc;
+        }
+    }
     // dh is now d L / d h_{-1} = the decoder's share of dHx (per row); constant-input sums -> dx_z
     if (!a.dxz) return;                                    // encoders: inputs are data, nothing upstream
 #pragma unroll
@@ -380,6 +391,22 @@ __global__ __launch_bounds__(256) void k_reduce_slices8(const float* __restrict_
         float* o = out + (size_t)(i / N) * ldo + (i % N);
         *o = accumulate ? (*o + t) : t;
     }
+}
+__global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part, int nparts, int ld, int off, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float sacc = 0.f;
+    if (n < N) for (int pth = g; pth < nparts; pth += 8) sacc += part[(size_t)pth * ld + off + n];
+    red[g][c] = sacc;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        const float t = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+void launch_reduce_parts(const float* part, int nparts, int ld, int off, int N, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3((N + 31) / 32), dim3(256), 0, s, part, nparts, ld, off, N, out, accumulate);
 }
 static void reduce_slices(const float* partial, int nslices, int Kd, int N, float* out, int ldo, int accumulate, hipStream_t s) {
     const int n = Kd * N;
@@ -943,6 +970,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         DR[r * LDR + c] = (c < 2 * a.T && row0 + r < a.R) ? a.dYr[(size_t)(row0 + r) * 2 * a.T + c] : 0.f;
     }
     __syncthreads();
+    float cs_r = 0.f, cs_u = 0.f, cs_c = 0.f, cs_p = 0.f;   // this lane's column sums of da_r, da_u, da_c, dpre_r over its rows and all steps
     f32x16 dh = zero16();
     mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
 
@@ -1010,6 +1038,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             if (row0 + rl < a.R) {
                 o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
                 o_dag[tl(i, t) * 2 * H + H + col] = dau;
+                cs_c += dac; cs_u += dau;
             }
             rr[i] = r; hp[i] = hprev;
         }
@@ -1025,7 +1054,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             dhp[i] += drh[i] * rr[i];
             const float dar = dr * rr[i] * (1.0f - rr[i]);
             A2[rl * LD2 + col] = dar;
-            if (row0 + rl < a.R) o_dag[tl(i, t) * 2 * H + col] = dar;
+            if (row0 + rl < a.R) { o_dag[tl(i, t) * 2 * H + col] = dar; cs_r += dar; }
         }
         __syncthreads();
         // da_c is consumed: its tile now takes h_{t-1} for the pooled rebuild (visible after the next barrier)
@@ -1044,7 +1073,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 const float dpr = er > 0.f ? der[i] : 0.f;
                 A3[rl * LD1 + col] = dpr;
                 if (row0 + rl < a.R) {
-                    o_dpr[tl(i, t) * H + col] = dpr;
+                    o_dpr[tl(i, t) * H + col] = dpr; cs_p += dpr;
                     if (cb == 0 && (lane & 31) < EV) {
                         const float ev = svx[ixx + (lane & 31)];
                         o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
@@ -1145,6 +1174,13 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
+    }
+    if (a.bias_part) {                                     // one part per 32-row block: [da_r | da_u | da_c | dpre_r] column sums
+        cs_r += __shfl_xor(cs_r, 32); cs_u += __shfl_xor(cs_u, 32); cs_c += __shfl_xor(cs_c, 32); cs_p += __shfl_xor(cs_p, 32);
+        if (lane < 32) {
+            float* part = a.bias_part + ((size_t)blockIdx.x * (TM / 32) + mt) * 4 * H;
+            part[col] = cs_r; part[H + col] = cs_u; part[2 * H + col] = cs_c; part[3 * H + col] = cs_p;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i)

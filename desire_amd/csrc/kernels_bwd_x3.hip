@@ -430,6 +430,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         DR[r * LDR + c] = (c < 2 * a.T && row0 + r < a.R) ? a.dYr[(size_t)(row0 + r) * 2 * a.T + c] : 0.f;
     }
     __syncthreads();
+    float cs_r = 0.f, cs_u = 0.f, cs_c = 0.f, cs_p = 0.f;   // this lane's column sums of da_r, da_u, da_c, dpre_r over its rows and all steps
     f32x16 dh = zero16();
     mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
 
@@ -498,6 +499,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 if (row0 + rl < a.R) {
                     o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
                     o_dag[tl(i, t) * 2 * H + H + col] = dau;
+                    cs_c += dac; cs_u += dau;
                 }
                 rr[i] = r; hp[i] = hprev;
             }
@@ -522,7 +524,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                     dhp[i] += t2[0][i] * rr[i];
                     const float dar = dr * rr[i] * (1.0f - rr[i]);
                     darv[e] = dar;
-                    if (row0 + rl < a.R) o_dag[tl(i, t) * 2 * H + col] = dar;
+                    if (row0 + rl < a.R) { o_dag[tl(i, t) * 2 * H + col] = dar; cs_r += dar; }
                 }
                 put4(I2, LDB2, ILO2, col, q, darv[0], darv[1], darv[2], darv[3]);
             }
@@ -547,7 +549,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                     const float dpr = er > 0.f ? t2[1][i] : 0.f;
                     dprv[e] = dpr;
                     if (row0 + rl < a.R) {
-                        o_dpr[tl(i, t) * H + col] = dpr;
+                        o_dpr[tl(i, t) * H + col] = dpr; cs_p += dpr;
                         if (cb == 0 && (lane & 31) < EV) {
                             const float ev = svx[ixx + (lane & 31)];
                             o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
@@ -618,6 +620,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
+    }
+    if (a.bias_part) {                                     // one part per tile: [da_r | da_u | da_c | dpre_r] column sums
+        cs_r += __shfl_xor(cs_r, 32); cs_u += __shfl_xor(cs_u, 32); cs_c += __shfl_xor(cs_c, 32); cs_p += __shfl_xor(cs_p, 32);
+        if (lane < 32) {
+            float* part = a.bias_part + (size_t)blockIdx.x * 4 * H;
+            part[col] = cs_r; part[H + col] = cs_u; part[2 * H + col] = cs_c; part[3 * H + col] = cs_p;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i)

@@ -399,7 +399,13 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     b.R = (int)R; b.K = d.K; b.mno = d.mno; b.T = T; b.H = H;
     b.dag = W(h, "dec_dag"); b.dac = W(h, "dec_dac"); b.rh = W(h, "dec_rh"); b.hprev = W(h, "dec_hprev");
     b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = W(h, "dHx_rows");
+    // bias gradients = column sums of the gate-gradient streams: summed per tile inside the BPTT kernels (no further pass over the streams)
+    const int n_tiles32 = (int)((R + 31) / 32);
+    if (ensure(h, "bias_part", (size_t)(n_tiles32 + 1) * 4 * H * sizeof(float))) return fail(DESIRE_ERR_HIP, "hipMalloc failed for bias_part");
+    b.bias_part = W(h, "bias_part");
     { Timer t(h, s, "bwd_decoder"); launch_decoder_bwd(b, s); }
+    launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 0, 2 * H, G(h, "dec/gates/bias"), 0, s);
+    launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 2 * H, H, G(h, "dec/candidate/bias"), 0, s);
     {
         Timer t(h, s, "bwd_decoder_wgrad");
         tn(h, W(h, "dec_sv_h"), H, W(h, "dY0"), 2, R * T, H, 2, G(h, "head/w"), 2, 0, s);
@@ -407,11 +413,9 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         float* gk = G(h, "dec/gates/kernel");        // [(H+H), 2H]
         tn(h, W(h, "xz"), H, W(h, "dec_dxg"), 2 * H, R, H, 2 * H, gk, 2 * H, 0, s);
         tn(h, W(h, "dec_hprev"), H, W(h, "dec_dag"), 2 * H, R * T, H, 2 * H, gk + (size_t)H * 2 * H, 2 * H, 0, s);
-        colsum(h, W(h, "dec_dag"), 2 * H, R * T, 2 * H, G(h, "dec/gates/bias"), 0, s);
         float* ck = G(h, "dec/candidate/kernel");    // [(H+H), H]
         tn(h, W(h, "xz"), H, W(h, "dec_dxc"), H, R, H, H, ck, H, 0, s);
         tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, R * T, H, H, ck + (size_t)H * H, H, 0, s);
-        colsum(h, W(h, "dec_dac"), H, R * T, H, G(h, "dec/candidate/bias"), 0, s);
     }
     const int V = h->V, L = d.L, A = h->A;
     const bool bn1 = d.bn_mode != 0;                       // batch statistics -- per object (mode 1, the reference graph's batch of one) or over
@@ -452,7 +456,9 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
             q.dHx_rows = W(h, "dHx_rows");
             q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
-            if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
+            const bool cl_bwd = ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0);
+            q.bias_part = cl_bwd ? nullptr : W(h, "bias_part");           // (the cluster form keeps the separate column-sum passes)
+            if (cl_bwd) {
                 const size_t n_groups = (size_t)h->R / d.mno;
                 HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
                 if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
@@ -472,14 +478,17 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             float* gk = G(h, "ioc/gates/kernel");            // [(E+H), 2H]
             tn(h, sv_x, E, W(h, "ioc_dag"), 2 * H, RT, E, 2 * H, gk, 2 * H, acc, s);
             tn(h, W(h, "ioc_hprev"), H, W(h, "ioc_dag"), 2 * H, RT, H, 2 * H, gk + (size_t)E * 2 * H, 2 * H, acc, s);
-            colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), acc, s);
+            if (cl_bwd) colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 0, 2 * H, G(h, "ioc/gates/bias"), acc, s);
             float* ck = G(h, "ioc/candidate/kernel");        // [(E+H), H]
             tn(h, sv_x, E, W(h, "ioc_dac"), H, RT, E, H, ck, H, acc, s);
             tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, acc, s);
-            colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
+            if (cl_bwd) colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 2 * H, H, G(h, "ioc/candidate/bias"), acc, s);
             tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s,
                static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p), H);     // empty (row, t, bin) blocks are skipped
-            colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
+            if (cl_bwd) colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 3 * H, H, G(h, "ioc/social_fc/b"), acc, s);
             tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, acc, s);
             colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), acc, s);
         }
