@@ -304,12 +304,20 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
 #pragma unroll
                 for (int g = 0; g < RD; ++g) req(g);
                 const float* xp0 = XH + c31 * LDX + 8 * hi;
+                // the fragments of group g + 1 are split while the MFMAs of group g run (independent work between the same two fences)
+                FragP<NP> avn[RB];
+#pragma unroll
+                for (int m = 0; m < RB; ++m) avn[m] = fragp<NP>(xp0 + 32 * m * LDX);
 #pragma unroll
                 for (int g = 0; g < G16; ++g) {
                     const int sl = g % RD;
                     FragP<NP> av[RB];
 #pragma unroll
-                    for (int m = 0; m < RB; ++m) av[m] = fragp<NP>(xp0 + 32 * m * LDX + g * 16);
+                    for (int m = 0; m < RB; ++m) av[m] = avn[m];
+                    if (g + 1 < G16) {
+#pragma unroll
+                        for (int m = 0; m < RB; ++m) avn[m] = fragp<NP>(xp0 + 32 * m * LDX + (g + 1) * 16);
+                    }
 #pragma unroll
                     for (int pr = 0; pr < Pairs<NP>::N; ++pr) {     // smallest products first; six / four accumulators side by side
                         const int pa = Pairs<NP>::A[pr], pb = Pairs<NP>::B[pr];
