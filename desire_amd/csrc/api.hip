@@ -833,7 +833,9 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                 *h->host_err = 0;
                 return fail(DESIRE_ERR_HIP, "bin-split IOC hand-off timed out in an earlier call (workgroups of a tile were not co-resident)");
             }
-            HIPCHK(hipMemsetAsync(h->ws["cnt_s"].p, 0, tiles * sizeof(int), s));
+            // (a fill KERNEL, not hipMemsetAsync: memset nodes of a captured graph were seen to run out of order on replay -- section 6a --
+            //  and a counter that still holds the previous pass's arrivals lets every member read its peers' slots before they are written)
+            launch_fill_f32(W(h, "cnt_s"), tiles, 0.f, s);
             a.hex = W(h, "hex_s"); a.grp_cnt = static_cast<int*>(h->ws["cnt_s"].p); a.err = h->host_err;
             a.nspl = nspl;
         }

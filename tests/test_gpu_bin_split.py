@@ -61,3 +61,34 @@ def test_two_passes_run_the_plain_form(torch_cuda, monkeypatch):
     _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     np.testing.assert_array_equal(Ya, Yb)
     np.testing.assert_array_equal(sa, sb)
+
+
+def test_bin_split_forward_replays_from_a_hipgraph(torch_cuda):
+    """One window (literal configs[1]) captured once and replayed: the arrival counters of the bin-split IOC are reset by a fill KERNEL in
+    the captured sequence (a memset node was once seen to run out of order on replay: DESIGN.md 6a) -- a counter left at the previous
+    pass's value would let every member read its peers' slots before they are written.  Thirty replays, bit-identical to the direct call."""
+    import torch
+    from desire_amd import _lib
+    d = Dims(n_scenes=1, mno=32, K=20, T_obs=8, T_pred=40, n_grids=1, nb_w=0.2, nb_h=0.2, sx=1 / 1400.0, sy=1 / 1100.0)
+    w = init_weights(d, 5)
+    past, fut, eps, grids, gos = make_case(d, seed=6, n_absent=3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p, f, e, g = t(past), t(fut), t(eps), t(grids)
+    h = _lib.Handle(d); h.set_weights(w); h.set_scene_grids(g.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+    side = torch.cuda.Stream(); sp = side.cuda_stream
+    torch.cuda.synchronize()
+    h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)      # warm-up outside capture (lazy allocations)
+    side.synchronize()
+    Y_ref, s_ref = Y.clone(), sc.clone()
+    h.graph_begin(sp)
+    h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+    gid = h.graph_end(sp)
+    for _ in range(30):
+        Y.zero_(); sc.zero_()
+        torch.cuda.synchronize()
+        h.graph_launch(gid, sp)
+        side.synchronize()
+        assert torch.equal(Y, Y_ref) and torch.equal(sc, s_ref)
+    assert float(Y_ref.abs().max()) > 0
+    h.close()
