@@ -458,7 +458,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
             }
         };
-        load_hprev();                                    // part 1 reads each element, then overwrites it with da_c
+        load_hprev();                                    // read by part 1 and by the pooled rebuild of this step
         __syncthreads();
         // ---- P1: neighbour / observer masks ----
         {
@@ -530,8 +530,8 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             }
         }
         __syncthreads();
-        // part 1 has read h_{t-1}: reload it for the pooled rebuild (visible after the next barrier); da_c is consumed, its images take dpre_r
-        load_hprev();
+        // (h_{t-1} is still in its tile -- da_c went to the images, not over it as in the fp32 kernel -- so the pooled rebuild needs no reload);
+        // da_c is consumed, its images take dpre_r
         {
             f32x16 t2[2] = {zero16(), der};                       // dh (gates) | de_r
             mmax_groups<2, 2>(t2, a2_lane, ILO2, bg2, PLG, G32);
