@@ -1,7 +1,7 @@
 """VERDICT r02 item 5's acceptance, literally: on ALL 327 680 rows of the default bench batch (512 windows x K = 20 x 32 slots), the IOC pass
 of the fp32 kernels, of the six-product kernels (dims.bf16 = 3) and of the CPU oracle from ONE shared Y0 (the fp32 kernels' decoder
 output), i.e. the same cells and bins everywhere.  The numpy oracle takes ~10 minutes for this batch on the GPU box's host: this is a
-one-off evidence script (python profiles/x6_full_batch_check.py out.json), not part of bench.py or the test suite.  The oracle is used here as
+one-off evidence script (python -m tests.x6_full_batch_check out.json), not part of bench.py or the test suite.  The oracle is used here as
 the checker only, as in tests/."""
 import json
 import sys
