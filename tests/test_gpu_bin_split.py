@@ -92,3 +92,29 @@ def test_bin_split_forward_replays_from_a_hipgraph(torch_cuda):
         assert torch.equal(Y, Y_ref) and torch.equal(sc, s_ref)
     assert float(Y_ref.abs().max()) > 0
     h.close()
+
+
+def test_split_switched_off_restores_batch_size_invariance(torch_cuda):
+    """DESIRE_IOC_SPLIT=0 (read once per process, hence the subprocess): every launch runs the plain kernel, and a window's results are
+    bit-identical whether it is run alone or inside a larger batch -- the invariance the bin-split form trades for latency."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from desire_amd.spec import Dims, init_weights
+from tests.helpers import make_case
+from tests.test_gpu_parity import run_gpu
+d = Dims(n_scenes=4, mno=32, K=4, T_obs=8, T_pred=12, n_grids=1, nb_w=0.2, nb_h=0.2, sx=1 / 1400.0, sy=1 / 1100.0)
+w = init_weights(d, 5)
+past, fut, eps, grids, gos = make_case(d, seed=6, n_absent=3)
+_, Y4, s4 = run_gpu(torch, d, w, past, fut, eps, grids, gos)
+d1 = d.replace(n_scenes=1); r1 = d1.R
+_, Y1, s1 = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1])
+assert np.array_equal(Y4[:r1], Y1) and np.array_equal(s4[:r1], s1)
+print("invariant")
+'''
+    env = dict(os.environ, DESIRE_IOC_SPLIT="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "invariant" in r.stdout, r.stderr[-2000:]
