@@ -40,27 +40,57 @@ def ioc_flops_per_row(d):
     return d.iters * (T * (6.0 * H * (E + H) + 2.0 * B * H * H + 2 * H + 4 * d.E_v) + 2.0 * H * 2 * T)
 
 
-def committed_traffic(windows, bf16=False):
-    """HBM bytes per k_ioc launch from the committed rocprofv3 PMC passes (profiles/, collected from this very
-    command at the same windows/step in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
-    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  None when no matching profile is committed."""
-    name = {(128, False): "r01_final_bench_pmc_per_kernel.json", (128, True): "r01_bf16_bench_pmc_per_kernel.json",
-            (512, False): "r01_final_bench_w512_pmc_per_kernel.json"}.get((windows, bool(bf16)))
-    for newer in ("r02_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else ""),
-                  "r03_bench_w%d%s_pmc_per_kernel.json" % (windows, "_bf16" if bf16 else "")):
-        if os.path.exists(os.path.join(ROOT, "profiles", newer)):
-            name = newer
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if path is None or not os.path.exists(path):
-        return None
-    committed_traffic.source = "profiles/" + name
-    with open(path) as fh:
-        pmc = json.load(fh)
-    for name, c in pmc.items():
-        hit = ("k_ioc_bf16ILi128" in name) if bf16 else (("k_iocILi128" in name or name.startswith("void k_ioc<128"))
-                                                          and "ELb0ELb1E" not in name)     # (not the opt-in compact form of the `alt` pass)
-        if hit and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+def committed_traffic(d, bf16=False):
+    """HBM bytes per launch of the dominant IOC kernel from the committed rocprofv3 PMC passes (profiles/, collected from
+    `bench.py --headline-only` at the same shape in separate --pmc runs): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  The summaries are keyed per LAUNCH CLASS (symbol, workgroups,
+    workgroup size: profiles/summarise_pmc.py), and only the class whose grid is THIS launch's -- ceil(R / 32) tiles of 4 waves --
+    is accepted; a summary without grid information (rounds 1-2) is accepted only if its SQ_WAVES equals that wave count.  A figure
+    below the algorithmic bytes is physically impossible for the launch and is refused (a mixed-size average got
+    through).  None when no matching profile is committed."""
+    import glob
+    import re
+    committed_traffic.source = None
+    tiles = (d.R + 31) // 32
+    waves = tiles * 4
+    algorithmic = d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4
+    sym = "k_ioc_bf16" if bf16 else "k_ioc"
+
+    def is_headline_kernel(name):
+        """Mangled (`_Z5k_iocILi128ELi16ELi32ELi32ELb0ELb0ELi1EEv7IocArgs.kd`) or demangled (`void k_ioc<128, 16, 32, 32, false, false, 1>(IocArgs)`)
+        symbol of the plain inference form: this H, no saving / compact flag set, one workgroup per tile."""
+        m = re.match(r"^_Z\d+%s((?:I|L[ib]\d+E)+)E" % sym, name)
+        if m:
+            targs = re.findall(r"L([ib])(\d+)E", m.group(1))
+        else:
+            m = re.match(r"^void %s<([^>]*)>" % sym, name)
+            if not m:
+                return False
+            targs = [("b", {"true": "1", "false": "0"}[x.strip()]) if x.strip() in ("true", "false") else ("i", x.strip()) for x in m.group(1).split(",")]
+        ints = [int(v) for k, v in targs if k == "i"]
+        flags = [int(v) for k, v in targs if k == "b"]
+        if not ints or ints[0] != d.H or any(flags):
+            return False
+        return not (sym == "k_ioc" and len(ints) >= 5 and ints[4] != 1)            # NSPL > 1 = the bin-split form of few-window launches
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_per_kernel.json")), reverse=True):     # newest round first
+        base = os.path.basename(path)
+        if ("bf16" in base) != bool(bf16) or "x6" in base or "split" in base or "train" in base:
+            continue
+        with open(path) as fh:
+            pmc = json.load(fh)
+        for name, c in pmc.items():
+            if not is_headline_kernel(name) or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            if "workgroups" in c:
+                if c["workgroups"] != tiles:
+                    continue
+            elif int(round(c.get("SQ_WAVES", -1))) != waves:
+                continue
+            b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            if b < algorithmic:
+                continue
+            committed_traffic.source = "profiles/%s : %s" % (base, name)
+            return b
     return None
 
 
@@ -488,6 +518,9 @@ def main():
     ap.add_argument("--windows", type=int, default=None, help="loader windows (scenes) per step per GPU (128 = the size the per-kernel tables "
                                                              "in profiles/README.md were taken at; throughput saturates around 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed region of the headline: no alt / sdd / cpu_baseline / accuracy legs.  This is the command the "
+                         "rocprofv3 sets under profiles/ are collected from, so that every kernel symbol appears at ONE launch size")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16", action="store_true",
                     help="bf16 matrix operands in the IOC kernel (BASELINE configs[2] arithmetic; NOT the headline fp32 line)")
@@ -675,7 +708,9 @@ def main():
         comm = agent_sharded_comm(sharded, halves, fence, max(2, a.steps // 2), world, d.T_pred)
     # outside the timed region: the same steps through the opt-in row-compacted pooling, reported next to the headline
     alt = None
-    if world == 1 and not (a.train or a.bf16 or a.split or a.x6 or a.graph or a.compact) and a.shard == "scenes" and a.mno <= 32 and a.H <= 128:
+    if a.headline_only:
+        a.no_cpu_baseline, a.data = True, "synthetic"
+    if world == 1 and not a.headline_only and not (a.train or a.bf16 or a.split or a.x6 or a.graph or a.compact) and a.shard == "scenes" and a.mno <= 32 and a.H <= 128:
         os.environ["DESIRE_IOC_VARIANT"] = "8"                # read by the library at every launch
         try:
             step(); torch.cuda.synchronize()
@@ -836,6 +871,9 @@ def main():
     whole_exec_tflops = executed_per_sample * d.R * a.steps / dt / 1e12
 
     peak = BF16_MFMA_PEAK_TFLOPS if a.bf16 else FP32_MFMA_PEAK_TFLOPS
+    algorithmic_bytes = d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4
+    traffic = committed_traffic(d, a.bf16) if a.mno == 32 and a.grid == 4 and not (a.compact or a.split or a.x6) else None
+    assert traffic is None or traffic >= algorithmic_bytes, (traffic, algorithmic_bytes)
     if rank == 0 and a.train:
         samples = d.R * world * a.steps
         fwd = sum(v for k, v in kern_ms.items() if not k.startswith("bwd_"))
@@ -866,10 +904,11 @@ def main():
                        "flops_per_sample": flops_per_sample(d)},
             "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1,false>" if a.bf16 else "k_ioc<%d,16,32,32,false,%s>" % (d.H, "true" if a.compact else "false"), "achieved": ioc_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": (ioc_tflops / peak) if ioc_tflops else None,
-                         "traffic": committed_traffic(a.windows, a.bf16) if a.mno == 32 and a.H == 128 and a.grid == 4 else None,
-                         "traffic_unit": "bytes/launch", "traffic_source": "from_profile: %s (rocprofv3 --pmc passes of this command, committed; "
-                                                                           "not measured in this run)" % committed_traffic.source,
-                         "algorithmic_hbm_bytes_per_launch": d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4,
+                         "traffic": traffic, "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic else None,
+                         "traffic_unit": "bytes/launch", "traffic_source": ("from_profile: %s (rocprofv3 --pmc passes of `bench.py --headline-only` at this "
+                                                                           "launch size, committed; not measured in this run)" % committed_traffic.source)
+                                                                          if traffic else "no committed PMC profile of this launch class",
+                         "algorithmic_hbm_bytes_per_launch": algorithmic_bytes,
                          "kernel_ms": ioc_ms,
                          "algorithmic_flops_per_launch": ioc_flops_per_row(d) * d.R,
                          "whole_path_tflops": whole_tflops, "whole_path_frac": whole_tflops / peak,

@@ -25,3 +25,33 @@ def test_mismatched_world_size_names_both_ways_to_launch():
     env["WORLD_SIZE"] = "3"
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stdout + p.stderr)
+
+
+def test_committed_traffic_selects_the_launch_class_and_is_never_below_the_algorithmic_bytes():
+    """the driver's line carried 43 MB of `traffic` for a launch whose algorithmic bytes are 219 MB (a mixed-size
+    average out of a per-symbol summary).  The selection is now per launch class (workgroups = ceil(R / 32)) and a figure below
+    the algorithmic bytes is refused."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from desire_amd.spec import Dims
+    for windows in (128, 512):
+        d = Dims(n_scenes=windows, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4)
+        algorithmic = d.R * (2 * d.T_pred * 2 * 4 + 4) + d.A * d.H * 4
+        t = bench.committed_traffic(d)
+        assert t is not None and bench.committed_traffic.source, windows
+        assert algorithmic <= t < 4 * algorithmic, (windows, t, algorithmic, bench.committed_traffic.source)
+    # a launch size nobody profiled has no figure (rather than somebody else's)
+    d = Dims(n_scenes=16, mno=32, K=20, T_obs=8, T_pred=40, H=128, L=128, n_grids=1, grid_size=4)
+    assert bench.committed_traffic(d) is None and bench.committed_traffic.source is None
+
+
+def test_profile_summaries_of_this_round_are_per_launch_class():
+    """profiles/r04_*_pmc_per_kernel.json entries carry their grid; SQ_WAVES (where collected) equals workgroups x waves per workgroup."""
+    import glob
+    import json
+    paths = glob.glob(os.path.join(ROOT, "profiles", "r04_*pmc_per_kernel.json"))
+    for p in paths:
+        for name, c in json.load(open(p)).items():
+            assert "workgroups" in c and "workgroup_size" in c and "[wgs=" in name, (p, name)
+            if "SQ_WAVES" in c:
+                assert int(round(c["SQ_WAVES"])) == c["waves_expected"], (p, name, c["SQ_WAVES"], c["waves_expected"])

@@ -40,7 +40,8 @@ def test_default_contract_fields():
     # round 2: the real-SDD leg next to the dense headline, executed-flops fraction, labelled traffic, host core count
     assert o["sdd"]["value"] > 0 and "bookstore" in o["sdd"]["data"] and o["sdd"]["ms_per_step"] > 0
     assert 0 < r["whole_path_frac_executed"] < r["whole_path_frac"] < 1
-    assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] > 0)
+    assert "traffic_source" in r and (r["traffic"] is None or r["traffic"] >= r["algorithmic_hbm_bytes_per_launch"])
+    assert 0 < r["kernel_ms"] <= o["ms_per_step"]
     assert c["host_cores"] >= c["threads"] >= 1
     # the opt-in forms measured beside the headline: row-compacted pooling, split-bf16 IOC (same results to ~1e-5)
     sp = o["alt"]["split_bf16x3_ioc"]
@@ -66,6 +67,23 @@ def test_default_contract_fields():
         assert c2[tag]["value"] > 0 and 0 < c2[tag]["ioc_frac_of_bf16_peak"] < 1 and 0 < c2[tag]["whole_path_frac_of_bf16_peak"] < 1
     assert c2["accuracy"]["decoder_max_abs_err_vs_fp32_oracle"] < 1e-3
     assert c2["accuracy"]["ioc_max_abs_err_vs_rounding_oracle"] < 7e-3 * c2["accuracy"]["refinement_scale"]
+
+
+def test_headline_only_is_the_profiled_command_and_its_traffic_is_a_real_launch():
+    """`bench.py --headline-only` (what profiles/collect_r04.sh runs under rocprofv3): the timed region and nothing else, so every kernel
+    symbol is launched at one size; at a profiled size the line's traffic comes from that launch class and is >= the algorithmic bytes."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--windows", "128", "--headline-only"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = _last_json(p.stdout)
+    assert "alt" not in o and "sdd" not in o and "cpu_baseline" not in o
+    r = o["roofline"]
+    assert r["traffic"] is not None and r["traffic"] >= r["algorithmic_hbm_bytes_per_launch"]
+    assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_hbm_bytes_per_launch"]) < 1e-9 and r["traffic_over_algorithmic"] < 4
+    assert 0 < r["kernel_ms"] <= o["ms_per_step"] and 0.5 < r["frac"] < 1
 
 
 @pytest.mark.parametrize("extra", [[], ["--train"], ["--shard", "agents", "--mno", "16"]])
