@@ -542,7 +542,7 @@ def main():
                     help="social window (normalised units, square).  0.15 keeps every bin of every tile populated (the dense case the "
                          "headline is quoted on); the reference's flags -- 32 px on SDD frames -- are about 0.023, where most bins are empty")
     ap.add_argument("--compact", action="store_true",
-                    help="row-compacted social pooling (DESIRE_IOC_VARIANT=8, fp32, groups of up to 32 agents): the pooling MFMAs run "
+                    help="row-compacted social pooling (dims.ioc_form = DESIRE_IOC_COMPACT, fp32, groups of up to 32 agents): the pooling MFMAs run "
                          "on the rows that have a neighbour in the bin only; NOT the headline (fewer flops are executed than the "
                          "dense formula credits)")
     ap.add_argument("--graph", action="store_true",
@@ -568,8 +568,6 @@ def main():
         # pooled operand at 128 windows), so it stays at the size its profile was taken at
         a.windows = 128 if (a.train or a.bf16 or a.shard == "agents") else 512
 
-    if a.compact:
-        os.environ["DESIRE_IOC_VARIANT"] = "8"
     import torch
     import torch.distributed as dist
     from desire_amd import _lib
@@ -599,7 +597,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     d = Dims(n_scenes=a.windows, mno=a.mno, bf16=3 if a.x6 else 2 if a.split else int(a.bf16), bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[a.bn], K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
-             nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1)
+             nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1, ioc_form=8 if a.compact else 0)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
@@ -711,7 +709,7 @@ def main():
     if a.headline_only:
         a.no_cpu_baseline, a.data = True, "synthetic"
     if world == 1 and not a.headline_only and not (a.train or a.bf16 or a.split or a.x6 or a.graph or a.compact) and a.shard == "scenes" and a.mno <= 32 and a.H <= 128:
-        os.environ["DESIRE_IOC_VARIANT"] = "8"                # read by the library at every launch
+        h.set_option("ioc_form", 8)                           # DESIRE_IOC_COMPACT on the live handle (include/desire_hip.h: desire_set_option)
         try:
             step(); torch.cuda.synchronize()
             ta = time.perf_counter()
@@ -720,10 +718,10 @@ def main():
             torch.cuda.synchronize()
             alt_dt = (time.perf_counter() - ta) / max(2, a.steps // 2)
             alt = {"row_compacted_pooling": {"value": d.R / alt_dt, "ms_per_step": alt_dt * 1e3, "unit": "samples/s",
-                                             "note": "opt-in (DESIRE_IOC_VARIANT=8 / --compact): same results up to fp32 summation order; "
+                                             "note": "opt-in (dims.ioc_form = DESIRE_IOC_COMPACT / --compact): same results up to fp32 summation order; "
                                                      "executes fewer flops than the dense formula, hence not the headline"}}
         finally:
-            del os.environ["DESIRE_IOC_VARIANT"]
+            h.set_option("ioc_form", 0)
         # the same steps with split-bf16 operands in the IOC kernel (dims.bf16 = 2): fp32-equivalent results from three bf16 MFMAs per
         # product.  Its refinement is compared with the fp32 kernel's FROM THE SAME Y0 (positions decide cells and bins).
         h3 = _lib.Handle(d.replace(bf16=2))

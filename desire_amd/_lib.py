@@ -23,6 +23,7 @@ EXPORTS = [
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
     "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout", "desire_build_windows_la", "desire_adam_state",
+    "desire_set_option",
 ]
 
 
@@ -30,13 +31,14 @@ class DesireDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_scenes", "mno", "K", "T_obs", "T_pred", "H", "L", "S", "C", "Gh", "Gw", "n_grids",
                  "grid_size", "E_v", "iters", "posterior")] + \
-               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [("bin_mode", C.c_int32), ("bn_mode", C.c_int32), ("bf16", C.c_int32), ("ref_compat", C.c_int32), ("n_dec", C.c_int32)]
+               [(n, C.c_float) for n in ("nb_w", "nb_h", "sx", "sy")] + [(n, C.c_int32) for n in ("bin_mode", "bn_mode", "bf16", "ref_compat", "n_dec", "ioc_form", "ioc_split", "train_fp32_mask", "flags")]
 
     @classmethod
     def from_dims(cls, d: Dims) -> "DesireDims":
         return cls(d.n_scenes, d.mno, d.K, d.T_obs, d.T_pred, d.H, d.L, d.S, d.C, d.Gh, d.Gw, d.n_grids,
                    d.grid_size, d.E_v, d.iters, d.posterior, d.nb_w, d.nb_h, d.sx, d.sy, int(getattr(d, "bin_mode", 0)),
-                   int(getattr(d, "bn_mode", 0)), int(getattr(d, "bf16", 0)), int(getattr(d, "ref_compat", 0)), int(getattr(d, "n_dec", 0)))
+                   int(getattr(d, "bn_mode", 0)), int(getattr(d, "bf16", 0)), int(getattr(d, "ref_compat", 0)), int(getattr(d, "n_dec", 0)),
+                   int(getattr(d, "ioc_form", 0)), int(getattr(d, "ioc_split", 0)), int(getattr(d, "train_fp32_mask", 0)), int(getattr(d, "flags", 0)))
 
 
 class DesireError(RuntimeError):
@@ -67,6 +69,7 @@ def load() -> C.CDLL:
     lib.desire_last_error.restype = C.c_char_p
     lib.desire_create.argtypes = [C.POINTER(DesireDims), C.POINTER(vp)]
     lib.desire_destroy.argtypes = [vp]
+    lib.desire_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.desire_set_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
     lib.desire_finalize_weights.argtypes = [vp]
     lib.desire_set_scene_grids.argtypes = [vp, f32p, C.POINTER(C.c_int32)]
@@ -137,6 +140,11 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int) -> None:
+        """One of the behavioural switches of desire_dims ("ioc_form", "ioc_split", "train_fp32_mask", "flags") on the live handle."""
+        _chk(self.lib.desire_set_option(self._h, name.encode(), int(value)))
+        self.dims = self.dims.replace(**{name: int(value)})
 
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         for name, arr in weights.items():

@@ -173,6 +173,18 @@ void fold_bn(desire_ctx* h, const std::string& p, std::vector<float>& scale, std
     }
 }
 
+int check_options(const desire_dims& d) {
+    switch (d.ioc_form) {
+        case DESIRE_IOC_AUTO: case DESIRE_IOC_TILE64: case DESIRE_IOC_CLUSTER: case DESIRE_IOC_CLUSTER_BINS: case DESIRE_IOC_COMPACT:
+        case DESIRE_IOC_TRAIN_DENSE: case DESIRE_IOC_X6_TILE32: case DESIRE_IOC_X6_TILE64: break;
+        default: return fail(DESIRE_ERR_ARG, "ioc_form must be one of DESIRE_IOC_* (include/desire_hip.h)");
+    }
+    if (d.ioc_split < 0 || d.ioc_split > 4) return fail(DESIRE_ERR_ARG, "ioc_split must be 0 (auto), 1 (never split: batch-size invariant results) or 2..4 (cap)");
+    if (d.train_fp32_mask < 0 || d.train_fp32_mask > 15) return fail(DESIRE_ERR_ARG, "train_fp32_mask is a mask of bits 1, 2, 4, 8");
+    if (d.flags & ~DESIRE_FLAG_NO_FUSE34) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    return 0;
+}
+
 int check_dims(const desire_dims& d) {
     if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
     if (d.mno < 1 || d.mno > 128 || (d.mno <= 32 ? (32 % d.mno) : (d.mno % 32)))
@@ -196,6 +208,7 @@ int check_dims(const desire_dims& d) {
         return fail(DESIRE_ERR_ARG, "log-polar bins: grid_size >= 3 and 0 < nb_h (inner radius) < nb_w (outer radius)");
     if (!(d.nb_w > 0.f) || !(d.nb_h > 0.f)) return fail(DESIRE_ERR_ARG, "nb_w/nb_h must be > 0");
     if (d.ref_compat != 0 && d.ref_compat != 1) return fail(DESIRE_ERR_ARG, "ref_compat must be 0 or 1");
+    if (int rc = check_options(d)) return rc;
     if (d.ref_compat) {
         if (d.K != 1 || !d.posterior || d.bn_mode != 1 || d.bf16 || d.n_dec < 1 || d.H != 2 * d.T_obs || d.T_pred != d.T_obs)
             return fail(DESIRE_ERR_ARG, "ref_compat (the reference graph as written, model/model.py:116-311) needs K = 1 (one eps per object, "
@@ -205,6 +218,20 @@ int check_dims(const desire_dims& d) {
 }
 
 }  // namespace
+
+extern "C" int desire_set_option(desire_handle* h, const char* name, int32_t value) {
+    if (!h || !name) return fail(DESIRE_ERR_ARG, "null argument");
+    desire_dims d = h->d;
+    const std::string nm(name);
+    if (nm == "ioc_form") d.ioc_form = value;
+    else if (nm == "ioc_split") d.ioc_split = value;
+    else if (nm == "train_fp32_mask") d.train_fp32_mask = value;
+    else if (nm == "flags") d.flags = value;
+    else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags)");
+    if (int rc = check_options(d)) return rc;
+    h->d = d;
+    return DESIRE_OK;
+}
 
 extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
     if (!dims || !out) return fail(DESIRE_ERR_ARG, "null argument");
@@ -700,7 +727,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
     // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
     // two-piece operands are an IOC-kernel matter (sample generation must not move Y0 by more than fp32 rounding)
-    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask() & 8)))) && d.bn_mode == 0 && !d.ref_compat;
+    const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask(h) & 8)))) && d.bn_mode == 0 && !d.ref_compat;
     if (d.bf16 == 1 && d.L <= 512 && !(d.L & 15)) { g.Bp = D4(h, "vae_dec/deconv1/W16"); Timer t(h, s, "deconv1"); launch_deconv1_bf16(g, s); }
     else if (x6gen && rows_x6_supported(d.L, 64)) { g.Bp = D4(h, "vae_dec/deconv1/W6"); Timer t(h, s, "deconv1"); launch_deconv1_x6(g, s); }
     else if (d.bn_mode != 0) {
@@ -721,13 +748,9 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
            if (pobn) normd("vae_dec/deconv2", W(h, "d2"), 64, 64, 0); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
     c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = D(h, "vae_dec/deconv3/shift");
-    const bool fuse34 = d.bf16 == 1 && !getenv("DESIRE_NO_FUSE34");       // bf16: deconv3+deconv4 in one kernel, d3 never written
-    if (x6gen && !h->training && getenv("DESIRE_FUSE34_X6")) {             // six-product form, inference: likewise -- opt-in (A/B): 15.4 ms against 11.9 + 2.5 for
-                                                                           // the two kernels: the tap products cost the contracting waves more than the d3 pass did
-        c.Wp = D4(h, "vae_dec/deconv3/W6"); c.w_raw = D(h, "vae_dec/deconv4/raw");
-        Timer t(h, s, "deconv34");
-        launch_deconv34_x6(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), W(h, "xhat"), s);
-    } else
+    const bool fuse34 = d.bf16 == 1 && !(d.flags & DESIRE_FLAG_NO_FUSE34);       // bf16: deconv3+deconv4 in one kernel, d3 never written
+    // (the six-product form of that fusion was measured and dropped: 15.4 ms against 11.9 + 2.5 for the two kernels -- the tap products cost
+    //  the contracting waves more than the d3 pass did)
     if (fuse34) {
         c.Wp = D4(h, "vae_dec/deconv3/W16"); c.w_raw = D(h, "vae_dec/deconv4/W16"); c.out = W(h, "xhat");
         Timer t(h, s, "deconv34");
@@ -793,7 +816,7 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
-    { const char* v = getenv("DESIRE_IOC_VARIANT"); a.variant = v ? atoi(v) : 0; }
+    a.variant = d.ioc_form;
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
     // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
     // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
@@ -813,20 +836,27 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
         a.hex = W(h, "hex"); a.grp_cnt = static_cast<int*>(h->ws["grp_cnt"].p); a.err = static_cast<int*>(h->ws["ioc_err"].p);
     }
-    // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; DESIRE_IOC_SPLIT=0: off)
-    static const bool no_split = getenv("DESIRE_IOC_SPLIT") && atoi(getenv("DESIRE_IOC_SPLIT")) == 0;
-    if (!cluster && d.bf16 == 0 && !h->training && !no_split && a.variant == 0) {
+    // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; dims.ioc_split = 1: off).
+    // The members of a tile wait for each other, so the split is taken only when the whole launch is co-resident on THIS device
+    // (occupancy x compute units, not a constant: a partition with fewer CUs falls back to the plain form).
+    if (!cluster && d.bf16 == 0 && !h->training && d.ioc_split != 1 && a.variant == 0) {
         int nspl = ioc_bin_split(h->R, d.mno, d.H, d.grid_size * d.grid_size, d.iters);
-        if (nspl > 1 && getenv("DESIRE_IOC_NSPL")) nspl = std::min(nspl, std::max(1, atoi(getenv("DESIRE_IOC_NSPL"))));    // A/B: cap the split
+        if (nspl > 1 && d.ioc_split > 1) nspl = std::min(nspl, d.ioc_split);
+        const size_t tiles = ((size_t)h->R + 31) / 32;
+        while (nspl > 1 && (size_t)ioc_bin_split_capacity(a, nspl) < tiles * nspl) --nspl;
         if (nspl > 1) {
-            const size_t tiles = ((size_t)h->R + 31) / 32;
-            if (!h->ws.count("hex_s")) {
+            if (!h->ws.count("hex_s") || !h->ws["hex_s"].p || !h->ws["cnt_s"].p) {
                 if (h->ws["hex_s"].alloc(tiles * 2 * 4 * 32 * d.H * sizeof(float)) || h->ws["cnt_s"].alloc(tiles * sizeof(int)))
                     return fail(DESIRE_ERR_HIP, "hipMalloc failed for the bin-split exchange buffers");
-                // the error word is mapped host memory: no read-back (and no stream synchronisation) per call; a timed-out hand-off is
-                // reported by the NEXT call on this handle
-                if (hipHostMalloc(reinterpret_cast<void**>(&h->host_err), sizeof(int), hipHostMallocMapped) != hipSuccess)
+            }
+            // the error word is mapped host memory: no read-back (and no stream synchronisation) per call; a timed-out hand-off is
+            // reported by the NEXT call on this handle.  Allocated and checked on its own (a failure here must not leave a later call
+            // with exchange buffers and a null word); the kernels write it with system-scope atomics.
+            if (!h->host_err) {
+                if (hipHostMalloc(reinterpret_cast<void**>(&h->host_err), sizeof(int), hipHostMallocMapped) != hipSuccess || !h->host_err) {
+                    h->host_err = nullptr;
                     return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the bin-split error word");
+                }
                 *h->host_err = 0;
             }
             if (*static_cast<volatile int*>(h->host_err)) {
@@ -891,9 +921,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                                "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
         const char* ncl[10] = {"step top: positions + clear + bar", "P1 ev/es/masks", "wait for the peers", "copy peers' Ht + bar", "P2 pooling chains",
                                "exchange + e_r", "barrier 2", "P4 gates + r*h + cand frags", "bar 3 + P5 cand + publish stores", "drain + arrive + bar"};
-        const bool r2 = d.bf16 == 1 && !cluster && a.variant == 12 && ioc_bf16_r2_supported(d.mno, d.H, d.grid_size * d.grid_size);
-        const char** names = (x3 || x6 || r2) ? nx3 : d.bf16 == 1 ? (cluster ? ncl : n16) : n32;
-        const int nk = (x3 || x6 || r2 || (d.bf16 == 1 && cluster)) ? 10 : 9;
+        const char** names = (x3 || x6) ? nx3 : d.bf16 == 1 ? (cluster ? ncl : n16) : n32;
+        const int nk = (x3 || x6 || (d.bf16 == 1 && cluster)) ? 10 : 9;
         long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
         for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
     }

@@ -2,7 +2,7 @@
 // coherent and a CU's L1 is never refreshed by another CU's stores, so every hand-off is: plain stores -> s_waitcnt vmcnt(0)
 // -> __syncthreads -> ONE lane agent-scope release -> relaxed agent-scope add on the group's arrival counter; consumers poll
 // that one word relaxed, then one agent-scope acquire, __syncthreads, plain loads (MI355X_MICROARCH.md, inter-workgroup
-// visibility).  Every spin is bounded and reports through an error word.
+// visibility).  Every spin is bounded and reports through an error word (system-scope atomic: the word may be mapped host memory).
 #pragma once
 #include "common.h"
 
@@ -12,7 +12,7 @@ __device__ __forceinline__ bool group_wait(int* cnt, int target, int* err) {
         long spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > 40000000L) { atomicOr(err, 1); ok = false; break; }
+            if (++spins > 40000000L) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = false; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -54,7 +54,7 @@ __device__ __forceinline__ bool group_wait_wt(int* cnt, int target, int* err) {
         long spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > 160000000L) { atomicOr(err, 1); ok = false; break; }
+            if (++spins > 160000000L) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = false; break; }
         }
     }
     __syncthreads();

@@ -87,9 +87,9 @@ struct Timer {
     ~Timer() { if (on) (void)hipEventRecord(h->prof.back().e1, s); }
 };
 
-// A/B switch: which parts of the training step use split operands under dims.bf16 = 2 (1: weight-gradient reductions, 2: data-gradient
-// convolutions, 4: IOC BPTT, 8: six-product sample generation in the forward pass; default all)
-inline int train_x3_mask() { static const int m = getenv("DESIRE_TRAIN_X3") ? atoi(getenv("DESIRE_TRAIN_X3")) : 15; return m; }
+// which parts of the training step use split operands under dims.bf16 = 2 (1: weight-gradient reductions, 2: data-gradient
+// convolutions, 4: IOC BPTT, 8: six-product sample generation in the forward pass): everything dims.train_fp32_mask does not hold back
+inline int train_x3_mask(const desire_ctx* h) { return 15 & ~h->d.train_fp32_mask; }
 
 inline const float* D(desire_ctx* h, const char* name) { return h->dev.at(name).f(); }
 inline const float4* D4(desire_ctx* h, const char* name) { return reinterpret_cast<const float4*>(h->dev.at(name).f()); }

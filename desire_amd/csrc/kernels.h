@@ -49,7 +49,6 @@ struct ConvArgs {
                                                    // destination layer for the backward modes
 };
 void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
-void launch_deconv34_x6(const ConvArgs& a, const float* sc4, const float* sh4, float* xhat, hipStream_t s);   // six-product deconv3 + deconv4 fused (kernels_x6.hip, inference)
 void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
 void launch_conv2_x3(const ConvArgs& a, hipStream_t s);  // same with split-bf16 operands (kernels_bwd_x3.hip; a.Wp = [hi | lo] pack)
 void launch_conv3_x3(const ConvArgs& a, hipStream_t s);  // [n,8,8,64] -> [n,4,4,128]
@@ -103,7 +102,7 @@ struct IocArgs {
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c;   // K = E+H
     const float* w_score; const float* b_score;            // [H], [1]
     const float4* Wreg; const float* b_reg; int NTreg;     // [H, 2T] packed
-    int variant;                                           // A/B switch, see launch_ioc
+    int variant;                                           // dims.ioc_form (DESIRE_IOC_*, include/desire_hip.h)
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
     float* hex; int* grp_cnt; int* err;                    // cluster form: exchange buffer [2][R][H], group counters, error word
     int nspl;                                              // > 1: bin-split form of k_ioc (hex = [tiles][2][nspl][32 H], grp_cnt per tile)
@@ -131,6 +130,7 @@ inline int ioc_bin_split(int R, int mno, int H, int bins, int iters) {
         if (tiles * n <= 256 && bins >= n) return n;
     return 1;
 }
+int ioc_bin_split_capacity(const IocArgs& a, int n);           // resident workgroups of the n-member bin-split kernel on this device (kernels_rnn.hip)
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s);
 // bf16 cluster form (kernels_bf16_cl.hip): groups of 64 / 96 / 128 agents over mno/32 workgroups; returns != 0 when the
 // persistent grid cannot be made resident
@@ -147,8 +147,7 @@ bool decoder_x6_supported(int H);
 void launch_decoder_x6(const DecArgs& a, hipStream_t s);
 void launch_deconv2_x6(const ConvArgs& a, hipStream_t s);
 void launch_deconv3_x6(const ConvArgs& a, hipStream_t s);
-bool ioc_bf16_r2_supported(int mno, int H, int bins);          // 64-row tiles, two row blocks per wave (kernels_bf16_r2.hip)
-void launch_ioc_bf16_r2(const IocArgs& a, hipStream_t s);            // three bf16 pieces per operand, six products (dims.bf16 = 3)
+            // three bf16 pieces per operand, six products (dims.bf16 = 3)
 // agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
 struct IocStepArgs {
     int t; int rank; int nranks; int m_loc; int n_scenes; int K; int R;       // R = local rows = n_scenes * K * m_loc

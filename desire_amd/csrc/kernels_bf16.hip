@@ -445,10 +445,8 @@ static void launch16(const IocArgs& a, hipStream_t s) {
 // mno must divide 32 (32-row tiles, two workgroups per CU at H <= 128) or be 64 (64-row tiles, twice the waves);
 // a.variant == 2 forces 64-row tiles (A/B)
 void launch_ioc_bf16(const IocArgs& a, hipStream_t s) {
-    // a.variant == 12: 64-row tiles with two row blocks per wave (half the weight bytes per row, one workgroup per CU:
-    // kernels_bf16_r2.hip) -- bit-identical results, measured SLOWER (3.67 vs 3.20 ms per 81 920 rows: one wave per SIMD leaves the
-    // position-only phase, the exchange and the epilogues uncovered), so it stays an A/B form
-    if (a.variant == 12 && ioc_bf16_r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_bf16_r2(a, s); return; }
+    // (64-row tiles with two row blocks per wave -- half the weight bytes per row, one workgroup per CU -- were bit-identical and SLOWER,
+    //  3.67 vs 3.20 ms per 81 920 rows: one wave per SIMD leaves the position-only phase, the exchange and the epilogues uncovered; removed)
     const bool two = a.mno > 32 || a.variant == 2;
     if (a.H == 128) { if (two) launch16<128, 2>(a, s); else launch16<128, 1>(a, s); }
     else if (a.H == 64) { if (two) launch16<64, 2>(a, s); else launch16<64, 1>(a, s); }
@@ -536,94 +534,11 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2_bf16(ConvArgs a) {
         }
     }
 }
-// Two sample pairs per wave (workgroup = 2 waves = the two output-channel halves of 4 samples): every weight fragment feeds two MFMAs.
-// With one pair per wave the kernel ran at the CU's vector-memory rate -- 8 KB of fragments per tap and wave for 8 MFMAs, eight waves --
-// at a quarter of the matrix rate (TA busy 0.76, MfmaUtil 0.25).  Opt-in (DESIRE_DECONV2_BF16_M2): it LOSES, 1.24 vs 0.95 ms -- the 16-deep
-// LDS read-add-write scatter after every tap is as long as the MFMAs, and with two waves per workgroup nothing covers it.
-__global__ __launch_bounds__(128) void k_deconv2_bf16_m2(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float out_s16[];   // [4][64 px][64 co]
-    const int lane = lane_id(), hf = wave_id();
-    const int s0 = blockIdx.x * 4;
-    const int c = lane & 31, hi = lane >> 5;
-    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
-    for (int i = 0; i < 32; ++i) *reinterpret_cast<float4*>(out_s16 + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 af[2][8];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = lane & 31;
-        const int smp = min(s0 + 2 * m + (row >> 4), a.n - 1);
-        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 x0 = *reinterpret_cast<const float4*>(src + g * 16), x1 = *reinterpret_cast<const float4*>(src + g * 16 + 4);
-            af[m][g] = make_uint4(pk_bf16(x0.x, x0.y), pk_bf16(x0.z, x0.w), pk_bf16(x1.x, x1.y), pk_bf16(x1.z, x1.w));
-        }
-    }
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    auto load_b = [&](uint4 (&b)[8], int tap) {
-        const uint4* bp = Wp + ((size_t)(tap * 2 + hf) * 8) * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) b[g] = bp[g * 64];
-    };
-    auto do_tap = [&](const uint4 (&b)[8], int tap) {
-        const int ky = tap / 5, kx = tap - ky * 5;
-        f32x16 acc0 = zero16(), acc1 = zero16();
-#pragma unroll
-        for (int g = 0; g < 8; ++g) { acc0 = mfma16(af[0][g], b[g], acc0); acc1 = mfma16(af[1][g], b[g], acc1); }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            float* my = out_s16 + (2 * m) * 4096;
-            float* dst[16]; float old[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i & 3) + 8 * (i >> 2) + 4 * hi;
-                const int s = rr >> 4, p = rr & 15;
-                const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-                dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) old[i] = *dst[i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) *dst[i] = old[i] + (m == 0 ? acc0[i] : acc1[i]);
-        }
-    };
-    uint4 b0[8], b1[8];
-    load_b(b0, 0);
-#pragma clang loop unroll(disable)
-    for (int tap = 0; tap < 24; tap += 2) {
-        load_b(b1, tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        do_tap(b0, tap);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(b0, tap + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        do_tap(b1, tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    do_tap(b0, 24);
-    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
-    for (int i = 0; i < 32; ++i) {
-        const int sp_px = i * 8 + er;                                  // 0..255 = (sample, pixel)
-        const int smp = s0 + (sp_px >> 6);
-        if (smp < a.n) {
-            const float4 v = *reinterpret_cast<const float4*>(out_s16 + sp_px * 64 + ec);
-            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
-            float4 o;
-            o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);
-            o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
-            *reinterpret_cast<float4*>(a.out + ix) = o;
-        }
-    }
-}
+// (Measured and dropped: two sample pairs per wave -- half the weight-fragment stream, 1.24 vs 0.95 ms: with two waves per workgroup nothing
+// covers the 16-deep LDS read-add-write scatter after every tap.)
 void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s) {
-    static const bool two_pairs = getenv("DESIRE_DECONV2_BF16_M2") != nullptr;     // A/B: k_deconv2_bf16_m2 -- measured 1.24 vs 0.95 ms per 81 920 samples:
-    if (!two_pairs) {                                                              // half the fragment stream, but half the waves to hide the scatter behind
-        allow_big_lds(k_deconv2_bf16);
-        hipLaunchKernelGGL(k_deconv2_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
-        return;
-    }
-    allow_big_lds(k_deconv2_bf16_m2);
-    hipLaunchKernelGGL(k_deconv2_bf16_m2, dim3((a.n + 3) / 4), dim3(128), 4 * 4096 * sizeof(float), s, a);
+    allow_big_lds(k_deconv2_bf16);
+    hipLaunchKernelGGL(k_deconv2_bf16, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
 }
 
 // deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2, output-parity gather (see k_deconv3); one wave per sample,

@@ -140,92 +140,8 @@ void launch_conv3(const ConvArgs& a, hipStream_t s) {
 // Workgroup = 4 samples; wave = (co-half hf = w&1, sample pair sp = w>>1).
 // M-tile rows = (sample s in {0,1}, input pixel p in 0..15); A (K=128) lives in 64 VGPRs.
 // ------------------------------------------------------------------------------------------------
-// Two taps interleaved (FWD only, DESIRE_DECONV2_PAIR=1, A/B): taps t and t+1 contract side by side into two accumulators, MFMA by
-// MFMA, so every accumulator's next MFMA is issued one full MFMA later than in the single chain (the 64-deep dependent chain per tap
-// measured ~12 % of the kernel); B fragments in half-K units of 8 k-groups per tap (same 128 registers as the two tap-sized sets).
-__global__ __launch_bounds__(DS_WG) void k_deconv2_pair(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float out_s[];     // [4][64 px][64 co]
-    const int lane = lane_id(), w = wave_id();
-    const int hf = w & 1, sp = w >> 1;
-    const int s0 = blockIdx.x * 4 + sp * 2;
-    const int c = lane & 31, hi = lane >> 5;
-    float* my = out_s + (sp * 2) * 4096;
-    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
-    for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 af[16];
-    {
-        const int row = lane & 31;
-        const int smp = min(s0 + (row >> 4), a.n - 1);
-        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 4 * hi;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
-    }
-    // unit u = (tap pair p, K half kh): B fragments of taps 2p and 2p+1, k-groups [8kh, 8kh+8)
-    auto load_u = [&](float4 (&b)[2][8], int pr, int kh) {
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int tap = min(2 * pr + t2, 24);
-            const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16 + 8 * kh) * 64 + lane;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) b[t2][g] = bp[g * 64];
-        }
-    };
-    auto run_u = [&](f32x16& a0, f32x16& a1, const float4 (&b)[2][8], int kh) {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 av = af[8 * kh + g];
-            a0 = mfma32(av.x, b[0][g].x, a0); a1 = mfma32(av.x, b[1][g].x, a1);
-            a0 = mfma32(av.y, b[0][g].y, a0); a1 = mfma32(av.y, b[1][g].y, a1);
-            a0 = mfma32(av.z, b[0][g].z, a0); a1 = mfma32(av.z, b[1][g].z, a1);
-            a0 = mfma32(av.w, b[0][g].w, a0); a1 = mfma32(av.w, b[1][g].w, a1);
-        }
-    };
-    auto scatter = [&](const f32x16& acc, int tap) {
-        const int ky = tap / 5, kx = tap - ky * 5;
-        float* dst[16]; float old[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = acc_row(i);
-            const int s = rr >> 4, p = rr & 15;
-            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-            dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) old[i] = *dst[i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) *dst[i] = old[i] + acc[i];
-    };
-    float4 b0[2][8], b1[2][8];
-    load_u(b0, 0, 0);
-#pragma clang loop unroll(disable)
-    for (int pr = 0; pr < 13; ++pr) {                                   // 12 pairs + tap 24 alone (its partner's products are discarded)
-        f32x16 a0 = zero16(), a1 = zero16();
-        load_u(b1, pr, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        run_u(a0, a1, b0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_u(b0, pr + 1 < 13 ? pr + 1 : pr, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        run_u(a0, a1, b1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        scatter(a0, 2 * pr);
-        if (2 * pr + 1 < 25) scatter(a1, 2 * pr + 1);
-    }
-    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
-    for (int i = 0; i < 16; ++i) {
-        const int sp_px = i * 8 + er;
-        const int smp = s0 + (sp_px >> 6);
-        if (smp < a.n) {
-            const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
-            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
-            float4 o;
-            o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);
-            o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
-            *reinterpret_cast<float4*>(a.out + ix) = o;
-        }
-    }
-}
-
+// (Measured and dropped: two taps interleaved into two accumulators -- the 64-deep dependent chain per tap is ~12 % of the kernel, but
+// with the LDS scatter the paired form was slower)
 template <bool FWD>
 __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float out_s[];     // [4][64 px][64 co]
@@ -318,12 +234,6 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
 }
 void launch_deconv2(const ConvArgs& a, hipStream_t s) {
     allow_big_lds(k_deconv2<true>); allow_big_lds(k_deconv2<false>);
-    static const bool pair = getenv("DESIRE_DECONV2_PAIR") != nullptr;
-    if (a.mode == 0 && pair) {
-        allow_big_lds(k_deconv2_pair);
-        hipLaunchKernelGGL(k_deconv2_pair, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
-        return;
-    }
     if (a.mode == 0) hipLaunchKernelGGL(k_deconv2<true>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
     else hipLaunchKernelGGL(k_deconv2<false>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
 }
@@ -410,16 +320,10 @@ __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
         }
 }
 void launch_deconv3(const ConvArgs& a, hipStream_t s) {
-    static const int ns = getenv("DESIRE_DECONV3_NS2") ? 2 : 4;       // A/B: four 2-wave workgroups per CU measured 15 % slower
-    const size_t lds = (128 + (size_t)ns * 64 * 68) * sizeof(float);
+    const size_t lds = (128 + (size_t)4 * 64 * 68) * sizeof(float);
     allow_big_lds(k_deconv3<true, 4>); allow_big_lds(k_deconv3<false, 4>);
-    if (ns == 4) {
-        if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_deconv3<false, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
-    } else {
-        if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 2>), dim3((a.n + 1) / 2), dim3(128), lds, s, a);
-        else hipLaunchKernelGGL((k_deconv3<false, 2>), dim3((a.n + 1) / 2), dim3(128), lds, s, a);
-    }
+    if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_deconv3<false, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,6 +416,6 @@ __global__ __launch_bounds__(DS_WG) void k_deconv4_tp(ConvArgs a) {
     }
 }
 void launch_deconv4(const ConvArgs& a, hipStream_t s) {
-    if (a.mode == 0 && !getenv("DESIRE_DECONV4_GATHER")) hipLaunchKernelGGL(k_deconv4_tp, dim3((a.n + 3) / 4), dim3(DS_WG), 0, s, a);
+    if (a.mode == 0) hipLaunchKernelGGL(k_deconv4_tp, dim3((a.n + 3) / 4), dim3(DS_WG), 0, s, a);
     else hipLaunchKernelGGL(k_deconv4, dim3(a.n), dim3(DS_WG), 0, s, a);
 }

@@ -13,6 +13,8 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <map>
+#include <tuple>
 
 #define RNN_WG 512         // 8 waves: wave = (column block cb = w&3, M-tile mt = w>>2), two per SIMD
 
@@ -335,7 +337,7 @@ static void launch_decoder_t(const DecArgs& a, hipStream_t s) {
 void launch_decoder(const DecArgs& a, hipStream_t s) {
     if (a.H == 256) launch_decoder_t<256, 32>(a, s);
     else if (a.H == 128) {                              // 32-row tiles: 4 waves + 34 KB LDS -> two workgroups per CU
-        if (getenv("DESIRE_DEC_TM64")) launch_decoder_t<128, 64>(a, s); else launch_decoder_t<128, 32>(a, s);
+        launch_decoder_t<128, 32>(a, s);
     }
     else launch_decoder_t<64, 64>(a, s);
 }
@@ -812,7 +814,7 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * (TM / 32) * 64);
     if (a.sv_h) {                                              // training-mode forward: keeps x_t, r, u, c, h per step
         if constexpr (TM == 32 && H <= 128) {                  // 32-row tiles: the row-compacted pooling (k_ioc CP) also while training
-            if (a.variant != 9) {                              // (variant 9: dense pooling, A/B)
+            if (a.variant != 9) {                              // (DESIRE_IOC_TRAIN_DENSE: dense pooling, A/B)
                 allow_big_lds(k_ioc<H, 16, 32, 32, true, true>);
                 hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, true, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
                 return;
@@ -825,7 +827,7 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
         return;
     }
     if constexpr (TM == 32 && H <= 128) {
-        if (a.variant == 8) {                                  // opt-in: row-compacted pooling (see k_ioc)
+        if (a.variant == 8) {                                  // opt-in (DESIRE_IOC_COMPACT): row-compacted pooling (see k_ioc)
             allow_big_lds(k_ioc<H, 16, 32, 32, false, true>);
             hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
             return;
@@ -843,6 +845,30 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     }
     allow_big_lds(k_ioc<H, 16, 32, TM, false>);
     hipLaunchKernelGGL((k_ioc<H, 16, 32, TM, false>), grid, block, ioc_lds_bytes(a, TM), s, a);
+}
+// Workgroups of the bin-split k_ioc<H, ..., NSPL = n> this device keeps resident at once (occupancy x compute units); 0 when the shape has
+// no such form or the query fails.  The members of a tile wait for each other inside the kernel, so a launch is only safe when ALL of
+// its workgroups are co-resident: a partition with fewer CUs (CPX mode, CU masking) or a lower occupancy must fall back to the plain form.
+int ioc_bin_split_capacity(const IocArgs& a, int n) {
+    if (a.mno > 32 || a.H > 128 || n < 2 || n > 4) return 0;
+    static std::map<std::tuple<int, int, int, size_t>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const size_t lds = ioc_lds_bytes(a, 32);
+    const auto key = std::make_tuple(dev, a.H, n, lds);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const void* kern = nullptr;
+    if (a.H == 128) kern = n == 2 ? (const void*)k_ioc<128, 16, 32, 32, false, false, 2> : n == 3 ? (const void*)k_ioc<128, 16, 32, 32, false, false, 3> : (const void*)k_ioc<128, 16, 32, 32, false, false, 4>;
+    else kern = n == 2 ? (const void*)k_ioc<64, 16, 32, 32, false, false, 2> : n == 3 ? (const void*)k_ioc<64, 16, 32, 32, false, false, 3> : (const void*)k_ioc<64, 16, 32, 32, false, false, 4>;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int per_cu = 0, cus = 0;
+    int cap = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (a.H / 32) * 64, lds) == hipSuccess && per_cu > 0 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+        cap = per_cu * cus;
+    cache[key] = cap;
+    return cap;
 }
 void launch_ioc_cluster(const IocArgs& a, hipStream_t s);
 void launch_ioc(const IocArgs& a, hipStream_t s) {

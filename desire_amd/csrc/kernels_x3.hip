@@ -498,11 +498,11 @@ static void launch_x3(const IocArgs& a, hipStream_t s) {
     }
 }
 void launch_ioc_x3(const IocArgs& a, hipStream_t s) {
-    // 64-row tiles with two row blocks per wave on fp32 LDS tiles split on the fly (kernels_x6r2.hip with two pieces: every weight fragment
-    // used twice); a.variant 16 forces it for smaller groups (A/B, tests)
-    // (measured: 30.7 vs 29.1 ms at 512 windows -- with two pieces the 32-row tiles' second workgroup per CU is worth more than the halved
-    // weight stream, so the 64-row form is the default only where it is the only one: groups of 64 agents)
-    if (!a.sv_h && (a.mno > 32 || a.variant == 16) && ioc_x6r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_x3r2(a, s); return; }
+    // groups of 64 agents: 64-row tiles with two row blocks per wave on fp32 LDS tiles split on the fly (kernels_x6r2.hip with two pieces:
+    // every weight fragment used twice).  For groups of <= 32 agents that form was measured slower (30.7 vs 29.1 ms at 512 windows -- with
+    // two pieces the 32-row tiles' second workgroup per CU is worth more than the halved weight stream), so it serves only the shape
+    // it alone can
+    if (!a.sv_h && a.mno > 32 && ioc_x6r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_x3r2(a, s); return; }
     if (a.H == 128) launch_x3<128>(a, s); else launch_x3<64>(a, s);
 }
 // three pieces per operand, six products per fp32 product (dims.bf16 = 3): same shapes, inference only
@@ -514,7 +514,7 @@ static void launch_x6(const IocArgs& a, hipStream_t s) {
 }
 void launch_ioc_x6(const IocArgs& a, hipStream_t s) {
     // default: 64-row tiles, two row blocks per wave, fp32 operand tiles split on the fly (kernels_x6r2.hip; results within 1-2 ulp);
-    // a.variant == 13 keeps the 32-row / three-image form below (A/B), which also serves the shapes whose masks do not fit beside a
+    // a.variant == 13 (DESIRE_IOC_X6_TILE32) keeps the 32-row / three-image form below (A/B), which also serves the shapes whose masks do not fit beside a
     // 64-row tile -- and launches that would leave CUs idle with 64-row tiles (a few windows: one window = 20 tiles of 32 rows on 20 CUs
     // takes 1.29 ms, 10 tiles of 64 rows 2.39 ms)
     if ((a.mno > 32 || (a.variant != 13 && ((a.R + 63) / 64 >= 256 || a.variant == 14))) && ioc_x6r2_supported(a.mno, a.H, a.G * a.G)) { launch_ioc_x6r2(a, s); return; }    // (14: always, A/B and tests)

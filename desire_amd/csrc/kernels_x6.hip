@@ -255,102 +255,14 @@ void launch_deconv2_x6(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2, output-parity gather (k_deconv3): one wave per sample, the sample's fp32
-// input staged in LDS, contracted TRANSPOSED (weights = A operand: lane = output channel) so the accumulators hold D[co][pixel]
-// with lane = pixel and runs of four channels -> float4 stores.  A pixel fragment (8 input channels) is split on the fly and feeds six
-// MFMAs; K = 64 = 4 k-groups per tap; the next tap's weight fragments are in flight.
+// deconv3: [n,8,8,64] -> [n,16,16,32], 5x5 SAME stride 2, output-parity gather (k_deconv3), contracted TRANSPOSED (weights = A operand:
+// lane = output channel) so the accumulators hold D[co][pixel] with lane = pixel and runs of four channels -> float4 stores.  A pixel
+// fragment (8 input channels) feeds six MFMAs; K = 64 = 4 k-groups per tap; the next tap's weight fragments are in flight.
+// The operand comes from three pre-split bf16 images of the sample's input in LDS (one conversion per element instead of one per
+// fragment use: 25 taps read every pixel ~6 times; the form that split fragments on the fly was measured slower and is gone): two
+// samples per workgroup, two waves per sample -- wave (sample, half) owns the output parity classes {(0,0), (1,1)} (4 + 9 taps) or
+// {(0,1), (1,0)} (6 + 6) -- so that the images (56 KB) still leave two workgroups per CU.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6(ConvArgs a, size_t plo) {
-    constexpr int LDP = 68;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* zero_row = smem;
-    float* in_s = smem + LDP;                                          // [4][64][LDP]
-    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int s0 = blockIdx.x * 4;
-    for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
-    for (int i = tid; i < 4 * 64 * 16; i += DS_WG) {
-        const int pix = i >> 4, c4 = i & 15;
-        const int smp = s0 + (pix >> 6);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
-        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
-    }
-    __syncthreads();
-    const int smp = s0 + w;
-    const float* mine = in_s + w * 64 * LDP;
-    const int hi = lane >> 5;
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
-        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
-    }
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    int qy[2], qx[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
-    for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-            f32x16 acc[2] = {zero16(), zero16()};
-            const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
-            auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
-            uint4 bc[4][3], bn[4][3];
-            auto ldw = [&](uint4 (&b)[4][3], int tap) {
-                const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) b[g][i] = bp[i * plo + g * 64];
-            };
-            ldw(bc, tap_of(0));
-#pragma clang loop unroll(disable)
-            for (int t = 0; t < ntap; ++t) {
-                const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
-                ldw(bn, tap_of(min(t + 1, ntap - 1)));
-                __builtin_amdgcn_sched_barrier(0);
-                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
-                const float* xp[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int iy = qy[m] + dy, ix = qx[m] + dx;
-                    const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
-                    xp[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row) + 8 * hi;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const FragP<3> f0 = frag6(xp[0] + 16 * g), f1 = frag6(xp[1] + 16 * g);
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr) {                       // D[co][pixel]: the two row blocks alternate on the pipe
-                        acc[0] = mfma16(bc[g][Pairs<3>::B[pr]], f0.p[Pairs<3>::A[pr]], acc[0]);
-                        acc[1] = mfma16(bc[g][Pairs<3>::B[pr]], f1.p[Pairs<3>::A[pr]], acc[1]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) bc[g][i] = bn[g][i];
-            }
-            if (smp < a.n) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
-                    const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float4 o;
-                        o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
-                        o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
-                        *reinterpret_cast<float4*>(a.out + base + 8 * q) = o;
-                    }
-                }
-            }
-        }
-}
-// The same contraction from three pre-split bf16 images of the input (one conversion per element instead of one per fragment use:
-// 25 taps read every pixel ~6 times): two samples per workgroup, two waves per sample -- wave (sample, half) owns the output parity
-// classes {(0,0), (1,1)} (4 + 9 taps) or {(0,1), (1,0)} (6 + 6) -- so that the images (56 KB) still leave two workgroups per CU.
-// Same pieces, same products, same order: bit-identical to k_deconv3_x6.
 __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo) {
     // bf16 elements per piece image: 128 pixels, then 384 bytes of zeros for the taps outside.  A lane whose tap is outside reads the
     // zeros at the byte offset (mod 256) its pixel WOULD have had: ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row,
@@ -454,160 +366,10 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
         }
     }
 }
-// deconv3 + deconv4 in one kernel (inference: d3 is never written, 10.7 GB per 327 680 samples, and k_deconv4_tp's pass over it goes):
-// deconv4 has ONE output channel, so a d3 pixel contributes 25 scalars T[tap] = sum_c d3[pixel, c] w4[tap, c] to the 32 x 32 output at
-// (2 oy + ky - 1, 2 ox + kx - 1) -- k_deconv4_tp's "tap products first".  Here the pixel's channels sit in the accumulators of the wave
-// that just contracted it (16 per lane, the other 16 in lane ^ 32): 16 FMAs + one cross-half add per tap, then a plain LDS
-// read-add-write into the WAVE's own fp32 image (all lanes of an instruction hold the same tap of different pixels: distinct targets;
-// the two waves of a sample own disjoint parity classes of d3 but overlapping outputs, hence one image per wave, added at the end in
-// wave order: deterministic).  a.w_raw = deconv4's raw taps [25][32]; sc4 / sh4 its folded scale / shift; out4 = xhat [n, 1024].
-__global__ __launch_bounds__(DS_WG, 2) void k_deconv34_x6(ConvArgs a, size_t plo, const float* __restrict__ sc4p, const float* __restrict__ sh4p,
-                                                          float* __restrict__ out4) {
-    // bf16 elements per piece image: 128 pixels, then 384 bytes of zeros for the taps outside.  A lane whose tap is outside reads the
-    // zeros at the byte offset (mod 256) its pixel WOULD have had: ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row,
-    // consecutive pixels (144 bytes apart) fill its sixteen 16-byte slots exactly once, and one shared zero address would sit on the
-    // slot of some valid lane of the group (a second LDS cycle for every group of a border tap: 31 % of this kernel's LDS cycles)
-    constexpr int LDB = 72, NPX = 2 * 64, ZB = NPX * LDB, IMG = ZB + 192;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    u16* img = reinterpret_cast<u16*>(smem);                           // [3][IMG]
-    float* w4s = reinterpret_cast<float*>(img + 3 * IMG);              // [25][32] deconv4 taps
-    float* xacc = w4s + 800;                                           // [4 waves][32 x 32] output images
-    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int s0 = blockIdx.x * 2;
-    for (int i = tid; i < 3 * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
-    for (int i = tid; i < NPX * 16; i += DS_WG) {
-        const int pix = i >> 4, c4 = i & 15;
-        const int smp = s0 + (pix >> 6);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
-        unsigned p0[3], p1[3];
-        splitp<3>(v.x, v.y, p0); splitp<3>(v.z, v.w, p1);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
-    }
-    for (int i = tid; i < 800; i += DS_WG) w4s[i] = a.w_raw[i];
-    for (int i = tid; i < 4 * 1024; i += DS_WG) xacc[i] = 0.f;
-    __syncthreads();
-    const int ls = w >> 1, half = w & 1, smp = s0 + ls;
-    float* xa = xacc + w * 1024;
-    const int hi = lane >> 5;
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
-        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
-    }
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    int qy[2], qx[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
-    for (int cls = 0; cls < 2; ++cls) {
-        const int py = cls, px = half ? 1 - cls : cls;                 // half 0: (0,0), (1,1);  half 1: (0,1), (1,0)
-        f32x16 acc[2] = {zero16(), zero16()};
-        const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
-        auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
-        uint4 bc[4][3], bn[4][3];
-        auto ldw = [&](uint4 (&b)[4][3], int tap) {
-            const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 3; ++i) b[g][i] = bp[i * plo + g * 64];
-        };
-        auto run = [&](const uint4 (&b)[4][3], int t) {
-            const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
-            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
-            const u16* xp[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int iy = qy[m] + dy, ix = qx[m] + dx;
-                const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
-                xp[m] = img + (ok ? (ls * 64 + iy * 8 + ix) * LDB : ZB + ((((ls * 64 + iy * 8 + ix + 64) * LDB * 2) & 255) >> 1)) + 8 * hi;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint4 f0[3], f1[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    f0[i] = *reinterpret_cast<const uint4*>(xp[0] + i * IMG + 16 * g);
-                    f1[i] = *reinterpret_cast<const uint4*>(xp[1] + i * IMG + 16 * g);
-                }
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {                       // D[co][pixel]: the two row blocks alternate on the pipe
-                    acc[0] = mfma16(b[g][Pairs<3>::B[pr]], f0[Pairs<3>::A[pr]], acc[0]);
-                    acc[1] = mfma16(b[g][Pairs<3>::B[pr]], f1[Pairs<3>::A[pr]], acc[1]);
-                }
-            }
-        };
-        // weight fragments of the next tap in flight while this tap's 48 MFMAs run: two named register sets, no copies
-        ldw(bc, tap_of(0));
-        int t = 0;
-#pragma clang loop unroll(disable)
-        for (; t + 2 <= ntap; t += 2) {
-            ldw(bn, tap_of(t + 1));
-            __builtin_amdgcn_sched_barrier(0);
-            run(bc, t);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntap) ldw(bc, tap_of(t + 2));
-            __builtin_amdgcn_sched_barrier(0);
-            run(bn, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t < ntap) run(bc, t);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;           // this lane's d3 pixel
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[4 * q] = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); v[4 * q + 1] = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
-                v[4 * q + 2] = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); v[4 * q + 3] = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
-            }
-#pragma unroll 1
-            for (int ky4 = 0; ky4 < 5; ++ky4) {
-                const int Y = 2 * oy + ky4 - 1;
-#pragma unroll
-                for (int kx4 = 0; kx4 < 5; ++kx4) {
-                    const float* wt = w4s + (ky4 * 5 + kx4) * 32 + 4 * hi;     // this lane's channels: 8 q + 4 hi + 0..3
-                    float t = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 ww = *reinterpret_cast<const float4*>(wt + 8 * q);
-                        t = fmaf(v[4 * q], ww.x, t); t = fmaf(v[4 * q + 1], ww.y, t); t = fmaf(v[4 * q + 2], ww.z, t); t = fmaf(v[4 * q + 3], ww.w, t);
-                    }
-                    t += __shfl_xor(t, 32);
-                    const int X = 2 * ox + kx4 - 1;
-                    if (hi == 0 && Y >= 0 && Y < 32 && X >= 0 && X < 32) xa[Y * 32 + X] += t;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // the sample's two wave images, added in wave order, then deconv4's folded batch-norm + sigmoid
-    const float sc4 = sc4p[0], sh4 = sh4p[0];
-    for (int i = tid; i < 2 * 1024; i += DS_WG) {
-        const int l2 = i >> 10, o = i & 1023;
-        if (s0 + l2 < a.n) out4[(size_t)(s0 + l2) * 1024 + o] = sigmoidf_((xacc[(2 * l2) * 1024 + o] + xacc[(2 * l2 + 1) * 1024 + o]) * sc4 + sh4);
-    }
-}
-// a.Wp = deconv3's three-piece pack, a.w_raw = deconv4's raw taps, a.scale / a.shift = deconv3's; writes xhat only
-void launch_deconv34_x6(const ConvArgs& a, const float* sc4, const float* sh4, float* xhat, hipStream_t s) {
-    const size_t lds = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16) + (size_t)(800 + 4 * 1024) * sizeof(float);
-    allow_big_lds(k_deconv34_x6);
-    hipLaunchKernelGGL(k_deconv34_x6, dim3((a.n + 1) / 2), dim3(DS_WG), lds, s, a, (size_t)25 * 1 * 4 * 64, sc4, sh4, xhat);
-}
 void launch_deconv3_x6(const ConvArgs& a, hipStream_t s) {
-    static const bool fly = getenv("DESIRE_DECONV3_X6_FLY") != nullptr;     // A/B: the form that splits fragments on the fly
-    if (!fly) {
-        const size_t ldsi = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16);
-        allow_big_lds(k_deconv3_x6i);
-        hipLaunchKernelGGL(k_deconv3_x6i, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, (size_t)25 * 1 * 4 * 64);
-        return;
-    }
-    const size_t lds = (68 + (size_t)4 * 64 * 68) * sizeof(float);
-    allow_big_lds(k_deconv3_x6);
-    const size_t plo = (size_t)25 * 1 * 4 * 64;                        // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
-    hipLaunchKernelGGL(k_deconv3_x6, dim3((a.n + 3) / 4), dim3(DS_WG), lds, s, a, plo);
+    const size_t ldsi = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16);
+    allow_big_lds(k_deconv3_x6i);
+    hipLaunchKernelGGL(k_deconv3_x6i, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, (size_t)25 * 1 * 4 * 64);     // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
         int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0) {
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
-    a.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
+    a.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
     long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
@@ -317,7 +317,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     }
     const desire_dims& d = h->d;
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
-    if (d.bf16 == 1 || d.bf16 == 3) return fail(DESIRE_ERR_STATE, "training runs on fp32 operands (dims.bf16 = 0 or 2; 2 trains with the fp32 kernels)");
+    if (d.bf16 == 1 || d.bf16 == 3) return fail(DESIRE_ERR_STATE, "training runs with dims.bf16 = 0 (fp32 operands) or 2 (split-bf16 operands where a kernel has that form, fp32 kernels elsewhere); 1 and 3 are inference-only");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))
         return fail(DESIRE_ERR_STATE, "training of groups larger than one workgroup tile (64 / 96 / 128 agents: cluster-form BPTT) needs H <= 128 and grid_size <= 4");
@@ -367,8 +367,8 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     }
     if (d.bn_mode == 2 && (ensure(h, "bn_part2", (size_t)512 * 256 * f) || ensure(h, "bn_stat2", (size_t)2 * 128 * f) || ensure(h, "bn_statb", (size_t)2 * 128 * f)))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the batch-norm backward scratch");
-    if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f))
-        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss buffers");
+    if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f) || ensure(h, "bias_part", ((R + 31) / 32 + 1) * 4 * H * f))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss / bias-gradient buffers");
     if (int rc = build_repack_maps(h)) return rc;
     h->adam_t = 0;
     h->training = true;
@@ -401,8 +401,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = W(h, "dHx_rows");
     // bias gradients = column sums of the gate-gradient streams: summed per tile inside the BPTT kernels (no further pass over the streams)
     const int n_tiles32 = (int)((R + 31) / 32);
-    if (ensure(h, "bias_part", (size_t)(n_tiles32 + 1) * 4 * H * sizeof(float))) return fail(DESIRE_ERR_HIP, "hipMalloc failed for bias_part");
-    b.bias_part = W(h, "bias_part");
+    b.bias_part = W(h, "bias_part");                            // (allocated by desire_set_training: no hipMalloc inside a call that may be under stream capture)
     { Timer t(h, s, "bwd_decoder"); launch_decoder_bwd(b, s); }
     launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 0, 2 * H, G(h, "dec/gates/bias"), 0, s);
     launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 2 * H, H, G(h, "dec/candidate/bias"), 0, s);
@@ -464,7 +463,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                 if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
                 if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
                     return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
-            } else if (d.bf16 == 2 && (train_x3_mask() & 4) && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
+            } else if (d.bf16 == 2 && (train_x3_mask(h) & 4) && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
                 q.WcT_h = D4(h, "ioc/WcT16"); q.WgT_h = D4(h, "ioc/WgT16"); q.WsT = D4(h, "ioc/WsT16");
                 launch_ioc_bwd_x3(q, s);
             } else
@@ -521,12 +520,12 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_conv1(c, s);
         if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
         ConvWgradArgs wg{};
-        wg.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
+        wg.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
         wg.n = (int)R; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
         if (!bn1) colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
-        const bool x3 = h->d.bf16 == 2 && (train_x3_mask() & 2);                  // split-bf16 operands in the two large data-gradient convolutions
+        const bool x3 = h->d.bf16 == 2 && (train_x3_mask(h) & 2);                  // split-bf16 operands in the two large data-gradient convolutions
         c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, x3 ? "vae_dec/deconv3/Wbwd16" : "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
         if (x3) launch_conv2_x3(c, s); else launch_conv2(c, s);
@@ -561,7 +560,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_gemm_rows(g, EPI_ELUGRAD, s);
         const int NSL = A >= 2048 ? 64 : (A >= 256 ? 16 : 4);
         ConvWgradArgs wg{};
-        wg.np = (h->d.bf16 == 2 && (train_x3_mask() & 1)) ? 2 : 0;
+        wg.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
         wg.n = A; wg.partial = W(h, "tn_partial");
         wg.S = W(h, "dconvE3"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "c2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_enc/conv3/w"), s);

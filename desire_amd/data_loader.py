@@ -103,6 +103,60 @@ def window_to_slots(window: np.ndarray, seq_length: int, max_num_obj: int) -> Tu
     return src, tgt
 
 
+def windows_to_slots_batch(windows: np.ndarray, seq_length: int, max_num_obj: int, out_src: Optional[np.ndarray] = None,
+                           out_tgt: Optional[np.ndarray] = None, chunk: int = 8) -> Optional[Tuple[np.ndarray, Optional[np.ndarray]]]:
+    """window_to_slots for a whole batch (the loader-in-the-loop path: a few numpy passes per CHUNK of windows instead of ~40 small calls
+    per window; utils/data_loader.py:205-229 for every window).  windows [n, T+1, MNO, 3] -> (source, target) [n, T, MNO, 3], written
+    into out_src / out_tgt when given (any float dtype: the prefetcher hands pinned float32 staging buffers; out_tgt=False skips the
+    target), else fresh float64 arrays.  Returns None when the batch needs the per-window path: an id that is not a small non-negative
+    integer, or a window in which the reference would raise (more unique ids than slots, an id twice in a frame) -- the caller then
+    walks the windows one by one and gets the reference's exception at the reference's window.  Slot = rank of the id among the
+    window's unique ids (0 included when present), from a presence bitmap and its prefix sum, as the device builder does
+    (csrc/kernels_aux.hip).  Chunks of 8 windows keep every temporary below the allocator's mmap threshold: fresh multi-megabyte
+    temporaries cost a page fault per 4 KB on first touch, which was 5x the arithmetic."""
+    w = np.asarray(windows, np.float64)
+    n, t1, m = w.shape[0], w.shape[1], w.shape[2]
+    T = seq_length
+    want_tgt = out_tgt is not False
+    src = np.zeros((n, T, max_num_obj, 3)) if out_src is None else out_src
+    tgt = (np.zeros((n, T, max_num_obj, 3)) if out_tgt is None else out_tgt) if want_tgt else None
+    src2, tgt2 = src.reshape(-1, 3), (tgt.reshape(-1, 3) if want_tgt else None)
+    w2 = w.reshape(-1, 3)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        k = c1 - c0
+        ids = w[c0:c1, :, :, 0]
+        ii = ids.astype(np.int64)
+        if not np.isfinite(ids).all() or (ii != ids).any() or ii.min() < 0 or ii.max() > 65535:
+            return None
+        top = int(ii.max()) + 1
+        flat = ii.reshape(k, -1)
+        rows = np.arange(k)[:, None]
+        seen = np.zeros((k, top), np.bool_)
+        seen[rows, flat] = True
+        rank = np.cumsum(seen, axis=1, dtype=np.int64) - 1               # rank[w, id] = #unique ids of window w below id
+        slot = rank[rows, flat].reshape(k, t1, m)
+        present = ii != 0
+        if (present & (slot >= max_num_obj)).any():
+            return None                                                  # IndexError in the reference (:227)
+        srt = np.sort(ii, axis=2)
+        if ((srt[:, :, 1:] == srt[:, :, :-1]) & (srt[:, :, 1:] != 0)).any():
+            return None                                                  # ValueError in the reference (:224-229)
+        if out_src is not None:
+            src[c0:c1] = 0
+        if want_tgt and out_tgt is not None:
+            tgt[c0:c1] = 0
+        wi, ti, mi = np.nonzero(present)
+        lin = ((wi + c0) * t1 + ti) * m + mi                              # row of w2
+        dst = ((wi + c0) * T + ti) * max_num_obj + slot[wi, ti, mi]       # row of src2 for frame ti; frame ti feeds target row ti - 1
+        s_ok = ti < T
+        src2[dst[s_ok]] = w2[lin[s_ok]]
+        if want_tgt:
+            t_ok = ti >= 1
+            tgt2[dst[t_ok] - max_num_obj] = w2[lin[t_ok]]
+    return src, tgt
+
+
 class DataLoader(object):
     """Drop-in for utils/data_loader.py:20 (same positional arguments and defaults)."""
 
@@ -173,6 +227,70 @@ class DataLoader(object):
         self.num_batches = int(counter / self.batch_size) * 2
 
     def next_batch(self, random_update=True):
+        """utils/data_loader.py:185-247.  The pointer walk (and its random.randint draws) runs first, in the reference's order; the
+        windows are then cut and slot-assigned in ONE batched pass (windows_to_slots_batch).  If that pass declines -- a window in
+        which the reference would raise, or ids that are not small integers -- the walk is rewound and redone window by window, so
+        the exception, its type and the pointer state it leaves behind are the reference's."""
+        state = (self.dataset_pointer, self.frame_pointer, random.getstate() if random_update else None)
+        picks, dval = self._walk(random_update)
+        out = self._fill(picks, None, None)
+        if out is None:
+            self.dataset_pointer, self.frame_pointer = state[0], state[1]
+            if random_update:
+                random.setstate(state[2])
+            return self._next_batch_scalar(random_update)
+        return list(out[0]), list(out[1]), dval
+
+    def _walk(self, random_update):
+        """The pointer walk of utils/data_loader.py:190-247 without the window work: [(video, first frame)] and d."""
+        picks, dval = [], []
+        guard = 0
+        while len(picks) < self.batch_size:
+            current_data = self.data[self.dataset_pointer]
+            idx = self.frame_pointer
+            if idx + self.seq_length < current_data.shape[0]:
+                picks.append((self.dataset_pointer, idx))
+                if random_update:
+                    self.frame_pointer += random.randint(1, self.seq_length)
+                else:
+                    self.frame_pointer += self.seq_length
+                dval.append(self.dataset_pointer)
+                guard = 0
+            else:
+                self.tick_batch_pointer()
+                guard += 1
+                if guard > len(self.data):
+                    raise RuntimeError("no video holds seq_length+1 frames")  # the ref spins forever
+        return picks, dval
+
+    def _fill(self, picks, out_x, out_y):
+        T = self.seq_length
+        win = getattr(self, "_cut", None)                        # persistent cut buffer: no fresh 19 MB allocation per batch
+        if win is None or win.shape[0] != len(picks):
+            win = self._cut = np.empty((len(picks), T + 1, self.max_num_obj, 3))
+        for i, (v, idx) in enumerate(picks):
+            win[i] = self.data[v][idx:idx + T + 1]
+        return windows_to_slots_batch(win, T, self.max_num_obj, out_x, out_y)
+
+    def next_batch_into(self, out_x: np.ndarray, out_y=False, random_update=True):
+        """next_batch() writing its x (and, with out_y an array, its y) straight into caller-owned [batch_size, seq_length, max_num_obj, 3]
+        buffers of any float dtype -- the prefetcher's pinned float32 staging -- instead of returning fresh float64 lists.  Same pointer
+        walk, same random draws, same windows, same exceptions as next_batch (one rounding to the buffer's dtype).  Returns d."""
+        state = (self.dataset_pointer, self.frame_pointer, random.getstate() if random_update else None)
+        picks, dval = self._walk(random_update)
+        if self._fill(picks, out_x, out_y) is None:
+            self.dataset_pointer, self.frame_pointer = state[0], state[1]
+            if random_update:
+                random.setstate(state[2])
+            x, y, dval = self._next_batch_scalar(random_update)
+            out_x[...] = np.stack(x)
+            if out_y is not False:
+                out_y[...] = np.stack(y)
+        return dval
+
+    def _next_batch_scalar(self, random_update=True):
+        """The per-window walk (the reference's own loop structure): exceptions surface at the window, and with the pointer state, the
+        reference would have."""
         x_batch, y_batch, dval = [], [], []
         i = 0
         guard = 0

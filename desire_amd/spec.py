@@ -25,6 +25,10 @@ import numpy as np
 BN_EPS = 1e-3  # variance_epsilon, model/model.py:460,479
 
 
+IOC_AUTO, IOC_TILE64, IOC_CLUSTER, IOC_CLUSTER_BINS, IOC_COMPACT, IOC_TRAIN_DENSE, IOC_X6_TILE32, IOC_X6_TILE64 = 0, 2, 4, 6, 8, 9, 13, 14   # desire_hip.h: DESIRE_IOC_*
+FLAG_NO_FUSE34 = 1
+
+
 @dataclass(frozen=True)
 class Dims:
     """Static sizes of one forward call.  Row index r = (scene*K + k)*mno + slot."""
@@ -56,6 +60,12 @@ class Dims:
                            #    3: three bf16 pieces, six MFMAs per product: fp32-class accuracy (inference only)
     ref_compat: int = 0    # 1: the reference graph as written (model/model.py:116-311): n_dec decoder states re-read as T_obs points
     n_dec: int = 0         # ref_compat only: decoder steps (the reference hard-codes 7, model/model.py:280)
+    # behavioural switches (include/desire_hip.h: desire_dims; all zero = the measured winners; Handle.set_option changes them live)
+    ioc_form: int = 0      # IOC_* below: which form of the IOC kernel serves the shape
+    ioc_split: int = 0     # bin-split regime of the fp32 inference IOC kernel: 0 auto (a window's result then depends on the batch it is in, <= 2e-6),
+                           #    1 never (bit-identical across batch sizes), 2..4 cap on the workgroups per tile
+    train_fp32_mask: int = 0   # dims.bf16 = 2 training: parts kept on fp32 operands (1 weight gradients, 2 data-gradient convs, 4 IOC BPTT, 8 sample generation)
+    flags: int = 0         # FLAG_NO_FUSE34 = 1: bf16 deconv3 / deconv4 as separate kernels
 
     @property
     def A(self) -> int:

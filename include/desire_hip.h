@@ -75,12 +75,43 @@ typedef struct desire_dims {
                               dev_Yhat [A, n_dec, T_obs, 2] = output_states; desire_ioc_refine is an error.  sx = sy = 1
                               reproduces the raw-pixel inputs of :216-231. */
     int32_t n_dec;         /* ref_compat only: decoder steps (the reference hard-codes 7); 0 otherwise */
+    /* ---- behavioural switches (round 4: these were environment variables read inside the library; a C caller could neither see nor
+     * set them).  All zero = the measured winners.  desire_set_option changes them on a live handle. ---- */
+    int32_t ioc_form;      /* which form of the IOC kernel serves the shape: DESIRE_IOC_* below.  Every form computes the same function;
+                              forms differ in fp32 summation order only (<= 2e-6 on trajectories), except DESIRE_IOC_COMPACT, which also
+                              executes fewer products (exact zeros skipped). */
+    int32_t ioc_split;     /* the BIN-SPLIT regime of the fp32 inference IOC kernel.  A call with few 32-row tiles (tiles * n <= the
+                              workgroups the device keeps resident, n = 2..4) spreads the social bins of every tile over n workgroups that
+                              exchange partial sums once per step: one window 3.5 -> 2.4 ms.  CONSEQUENCE: with the default (0 = auto)
+                              the fp32 result of a window depends on HOW MANY windows share the call -- the partial sums of the social
+                              embedding are regrouped, a difference of <= 2e-6 in trajectories and scores (inside every gate of
+                              tests/, but not bit-identical across batch sizes).  1 = never split: results of a window are bit-identical
+                              whatever the batch (the rounds 1-2 behaviour).  n > 1 = at most n workgroups per tile. */
+    int32_t train_fp32_mask; /* dims.bf16 = 2 training step: bit mask of the parts that stay on fp32 operands instead of split-bf16 ones
+                              (1 weight-gradient reductions, 2 data-gradient convolutions, 4 IOC BPTT, 8 six-product sample generation
+                              in the forward pass); 0 = everything that has a split form uses it. */
+    int32_t flags;         /* DESIRE_FLAG_* below */
 } desire_dims;
+
+#define DESIRE_IOC_AUTO 0          /* the measured winner per shape */
+#define DESIRE_IOC_TILE64 2        /* 64-row tiles also for groups of <= 32 agents (fp32 and bf16 operands) */
+#define DESIRE_IOC_CLUSTER 4       /* groups of 64 agents through the cluster form (one group = two workgroups exchanging hidden states
+                                      through global memory; the default for 96 / 128 agents); bf16 operands: with column-split pooling */
+#define DESIRE_IOC_CLUSTER_BINS 6  /* bf16 operands, 64 agents: the cluster form with the pooling split over bins (what 96 / 128 run) */
+#define DESIRE_IOC_COMPACT 8       /* row-compacted social pooling (fp32 inference, groups of <= 32 agents, H <= 128): the pooling MFMAs
+                                      run on the rows that have a neighbour in the bin only */
+#define DESIRE_IOC_TRAIN_DENSE 9   /* training-mode forward with the dense pooling (default there: the compacted one) */
+#define DESIRE_IOC_X6_TILE32 13    /* dims.bf16 = 3: the 32-row / three-image six-product kernel whatever the launch size */
+#define DESIRE_IOC_X6_TILE64 14    /* dims.bf16 = 3: the 64-row six-product kernel whatever the launch size (default: launches of >= 256 tiles) */
+#define DESIRE_FLAG_NO_FUSE34 1    /* dims.bf16 = 1: deconv3 and deconv4 as separate kernels (default: fused, d3 never written) */
 
 typedef struct desire_ctx desire_handle;
 
 const char* desire_last_error(void);
 int desire_version(void);
+/* Changes one of the behavioural switches of desire_dims on a live handle: name = "ioc_form", "ioc_split", "train_fp32_mask" or
+ * "flags"; takes effect at the next call.  Unknown name or value out of range: DESIRE_ERR_ARG. */
+int desire_set_option(desire_handle* h, const char* name, int32_t value);
 
 /* Replaces DESIREModel.__init__/build_model graph construction (model/model.py:36-77). */
 int desire_create(const desire_dims* dims, desire_handle** out);

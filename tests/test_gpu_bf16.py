@@ -75,9 +75,9 @@ def test_ioc_bf16_second_refinement_pass_runs(torch_cuda):
 
 
 @pytest.mark.parametrize("variant", ["4", "6"])
-def test_ioc_bf16_cluster_equals_one_workgroup_form(torch_cuda, variant, monkeypatch):
-    """64 agents fit one workgroup (the 64-row tile) AND two cluster members (DESIRE_IOC_VARIANT 4: pooling split over
-    columns, 6: over bins): same neighbour-chunk order, same chain-ordered weights -> one pass agrees up to fp32 summation order.
+def test_ioc_bf16_cluster_equals_one_workgroup_form(torch_cuda, variant):
+    """64 agents fit one workgroup (the 64-row tile) AND two cluster members (dims.ioc_form 4 = DESIRE_IOC_CLUSTER: pooling split over
+    columns, 6 = DESIRE_IOC_CLUSTER_BINS: over bins): same neighbour-chunk order, same chain-ordered weights -> one pass agrees up to fp32 summation order.
     A second pass re-bins from positions that differ by that rounding, so it is compared in the mean (as for every two-pass
     bf16 check); it exercises the pass-end hand-off."""
     d32 = small_dims(mno=64, n_scenes=2, K=3, n_grids=1, T_pred=9)
@@ -86,9 +86,8 @@ def test_ioc_bf16_cluster_equals_one_workgroup_form(torch_cuda, variant, monkeyp
     ref32 = oracle_forward(d32, w, past, fut, eps, grids, gos)
     _, Y1, s1 = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
     _, Y1b, _ = run_gpu(torch_cuda, d32.replace(bf16=1, iters=2), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", variant)
-    _, Y2, s2 = run_gpu(torch_cuda, d32.replace(bf16=1), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
-    _, Y2b, _ = run_gpu(torch_cuda, d32.replace(bf16=1, iters=2), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
+    _, Y2, s2 = run_gpu(torch_cuda, d32.replace(bf16=1, ioc_form=int(variant)), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
+    _, Y2b, _ = run_gpu(torch_cuda, d32.replace(bf16=1, iters=2, ioc_form=int(variant)), w, past, fut, eps, grids, gos, Y_in=ref32["Y0"])
     assert np.isfinite(Y2).all() and np.isfinite(Y2b).all()
     # the forms sum the per-bin partial products in different orders; an e_r that lands on the other side of a bf16 rounding
     # boundary (2^-8 relative) then moves the result like in the rounding-oracle test: 3e-3 of the offset scale
@@ -111,15 +110,14 @@ def test_bf16_is_inference_only_and_validated(torch_cuda):
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64)])
 @pytest.mark.parametrize("fused", [True, False])
-def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw, fused, monkeypatch):
+def test_cvae_decoder_bf16_convs_match_rounding_oracle(torch_cuda, kw, fused):
     """deconv2 / deconv3 (/ deconv4 when fused) with bf16 operands: d2, d3 and xhat against the oracle's decoder with the
     same operand rounding (fed with the kernel's own z so the comparison isolates these layers), and against plain fp32.
-    Default = deconv3+deconv4 fused (d3 never exists); DESIRE_NO_FUSE34 keeps the separate kernels (fp32 deconv4)."""
+    Default = deconv3+deconv4 fused (d3 never exists); dims.flags = DESIRE_FLAG_NO_FUSE34 keeps the separate kernels (fp32 deconv4)."""
     from oracle import desire_oracle as O
-    if not fused:
-        monkeypatch.setenv("DESIRE_NO_FUSE34", "1")
+    from desire_amd.spec import FLAG_NO_FUSE34
     d32 = small_dims(**kw)
-    d16 = d32.replace(bf16=1)
+    d16 = d32.replace(bf16=1, flags=0 if fused else FLAG_NO_FUSE34)
     w = init_weights(d32, 5)
     past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=2)
     h, _, _ = run_gpu(torch_cuda, d16, w, past, fut, eps, grids, gos)
@@ -256,21 +254,3 @@ def test_ioc_bf16_error_budget_per_pass(torch_cuda, kw):
         assert e16 < 7e-3 * scale and e32 < 3e-2 * scale, (p, e16, e32)
         assert np.abs(score - r16["score"]).max() < 2e-2 * max(1.0, np.abs(r16["score"]).max())
         Yin = r32["Y"].astype(np.float32)              # the next pass starts from the exact first-pass result
-
-
-@pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(mno=64, n_scenes=2, K=3, n_grids=1),
-                                dict(mno=8, n_scenes=5, K=3), dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2), dict(nb_w=0.04, nb_h=0.04, K=2),
-                                dict(iters=2, K=2), dict(mno=1, n_scenes=3, K=2), dict(H=32, T_pred=9, K=2, mno=8)])
-def test_two_row_blocks_per_wave_is_bit_identical_to_the_32_row_tiles(torch_cuda, kw, monkeypatch):
-    """kernels_bf16_r2.hip (64-row tiles, every weight fragment used for two row blocks, one workgroup per CU; the A/B form
-    DESIRE_IOC_VARIANT=12) keeps k_ioc_bf16's rounding points AND its per-row summation order: trajectories and scores equal the
-    default 32-row / 8-wave forms' bit for bit, ragged last tiles and 64-agent groups included."""
-    d = small_dims(bf16=1, **kw)
-    w = init_weights(d, 31)
-    past, fut, eps, grids, gos = make_case(d, seed=32, n_absent=min(2, d.mno - 1))
-    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "12")
-    _, Yb, sb = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
-    assert np.isfinite(Ya).all() and np.abs(Ya).max() > 0
-    np.testing.assert_array_equal(Ya, Yb)
-    np.testing.assert_array_equal(sa, sb)

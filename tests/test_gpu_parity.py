@@ -176,8 +176,8 @@ def test_config1_shape_properties(torch_cuda):
     ref = O.forward(to_oracle_layout(past[:1]), to_oracle_layout(fut[:1]), eps[:r1], grids, gos[:1], w, d1)
     _, Yw, sw = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1], Y_in=ref["Y0"])
     assert np.abs(Yw - ref["Y"]).max() < TOL_Y
-    # one window on its own: 20 tiles run the bin-split IOC with 8 workgroups per tile, the 4-window batch above with 2 -- the partial sums
-    # of e_r group differently, so the two agree to fp32 rounding (bit-identical under DESIRE_IOC_SPLIT=0, where both run the plain form)
+    # one window on its own: 20 tiles run the bin-split IOC with 4 workgroups per tile, the 4-window batch above with 3 -- the partial sums
+    # of e_r group differently, so the two agree to fp32 rounding (bit-identical under dims.ioc_split = 1, where both run the plain form)
     Y1w = run_gpu(torch, d1, w, past[:1], fut[:1], eps[:r1], grids, gos[:1])[1]
     assert np.abs(Y1[:r1] - Y1w).max() < 2e-6
 
@@ -347,12 +347,11 @@ def test_next_rows_window_builder_gaussian_head_ade_fde(torch_cuda, golden_dir):
     dict(mno=96, n_scenes=1, K=2, n_grids=1, T_pred=5, iters=2),         # 3 per group, two refinement passes
     dict(mno=64, n_scenes=2, K=3, n_grids=1, T_pred=9, nb_w=0.04, nb_h=0.04),   # sparse windows: empty bins skipped per tile
 ])
-def test_ioc_cluster_form(torch_cuda, kw, monkeypatch):
+def test_ioc_cluster_form(torch_cuda, kw):
     """Groups larger than one workgroup tile: tpg workgroups exchange hidden states through global memory each
     step (agent-scope release/acquire hand-off).  Checked against the oracle, and -- where the single-workgroup
     64-row kernel exists -- bitwise against it (same summation order)."""
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "4")
-    d = small_dims(**kw)
+    d = small_dims(ioc_form=4, **kw)                                      # DESIRE_IOC_CLUSTER (the default form for 96 / 128 agents anyway)
     w = init_weights(d, 13)
     past, fut, eps, grids, gos = make_case(d, seed=14, n_absent=5, spread=0.3)
     ref = oracle_forward(d, w, past, fut, eps, grids, gos)
@@ -361,24 +360,21 @@ def test_ioc_cluster_form(torch_cuda, kw, monkeypatch):
     assert np.abs(Y2 - ref["Y"]).max() < TOL_Y, np.abs(Y2 - ref["Y"]).max()
     assert np.abs(score2 - ref["score"]).max() < 5e-3
     if d.mno == 64 and d.H <= 128:
-        monkeypatch.setenv("DESIRE_IOC_VARIANT", "0")
-        _, Y3, score3 = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+        _, Y3, score3 = run_gpu(torch_cuda, d.replace(ioc_form=0), w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
         np.testing.assert_array_equal(Y2, Y3)
         np.testing.assert_array_equal(score2, score3)
 
 
-def test_ioc_cluster_form_under_load_is_bitwise_stable(torch_cuda, monkeypatch):
+def test_ioc_cluster_form_under_load_is_bitwise_stable(torch_cuda):
     """800 tiles on a 256-workgroup persistent grid (every workgroup walks several groups, all CUs busy, the
     hand-off buffers are re-used and L1-warm): the cluster form must equal the single-workgroup 64-row kernel
     bit for bit, twice in a row."""
     d = Dims(n_scenes=20, mno=64, K=20, T_obs=8, T_pred=40, n_grids=1, nb_w=0.2, nb_h=0.2, sx=1 / 1400.0, sy=1 / 1100.0)
     w = init_weights(d, 21)
     past, fut, eps, grids, gos = make_case(d, seed=22, n_absent=7)
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "0")
     _, Y_ref, s_ref = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "4")
     for _ in range(2):
-        _, Y_cl, s_cl = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+        _, Y_cl, s_cl = run_gpu(torch_cuda, d.replace(ioc_form=4), w, past, fut, eps, grids, gos)
         np.testing.assert_array_equal(Y_cl, Y_ref)
         np.testing.assert_array_equal(s_cl, s_ref)
 
@@ -638,8 +634,8 @@ def test_batch_statistics_modes_are_fp32_and_both_train(torch_cuda):
     dict(iters=2, K=2),
     dict(mno=1, n_scenes=3, K=2, n_absent=0),
 ])
-def test_row_compacted_pooling_form(torch_cuda, kw, monkeypatch):
-    """DESIRE_IOC_VARIANT=8: the pooling contraction runs on the rows that have a neighbour in the bin only (packed into
+def test_row_compacted_pooling_form(torch_cuda, kw):
+    """dims.ioc_form = 8 (DESIRE_IOC_COMPACT): the pooling contraction runs on the rows that have a neighbour in the bin only (packed into
     16-row MFMA tiles, results added back into their rows).  Same function as the default form up to fp32 summation order:
     checked against the oracle and against the default form."""
     kw = dict(kw)
@@ -653,8 +649,7 @@ def test_row_compacted_pooling_form(torch_cuda, kw, monkeypatch):
         tab = _lib.Handle(d).bin_table()
     ref = oracle_forward(d, w, past, fut, eps, grids, gos, **({"bin_tab": tab} if tab is not None else {}))
     _, Yd, sd = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "8")
-    _, Yc, sc = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    _, Yc, sc = run_gpu(torch_cuda, d.replace(ioc_form=8), w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
     if d.iters == 1:
         assert np.abs(Yc - ref["Y"]).max() < TOL_Y, np.abs(Yc - ref["Y"]).max()
         assert np.abs(sc - ref["score"]).max() < 5e-3

@@ -375,17 +375,12 @@ def test_six_product_form_refuses_training_and_falls_back_on_other_shapes(torch_
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(T_pred=40, K=2), dict(posterior=0, K=3),
                                 dict(H=16, T_pred=8, T_obs=8, K=2, mno=4, n_scenes=3)])
-@pytest.mark.parametrize("fused", [False, True])
-def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cuda, kw, fused, monkeypatch):
+def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cuda, kw):
     """dims.bf16 = 3 also runs the GRU decoder, deconv1-3 and the mask fc as six bf16 MFMAs per fp32 product (kernels_x6.hip).  Sample
     generation feeds a DISCONTINUOUS refinement (cells and bins are floors of the sampled positions), so the claim is strict: every stage
     sits where the fp32 kernels sit -- against the oracle no further than twice the fp32 kernel's own distance (or 1e-6), and within 2e-6
-    of the fp32 kernels themselves.  fused: deconv3 + deconv4 in one kernel (opt-in, DESIRE_FUSE34_X6: measured slower than the two
-    kernels; d3 is never written, so it is not compared there)."""
-    if fused:
-        monkeypatch.setenv("DESIRE_FUSE34_X6", "1")
-    else:
-        monkeypatch.delenv("DESIRE_FUSE34_X6", raising=False)
+    of the fp32 kernels themselves.  (The fused deconv3 + deconv4 six-product kernel of round 3 was measured slower
+    than the two kernels and is gone.)"""
     d = small_dims(**kw)
     w = init_weights(d, 9)
     past, fut, eps, grids, gos = make_case(d, seed=10, n_absent=min(3, d.mno - 1))
@@ -394,8 +389,6 @@ def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cud
     hf, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     rep = {}
     for name, shp in (("d2", (d.R, 4096)), ("d3", (d.R, 8192)), ("xhat", (d.R, 1024)), ("xz", (d.R, d.H)), ("Y0", (d.R, d.T_pred, 2))):
-        if fused and name == "d3":
-            continue
         g6, gf, r = h6.read_buffer(name, shp), hf.read_buffer(name, shp), ref[name].reshape(shp)
         e6, ef, e6f = float(np.abs(g6 - r).max()), float(np.abs(gf - r).max()), float(np.abs(g6 - gf).max())
         rep[name] = (e6, ef, e6f)
@@ -408,9 +401,9 @@ def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cud
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3), dict(mno=64, n_scenes=2, K=3, n_grids=1),
                                 dict(mno=8, n_scenes=5, K=3), dict(nb_w=0.04, nb_h=0.04, K=2), dict(iters=2, K=2), dict(mno=1, n_scenes=3, K=2),
                                 dict(bin_mode=1, grid_size=4, nb_w=0.45, nb_h=0.04, K=2), dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2)])
-def test_six_product_ioc_on_64_row_tiles_matches_the_32_row_form(torch_cuda, kw, monkeypatch):
+def test_six_product_ioc_on_64_row_tiles_matches_the_32_row_form(torch_cuda, kw):
     """kernels_x6r2.hip (two row blocks per wave, fp32 operand tiles split on the fly; the default six-product IOC kernel wherever a
-    64-row tile fits) issues the same products in the same per-accumulator order as k_ioc_x3<NP = 3> (DESIRE_IOC_VARIANT=13): refined
+    64-row tile fits) issues the same products in the same per-accumulator order as k_ioc_x3<NP = 3> (dims.ioc_form = DESIRE_IOC_X6_TILE32): refined
     trajectories and scores agree to an ulp or two -- ragged last tiles, 64-agent groups (which the 32-row form does not have: there
     the reference point is the fp32 kernel, 2e-6) and the 36-bin fallback included."""
     d = small_dims(bf16=3, **kw)
@@ -418,14 +411,13 @@ def test_six_product_ioc_on_64_row_tiles_matches_the_32_row_form(torch_cuda, kw,
     past, fut, eps, grids, gos = make_case(d, seed=34, n_absent=min(2, d.mno - 1))
     ha, _, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
     Y0 = ha.read_buffer("Y0", (d.R, d.T_pred, 2))
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "14")       # 64-row tiles whatever the launch size (by default only launches of >= 256 such tiles)
-    _, Ya, sa = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=Y0)
-    monkeypatch.setenv("DESIRE_IOC_VARIANT", "13")
-    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3 if d.mno <= 32 else 0), w, past, fut, eps, grids, gos, Y_in=Y0)   # (64-agent groups: the fp32 kernel)
+    # DESIRE_IOC_X6_TILE64: 64-row tiles whatever the launch size (by default only launches of >= 256 such tiles)
+    _, Ya, sa = run_gpu(torch_cuda, d.replace(ioc_form=14), w, past, fut, eps, grids, gos, Y_in=Y0)
+    _, Yb, sb = run_gpu(torch_cuda, d.replace(bf16=3, ioc_form=13) if d.mno <= 32 else d.replace(bf16=0), w, past, fut, eps, grids, gos, Y_in=Y0)   # (64-agent groups: the fp32 kernel)
     assert np.isfinite(Ya).all() and np.abs(Ya - Y0).max() > 0
     # same products, same per-accumulator order -- but not the same bits: the 32-row form splits r*h (and friends) where it computes
     # them, and hipcc contracts the product into the split's subtraction (the pieces then carry the UNROUNDED product); a tile's
-    # occupied-bin set (two row blocks vs one) also regroups the partial sums.  One or two ulp.  (Variant 13 at 64 agents per
-    # group = the fp32 kernel.)
+    # occupied-bin set (two row blocks vs one) also regroups the partial sums.  One or two ulp.  (At 64 agents per group the
+    # comparison point is the fp32 kernel.)
     assert np.abs(Ya - Yb).max() < (5e-7 if d.mno <= 32 and d.iters == 1 else 2e-6)
     assert np.abs(sa - sb).max() < 2e-5 * max(1.0, np.abs(sb).max())

@@ -15,14 +15,13 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 @pytest.mark.parametrize("kw", [dict(mno=96, n_scenes=1, K=2, H=128), dict(mno=128, n_scenes=2, K=2, H=64, L=64),
                                 dict(mno=64, n_scenes=1, K=3, H=64, L=64, variant4=True)])
-def test_cluster_gradients_match_autograd(kw, monkeypatch):
+def test_cluster_gradients_match_autograd(kw):
     import torch
     from desire_amd import _lib
     from oracle import desire_torch as OT
     kw = dict(kw)
-    if kw.pop("variant4", False):
-        monkeypatch.setenv("DESIRE_IOC_VARIANT", "4")          # 64 agents through the cluster forward (the backward stays the 64-row tile)
-    d = small_dims(T_obs=5, T_pred=6, n_grids=1, **kw)
+    form = 4 if kw.pop("variant4", False) else 0               # DESIRE_IOC_CLUSTER: 64 agents through the cluster forward (the backward stays the 64-row tile)
+    d = small_dims(T_obs=5, T_pred=6, n_grids=1, ioc_form=form, **kw)
     w = init_weights(d, 61)
     for k in w:
         if k.startswith("vae_dec/") and k.endswith("/w"):
