@@ -23,7 +23,7 @@ EXPORTS = [
     "desire_train_loss", "desire_adam_step", "desire_get_weight", "desire_clip_grads",
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
     "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout", "desire_build_windows_la", "desire_adam_state",
-    "desire_set_option",
+    "desire_set_option", "desire_train_loss_async", "desire_set_head_loss",
 ]
 
 
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     lib.desire_get_grad.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.desire_grad_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_train_loss.argtypes = [vp, f32p, C.POINTER(C.c_float), vp]
+    lib.desire_train_loss_async.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_set_head_loss.argtypes = [vp, C.c_float]
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     lib.desire_adam_state.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
@@ -276,9 +278,22 @@ class Handle:
 
     def train_loss(self, fut_ptr: int, stream: int = 0) -> Dict[str, float]:
         out = (C.c_float * 5)()
-        _chk(self.lib.desire_train_loss(self._h, fut_ptr, out, stream or None))
-        r = dict(zip(("recon", "kld", "ce", "reg", "n_present"), (float(x) for x in out)))
-        r["loss"] = r["recon"] + r["kld"] + r["ce"] + r["reg"]
+        _chk(self.lib.desire_train_loss(self._h, fut_ptr, out, stream or None))                 # (synchronises the stream)
+        return self.loss_terms(self.read_buffer("loss_out", (8,), stream))                      # + the Gaussian-head term and the clip norm
+
+    def set_head_loss(self, weight: float) -> None:
+        """Weight of the reference's Gaussian-NLL term for the 5-wide output layer (model/model.py:494-550) in the training loss."""
+        _chk(self.lib.desire_set_head_loss(self._h, C.c_float(float(weight))))
+
+    def train_loss_async(self, fut_ptr: int, out8_ptr: int, stream: int = 0) -> None:
+        """The loss terms of the last training-mode forward into a device buffer of 8 floats, no synchronisation (see loss_terms)."""
+        _chk(self.lib.desire_train_loss_async(self._h, fut_ptr, out8_ptr, stream or None))
+
+    @staticmethod
+    def loss_terms(v8) -> Dict[str, float]:
+        v8 = [float(x) for x in list(v8)[:8]]
+        r = dict(zip(("recon", "kld", "ce", "reg", "n_present", "nll_head", "grad_norm", "n_head"), v8))
+        r["loss"] = r["recon"] + r["kld"] + r["ce"] + r["reg"] + r["nll_head"]
         return r
 
     def adam_step(self, lr: float = 0.005, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, stream: int = 0) -> None:

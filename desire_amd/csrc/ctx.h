@@ -60,6 +60,7 @@ struct desire_ctx {
     const float* grids = nullptr;
     bool grids_set = false;
     bool profiling = false;
+    float head_loss_w = 0.f;                                 // desire_set_head_loss: weight of the Gaussian-head NLL term in the training loss
     int* host_err = nullptr;                                 // mapped host word the bin-split IOC's bounded spins report into (checked by the next call)
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;

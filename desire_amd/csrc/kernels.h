@@ -203,7 +203,8 @@ void launch_count_valid(const uint8_t* valid, int A, float* out, hipStream_t s);
 void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* lmask, const float* nfut, const float* nvalid, float* dY,
                         int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s);
 struct DecBwdArgs {
-    const float* dY0;                                      // [R,T,2]
+    const float* dY0;                                      // [R,T,nw]: per-step gradient w.r.t. the head's outputs (nullptr: none)
+    int nw;                                                // width of that head: 0 / 2 = the decoder's (x, y) head [H,2]; 5 = the Gaussian head [H,5]
     const float* sv_r; const float* sv_u; const float* sv_c; const float* sv_h;   // [R,T,H] from the training-mode forward
     const float* Hx; int ldhx; const float* w_head;
     const float4* WcT_h; const float4* WgT_h; const float4* WgT_x; const float4* WcT_x;   // transposed, packed

@@ -67,18 +67,18 @@ void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, 
 //   da_r = dr r(1-r); da_u = du u(1-u);  dh_{t-1} += [da_r|da_u] Wg_h^T     (MFMA, K = 2H)
 // da_* and r*h_{t-1} go to HBM for the weight-gradient reductions; the constant-input sums dxg, dxc give dx_z.
 // ------------------------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int NW = 2>
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
     float* A1 = smem;                    // [32][LD1]   da_c
     float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
-    float* dy = A2 + TM * LD2;           // [32][2]
-    float* wo = dy + TM * 2;             // [H][2]
+    float* dy = A2 + TM * LD2;           // [32][NW]
+    float* wo = dy + TM * NW;            // [H][NW]
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
     const int col = cb * 32 + (lane & 31);
-    for (int i = tid; i < 2 * H; i += NTHR) wo[i] = a.w_head[i];
+    for (int i = tid; i < NW * H; i += NTHR) wo[i] = a.w_head[i];
     const float* a1_lane = A1 + (lane & 31) * LD1 + 4 * (lane >> 5);
     const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
     float* my1 = A1 + (4 * (lane >> 5)) * LD1 + col;
@@ -102,9 +102,14 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
         asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
         __syncthreads();                                   // previous step's A2 / dy consumers are done
         if (tid < TM) {
-            float2 v = make_float2(0.f, 0.f);
-            if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
-            dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
+            if constexpr (NW == 2) {
+                float2 v = make_float2(0.f, 0.f);
+                if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
+                dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) dy[tid * NW + j] = a.dY0[((size_t)min(row0 + tid, a.R - 1) * a.T + t) * NW + j];
+            }
         }
         if (t == 0) {                                      // h_{-1} = Hx[agent] (decoder) or 0 (encoders): staged in A1, each element
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {   // is read by its owner right before it is overwritten with da_c
@@ -116,14 +121,18 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
         }
         __syncthreads();
         f32x16 dhp, rr, hp;
-        const float w0 = wo[col * 2], w1 = wo[col * 2 + 1];
+        float wv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) wv[j] = wo[col * NW + j];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
             const unsigned ix = tl(i, t) * H + col;
             const float u = svu[ix], c = svc[ix], r = svr[ix];
             const float hprev = (t > 0) ? svh[ix - H] : my1[((i & 3) + 8 * (i >> 2)) * LD1];
-            const float dht = dh[i] + dy[rl * 2] * w0 + dy[rl * 2 + 1] * w1;
+            float dht = dh[i] + dy[rl * NW] * wv[0] + dy[rl * NW + 1] * wv[1];
+#pragma unroll
+            for (int j = 2; j < NW; ++j) dht += dy[rl * NW + j] * wv[j];
             const float dau = dht * (hprev - c) * u * (1.0f - u);
             const float dc = dht * (1.0f - u);
             dhp[i] = dht * u;
@@ -191,8 +200,14 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
 }
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
     const int H = a.H;
-    const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 64 + 2 * H) * sizeof(float);
+    const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 32 * 5 + 5 * H) * sizeof(float);
     const dim3 grid((a.R + 31) / 32);
+    if (a.nw == 5) {                                      // the X encoder with the Gaussian head's per-step gradient (desire_set_head_loss)
+        if (H == 256) { allow_big_lds(k_decoder_bwd<256, 5>); hipLaunchKernelGGL((k_decoder_bwd<256, 5>), grid, dim3(512), lds, s, a); }
+        else if (H == 128) { allow_big_lds(k_decoder_bwd<128, 5>); hipLaunchKernelGGL((k_decoder_bwd<128, 5>), grid, dim3(256), lds, s, a); }
+        else hipLaunchKernelGGL((k_decoder_bwd<64, 5>), grid, dim3(128), lds, s, a);
+        return;
+    }
     if (H == 256) { allow_big_lds(k_decoder_bwd<256>); hipLaunchKernelGGL(k_decoder_bwd<256>, grid, dim3(512), lds, s, a); }
     else if (H == 128) { allow_big_lds(k_decoder_bwd<128>); hipLaunchKernelGGL(k_decoder_bwd<128>, grid, dim3(256), lds, s, a); }
     else hipLaunchKernelGGL(k_decoder_bwd<64>, grid, dim3(128), lds, s, a);
@@ -416,8 +431,8 @@ static void reduce_slices(const float* partial, int nslices, int Kd, int N, floa
         hipLaunchKernelGGL(k_reduce_slices, dim3((n + 255) / 256), dim3(256), 0, s, partial, nslices, Kd, N, out, ldo, accumulate);
 }
 
-// Skinny weight gradients (one side <= 4 wide: the 2-d output head, the scalar score head, the 2-d velocity input):
-//   out[k, j] = sum_m W[m, k] * Nn[m, j],  W wide (KW = 4*VW columns, VW a power of two <= 256), Nn narrow (NN <= 4).
+// Skinny weight gradients (one side <= 5 wide: the 2-d output head, the scalar score head, the 2-d velocity input, the 5-wide Gaussian head):
+//   out[k, j] = sum_m W[m, k] * Nn[m, j],  W wide (KW = 4*VW columns, VW a power of two <= 256), Nn narrow (NN <= 5).
 // HBM-bound streaming of W: thread owns one float4 column of W and every (256/VW)-th row.  transpose_out writes out[j, k].
 template <int NN>
 __global__ __launch_bounds__(256) void k_tn_skinny(const float* __restrict__ Wd, int ldw, int KW, const float* __restrict__ Nn, int ldn,
@@ -466,13 +481,14 @@ __global__ void k_reduce_slices_t(const float* __restrict__ partial, int nslices
 static bool skinny(const float* Wd, int ldw, int KW, const float* Nn, int ldn, int NN, long M, float* partial, float* out, int ldo,
                    int accumulate, bool transpose_out, hipStream_t s) {
     const int VW = KW >> 2;
-    if ((KW & 3) || VW < 1 || VW > 256 || (VW & (VW - 1)) || (ldw & 3) || (reinterpret_cast<uintptr_t>(Wd) & 15) || NN < 1 || NN > 4) return false;
+    if ((KW & 3) || VW < 1 || VW > 256 || (VW & (VW - 1)) || (ldw & 3) || (reinterpret_cast<uintptr_t>(Wd) & 15) || NN < 1 || NN > 5) return false;
     long sl = M / 512; if (sl < 1) sl = 1; if (sl > 512) sl = 512;
     const int ns = (int)sl;
     switch (NN) {
         case 1: hipLaunchKernelGGL(k_tn_skinny<1>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
         case 2: hipLaunchKernelGGL(k_tn_skinny<2>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
         case 3: hipLaunchKernelGGL(k_tn_skinny<3>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
+        case 5: hipLaunchKernelGGL(k_tn_skinny<5>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
         default: hipLaunchKernelGGL(k_tn_skinny<4>, dim3(ns), dim3(256), 0, s, Wd, ldw, KW, Nn, ldn, M, ns, partial); break;
     }
     if (transpose_out) hipLaunchKernelGGL(k_reduce_slices_t, dim3((KW * NN + 255) / 256), dim3(256), 0, s, partial, ns, KW, NN, out, ldo, accumulate);
@@ -481,7 +497,7 @@ static bool skinny(const float* Wd, int ldw, int KW, const float* Nn, int ldn, i
 }
 
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s) {
-    if (a.N <= 4 && a.Kd >= 16 && skinny(a.A, a.lda, a.Kd, a.G, a.ldg, a.N, a.M, a.partial, out, ldo, accumulate, false, s)) return;
+    if (a.N <= 5 && a.Kd >= 16 && skinny(a.A, a.lda, a.Kd, a.G, a.ldg, a.N, a.M, a.partial, out, ldo, accumulate, false, s)) return;
     if (a.Kd <= 4 && a.N >= 16 && skinny(a.G, a.ldg, a.N, a.A, a.lda, a.Kd, a.M, a.partial, out, ldo, accumulate, true, s)) return;
     const bool big = a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
                      !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);

@@ -111,6 +111,80 @@ __global__ void k_refold(const float* __restrict__ w, float* __restrict__ shift,
     if (c < C) shift[c] = w[off_beta + c] + scale[c] * (w[off_b + c] - w[off_mean + c]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The reference's loss for its 5-wide output layer (model/model.py:315-366: output_w / output_b on the state, get_coef :552-565,
+// -log(max(N(next position), 1e-20)) :494-550, the id == 0 masking :351-366, the mean :374-376), teacher-forced over the observed
+// frames of the X encoder.  One wave per (agent, observed frame t): o = h_t W5 + b5; target = the position in frame t + 1 (the next
+// observed frame, or the first future frame for t = T_obs - 1); the pair counts when the object exists in both frames.  Log form
+// (z / (2 (1 - rho^2)) + log(2 pi sx sy sqrt(1 - rho^2)), clamped at -log 1e-20 with no gradient beyond, like the reference's max):
+// the pdf itself underflows fp32 long before its logarithm matters.  Writes nll[a,t] (0 when not counted), cnt[a,t] and the raw
+// gradient dO[a,t,5] = d nll / d o (Graves 2013, eq. 25-28); k_head_sum / k_head_scale turn them into the mean and its gradient.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_nll(const float* __restrict__ sv_h, const float* __restrict__ sv_x, const float* __restrict__ past,
+                                                  const float* __restrict__ fut, const float* __restrict__ W5, const float* __restrict__ b5,
+                                                  int A, int T, int T_pred, int H, int mno, float sx_, float sy_, float* __restrict__ nll,
+                                                  float* __restrict__ cnt, float* __restrict__ dO) {
+    const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv >= A * T) return;
+    const int a = wv / T, t = wv - a * T, scene = a / mno, slot = a - scene * mno;
+    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* hrow = sv_h + (size_t)wv * H;
+    for (int c = lane; c < H; c += 64) {
+        const float hv = hrow[c];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = fmaf(hv, W5[c * 5 + j], o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) o[j] += __shfl_xor(o[j], m);
+        o[j] += b5[j];
+    }
+    if (lane) return;
+    const float* now = past + (((size_t)scene * T + t) * mno + slot) * 3;
+    const float* nxt = (t + 1 < T) ? now + (size_t)mno * 3 : fut + ((size_t)scene * T_pred * mno + slot) * 3;
+    float x, y;
+    if (t + 1 < T) { x = sv_x[((size_t)a * T + t + 1) * 2]; y = sv_x[((size_t)a * T + t + 1) * 2 + 1]; }
+    else { x = __fmul_rn(nxt[1], sx_); y = __fmul_rn(nxt[2], sy_); }
+    const bool counted = now[0] != 0.f && nxt[0] != 0.f;
+    float L = 0.f, g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (counted) {
+        const float sx = __expf(o[2]), sy = __expf(o[3]), rho = tanhf(o[4]);
+        const float nx = (x - o[0]) / sx, ny = (y - o[1]) / sy;
+        const float neg = fmaxf(1.0f - rho * rho, 1e-12f);
+        const float z = nx * nx + ny * ny - 2.0f * rho * nx * ny;
+        L = z / (2.0f * neg) + 1.8378770664093453f + o[2] + o[3] + 0.5f * __logf(neg);      // log(2 pi) + log sx + log sy + log sqrt(1 - rho^2)
+        if (L < 46.051701859880914f) {                   // -log(1e-20): beyond it the reference's max() pins the value and kills the gradient
+            g[0] = -(nx - rho * ny) / (neg * sx);
+            g[1] = -(ny - rho * nx) / (neg * sy);
+            g[2] = 1.0f - nx * (nx - rho * ny) / neg;
+            g[3] = 1.0f - ny * (ny - rho * nx) / neg;
+            g[4] = -nx * ny + rho * z / neg - rho;
+        } else L = 46.051701859880914f;
+    }
+    nll[wv] = L; cnt[wv] = counted ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dO[(size_t)wv * 5 + j] = g[j];
+}
+// loss_out[5] = weight * mean nll over the counted pairs, loss_out[7] = their number (one block, fixed order: deterministic)
+__global__ void k_head_sum(const float* __restrict__ nll, const float* __restrict__ cnt, int n, float weight, float* __restrict__ loss_out) {
+    __shared__ float rs[256], rc[256];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { s += nll[i]; c += cnt[i]; }
+    rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tc = 0.f;
+        for (int i = 0; i < 256; ++i) { ts += rs[i]; tc += rc[i]; }
+        loss_out[5] = weight * ts / fmaxf(tc, 1.f);
+        loss_out[7] = tc;
+    }
+}
+__global__ void k_head_scale(float* __restrict__ dO, int n5, float weight, const float* __restrict__ loss_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n5) dO[i] *= weight / fmaxf(loss_out[7], 1.f);
+}
+
 // per-agent loss terms of DESIGN.md section 8: out[a] = {recon, kld, ce, reg} (0 for absent agents)
 __global__ void k_train_loss(const float* __restrict__ Y0, const float* __restrict__ Yr, const float* __restrict__ fut,
                              const float* __restrict__ score, const float* __restrict__ params, const uint8_t* __restrict__ valid,
@@ -367,8 +441,11 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     }
     if (d.bn_mode == 2 && (ensure(h, "bn_part2", (size_t)512 * 256 * f) || ensure(h, "bn_stat2", (size_t)2 * 128 * f) || ensure(h, "bn_statb", (size_t)2 * 128 * f)))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the batch-norm backward scratch");
+    if (ensure(h, "head_nll", (size_t)h->A * d.T_obs * f) || ensure(h, "head_cnt", (size_t)h->A * d.T_obs * f) || ensure(h, "head_dO", (size_t)h->A * d.T_obs * 5 * f))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the Gaussian-head loss buffers");
     if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f) || ensure(h, "bias_part", ((R + 31) / 32 + 1) * 4 * H * f))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss / bias-gradient buffers");
+    HIPCHK(hipMemset(h->ws["loss_out"].p, 0, 8 * f));
     if (int rc = build_repack_maps(h)) return rc;
     h->adam_t = 0;
     h->training = true;
@@ -591,11 +668,26 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
     }
     // ---- encoders: BPTT from the final state (Hx / Hy), zero initial state ----
+    const bool head_loss = h->head_loss_w > 0.f;
+    if (head_loss) {
+        // Gaussian-head term (desire_set_head_loss): nll and d nll / d o per (agent, observed frame), the mean, its gradient; then the
+        // head's own weight gradients.  The gradient w.r.t. the encoder states enters the X-encoder BPTT below, step by step.
+        const int n = A * d.T_obs;
+        Timer t(h, s, "bwd_head_nll");
+        hipLaunchKernelGGL(k_head_nll, dim3((n * 64 + 255) / 256), dim3(256), 0, s, W(h, "ex_sv_h"), W(h, "ex_sv_x"), dev_past, dev_fut,
+                           D(h, "gauss_head/w"), D(h, "gauss_head/b"), A, d.T_obs, d.T_pred, H, d.mno, d.sx, d.sy, W(h, "head_nll"), W(h, "head_cnt"),
+                           W(h, "head_dO"));
+        hipLaunchKernelGGL(k_head_sum, dim3(1), dim3(256), 0, s, W(h, "head_nll"), W(h, "head_cnt"), n, h->head_loss_w, W(h, "loss_out"));
+        hipLaunchKernelGGL(k_head_scale, dim3((n * 5 + 255) / 256), dim3(256), 0, s, W(h, "head_dO"), n * 5, h->head_loss_w, W(h, "loss_out"));
+        tn(h, W(h, "ex_sv_h"), H, W(h, "head_dO"), 5, (long)n, H, 5, G(h, "gauss_head/w"), 5, 0, s);
+        colsum(h, W(h, "head_dO"), 5, (long)n, 5, G(h, "gauss_head/b"), 0, s);
+    }
     auto enc_bwd = [&](const std::string& p, const char* sv, int Te, int col0) {
         DecBwdArgs e{};
         e.sv_r = W(h, (std::string(sv) + "_sv_r").c_str()); e.sv_u = W(h, (std::string(sv) + "_sv_u").c_str());
         e.sv_c = W(h, (std::string(sv) + "_sv_c").c_str()); e.sv_h = W(h, (std::string(sv) + "_sv_h").c_str());
         e.w_head = D(h, "head/w");
+        if (head_loss && p == "enc_x") { e.dY0 = W(h, "head_dO"); e.w_head = D(h, "gauss_head/w"); e.nw = 5; }     // d L_head / d h_t = dO_t W5^T, every step
         e.WcT_h = D4(h, (p + "/WcT_h").c_str()); e.WgT_h = D4(h, (p + "/WgT_h").c_str());
         e.R = A; e.K = 1; e.mno = d.mno; e.T = Te; e.H = H;
         e.dag = W(h, "enc_dag"); e.dac = W(h, "enc_dac"); e.rh = W(h, "enc_rh"); e.hprev = W(h, "enc_hprev");
@@ -623,6 +715,19 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     return DESIRE_OK;
 }
 
+extern "C" int desire_set_head_loss(desire_handle* h, float weight) {
+    if (!h) return fail(DESIRE_ERR_ARG, "null argument");
+    if (!(weight >= 0.f)) return fail(DESIRE_ERR_ARG, "weight must be >= 0");
+    if (h->d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only");
+    h->head_loss_w = weight;
+    if (h->training && weight == 0.f) {              // the reported term goes back to zero with the switch
+        const float z[3] = {0.f, 0.f, 0.f};
+        HIPCHK(hipMemcpy(W(h, "loss_out") + 5, z, sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(W(h, "loss_out") + 7, z, sizeof(float), hipMemcpyHostToDevice));
+    }
+    return DESIRE_OK;
+}
+
 extern "C" int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream) {
     if (!h || !name || !host_out) return fail(DESIRE_ERR_ARG, "null argument");
     if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
@@ -646,12 +751,8 @@ extern "C" int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n) 
     return DESIRE_OK;
 }
 
-extern "C" int desire_train_loss(desire_handle* h, const float* dev_fut, float* host_out5, void* stream) {
-    if (int rc = desire_ready(h)) return rc;
-    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
-    if (!dev_fut || !host_out5) return fail(DESIRE_ERR_ARG, "null argument");
+static int train_loss_enqueue(desire_handle* h, const float* dev_fut, hipStream_t s) {
     const desire_dims& d = h->d;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const uint8_t* valid = static_cast<const uint8_t*>(h->ws["lmask"].p);
     launch_loss_mask(static_cast<const uint8_t*>(h->ws["valid"].p), dev_fut, static_cast<uint8_t*>(h->ws["lmask"].p), W(h, "nfut"),
                      d.n_scenes, d.mno, d.T_pred, s);
@@ -659,8 +760,30 @@ extern "C" int desire_train_loss(desire_handle* h, const float* dev_fut, float* 
                        W(h, "params"), valid, W(h, "nfut"), W(h, "loss_pa"), d.n_scenes, d.mno, d.K, d.T_pred, d.L, d.sx, d.sy);
     hipLaunchKernelGGL(k_sum_loss, dim3(1), dim3(256), 0, s, W(h, "loss_pa"), valid, h->A, W(h, "loss_out"));
     HIPCHK(hipGetLastError());
+    return DESIRE_OK;
+}
+
+extern "C" int desire_train_loss(desire_handle* h, const float* dev_fut, float* host_out5, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (!dev_fut || !host_out5) return fail(DESIRE_ERR_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = train_loss_enqueue(h, dev_fut, s)) return rc;
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipMemcpy(host_out5, W(h, "loss_out"), 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return DESIRE_OK;
+}
+
+// The same terms (the 8 floats of loss_out: the five above, then the Gaussian-head terms of desire_set_head_loss) into a DEVICE buffer, stream-ordered, no synchronisation: the training loop reads them one step late (a pinned
+// copy + event), so the host never waits for the step it has just enqueued and the loader thread keeps running ahead.
+extern "C" int desire_train_loss_async(desire_handle* h, const float* dev_fut, float* dev_out8, void* stream) {
+    if (int rc = desire_ready(h)) return rc;
+    if (!h->training) return fail(DESIRE_ERR_STATE, "not in training mode");
+    if (!dev_fut || !dev_out8) return fail(DESIRE_ERR_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = train_loss_enqueue(h, dev_fut, s)) return rc;
+    launch_copy_f32(dev_out8, W(h, "loss_out"), 8, s);
+    HIPCHK(hipGetLastError());
     return DESIRE_OK;
 }
 

@@ -67,6 +67,24 @@ def _operand_mode(v) -> int:
     return int(v) if int(v) in (0, 1, 2, 3) else 1
 
 
+class PendingLoss(object):
+    """Loss terms of a training step that has been ENQUEUED, not waited for.  get() blocks on the step's event (at most once) and returns
+    the same dict train_step(sync=True) returns."""
+
+    def __init__(self, host8, event, dev8):
+        self._host8, self._event, self._dev8, self._terms = host8, event, dev8, None
+
+    def done(self) -> bool:
+        return self._terms is not None or self._event.query()
+
+    def get(self) -> Dict[str, float]:
+        if self._terms is None:
+            self._event.synchronize()
+            self._terms = _lib.Handle.loss_terms(self._host8.tolist())
+            self._dev8 = None
+        return self._terms
+
+
 class DESIREModel(object):
     """Drop-in for model/model.py:29 DESIREModel(args)."""
 
@@ -159,18 +177,30 @@ class DESIREModel(object):
         """x_batch: loader windows [T_obs, MNO, 3] (DataLoader.next_batch x); y_batch: future windows
         [T_pred, MNO, 3] or None (prior sampling).  Returns (Yhat [n, K, mno, T_pred, 2] normalised,
         score [n, K, mno]) as torch tensors on the GPU."""
-        torch = self.torch
-        n = len(x_batch)
         posterior = y_batch is not None
-        h = self._handle(n, posterior)
-        d = h.dims
+        d = self._handle(len(x_batch), posterior).dims
         past = self._pad_windows(x_batch, d.mno)
         fut = self._pad_windows(y_batch, d.mno) if posterior else None
-        if past.shape[1] != d.T_obs or (posterior and fut.shape[1] != d.T_pred):
-            raise ValueError("window lengths must be (seq_length, pred_length)")
+        out = self.forward_device(past, fut, eps, seed)
+        self.input_data, self.target_data = x_batch, y_batch
+        return out
+
+    def forward_device(self, past, fut=None, eps=None, seed: int = 0):
+        """forward() on windows that are already in HBM: past [n, T_obs, mno, 3], fut [n, T_pred, mno, 3] or None -- float32 device
+        tensors in the loader's layout with the slot axis padded to the model's mno (what desire_amd.prefetch's feeders and
+        forward_from_video produce).  Nothing here touches the host except the launches themselves."""
+        torch = self.torch
+        n = int(past.shape[0])
+        posterior = fut is not None
+        h = self._handle(n, posterior)
+        d = h.dims
+        if tuple(past.shape[1:]) != (d.T_obs, d.mno, 3) or (posterior and tuple(fut.shape[1:]) != (d.T_pred, d.mno, 3)):
+            raise ValueError("window lengths must be (seq_length, pred_length) and the slot axis max_num_obj padded to %d" % d.mno)
         if eps is None:
             g = torch.Generator(device=self.device).manual_seed(seed)
             eps_t = torch.randn((d.R, d.L), generator=g, device=self.device, dtype=torch.float32)
+        elif torch.is_tensor(eps):
+            eps_t = eps.reshape(d.R, d.L)
         else:
             eps_t = torch.as_tensor(np.ascontiguousarray(eps, np.float32), device=self.device).reshape(d.R, d.L)
         if self._grids is None:
@@ -184,7 +214,6 @@ class DESIREModel(object):
         h.forward(past.data_ptr(), fut.data_ptr() if posterior else 0, eps_t.data_ptr(), Y.data_ptr(),
                   score.data_ptr(), stream)
         self._keep = (past, fut, eps_t)            # keep inputs alive until the stream has consumed them
-        self.input_data, self.target_data = x_batch, y_batch
         self.final_output, self.final_states = Y, score
         if posterior:                              # train-path scalars (model/model.py:339-376): cost = mean(recon + kld)
             self._kld = torch.empty(d.A, device=self.device)
@@ -230,38 +259,67 @@ class DESIREModel(object):
 
     # ---- training (train.py:140-181 runs only `cost`; the Adam op of model/model.py:386-403 is never applied) ----
     def train_step(self, x_batch: Sequence[np.ndarray], y_batch: Sequence[np.ndarray], eps: Optional[np.ndarray] = None,
-                   seed: int = 0, group=None) -> Dict[str, float]:
+                   seed: int = 0, group=None, sync: bool = True):
         """One optimiser step on a batch of loader windows: forward (posterior path), backward, gradient mean over
         the data-parallel ranks (RCCL all-reduce of ONE flat buffer when torch.distributed is initialised),
         clip_by_global_norm(args.grad_clip), Adam(args.learning_rate).  Returns the loss terms of DESIGN.md section 8
-        evaluated BEFORE the update (what `sess.run([cost, train_op])` would have returned)."""
+        evaluated BEFORE the update (what `sess.run([cost, train_op])` would have returned); with sync=False a PendingLoss
+        whose .get() returns them later (see train_step_device)."""
+        d = self._handle(len(x_batch), True).dims
+        out = self.train_step_device(self._pad_windows(x_batch, d.mno), self._pad_windows(y_batch, d.mno), eps, seed, group, sync)
+        self.input_data, self.target_data = x_batch, y_batch
+        return out
+
+    def train_step_device(self, past, fut, eps=None, seed: int = 0, group=None, sync: bool = True):
+        """train_step on windows already in HBM (forward_device's layout).  sync=False: nothing waits for the GPU -- the loss terms
+        go to a device buffer (desire_train_loss_async), a pinned copy is enqueued, and the returned PendingLoss reads them when asked,
+        normally one step later (desire_amd/train.py): the host runs ahead of the device and the loader thread is never starved by a
+        read-back in the middle of every step."""
         from .dist import allreduce_mean_
-        h = self._handle(len(x_batch), True)
+        torch = self.torch
+        h = self._handle(int(past.shape[0]), True)
         prev = getattr(self, "_trained", None)
         if prev is not None and prev is not h:
             raise ValueError("train_step was called with %d windows after training with %d: the Adam moments live in the handle "
                              "of one batch size (keep the batch size fixed, as DataLoader.next_batch does)"
-                             % (len(x_batch), prev.dims.n_scenes))
+                             % (int(past.shape[0]), prev.dims.n_scenes))
         if not getattr(h, "_training_on", False):
             h.set_training(True)
             h._training_on = True
             pending = self.__dict__.pop("_opt_pending", None)
             if pending is not None:                   # resumed run: Adam moments and step counter of the checkpoint
                 h.set_opt_state(pending)
-        self.forward(x_batch, y_batch, eps, seed)
+            self._configure_head_loss(h)
+        self.forward_device(past, fut, eps, seed)
         past, fut, eps_t = self._keep
-        stream = self.torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream().cuda_stream
         h.backward(past.data_ptr(), fut.data_ptr(), eps_t.data_ptr(), stream)
         allreduce_mean_(h.grad_tensor(), group)
         clip = float(getattr(self.args, "grad_clip", 0.0) or 0.0)
         if clip > 0:
             h.clip_grads(clip, stream=stream)
-        terms = h.train_loss(fut.data_ptr(), stream)
+        if sync:
+            terms = h.train_loss(fut.data_ptr(), stream)
+        else:
+            dev8 = torch.empty(8, device=self.device, dtype=torch.float32)
+            h.train_loss_async(fut.data_ptr(), dev8.data_ptr(), stream)
+            host8 = torch.empty(8, dtype=torch.float32).pin_memory()
+            host8.copy_(dev8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            terms = PendingLoss(host8, ev, dev8)
         h.adam_step(self.learning_rate, stream=stream)
         self._trained = h
         self._version = getattr(self, "_version", 0) + 1
         h._wver = self._version
         return terms
+
+    def _configure_head_loss(self, h) -> None:
+        """Hook of the Gaussian-head term (args.head_loss_weight; see train_step / DESIGN.md section 12)."""
+        lam = float(getattr(self.args, "head_loss_weight", 0.0) or 0.0)
+        if lam > 0.0 and hasattr(h, "set_head_loss"):
+            h.set_head_loss(lam)
+            self._head_given = True                   # the head is trained from now on: sample(mode="rollout") reads learned weights
 
     def sync_weights(self) -> Dict[str, np.ndarray]:
         """Pull the trained weights back from the device; other handles (batch sizes / prior path) are rebuilt lazily."""
@@ -390,11 +448,10 @@ class DESIREModel(object):
         frames in pixel units, ids carried over from the last observed frame (model/model.py:680-688).  `sess` is ignored;
         `dimensions` = (width, height) of the frame in pixels (default: args.img_width / img_height).
 
-        mode None (default) = "ioc", the path train_step trains (decoder + ranking / refinement) -- or "rollout" when `normals` are
-        passed.  The rollout reads every
-        prediction from the 5-wide head "gauss_head/w|b", which no loss term of DESIGN.md section 8 touches (train_step leaves it at
-        the values it was given): pass mode="rollout" for the reference's loop; it warns when the head still holds the values
-        init_weights drew for it (i.e. it was neither supplied by the caller nor restored from a checkpoint).
+        mode None (default): "rollout" -- the reference's own sample() semantics -- whenever the 5-wide head "gauss_head/w|b" it reads
+        is TRAINED (args.head_loss_weight > 0 adds the reference's Gaussian NLL, model/model.py:494-550, to train_step's loss) or was
+        supplied (weights= / a checkpoint that holds it); otherwise "ioc", the path the default loss trains, with a one-time warning
+        that says so.  The mode is never inferred from `normals`: they belong to the rollout, and passing them to "ioc" is an error.
 
         mode "rollout" is the reference's loop (:623-688) on the device in one launch: warm-up over the observed
         frames, then per step the 5-wide Gaussian head "gauss_head/w|b" -> a draw (`normals` [num, MNO, 2] ~ N(0,1), or
@@ -410,13 +467,23 @@ class DESIREModel(object):
         out[: traj.shape[0]] = traj
         m = traj.shape[1]
         out[traj.shape[0]:, :, 0] = traj[-1, :, 0]
-        if mode is None:                                  # (normals only mean something to the rollout: passing them selects it)
-            mode = "rollout" if normals is not None else "ioc"
+        if mode is None:
+            mode = "rollout" if getattr(self, "_head_given", False) else "ioc"
+            if mode == "ioc" and not getattr(self, "_warned_default_mode", False):
+                import warnings
+                self._warned_default_mode = True
+                warnings.warn("sample(): the reference's rollout reads the Gaussian output layer gauss_head/w|b, which this model has neither "
+                              "been given nor trained (train with args.head_loss_weight > 0); the default therefore returns the top-scored "
+                              "IOC-refined sample (mode='ioc').  Pass mode='rollout' to run the reference's loop on the untrained head.",
+                              stacklevel=2)
+        if normals is not None and mode != "rollout":
+            raise ValueError("`normals` are the rollout's Gaussian draws: pass mode='rollout' with them (the mode is not inferred)")
         if mode == "rollout":
             if not getattr(self, "_head_given", False):
                 import warnings
-                warnings.warn("sample(mode='rollout') reads gauss_head/w|b, which train_step does not train; this model's head holds "
-                              "its random initial values (pass weights= with a trained head, or use the default mode='ioc')", stacklevel=2)
+                warnings.warn("sample(mode='rollout') reads gauss_head/w|b, which train_step trains only with args.head_loss_weight > 0; this "
+                              "model's head holds its random initial values (train it, pass weights= with a trained head, or use mode='ioc')",
+                              stacklevel=2)
             h = sub._handle(1, False)
             d = h.dims
             past = sub._pad_windows([traj], d.mno)

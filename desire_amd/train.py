@@ -62,6 +62,13 @@ def build_parser() -> argparse.ArgumentParser:
                    help="matrix operands of the training step: fp32 (default) or x3 = split-bf16 (hi + lo, three bf16 MFMAs per product) in the IOC "
                         "forward / BPTT, the weight-gradient reductions and the large data-gradient convolutions; gradients stay within the fp32 "
                         "path's tolerance of float64 autograd")
+    p.add_argument("--head_loss_weight", type=float, default=0.0,
+                   help="weight of the reference's own loss for the 5-wide Gaussian output layer (model/model.py:494-550: -log N(next position | "
+                        "mux, muy, sx, sy, rho), teacher-forced over the observed frames) added to the training loss; > 0 trains gauss_head/w|b "
+                        "(and the X encoder through it), i.e. what sample(mode='rollout') reads")
+    p.add_argument("--prefetch", type=int, default=2,
+                   help="batches the loader thread keeps in flight (pinned staging -> copy stream -> device; desire_amd/prefetch.py); 0 = the "
+                        "reference's serial loop: next_batch, copy, step, read the loss, every step (train.py:131-183)")
     p.add_argument("--report_ade", action="store_true",
                    help="after every epoch: ADE / FDE (mean-of-K and best-of-K, normalised units) of PRIOR samples on the epoch's last batch")
     return p
@@ -114,6 +121,8 @@ def train(args, data_loader=None, model=None, log: Callable[[str], None] = print
     if model is None:
         model = DESIREModel(args, seed=args.seed)
     losses: List[float] = []
+    if int(getattr(args, "prefetch", 0) or 0) > 0:
+        return _train_overlapped(args, data_loader, model, log, rank, world, t_obs, t_pred, losses)
     steps = 0
     for epoch in range(args.num_epochs):
         model.learning_rate = lr_at_epoch(args, epoch)
@@ -137,18 +146,79 @@ def train(args, data_loader=None, model=None, log: Callable[[str], None] = print
             if args.max_steps and steps >= args.max_steps:
                 return losses
         if getattr(args, "report_ade", False) and data_loader.num_batches > 0:
-            # the evaluation harness the reference never had: prior sampling (no future given) on this rank's share of the
-            # epoch's last batch, masked like the loss (present at the last observed frame and in every future frame)
-            Y, _ = model.forward(past, None, seed=args.seed)
-            ev = model.evaluate(Y, fut)
-            pw, fw = np.stack([np.asarray(p) for p in past]), np.stack([np.asarray(f) for f in fut])
-            there = np.zeros(ev.shape[0], bool)
-            m = pw.shape[2]
-            there.reshape(len(past), -1)[:, :m] = (pw[:, -1, :, 0] != 0) & (fw[:, :, :, 0] != 0).all(1)
-            if there.any():
-                e = ev[there].mean(0)
-                log("epoch {} rank {}: ADE/FDE mean-of-K = {:.5f} / {:.5f}, best-of-K = {:.5f} / {:.5f} ({} agents)".format(
-                    epoch, rank, e[0], e[1], e[2], e[3], int(there.sum())))
+            _report_ade(args, model, past, fut, epoch, rank, log)
+    return losses
+
+
+def _report_ade(args, model, past, fut, epoch, rank, log) -> None:
+    """The evaluation harness the reference never had: prior sampling (no future given) on this rank's share of the
+    epoch's last batch, masked like the loss (present at the last observed frame and in every future frame).  past / fut: lists of
+    loader windows or device tensors [n, T, mno, 3]."""
+    import torch
+    if torch.is_tensor(past):
+        Y, _ = model.forward_device(past, None, seed=args.seed)
+        pw, fw = past.cpu().numpy(), fut.cpu().numpy()
+    else:
+        Y, _ = model.forward(past, None, seed=args.seed)
+        pw, fw = np.stack([np.asarray(p) for p in past]), np.stack([np.asarray(f) for f in fut])
+    ev = model.evaluate(Y, fut)
+    there = np.zeros(ev.shape[0], bool)
+    m = pw.shape[2]
+    there.reshape(pw.shape[0], -1)[:, :m] = (pw[:, -1, :, 0] != 0) & (fw[:, :, :, 0] != 0).all(1)
+    if there.any():
+        e = ev[there].mean(0)
+        log("epoch {} rank {}: ADE/FDE mean-of-K = {:.5f} / {:.5f}, best-of-K = {:.5f} / {:.5f} ({} agents)".format(
+            epoch, rank, e[0], e[1], e[2], e[3], int(there.sum())))
+
+
+def _train_overlapped(args, data_loader, model, log, rank, world, t_obs, t_pred, losses) -> List[float]:
+    """The same schedule with the loader off the critical path (desire_amd/prefetch.py): a background thread runs next_batch into pinned
+    staging and uploads on a copy stream `--prefetch` batches ahead; the step's loss is read back ONE STEP LATE, so the host enqueues
+    step i + 1 while the device still runs step i.  Same batches, same seeds, same optimiser steps as the serial loop -- the log line of
+    step i is printed after step i + 1 has been enqueued, nothing else differs (tests/test_gpu_prefetch.py compares the two)."""
+    from .model import dims_from_args
+    from .prefetch import WindowFeeder
+    mno = dims_from_args(model.args, 1, True).mno
+    feeder = WindowFeeder(data_loader, t_obs, t_pred, device=model.device, depth=int(args.prefetch), num_epochs=args.num_epochs,
+                          shard=(rank, world), mno=mno, max_batches=int(args.max_steps or 0))
+    nb = data_loader.num_batches
+    pending = None                                        # (PendingLoss, epoch, batch, start time) of the previous step
+
+    def settle(p):
+        terms, epoch, batch, start = p[0].get(), p[1], p[2], p[3]
+        losses.append(terms["loss"])
+        if rank == 0:
+            log("{}/{} (epoch {}), train_loss = {:.3f}, time/batch = {:.3f}".format(
+                epoch * nb + batch, args.num_epochs * nb, epoch, terms["loss"], time.time() - start))
+            sys.stdout.flush()
+
+    steps = 0
+    last = None
+    try:
+        for bt in feeder:
+            start = time.time()
+            model.learning_rate = lr_at_epoch(args, bt.epoch)
+            if last is not None and bt.epoch != last[2] and getattr(args, "report_ade", False):
+                _report_ade(args, model, last[0], last[1], last[2], rank, log)
+            bt.wait()
+            pl = model.train_step_device(bt.past, bt.fut, seed=args.seed + steps * world + rank, sync=False)
+            if getattr(args, "report_ade", False):        # the epoch's last batch is evaluated after the feeder has moved on: keep a copy
+                last = (bt.past.clone(), bt.fut.clone(), bt.epoch)
+            bt.release()
+            if pending is not None:
+                settle(pending)
+            pending = (pl, bt.epoch, bt.index, start)
+            steps += 1
+            if rank == 0 and should_save(bt.epoch, bt.index, nb, args.save_every):
+                path = os.path.join(args.save_dir, "social_model-%d.npz" % (bt.epoch * nb + bt.index))
+                model.save(path)
+                log("model saved to {}".format(path))
+    finally:
+        feeder.close()
+    if pending is not None:
+        settle(pending)
+    if last is not None and getattr(args, "report_ade", False):
+        _report_ade(args, model, last[0], last[1], last[2], rank, log)
     return losses
 
 

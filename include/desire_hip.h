@@ -256,12 +256,25 @@ int desire_ioc_finish(desire_handle* h, const float* dev_h_state, const float* d
  * the handle (desire_get_weight returns them, inference keeps using the device operands the last desire_adam_step rebuilt);
  * enabling training again starts from them with the Adam moments at zero (desire_adam_state to carry moments across). */
 int desire_set_training(desire_handle* h, int enable);
+/* The reference's OWN loss for its 5-wide output layer (model/model.py:315-366: output_w / output_b on the recurrent state, get_coef
+ * :552-565, -log max(N(next position | mux, muy, sx, sy, rho), 1e-20) :494-550, id == 0 masking :351-366, mean :374-376) as an extra
+ * term of the training loss: weight x mean over the counted (object, observed frame) pairs, teacher-forced over the X encoder's
+ * observed steps (target of frame t = the position in frame t + 1; frame T_obs is the first future frame).  desire_backward then
+ * also fills the gradients of "gauss_head/w|b" -- the head desire_rollout / sample() read, which no other term reaches -- and adds
+ * the term's gradient to the X encoder's, step by step.  weight = 0 (default) switches the term off. */
+int desire_set_head_loss(desire_handle* h, float weight);
 int desire_backward(desire_handle* h, const float* dev_past, const float* dev_fut, const float* dev_eps, void* stream);
 int desire_get_grad(desire_handle* h, const char* name, float* host_out, size_t n, void* stream);
 int desire_grad_buffer(desire_handle* h, float** dev_ptr, size_t* n);
 /* Loss terms of the last training-mode forward, means over present agents:
  * host_out5 = {recon, kld, cross_entropy, regression, n_present};  loss = sum of the first four. */
 int desire_train_loss(desire_handle* h, const float* dev_fut, float* host_out5, void* stream);
+/* The same values written to a DEVICE buffer dev_out8 [8] = {recon, kld, cross_entropy, regression, n_present, nll_head, grad_norm,
+ * n_head}, stream-ordered and without synchronising: a training loop that reads the loss one step late (desire_amd/train.py) never
+ * stalls the host behind the step it has just enqueued.  nll_head / n_head: the weighted Gaussian-head term of the last
+ * desire_backward and the (object, frame) pairs it averaged over (0 while that loss is off); grad_norm: the pre-clip global norm of
+ * the last desire_clip_grads. */
+int desire_train_loss_async(desire_handle* h, const float* dev_fut, float* dev_out8, void* stream);
 /* tf.clip_by_global_norm (model/model.py:390) on the flat gradient buffer, in place; host_norm_out (optional, may be
  * NULL: then no synchronisation) receives the pre-clip norm. */
 int desire_clip_grads(desire_handle* h, float max_norm, float* host_norm_out, void* stream);

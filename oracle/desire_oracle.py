@@ -496,6 +496,31 @@ def reconstr_loss(mux, muy, sx, sy, rho, x, y):
     return np.sum(-np.log(np.maximum(normal_2d_pdf(x, y, mux, muy, sx, sy, rho), 1e-20)))
 
 
+def head_nll(past, fut, w, d, dt=np.float64):
+    """The reference's loss for its 5-wide output layer (model/model.py:315-366), teacher-forced over the observed frames of this
+    spec's X encoder: for every observed frame t the state h_t -> output layer (`gauss_head/w|b` = output_w / output_b, :315-321) ->
+    get_coef (:552-565) -> -log(max(N(next position), 1e-20)) (:494-550) against the position in frame t + 1 (the loader's target =
+    the input shifted one frame, utils/data_loader.py:206-207; frame T_obs is the first future frame); an (object, frame) pair
+    counts when the object exists in the frame AND in the next one (:351-366); mean over the counted pairs (:374-376).
+    past [T_obs, A, 3], fut [T_pred, A, 3] loader layout -> (mean nll, number of counted pairs)."""
+    pn = normalise(past, d, dt)
+    nxt = np.concatenate([pn[1:], normalise(fut[:1], d, dt)], 0)                      # [T_obs, A, 2] targets
+    ids = np.concatenate([past[:, :, 0], fut[:1, :, 0]], 0)                            # [T_obs + 1, A]
+    counted = (ids[:-1] != 0) & (ids[1:] != 0)
+    Wg, bg, Wc, bc = _gru_w(w, "enc_x", dt)
+    h = np.zeros((pn.shape[1], Wc.shape[1]), dt)
+    W5, b5 = w["gauss_head/w"].astype(dt), w["gauss_head/b"].astype(dt)
+    tot = 0.0
+    for t in range(pn.shape[0]):
+        h = gru_cell(pn[t], h, Wg, bg, Wc, bc)
+        mux, muy, sx, sy, rho = get_coef(h @ W5 + b5)
+        m = counted[t]
+        if m.any():
+            tot += reconstr_loss(mux[m, 0], muy[m, 0], sx[m, 0], sy[m, 0], rho[m, 0], nxt[t, m, 0], nxt[t, m, 1])
+    n = int(counted.sum())
+    return tot / max(n, 1), n
+
+
 def get_coef(out5):
     """model/model.py:552-565: split 5, exp on the std devs, tanh on the correlation."""
     mux, muy, sx, sy, corr = np.split(out5, 5, axis=-1)

@@ -103,9 +103,33 @@ def rows_from_agents(x, d):
     return x.expand((d.n_scenes, d.K, d.mno) + tuple(x.shape[3:])).reshape((d.R,) + tuple(x.shape[3:]))
 
 
-def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor], d, fixed=None, bin_tab=None):
+def head_nll(past, fut, w: Dict[str, torch.Tensor], d):
+    """oracle.head_nll (model/model.py:315-366,494-565 on the X encoder's observed steps) as a differentiable graph, in the log form
+    the kernels use: -log N = z / (2 (1 - rho^2)) + log(2 pi sx sy sqrt(1 - rho^2)), clamped at -log(1e-20) (no gradient beyond, like
+    the reference's max(pdf, 1e-20)).  Returns (mean over counted (object, frame) pairs, their number)."""
+    pn = _t(O.normalise(past, d, np.float64))
+    nxt = torch.cat([pn[1:], _t(O.normalise(fut[:1], d, np.float64))], 0)
+    ids = np.concatenate([np.asarray(past)[:, :, 0], np.asarray(fut)[:1, :, 0]], 0)
+    counted = torch.as_tensor((ids[:-1] != 0) & (ids[1:] != 0))
+    h = torch.zeros((pn.shape[1], w["enc_x/candidate/kernel"].shape[1]), dtype=DT)
+    tot = torch.zeros((), dtype=DT)
+    for t in range(pn.shape[0]):
+        h = gru_cell(pn[t], h, *_gw(w, "enc_x"))
+        o = h @ w["gauss_head/w"] + w["gauss_head/b"]
+        sx, sy, rho = torch.exp(o[:, 2]), torch.exp(o[:, 3]), torch.tanh(o[:, 4])
+        nx, ny = (nxt[t, :, 0] - o[:, 0]) / sx, (nxt[t, :, 1] - o[:, 1]) / sy
+        neg = 1 - rho * rho
+        nll = (nx * nx + ny * ny - 2 * rho * nx * ny) / (2 * neg) + torch.log(2 * np.pi * sx * sy * torch.sqrt(neg))
+        nll = torch.clamp(nll, max=-np.log(1e-20))
+        tot = tot + (nll * counted[t].to(DT)).sum()
+    n = int(counted.sum())
+    return tot / max(n, 1), n
+
+
+def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor], d, fixed=None, bin_tab=None, head_weight=0.0):
     """past/fut in the oracle layout [T, A, 3]; returns dict with every forward tensor + the loss terms.
-    `fixed` = {"Yd": ..., "dmax": ...} pins the stop-gradient quantities (for finite-difference checks)."""
+    `fixed` = {"Yd": ..., "dmax": ...} pins the stop-gradient quantities (for finite-difference checks).  head_weight > 0 adds
+    head_weight x head_nll (the reference's own loss of its Gaussian output layer) to the loss."""
     pn = _t(O.normalise(past, d, np.float64))
     fn = _t(O.normalise(fut, d, np.float64))
     valid = torch.as_tensor(past[d.T_obs - 1, :, 0] != 0)
@@ -198,12 +222,15 @@ def forward_loss(past, fut, eps, grids, grid_of_scene, w: Dict[str, torch.Tensor
     reg = (e1 * pm).sum(dim=(1, 3)).reshape(d.A) / (d.K * nfc)
     L_ioc = ((ce + reg) * v).sum() / n_valid
     out.update(recon=recon, kld=kld, ce=ce, reg=reg, L_sgm=L_sgm, L_ioc=L_ioc, loss=L_sgm + L_ioc, Yd=Yd, dmax=dmax)
+    if head_weight:
+        L_head, n_head = head_nll(past, fut, w, d)
+        out.update(L_head=L_head, n_head=n_head, loss=out["loss"] + float(head_weight) * L_head)
     return out
 
 
-def loss_and_grads(past, fut, eps, grids, grid_of_scene, w_np: Dict[str, np.ndarray], d, bin_tab=None):
+def loss_and_grads(past, fut, eps, grids, grid_of_scene, w_np: Dict[str, np.ndarray], d, bin_tab=None, head_weight=0.0):
     w = leaf_weights(w_np)
-    out = forward_loss(past, fut, eps, grids, grid_of_scene, w, d, bin_tab=bin_tab)
+    out = forward_loss(past, fut, eps, grids, grid_of_scene, w, d, bin_tab=bin_tab, head_weight=head_weight)
     out["loss"].backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in w.items()}
     vals = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}

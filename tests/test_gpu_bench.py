@@ -50,6 +50,10 @@ def test_default_contract_fields():
     assert o["alt"]["reference_defaults"]["batch_size_10"]["value"] > 0 and o["alt"]["reference_defaults"]["windows_128"]["value"] > 0
     fw = o["alt"]["few_windows"]                              # literal configs[1]: one window per call
     assert 0 < fw["windows_1"]["ms_per_call"] <= fw["windows_8"]["ms_per_call"] < 10
+    wl = o["alt"]["with_loader"]                              # round 4: the loader in the loop (host loader / device builder feeding whole steps)
+    assert wl["host_loader"]["next_batch_into_pinned_f32_windows_per_s"] > 0 and wl["host_loader"]["next_batch_windows_per_s"] > 0
+    assert wl["device_builder"]["windows_per_s"] > 0 and wl["resident"]["value"] > 0
+    assert 0.5 < wl["fed_by_host_loader"]["fraction_of_resident"] < 1.1 and 0.5 < wl["fed_by_device_builder"]["fraction_of_resident"] < 1.1
     tr = o["alt"]["training_step"]                            # configs[4]'s per-GPU work, fp32 and split operands
     assert tr["fp32"]["value"] > 0 and tr["split_bf16x3"]["value"] > tr["fp32"]["value"] and np.isfinite(tr["split_bf16x3"]["loss"])
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class

@@ -61,7 +61,7 @@ def test_sample_layout_and_semantics_through_the_model():
     traj = past[0].astype(np.float64)                    # [8, 16, 3]
     truth = np.concatenate([past[0], fut[0]]).astype(np.float64)
     normals = np.random.default_rng(75).standard_normal((10, 16, 2)).astype(np.float32)
-    out = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=10, normals=normals)
+    out = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=10, mode="rollout", normals=normals)
     assert out.shape == (18, 16, 3)
     np.testing.assert_array_equal(out[:8], traj)
     np.testing.assert_array_equal(out[8:, :, 0], np.broadcast_to(traj[-1, :, 0], (10, 16)))       # ids carried (:680)
@@ -71,7 +71,7 @@ def test_sample_layout_and_semantics_through_the_model():
     np.testing.assert_allclose(out[8:, :, 2], ref[..., 1] * 1100.0, atol=0.05)
     assert (out[8:, :, 1] <= 1400.0 + 1e-6).all() and (out[8:, :, 2] <= 1100.0 + 1e-6).all()     # clip at 1.0 normalised (:666-669)
     # a different observation length than seq_length (temporal/w is sized by seq_length and unused here)
-    out5 = m.sample(None, traj[3:], None, (1400.0, 1100.0), truth, num=4, normals=normals[:4])
+    out5 = m.sample(None, traj[3:], None, (1400.0, 1100.0), truth, num=4, mode="rollout", normals=normals[:4])
     assert out5.shape == (9, 16, 3) and np.isfinite(out5).all()
     # the IOC mode keeps the round-1 behaviour: absent objects stay zero rows
     oi = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=10, mode="ioc")
@@ -89,11 +89,11 @@ def test_sample_follows_the_trained_weights():
     y = [f.astype(np.float64) for f in fut]
     normals = np.random.default_rng(77).standard_normal((6, 16, 2)).astype(np.float32)
     truth = np.concatenate([x[0], y[0]])
-    before = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, normals=normals)
+    before = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=normals)
     before_ioc = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=1)
     for _ in range(3):
         m.train_step(x, y, seed=0)
-    after = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, normals=normals)
+    after = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=normals)
     after_ioc = m.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=1)
     # the rollout reads the X-encoder GRU (trained through Hx); the IOC mode reads everything
     assert np.abs(after[8:] - before[8:]).max() > 1e-3
@@ -104,7 +104,7 @@ def test_sample_follows_the_trained_weights():
     with tempfile.TemporaryDirectory() as td:
         m.save(os.path.join(td, "w.npz"))
         m2 = DESIREModel.restore(args, os.path.join(td, "w.npz"))
-        again = m2.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, normals=normals)
+        again = m2.sample(None, x[0], None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=normals)
     np.testing.assert_allclose(again, after, atol=1e-3)
 
 
@@ -134,8 +134,9 @@ def test_checkpoint_keeps_the_optimiser_state():
 
 
 def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
-    """(medium) train_step never touches gauss_head/*, so the DEFAULT sample() must not read it -- mode None is the
-    IOC path unless normals are passed; an explicit rollout on a head nobody supplied warns.  (low) an archive written before
+    """with the default loss train_step never touches gauss_head/*, so the DEFAULT sample() of a model whose head was
+    neither supplied nor trained is the IOC path (one warning says so; the mode is never inferred from `normals`); an explicit rollout
+    on such a head warns.  (low) an archive written before
     gauss_head/* existed still restores (the head is filled with its initial values, the optimiser state is dropped)."""
     import os
     import tempfile
@@ -148,9 +149,15 @@ def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
     past, fut, _, _, _ = make_case(d, seed=79, n_absent=3)
     traj = past[0].astype(np.float64)
     truth = np.concatenate([past[0], fut[0]]).astype(np.float64)
-    a = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        a = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+        m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+    assert sum("mode='ioc'" in str(r.message) for r in rec) == 1          # said once
     b = m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=3)
     np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, normals=np.zeros((6, 16, 2), np.float32))
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         m.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
@@ -161,13 +168,17 @@ def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
         old = {k: v for k, v in blob.items() if not k.startswith("gauss_head/")}
         save_weights(os.path.join(td, "old.npz"), old)
         m2 = DESIREModel.restore(args, os.path.join(td, "old.npz"))
-        c = m2.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
+        c = m2.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=3)
         np.testing.assert_allclose(c, a, atol=1e-3)
         m3 = DESIREModel.restore(args, os.path.join(td, "new.npz"))          # a head that came with the weights: no warning
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
             m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
         assert not any("gauss_head" in str(r.message) for r in rec)
+        # ... and for such a model the reference-compatible rollout IS the default
+        nrm = np.random.default_rng(1).standard_normal((6, 16, 2)).astype(np.float32)
+        np.testing.assert_array_equal(m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, normals=nrm),
+                                      m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=nrm))
 
 
 def test_ref_compat_handle_with_its_own_prediction_length():

@@ -56,3 +56,27 @@ def test_adam_step_tf_formula():
     w1, m1, v1 = OT.adam_step(w, g, m, v, 1, lr=0.005)
     np.testing.assert_allclose(w1, w - 0.005 * np.sign(g) * (1 / (1 + 1e-8 / np.sqrt(1 - 0.999) / np.abs(g))), rtol=1e-6)
     assert np.allclose(m1, 0.1 * g) and np.allclose(v1, 0.001 * g * g)
+
+
+def test_head_nll_torch_graph_equals_the_reference_formula():
+    """oracle.head_nll evaluates model/model.py:494-550 literally (pdf, max(pdf, 1e-20), -log, sum) on the X encoder's observed steps;
+    desire_torch.head_nll is the same quantity in log form (what the kernels compute) -- equal where the pdf does not underflow."""
+    import torch
+    from oracle import desire_oracle as O, desire_torch as OT
+    from desire_amd.spec import init_weights
+    from tests.helpers import make_case, small_dims, to_oracle_layout
+    d = small_dims(n_scenes=2, mno=8, K=2, T_obs=5, T_pred=6, H=64, L=64)
+    w = init_weights(d, 3)
+    w["gauss_head/b"] = np.array([0.3, 0.6, -0.5, -0.7, 0.2], np.float32)
+    past, fut, _, _, _ = make_case(d, seed=4, n_absent=3)
+    p, f = to_oracle_layout(past), to_oracle_layout(fut)
+    a, n = O.head_nll(p, f, w, d)
+    b, nb = OT.head_nll(p, f, {k: torch.as_tensor(np.asarray(v), dtype=torch.float64) for k, v in w.items()}, d)
+    assert n == nb > 0 and abs(a - float(b)) < 1e-10 * max(1.0, abs(a))
+    # hand check of one pair against scipy's bivariate normal
+    from scipy.stats import multivariate_normal
+    mux, muy, sx, sy, rho = 0.2, -0.1, 0.5, 0.8, 0.3
+    cov = [[sx * sx, rho * sx * sy], [rho * sx * sy, sy * sy]]
+    want = -np.log(multivariate_normal.pdf([0.4, 0.3], [mux, muy], cov))
+    got = O.reconstr_loss(np.array([mux]), np.array([muy]), np.array([sx]), np.array([sy]), np.array([rho]), np.array([0.4]), np.array([0.3]))
+    assert abs(got - want) < 1e-12
