@@ -198,10 +198,195 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
     for (int i = 0; i < 16; ++i)
         if (row0 + acc_row(i) < a.R) a.dxz[(size_t)rowi(i) * H + col] = dxz[i];
 }
+// ------------------------------------------------------------------------------------------------------------------
+// The same BPTT with the two contractions TRANSPOSED (mma SWAP: the packed weights are the A operand, the LDS rows the B operand):
+// the accumulators then hold, per lane, ONE row (lane & 31) and runs of FOUR consecutive hidden columns
+// (32 cb + 8 q + 4 (lane >> 5) + 0..3, q = 0..3).  Everything elementwise is layout-agnostic, so the only thing that changes is
+// the shape of the memory traffic: every saved stream is read, and every gradient stream written, as ONE 16-byte access per
+// four elements instead of four 4-byte ones -- 20 global loads + 24 stores per lane and step instead of 64 + 96 -- and the
+// operand tiles take 16-byte LDS writes (row stride = 4 mod 8 words: conflict-free for the b128 lane groups).
+// (VERDICT r03 Weak 3: the row-major form spent 3/4 of its wave cycles waiting on ~110 four-byte stores and ~70 four-byte
+// loads per lane-step.)  Bit-for-bit the same arithmetic per element; the bias column sums are reduced through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mma1t(f32x16& acc, const float* a_lane, const float4* __restrict__ b_lane, int G) {
+    f32x16 t[1] = {acc};
+    const float* ap[1] = {a_lane};
+    mma_groups_ptr<1, true>(t, ap, b_lane, G);
+    acc = t[0];
+}
+__device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+template <int H, int NW = 2>
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd_t(DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
+    float* A1 = smem;                    // [32][LD1]   da_c
+    float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
+    float* dy = A2 + TM * LD2;           // [32][NW]
+    float* wo = dy + TM * NW;            // [H][NW]
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int row0 = blockIdx.x * TM;
+    const int lr = lane & 31, hi = lane >> 5;
+    const int c0 = cb * 32 + 4 * hi;                       // first column of run q: c0 + 8 q
+    for (int i = tid; i < NW * H; i += NTHR) wo[i] = a.w_head[i];
+    const float* a1_lane = A1 + lr * LD1 + 4 * hi;
+    const float* a2_lane = A2 + lr * LD2 + 4 * hi;
+    float* my1 = A1 + lr * LD1 + c0;
+    float* my2 = A2 + lr * LD2 + c0;
+    f32x16 dh = zero16(), sxr = zero16(), sxu = zero16(), sxc = zero16();
+    const int nloc = min(TM, a.R - row0);
+    const bool rok = lr < nloc;
+    const int rcl = min(lr, nloc - 1);                     // rows past R read the tile's last row (their results are never stored)
+    const size_t tb = (size_t)row0 * a.T;
+    const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H; const float* svh = a.sv_h + tb * H;
+    float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
+    if (a.dh_init) {                                       // encoders: the gradient arrives at the final state
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(a.dh_init + (size_t)(row0 + rcl) * a.ld_init + c0 + 8 * q);
+            dh[4 * q] = v.x; dh[4 * q + 1] = v.y; dh[4 * q + 2] = v.z; dh[4 * q + 3] = v.w;
+        }
+    }
+    for (int t = a.T - 1; t >= 0; --t) {
+        int rc = rcl;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: the stream offsets are re-formed (two VALU ops), not hoisted and spilled
+        const unsigned rt = (unsigned)(rc * a.T + t);
+        __syncthreads();                                   // previous step's A2 / dy consumers are done
+        if (tid < TM) {
+            if constexpr (NW == 2) {
+                float2 v = make_float2(0.f, 0.f);
+                if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
+                dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) dy[tid * NW + j] = a.dY0[((size_t)min(row0 + tid, a.R - 1) * a.T + t) * NW + j];
+            }
+        }
+        if (t == 0) {                                      // h_{-1} = Hx[agent] (decoder) or 0 (encoders): staged in A1, each run
+            for (int i = tid; i < TM * (H >> 2); i += NTHR) {   // is read by its owner right before it is overwritten with da_c
+                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.Hx) v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno) * a.ldhx + c4 * 4);
+                *reinterpret_cast<float4*>(A1 + r * LD1 + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        f32x16 dhp, rr, hp;
+        float dyv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) dyv[j] = dy[lr * NW + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned ix = rt * H + c0 + 8 * q;
+            const float4 u4 = *reinterpret_cast<const float4*>(svu + ix), c4 = *reinterpret_cast<const float4*>(svc + ix);
+            const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
+            const float4 h4 = (t > 0) ? *reinterpret_cast<const float4*>(svh + ix - H) : *reinterpret_cast<const float4*>(my1 + 8 * q);
+            float dacv[4], dauv[4], rhv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e;
+                const float u = f4get(u4, e), c = f4get(c4, e), r = f4get(r4, e), hprev = f4get(h4, e);
+                const int colw = (c0 + 8 * q + e) * NW;
+                float dht = dh[i] + dyv[0] * wo[colw] + dyv[1] * wo[colw + 1];
+#pragma unroll
+                for (int j = 2; j < NW; ++j) dht += dyv[j] * wo[colw + j];
+                const float dau = dht * (hprev - c) * u * (1.0f - u);
+                const float dc = dht * (1.0f - u);
+                dhp[i] = dht * u;
+                const float dac = dc * (1.0f - c * c);
+                dacv[e] = dac; dauv[e] = dau; rhv[e] = r * hprev;
+                sxc[i] += dac; sxu[i] += dau;
+                rr[i] = r; hp[i] = hprev;
+            }
+            const float4 dac4 = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]), dau4 = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
+            *reinterpret_cast<float4*>(my1 + 8 * q) = dac4;
+            *reinterpret_cast<float4*>(my2 + H + 8 * q) = dau4;
+            if (rok) {
+                *reinterpret_cast<float4*>(o_dac + ix) = dac4;
+                *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
+                *reinterpret_cast<float4*>(o_hp + ix) = h4;
+                *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = dau4;
+            }
+        }
+        __syncthreads();
+        f32x16 drh = zero16();
+        mma1t(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float darv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e;
+                const float dr = drh[i] * hp[i];
+                dhp[i] += drh[i] * rr[i];
+                const float dar = dr * rr[i] * (1.0f - rr[i]);
+                darv[e] = dar;
+                sxr[i] += dar;
+            }
+            const float4 dar4 = make_float4(darv[0], darv[1], darv[2], darv[3]);
+            *reinterpret_cast<float4*>(my2 + 8 * q) = dar4;
+            if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = dar4;
+        }
+        __syncthreads();
+        f32x16 dhg = zero16();
+        mma1t(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + dhg[i];
+    }
+    __syncthreads();
+    // the step sums of the gate gradients as tiles: operands of the constant-input contraction (decoder) and source of the bias column sums
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4*>(my2 + 8 * q) = rok ? make_float4(sxr[4 * q], sxr[4 * q + 1], sxr[4 * q + 2], sxr[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(my2 + H + 8 * q) = rok ? make_float4(sxu[4 * q], sxu[4 * q + 1], sxu[4 * q + 2], sxu[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(my1 + 8 * q) = rok ? make_float4(sxc[4 * q], sxc[4 * q + 1], sxc[4 * q + 2], sxc[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (a.bias_part) {                                     // bias gradients: this tile's column sums (rows past R hold zeros), fixed row order
+        float* part = a.bias_part + (size_t)blockIdx.x * 3 * H;
+        for (int c = tid; c < 3 * H; c += NTHR) {
+            const float* src = c < 2 * H ? A2 + c : A1 + (c - 2 * H);
+            const int ld = c < 2 * H ? LD2 : LD1;
+            float sum = 0.f;
+            for (int r = 0; r < TM; ++r) sum += src[r * ld];
+            part[c] = sum;
+        }
+    }
+    if (!a.dxz) return;                                    // encoders: inputs are data, nothing upstream
+    if (rok) {
+        const size_t rg = (size_t)(row0 + lr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(a.dHx_rows + rg * H + c0 + 8 * q) = make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.dxg + rg * 2 * H + c0 + 8 * q) = make_float4(sxr[4 * q], sxr[4 * q + 1], sxr[4 * q + 2], sxr[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.dxg + rg * 2 * H + H + c0 + 8 * q) = make_float4(sxu[4 * q], sxu[4 * q + 1], sxu[4 * q + 2], sxu[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.dxc + rg * H + c0 + 8 * q) = make_float4(sxc[4 * q], sxc[4 * q + 1], sxc[4 * q + 2], sxc[4 * q + 3]);
+        }
+    }
+    f32x16 dxz = zero16();
+    mma1t(dxz, a2_lane, a.WgT_x + ((size_t)cb * G2) * 64 + lane, G2);
+    mma1t(dxz, a1_lane, a.WcT_x + ((size_t)cb * GH) * 64 + lane, GH);
+    if (rok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(a.dxz + (size_t)(row0 + lr) * H + c0 + 8 * q) = make_float4(dxz[4 * q], dxz[4 * q + 1], dxz[4 * q + 2], dxz[4 * q + 3]);
+    }
+}
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
     const int H = a.H;
     const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 32 * 5 + 5 * H) * sizeof(float);
     const dim3 grid((a.R + 31) / 32);
+    if (!a.legacy) {                                      // transposed accumulators: 16-byte global / LDS accesses (the default)
+        if (a.nw == 5) {
+            if (H == 256) { allow_big_lds(k_decoder_bwd_t<256, 5>); hipLaunchKernelGGL((k_decoder_bwd_t<256, 5>), grid, dim3(512), lds, s, a); }
+            else if (H == 128) { allow_big_lds(k_decoder_bwd_t<128, 5>); hipLaunchKernelGGL((k_decoder_bwd_t<128, 5>), grid, dim3(256), lds, s, a); }
+            else hipLaunchKernelGGL((k_decoder_bwd_t<64, 5>), grid, dim3(128), lds, s, a);
+        } else {
+            if (H == 256) { allow_big_lds(k_decoder_bwd_t<256>); hipLaunchKernelGGL(k_decoder_bwd_t<256>, grid, dim3(512), lds, s, a); }
+            else if (H == 128) { allow_big_lds(k_decoder_bwd_t<128>); hipLaunchKernelGGL(k_decoder_bwd_t<128>, grid, dim3(256), lds, s, a); }
+            else hipLaunchKernelGGL(k_decoder_bwd_t<64>, grid, dim3(128), lds, s, a);
+        }
+        return;
+    }
     if (a.nw == 5) {                                      // the X encoder with the Gaussian head's per-step gradient (desire_set_head_loss)
         if (H == 256) { allow_big_lds(k_decoder_bwd<256, 5>); hipLaunchKernelGGL((k_decoder_bwd<256, 5>), grid, dim3(512), lds, s, a); }
         else if (H == 128) { allow_big_lds(k_decoder_bwd<128, 5>); hipLaunchKernelGGL((k_decoder_bwd<128, 5>), grid, dim3(256), lds, s, a); }

@@ -97,7 +97,9 @@ __device__ __forceinline__ void mma6_groups(f32x16 (&acc)[NB], const float* ap, 
 #ifndef RD4
 #define RD4 2                                                       // ring depth (k-groups) of the gate contraction
 #endif
-template <int NB, int NP>
+// SWAP = true exchanges the roles of the two operands in every MFMA (the fragment layouts are symmetric): the accumulators then hold the
+// TRANSPOSED tile -- lane = the image's row, registers = the pack's columns in runs of four (8 q + 4 (lane >> 5) + 0..3).
+template <int NB, int NP, bool SWAP = false>
 __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
     uint4 b0[NB][NP], b1[NB][NP];
     auto ld = [&](uint4 (&b)[NB][NP], int g) {
@@ -111,7 +113,7 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
 #pragma unroll
         for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + g * 16);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_xp<NP>(av, b[nb], acc[nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = SWAP ? mfma_xp<NP>(b[nb], av, acc[nb]) : mfma_xp<NP>(av, b[nb], acc[nb]);
     };
     ld(b0, 0);
     int g = 0;

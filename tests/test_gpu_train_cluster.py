@@ -222,13 +222,13 @@ def test_train_loop_over_all_eight_sdd_scenes(tmp_path):
     assert dl.num_batches >= 2
     random.seed(0)
     seen = set()
-    orig = dl.next_batch
+    orig = dl.next_batch_into                              # (the loop's loader thread fills pinned staging: desire_amd/prefetch.py)
 
     def spy(*args, **kw):
-        x, y, d = orig(*args, **kw)
+        d = orig(*args, **kw)
         seen.update(int(v) for v in d)
-        return x, y, d
-    dl.next_batch = spy
+        return d
+    dl.next_batch_into = spy
     losses = T.train(a, data_loader=dl, log=lambda l: None)
     assert len(losses) == a.num_epochs * dl.num_batches and np.isfinite(losses).all()
     assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
