@@ -649,7 +649,7 @@ def main():
                     help="row-compacted social pooling (dims.ioc_form = DESIRE_IOC_COMPACT, fp32, groups of up to 32 agents): the pooling MFMAs run "
                          "on the rows that have a neighbour in the bin only; NOT the headline (fewer flops are executed than the "
                          "dense formula credits)")
-    ap.add_argument("--flags", type=int, default=0, help="dims.flags (DESIRE_FLAG_* of include/desire_hip.h), for A/B runs: 2 = the row-major BPTT kernels")
+    ap.add_argument("--flags", type=int, default=0, help="dims.flags (DESIRE_FLAG_* of include/desire_hip.h), for A/B runs")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
                          "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")

@@ -181,7 +181,7 @@ int check_options(const desire_dims& d) {
     }
     if (d.ioc_split < 0 || d.ioc_split > 4) return fail(DESIRE_ERR_ARG, "ioc_split must be 0 (auto), 1 (never split: batch-size invariant results) or 2..4 (cap)");
     if (d.train_fp32_mask < 0 || d.train_fp32_mask > 15) return fail(DESIRE_ERR_ARG, "train_fp32_mask is a mask of bits 1, 2, 4, 8");
-    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_BPTT_LEGACY)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if (d.flags & ~DESIRE_FLAG_NO_FUSE34) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
     return 0;
 }
 

@@ -212,7 +212,6 @@ struct DecBwdArgs {
     float* dag; float* dac; float* rh; float* hprev;       // [R,T,2H], [R,T,H] x3: gate gradients, r*h_{t-1}, h_{t-1}
     float* dxg; float* dxc; float* dxz; float* dHx_rows;   // [R,2H], [R,H], [R,H], [R,H]  (dxz == null: encoder use)
     const float* dh_init; int ld_init;                     // optional gradient w.r.t. the FINAL state (encoders)
-    int legacy;                                            // 1: the row-major-accumulator kernel (A/B: dims.flags & DESIRE_FLAG_BPTT_LEGACY)
     float* bias_part;                                      // optional [tiles][3H]: per-tile column sums of da_r | da_u | da_c over rows and steps
 };                                                         // (the bias gradients, without another pass over the gate-gradient streams)
 // out[n] (+)= sum_p part[p * ld + off + n], n < N: fixed order over p (deterministic)

@@ -66,147 +66,12 @@ void launch_loss_grad_y(const float* Y, const float* fut, const uint8_t* valid, 
 //   dr = d(rh) h_{t-1};     dh_{t-1} += d(rh) r
 //   da_r = dr r(1-r); da_u = du u(1-u);  dh_{t-1} += [da_r|da_u] Wg_h^T     (MFMA, K = 2H)
 // da_* and r*h_{t-1} go to HBM for the weight-gradient reductions; the constant-input sums dxg, dxc give dx_z.
-// ------------------------------------------------------------------------------------------------------------------
-template <int H, int NW = 2>
-__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
-    float* A1 = smem;                    // [32][LD1]   da_c
-    float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
-    float* dy = A2 + TM * LD2;           // [32][NW]
-    float* wo = dy + TM * NW;            // [H][NW]
-    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
-    const int row0 = blockIdx.x * TM;
-    const int col = cb * 32 + (lane & 31);
-    for (int i = tid; i < NW * H; i += NTHR) wo[i] = a.w_head[i];
-    const float* a1_lane = A1 + (lane & 31) * LD1 + 4 * (lane >> 5);
-    const float* a2_lane = A2 + (lane & 31) * LD2 + 4 * (lane >> 5);
-    float* my1 = A1 + (4 * (lane >> 5)) * LD1 + col;
-    float* my2 = A2 + (4 * (lane >> 5)) * LD2 + col;
-    f32x16 dh = zero16(), sxr = zero16(), sxu = zero16(), sxc = zero16();
-    auto rowi = [&](int i) { return min(row0 + acc_row(i), a.R - 1); };
-    // saved activations / gradient streams: (uniform tile base) + (32-bit offset inside the tile); rows past R clamp to the last one
-    const int nloc = min(TM, a.R - row0);
-    int nlv = nloc;                                        // re-defined opaquely per step: the per-element row clamps below are then
-                                                           // recomputed (two VALU ops) instead of hoisted out of the time loop and spilled
-    auto tl = [&](int i, int t) { return (unsigned)(min(acc_row(i), nlv - 1) * a.T + t); };
-    const size_t tb = (size_t)row0 * a.T;
-    const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H; const float* svh = a.sv_h + tb * H;
-    float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
-    if (a.dh_init) {                                       // encoders: the gradient arrives at the final state
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = a.dh_init[(size_t)rowi(i) * a.ld_init + col];
-    }
-
-    for (int t = a.T - 1; t >= 0; --t) {
-        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
-        __syncthreads();                                   // previous step's A2 / dy consumers are done
-        if (tid < TM) {
-            if constexpr (NW == 2) {
-                float2 v = make_float2(0.f, 0.f);
-                if (a.dY0) v = *reinterpret_cast<const float2*>(a.dY0 + ((size_t)min(row0 + tid, a.R - 1) * a.T + t) * 2);
-                dy[tid * 2] = v.x; dy[tid * 2 + 1] = v.y;
-            } else {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) dy[tid * NW + j] = a.dY0[((size_t)min(row0 + tid, a.R - 1) * a.T + t) * NW + j];
-            }
-        }
-        if (t == 0) {                                      // h_{-1} = Hx[agent] (decoder) or 0 (encoders): staged in A1, each element
-            for (int i = tid; i < TM * (H >> 2); i += NTHR) {   // is read by its owner right before it is overwritten with da_c
-                const int r = i / (H >> 2), c4 = i - r * (H >> 2);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.Hx) v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno) * a.ldhx + c4 * 4);
-                *reinterpret_cast<float4*>(A1 + r * LD1 + c4 * 4) = v;
-            }
-        }
-        __syncthreads();
-        f32x16 dhp, rr, hp;
-        float wv[NW];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) wv[j] = wo[col * NW + j];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            const unsigned ix = tl(i, t) * H + col;
-            const float u = svu[ix], c = svc[ix], r = svr[ix];
-            const float hprev = (t > 0) ? svh[ix - H] : my1[((i & 3) + 8 * (i >> 2)) * LD1];
-            float dht = dh[i] + dy[rl * NW] * wv[0] + dy[rl * NW + 1] * wv[1];
-#pragma unroll
-            for (int j = 2; j < NW; ++j) dht += dy[rl * NW + j] * wv[j];
-            const float dau = dht * (hprev - c) * u * (1.0f - u);
-            const float dc = dht * (1.0f - u);
-            dhp[i] = dht * u;
-            const float dac = dc * (1.0f - c * c);
-            my1[((i & 3) + 8 * (i >> 2)) * LD1] = dac;
-            my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = dau;
-            o_dac[ix] = dac;
-            o_rh[ix] = r * hprev;
-            o_hp[ix] = hprev;
-            o_dag[tl(i, t) * 2 * H + H + col] = dau;
-            sxc[i] += dac; sxu[i] += dau;
-            rr[i] = r; hp[i] = hprev;
-        }
-        __syncthreads();
-        f32x16 drh = zero16();
-        mma1b(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float dr = drh[i] * hp[i];
-            dhp[i] += drh[i] * rr[i];
-            const float dar = dr * rr[i] * (1.0f - rr[i]);
-            my2[((i & 3) + 8 * (i >> 2)) * LD2] = dar;
-            o_dag[tl(i, t) * 2 * H + col] = dar;
-            sxr[i] += dar;
-        }
-        __syncthreads();
-        f32x16 dhg = zero16();
-        mma1b(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + dhg[i];
-    }
-    __syncthreads();
-    if (a.bias_part) {                                     // bias gradients: this tile's column sums of the gate gradients (rows < R only)
-        float vr = 0.f, vu = 0.f, vc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (row0 + acc_row(i) < a.R) { vr += sxr[i]; vu += sxu[i]; vc += sxc[i]; }
-        vr += __shfl_xor(vr, 32); vu += __shfl_xor(vu, 32); vc += __shfl_xor(vc, 32);
-        if (lane < 32) {
-            float* part = a.bias_part + (size_t)blockIdx.x * 3 * H;
-            part[col] = vr; part[H + col] = vu; part[2 * H + col] = vc;
-        }
-    }
-    // dh is now d L / d h_{-1} = the decoder's share of dHx (per row); constant-input sums -> dx_z
-    if (!a.dxz) return;                                    // encoders: inputs are data, nothing upstream
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (row0 + acc_row(i) < a.R) {
-            a.dHx_rows[(size_t)rowi(i) * H + col] = dh[i];
-            a.dxg[(size_t)rowi(i) * 2 * H + col] = sxr[i];
-            a.dxg[(size_t)rowi(i) * 2 * H + H + col] = sxu[i];
-            a.dxc[(size_t)rowi(i) * H + col] = sxc[i];
-        }
-        my2[((i & 3) + 8 * (i >> 2)) * LD2] = sxr[i];
-        my2[((i & 3) + 8 * (i >> 2)) * LD2 + H] = sxu[i];
-        my1[((i & 3) + 8 * (i >> 2)) * LD1] = sxc[i];
-    }
-    __syncthreads();
-    f32x16 dxz = zero16();
-    mma1b(dxz, a2_lane, a.WgT_x + ((size_t)cb * G2) * 64 + lane, G2);
-    mma1b(dxz, a1_lane, a.WcT_x + ((size_t)cb * GH) * 64 + lane, GH);
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (row0 + acc_row(i) < a.R) a.dxz[(size_t)rowi(i) * H + col] = dxz[i];
-}
-// ------------------------------------------------------------------------------------------------------------------
-// The same BPTT with the two contractions TRANSPOSED (mma SWAP: the packed weights are the A operand, the LDS rows the B operand):
-// the accumulators then hold, per lane, ONE row (lane & 31) and runs of FOUR consecutive hidden columns
-// (32 cb + 8 q + 4 (lane >> 5) + 0..3, q = 0..3).  Everything elementwise is layout-agnostic, so the only thing that changes is
-// the shape of the memory traffic: every saved stream is read, and every gradient stream written, as ONE 16-byte access per
-// four elements instead of four 4-byte ones -- 20 global loads + 24 stores per lane and step instead of 64 + 96 -- and the
-// operand tiles take 16-byte LDS writes (row stride = 4 mod 8 words: conflict-free for the b128 lane groups).
-// (VERDICT r03 Weak 3: the row-major form spent 3/4 of its wave cycles waiting on ~110 four-byte stores and ~70 four-byte
-// loads per lane-step.)  Bit-for-bit the same arithmetic per element; the bias column sums are reduced through LDS.
+// Both contractions run TRANSPOSED (mma SWAP: the packed weights are the A operand, the LDS rows the B operand): the accumulators
+// hold, per lane, ONE row (lane & 31) and runs of FOUR consecutive hidden columns (32 cb + 8 q + 4 (lane >> 5) + 0..3, q = 0..3).
+// Everything elementwise is layout-agnostic, so this only shapes the memory traffic: every saved stream is read, and every gradient
+// stream written, as one 16-byte access per four elements (20 global loads + 24 stores per lane and step; the row-major form of
+// rounds 1-3 issued 64 + 96 four-byte ones and spilled 63 dwords of stream offsets), and the operand tiles take 16-byte LDS writes
+// (row stride = 4 mod 8 words: conflict-free for the b128 lane groups).  The bias column sums are reduced through LDS at the end.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mma1t(f32x16& acc, const float* a_lane, const float4* __restrict__ b_lane, int G) {
     f32x16 t[1] = {acc};
@@ -216,18 +81,18 @@ __device__ __forceinline__ void mma1t(f32x16& acc, const float* a_lane, const fl
 }
 __device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 template <int H, int NW = 2>
-__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd_t(DecBwdArgs a) {
+__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, NT = H / 32, NTHR = NT * 64, LD1 = H + 4, LD2 = 2 * H + 4, GH = H / 8, G2 = 2 * H / 8;
     float* A1 = smem;                    // [32][LD1]   da_c
     float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
     float* dy = A2 + TM * LD2;           // [32][NW]
-    float* wo = dy + TM * NW;            // [H][NW]
+    float* wo = dy + TM * NW;            // [NW][H] (transposed: a lane reads the head weights of its four columns as one float4)
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
     const int lr = lane & 31, hi = lane >> 5;
     const int c0 = cb * 32 + 4 * hi;                       // first column of run q: c0 + 8 q
-    for (int i = tid; i < NW * H; i += NTHR) wo[i] = a.w_head[i];
+    for (int i = tid; i < NW * H; i += NTHR) wo[(i % NW) * H + i / NW] = a.w_head[i];
     const float* a1_lane = A1 + lr * LD1 + 4 * hi;
     const float* a2_lane = A2 + lr * LD2 + 4 * hi;
     float* my1 = A1 + lr * LD1 + c0;
@@ -281,14 +146,16 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd_t(DecBwdArgs a
             const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
             const float4 h4 = (t > 0) ? *reinterpret_cast<const float4*>(svh + ix - H) : *reinterpret_cast<const float4*>(my1 + 8 * q);
             float dacv[4], dauv[4], rhv[4];
+            float4 wj[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wj[j] = *reinterpret_cast<const float4*>(wo + j * H + c0 + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * q + e;
                 const float u = f4get(u4, e), c = f4get(c4, e), r = f4get(r4, e), hprev = f4get(h4, e);
-                const int colw = (c0 + 8 * q + e) * NW;
-                float dht = dh[i] + dyv[0] * wo[colw] + dyv[1] * wo[colw + 1];
+                float dht = dh[i] + dyv[0] * f4get(wj[0], e) + dyv[1] * f4get(wj[1], e);
 #pragma unroll
-                for (int j = 2; j < NW; ++j) dht += dyv[j] * wo[colw + j];
+                for (int j = 2; j < NW; ++j) dht += dyv[j] * f4get(wj[j], e);
                 const float dau = dht * (hprev - c) * u * (1.0f - u);
                 const float dc = dht * (1.0f - u);
                 dhp[i] = dht * u;
@@ -375,18 +242,6 @@ void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
     const int H = a.H;
     const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 32 * 5 + 5 * H) * sizeof(float);
     const dim3 grid((a.R + 31) / 32);
-    if (!a.legacy) {                                      // transposed accumulators: 16-byte global / LDS accesses (the default)
-        if (a.nw == 5) {
-            if (H == 256) { allow_big_lds(k_decoder_bwd_t<256, 5>); hipLaunchKernelGGL((k_decoder_bwd_t<256, 5>), grid, dim3(512), lds, s, a); }
-            else if (H == 128) { allow_big_lds(k_decoder_bwd_t<128, 5>); hipLaunchKernelGGL((k_decoder_bwd_t<128, 5>), grid, dim3(256), lds, s, a); }
-            else hipLaunchKernelGGL((k_decoder_bwd_t<64, 5>), grid, dim3(128), lds, s, a);
-        } else {
-            if (H == 256) { allow_big_lds(k_decoder_bwd_t<256>); hipLaunchKernelGGL(k_decoder_bwd_t<256>, grid, dim3(512), lds, s, a); }
-            else if (H == 128) { allow_big_lds(k_decoder_bwd_t<128>); hipLaunchKernelGGL(k_decoder_bwd_t<128>, grid, dim3(256), lds, s, a); }
-            else hipLaunchKernelGGL(k_decoder_bwd_t<64>, grid, dim3(128), lds, s, a);
-        }
-        return;
-    }
     if (a.nw == 5) {                                      // the X encoder with the Gaussian head's per-step gradient (desire_set_head_loss)
         if (H == 256) { allow_big_lds(k_decoder_bwd<256, 5>); hipLaunchKernelGGL((k_decoder_bwd<256, 5>), grid, dim3(512), lds, s, a); }
         else if (H == 128) { allow_big_lds(k_decoder_bwd<128, 5>); hipLaunchKernelGGL((k_decoder_bwd<128, 5>), grid, dim3(256), lds, s, a); }
@@ -1111,6 +966,10 @@ __device__ __forceinline__ int ffsm(unsigned m) { return __ffs((int)m); }
 __device__ __forceinline__ int ffsm(unsigned long long m) { return __ffsll((long long)m); }
 // TM = 32: whole groups of up to 32 agents per tile, 4 waves at H = 128, two workgroups per CU.  TM = 64: groups of 64 agents
 // (one per tile), wave (mt, cb) owns rows [32mt, 32mt+32) x columns [32cb, 32cb+32), one workgroup per CU (144 KB of LDS).
+// The 32 x 32 contractions run TRANSPOSED (mma SWAP, as in k_decoder_bwd): a lane holds ONE tile row and runs of four consecutive
+// hidden columns -- 16-byte stream and LDS accesses and a quarter of the stream offsets (the row-major kernel of rounds 1-3 spilled 94
+// dwords at H = 128 and took 7.4 ms longer per 81 920-row step); bias column sums by a butterfly over the rows (colsum16).  The packed
+// 16 x 16 dpool contraction (CPB) writes its own LDS rows and is unaffected.
 template <int H, int EV, int C, int TM>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 4) ? IOC_BWD_OCC : ((H / 32) * (TM / 32) <= 8 ? 2 : 1)) void k_ioc_bwd(IocBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1141,19 +1000,35 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
     const int row0 = blockIdx.x * TM;
-    const int col = cb * 32 + (lane & 31);
+    const int lr = lane & 31, hi = lane >> 5;
+    const int rl = mt * 32 + lr;                           // this lane's tile row; its column runs start at c0 + 8 q
+    const int c0 = cb * 32 + 4 * hi;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
     const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
     const float* a1_lane = A1 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
     const float* a2_lane = A2 + (mt * 32 + (lane & 31)) * LD2 + 4 * (lane >> 5);
     const float* a3_lane = A3 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
-    const int rofs = mt * 32 + 4 * (lane >> 5);   // + (i&3) + 8*(i>>2) = local row of accumulator element i
-    auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
     // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
     const int nloc = min(TM, a.R - row0);
-    int nlv = nloc;                                        // re-defined opaquely per step (see k_decoder_bwd)
-    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nlv - 1) * a.T + t); };   // (local row, t) index
+    const bool rok = rl < nloc;                            // rows past R read the tile's last row; nothing of theirs is stored or summed
+    const int rcl = min(rl, nloc - 1);
+    auto colsum16 = [&](const float (&x)[16]) {            // butterfly reduce-scatter over the 16 lanes sharing bits 0..3 (see k_ioc_bwd_x3)
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = x[i];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int n = 8 >> st, m = 1 << st;
+            const bool up = (lane >> st) & 1;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const float send = up ? v[j] : v[j + n], keep = up ? v[j + n] : v[j];
+                v[j] = keep + __shfl_xor(send, m);
+            }
+        }
+        return v[0];
+    };
     const size_t tb = (size_t)row0 * a.T;
     const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
     const float* svx = a.sv_x + tb * E;
@@ -1173,10 +1048,12 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     __syncthreads();
     float cs_r = 0.f, cs_u = 0.f, cs_c = 0.f, cs_p = 0.f;   // this lane's column sums of da_r, da_u, da_c, dpre_r over its rows and all steps
     f32x16 dh = zero16();
-    mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+    mma1t(dh, DR + rl * LDR + 4 * hi, a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
 
     for (int t = a.T - 1; t >= 0; --t) {
-        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
+        int rc = rcl;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
+        const unsigned rt = (unsigned)(rc * a.T + t);
         __syncthreads();
         // ---- P0: positions, cleared masks, h_{t-1} tile ----
         if (tid < TM) {
@@ -1223,64 +1100,100 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             a.pool_flags[(size_t)my_row * a.T + t] = fl;
         }
         f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
+        {
+            float sc_c[16], sc_u[16];
+            const float dscv = dsc[rl];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = rofs + (i & 3) + 8 * (i >> 2);
-            const unsigned ix = tl(i, t) * H + col;
-            const float u = svu[ix], c = svc[ix], r = svr[ix];
-            const float hprev = A1[rl * LD1 + col];
-            const float dht = dh[i] + dsc[rl] * wsc[col];
-            const float dau = dht * (hprev - c) * u * (1.0f - u);
-            const float dc = dht * (1.0f - u);
-            dhp[i] = dht * u;
-            const float dac = dc * (1.0f - c * c);
-            A1[rl * LD1 + col] = dac;
-            A2[rl * LD2 + H + col] = dau;             // (the dpool tiles that share A2 were last read before the step's barrier)
-            if (row0 + rl < a.R) {
-                o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
-                o_dag[tl(i, t) * 2 * H + H + col] = dau;
-                cs_c += dac; cs_u += dau;
+            for (int q = 0; q < 4; ++q) {
+                const unsigned ix = rt * H + c0 + 8 * q;
+                const float4 u4 = *reinterpret_cast<const float4*>(svu + ix), cc4 = *reinterpret_cast<const float4*>(svc + ix);
+                const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
+                const float4 h4 = *reinterpret_cast<const float4*>(A1 + rl * LD1 + c0 + 8 * q);
+                const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0 + 8 * q);
+                float dacv[4], dauv[4], rhv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    const float u = f4get(u4, e), c = f4get(cc4, e), r = f4get(r4, e), hprev = f4get(h4, e);
+                    const float dht = dh[i] + dscv * f4get(w4, e);
+                    const float dau = dht * (hprev - c) * u * (1.0f - u);
+                    const float dc = dht * (1.0f - u);
+                    dhp[i] = dht * u;
+                    const float dac = dc * (1.0f - c * c);
+                    dacv[e] = dac; dauv[e] = dau; rhv[e] = r * hprev;
+                    sc_c[i] = rok ? dac : 0.f; sc_u[i] = rok ? dau : 0.f;
+                    rr[i] = r; hp[i] = hprev;
+                }
+                const float4 dac4 = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]), dau4 = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
+                *reinterpret_cast<float4*>(A1 + rl * LD1 + c0 + 8 * q) = dac4;
+                *reinterpret_cast<float4*>(A2 + rl * LD2 + H + c0 + 8 * q) = dau4;             // (the dpool tiles that share A2 were last read before the step's barrier)
+                if (rok) {
+                    *reinterpret_cast<float4*>(o_dac + ix) = dac4;
+                    *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
+                    *reinterpret_cast<float4*>(o_hp + ix) = h4;
+                    *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = dau4;
+                }
             }
-            rr[i] = r; hp[i] = hprev;
+            cs_c += colsum16(sc_c); cs_u += colsum16(sc_u);
         }
         __syncthreads();
         f32x16 drh = zero16(), der = zero16(), dev = zero16();
-        mma1b(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
-        mma1b(der, a1_lane, a.WcT_er + ((size_t)cb * GH) * 64 + lane, GH);
-        if (cb == 0) mma1b(dev, a1_lane, a.WcT_ev + lane, GH);
+        mma1t(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
+        mma1t(der, a1_lane, a.WcT_er + ((size_t)cb * GH) * 64 + lane, GH);
+        if (cb == 0) mma1t(dev, a1_lane, a.WcT_ev + lane, GH);
+        {
+            float sc_r[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = rofs + (i & 3) + 8 * (i >> 2);
-            const float dr = drh[i] * hp[i];
-            dhp[i] += drh[i] * rr[i];
-            const float dar = dr * rr[i] * (1.0f - rr[i]);
-            A2[rl * LD2 + col] = dar;
-            if (row0 + rl < a.R) { o_dag[tl(i, t) * 2 * H + col] = dar; cs_r += dar; }
+            for (int q = 0; q < 4; ++q) {
+                float darv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    const float dr = drh[i] * hp[i];
+                    dhp[i] += drh[i] * rr[i];
+                    const float dar = dr * rr[i] * (1.0f - rr[i]);
+                    darv[e] = dar;
+                    sc_r[i] = rok ? dar : 0.f;
+                }
+                const float4 dar4 = make_float4(darv[0], darv[1], darv[2], darv[3]);
+                *reinterpret_cast<float4*>(A2 + rl * LD2 + c0 + 8 * q) = dar4;
+                if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = dar4;
+            }
+            cs_r += colsum16(sc_r);
         }
         __syncthreads();
         // da_c is consumed: its tile now takes h_{t-1} for the pooled rebuild (visible after the next barrier)
         load_hprev();
         {
             f32x16 dhg = zero16();
-            mma1b(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
-            mma1b(der, a2_lane, a.WgT_er + ((size_t)cb * G2) * 64 + lane, G2);
-            if (cb == 0) mma1b(dev, a2_lane, a.WgT_ev + lane, G2);
+            mma1t(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
+            mma1t(der, a2_lane, a.WgT_er + ((size_t)cb * G2) * 64 + lane, G2);
+            if (cb == 0) mma1t(dev, a2_lane, a.WgT_ev + lane, G2);
+            float sc_p[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = rofs + (i & 3) + 8 * (i >> 2);
-                dhp[i] += dhg[i];
-                const unsigned ixx = tl(i, t) * E;
-                const float er = svx[ixx + EV + C + col];
-                const float dpr = er > 0.f ? der[i] : 0.f;
-                A3[rl * LD1 + col] = dpr;
-                if (row0 + rl < a.R) {
-                    o_dpr[tl(i, t) * H + col] = dpr; cs_p += dpr;
-                    if (cb == 0 && (lane & 31) < EV) {
-                        const float ev = svx[ixx + (lane & 31)];
-                        o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0 + 8 * q);
+                float dprv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    dhp[i] += dhg[i];
+                    const float dpr = f4get(er4, e) > 0.f ? der[i] : 0.f;
+                    dprv[e] = dpr;
+                    sc_p[i] = rok ? dpr : 0.f;
+                }
+                const float4 dpr4 = make_float4(dprv[0], dprv[1], dprv[2], dprv[3]);
+                *reinterpret_cast<float4*>(A3 + rl * LD1 + c0 + 8 * q) = dpr4;
+                if (rok) {
+                    *reinterpret_cast<float4*>(o_dpr + (size_t)rt * H + c0 + 8 * q) = dpr4;
+                    if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
+                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
+                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
+                            make_float4(ev4.x > 0.f ? dev[4 * q] : 0.f, ev4.y > 0.f ? dev[4 * q + 1] : 0.f, ev4.z > 0.f ? dev[4 * q + 2] : 0.f, ev4.w > 0.f ? dev[4 * q + 3] : 0.f);
                     }
                 }
             }
+            cs_p += colsum16(sc_p);
         }
         __syncthreads();
         // ---- social pooling backward ----
@@ -1351,9 +1264,10 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 }
             } else {
                 f32x16 dpl = zero16();
-                mma1b(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+                mma1t(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[i];
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dp + rl * LD1 + c0 + 8 * q) = make_float4(dpl[4 * q], dpl[4 * q + 1], dpl[4 * q + 2], dpl[4 * q + 3]);
             }
             __syncthreads();
             mask_t m2 = obs[r8 * B + b];
@@ -1374,18 +1288,30 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(NB + r8 * LD1 + q8 * 4 + c * 4 * TPR) = nb[c];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
-    }
-    if (a.bias_part) {                                     // one part per 32-row block: [da_r | da_u | da_c | dpre_r] column sums
-        cs_r += __shfl_xor(cs_r, 32); cs_u += __shfl_xor(cs_u, 32); cs_c += __shfl_xor(cs_c, 32); cs_p += __shfl_xor(cs_p, 32);
-        if (lane < 32) {
-            float* part = a.bias_part + ((size_t)blockIdx.x * (TM / 32) + mt) * 4 * H;
-            part[col] = cs_r; part[H + col] = cs_u; part[2 * H + col] = cs_c; part[3 * H + col] = cs_p;
+        for (int q = 0; q < 4; ++q) {
+            const float4 n4 = *reinterpret_cast<const float4*>(NB + rl * LD1 + c0 + 8 * q);
+            dh[4 * q] = dhp[4 * q] + n4.x; dh[4 * q + 1] = dhp[4 * q + 1] + n4.y; dh[4 * q + 2] = dhp[4 * q + 2] + n4.z; dh[4 * q + 3] = dhp[4 * q + 3] + n4.w;
         }
     }
+    if (a.bias_part) {                                     // one part per 32-row block: [da_r | da_u | da_c | dpre_r] column sums
+        // after the butterfly a lane holds the sum over ITS 16-lane row group of one accumulator element; the other row group is lane ^ 16
+        cs_r += __shfl_xor(cs_r, 16); cs_u += __shfl_xor(cs_u, 16); cs_c += __shfl_xor(cs_c, 16); cs_p += __shfl_xor(cs_p, 16);
+        if (!(lane & 16)) {
+            const int el = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);     // accumulator element this lane ended up with
+            const int colb = c0 + 8 * (el >> 2) + (el & 3);
+            float* part = a.bias_part + ((size_t)blockIdx.x * (TM / 32) + mt) * 4 * H;
+            part[colb] = cs_r; part[H + colb] = cs_u; part[2 * H + colb] = cs_c; part[3 * H + colb] = cs_p;
+        }
+    }
+    if (rok) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (row0 + rofs + (i & 3) + 8 * (i >> 2) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
+        for (int q = 0; q < 4; ++q) {
+            float4* d4 = reinterpret_cast<float4*>(a.dHx_rows + (size_t)(row0 + rl) * H + c0 + 8 * q);
+            float4 v = *d4;
+            v.x += dh[4 * q]; v.y += dh[4 * q + 1]; v.z += dh[4 * q + 2]; v.w += dh[4 * q + 3];
+            *d4 = v;
+        }
+    }
 }
 static size_t ioc_bwd_lds(const IocBwdArgs& a, int TM) {
     const int H = a.H, LD1 = H + 4, B = a.G * a.G;

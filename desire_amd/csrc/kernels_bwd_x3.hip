@@ -352,6 +352,13 @@ __device__ __forceinline__ void mma1b(f32x16& acc, const float* a_lane, const fl
     acc = t[0];
 }
 namespace {
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+// ------------------------------------------------------------------------------------------------------------------
+// Every contraction runs TRANSPOSED (mmax_groups SWAP: the packs are the A operand, the images the B operand): a lane holds ONE tile
+// row and runs of four consecutive hidden columns, so the saved streams are read and the gradient streams written 16 bytes at a time,
+// the piece images take 8-byte writes, and the per-element stream offsets shrink to four per stream (the row-major kernel of round 3
+// spilled 54 dwords of them and took 4.3 ms longer per 81 920-row step).  Bias column sums by a butterfly over the rows (colsum16).
+// ------------------------------------------------------------------------------------------------------------------
 template <int H, int EV, int C>
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -380,22 +387,39 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
     const int row0 = blockIdx.x * TM;
-    const int col = cb * 32 + (lane & 31);
+    const int lr = lane & 31, hi = lane >> 5;              // this lane's tile row; its column runs start at c0 + 8 q
+    const int c0 = cb * 32 + 4 * hi;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
     const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
     const u16* a2_lane = I2 + (lane & 31) * LDB2 + 8 * (lane >> 5);
     const u16* a3_lane = I3 + (lane & 31) * LDB1 + 8 * (lane >> 5);
-    // four values of one accumulator column run (rows rofs + 8q + 0..3 of column c) -> both piece images of a row-major bf16 tile
-    auto put4 = [&](u16* img, int ld, int ilo, int c, int q, float v0, float v1, float v2, float v3) {
+    // four consecutive columns c..c+3 of this lane's row -> both piece images of a row-major bf16 tile: one 8-byte LDS write per piece
+    auto put4 = [&](u16* img, int ld, int ilo, int c, float v0, float v1, float v2, float v3) {
         unsigned pa[2], pb[2];
         splitp<2>(v0, v1, pa);
         splitp<2>(v2, v3, pb);
-        u16* x = img + (4 * (lane >> 5) + 8 * q) * ld + c;
+        u16* x = img + lr * ld + c;
+        *reinterpret_cast<uint2*>(x) = make_uint2(pa[0], pb[0]);
+        *reinterpret_cast<uint2*>(x + ilo) = make_uint2(pa[1], pb[1]);
+    };
+    // column sums over the tile's rows without 16 accumulators per tensor: a butterfly reduce-scatter over the 16 lanes that share
+    // bits 0..3 of the row (15 exchanges): lane bits (b0 b1 b2 b3) end up with the sum of accumulator element 8 b0 + 4 b1 + 2 b2 + b3
+    auto colsum16 = [&](const float (&x)[16]) {
+        float v[16];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            x[i * ilo] = (u16)pa[i]; x[i * ilo + ld] = (u16)(pa[i] >> 16); x[i * ilo + 2 * ld] = (u16)pb[i]; x[i * ilo + 3 * ld] = (u16)(pb[i] >> 16);
+        for (int i = 0; i < 16; ++i) v[i] = x[i];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int n = 8 >> st, m = 1 << st;
+            const bool up = (lane >> st) & 1;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const float send = up ? v[j] : v[j + n], keep = up ? v[j + n] : v[j];
+                v[j] = keep + __shfl_xor(send, m);
+            }
         }
+        return v[0];
     };
     // weight packs: [hi | lo], n-tiles [h columns | e_r columns | e_v tile] (api.hip: "ioc/WcT16", "ioc/WgT16"), per-bin blocks ("ioc/WsT16")
     const uint4* WcT = reinterpret_cast<const uint4*>(a.WcT_h);
@@ -407,12 +431,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     const uint4* bcv[1] = {WcT + ((size_t)(2 * NT) * G16) * 64 + lane};
     const uint4* bg2[2] = {WgT + ((size_t)cb * G32) * 64 + lane, WgT + ((size_t)(NT + cb) * G32) * 64 + lane};
     const uint4* bgv[1] = {WgT + ((size_t)(2 * NT) * G32) * 64 + lane};
-    const int rofs = mt * 32 + 4 * (lane >> 5);   // + (i&3) + 8*(i>>2) = local row of accumulator element i
-    auto rowi = [&](int i) { return min(row0 + rofs + (i & 3) + 8 * (i >> 2), a.R - 1); };   // global row of accumulator element i
     // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
     const int nloc = min(TM, a.R - row0);
-    int nlv = nloc;                                        // re-defined opaquely per step (see k_decoder_bwd)
-    auto tl = [&](int i, int t) { return (unsigned)(min(rofs + (i & 3) + 8 * (i >> 2), nlv - 1) * a.T + t); };   // (local row, t) index
+    const bool rok = lr < nloc;                            // rows past R read the tile's last row; nothing of theirs is stored or summed
+    const int rcl = min(lr, nloc - 1);
     const size_t tb = (size_t)row0 * a.T;
     const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
     const float* svx = a.sv_x + tb * E;
@@ -432,10 +454,17 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     __syncthreads();
     float cs_r = 0.f, cs_u = 0.f, cs_c = 0.f, cs_p = 0.f;   // this lane's column sums of da_r, da_u, da_c, dpre_r over its rows and all steps
     f32x16 dh = zero16();
-    mma1b(dh, DR + (mt * 32 + (lane & 31)) * LDR + 4 * (lane >> 5), a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+    {
+        f32x16 tt[1] = {dh};
+        const float* apr[1] = {DR + lr * LDR + 4 * hi};
+        mma_groups_ptr<1, true>(tt, apr, a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
+        dh = tt[0];
+    }
 
     for (int t = a.T - 1; t >= 0; --t) {
-        asm volatile("s_mov_b32 %0, %1" : "=s"(nlv) : "s"(nloc));
+        int rc = rcl;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
+        const unsigned rt = (unsigned)(rc * a.T + t);
         __syncthreads();
         // ---- P0: positions, cleared masks, h_{t-1} tile ----
         if (tid < TM) {
@@ -480,84 +509,95 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             a.pool_flags[(size_t)my_row * a.T + t] = fl;
         }
         f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
+        float sc_c[16], sc_u[16];
+        const float dscv = dsc[lr];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float dacv[4], dauv[4];
+            const unsigned ix = rt * H + c0 + 8 * q;
+            const float4 u4 = *reinterpret_cast<const float4*>(svu + ix), cc4 = *reinterpret_cast<const float4*>(svc + ix);
+            const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
+            const float4 h4 = *reinterpret_cast<const float4*>(A1 + lr * LD1 + c0 + 8 * q);
+            const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0 + 8 * q);
+            float dacv[4], dauv[4], rhv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * q + e;
-                const int rl = rofs + (i & 3) + 8 * (i >> 2);
-                const unsigned ix = tl(i, t) * H + col;
-                const float u = svu[ix], c = svc[ix], r = svr[ix];
-                const float hprev = A1[rl * LD1 + col];
-                const float dht = dh[i] + dsc[rl] * wsc[col];
+                const float u = f4e(u4, e), c = f4e(cc4, e), r = f4e(r4, e), hprev = f4e(h4, e);
+                const float dht = dh[i] + dscv * f4e(w4, e);
                 const float dau = dht * (hprev - c) * u * (1.0f - u);
                 const float dc = dht * (1.0f - u);
                 dhp[i] = dht * u;
                 const float dac = dc * (1.0f - c * c);
-                dacv[e] = dac; dauv[e] = dau;
-                if (row0 + rl < a.R) {
-                    o_dac[ix] = dac; o_rh[ix] = r * hprev; o_hp[ix] = hprev;
-                    o_dag[tl(i, t) * 2 * H + H + col] = dau;
-                    cs_c += dac; cs_u += dau;
-                }
+                dacv[e] = dac; dauv[e] = dau; rhv[e] = r * hprev;
+                sc_c[i] = rok ? dac : 0.f; sc_u[i] = rok ? dau : 0.f;
                 rr[i] = r; hp[i] = hprev;
             }
-            put4(I3, LDB1, ILO1, col, q, dacv[0], dacv[1], dacv[2], dacv[3]);
-            put4(I2, LDB2, ILO2, H + col, q, dauv[0], dauv[1], dauv[2], dauv[3]);      // (the dpool tiles that share A2 were last read before the step's barrier)
+            if (rok) {
+                *reinterpret_cast<float4*>(o_dac + ix) = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]);
+                *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
+                *reinterpret_cast<float4*>(o_hp + ix) = h4;
+                *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
+            }
+            put4(I3, LDB1, ILO1, c0 + 8 * q, dacv[0], dacv[1], dacv[2], dacv[3]);
+            put4(I2, LDB2, ILO2, H + c0 + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);      // (the dpool tiles that share A2 were last read before the step's barrier)
         }
+        cs_c += colsum16(sc_c); cs_u += colsum16(sc_u);
         __syncthreads();
         f32x16 dev = zero16(), der;
         {
             f32x16 t2[2] = {zero16(), zero16()};                  // drh | de_r, one pass over the da_c fragments
-            mmax_groups<2, 2>(t2, a3_lane, ILO1, bc2, PLC, G16);
-            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2>(tv, a3_lane, ILO1, bcv, PLC, G16); dev = tv[0]; }
+            mmax_groups<2, 2, true>(t2, a3_lane, ILO1, bc2, PLC, G16);
+            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2, true>(tv, a3_lane, ILO1, bcv, PLC, G16); dev = tv[0]; }
             der = t2[1];
+            float sc_r[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float darv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q + e;
-                    const int rl = rofs + (i & 3) + 8 * (i >> 2);
                     const float dr = t2[0][i] * hp[i];
                     dhp[i] += t2[0][i] * rr[i];
                     const float dar = dr * rr[i] * (1.0f - rr[i]);
                     darv[e] = dar;
-                    if (row0 + rl < a.R) { o_dag[tl(i, t) * 2 * H + col] = dar; cs_r += dar; }
+                    sc_r[i] = rok ? dar : 0.f;
                 }
-                put4(I2, LDB2, ILO2, col, q, darv[0], darv[1], darv[2], darv[3]);
+                if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = make_float4(darv[0], darv[1], darv[2], darv[3]);
+                put4(I2, LDB2, ILO2, c0 + 8 * q, darv[0], darv[1], darv[2], darv[3]);
             }
+            cs_r += colsum16(sc_r);
         }
         __syncthreads();
         // (h_{t-1} is still in its tile -- da_c went to the images, not over it as in the fp32 kernel -- so the pooled rebuild needs no reload);
         // da_c is consumed, its images take dpre_r
         {
             f32x16 t2[2] = {zero16(), der};                       // dh (gates) | de_r
-            mmax_groups<2, 2>(t2, a2_lane, ILO2, bg2, PLG, G32);
-            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2>(tv, a2_lane, ILO2, bgv, PLG, G32); dev = tv[0]; }
+            mmax_groups<2, 2, true>(t2, a2_lane, ILO2, bg2, PLG, G32);
+            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2, true>(tv, a2_lane, ILO2, bgv, PLG, G32); dev = tv[0]; }
+            float sc_p[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0 + 8 * q);
                 float dprv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q + e;
-                    const int rl = rofs + (i & 3) + 8 * (i >> 2);
                     dhp[i] += t2[0][i];
-                    const unsigned ixx = tl(i, t) * E;
-                    const float er = svx[ixx + EV + C + col];
-                    const float dpr = er > 0.f ? t2[1][i] : 0.f;
+                    const float dpr = f4e(er4, e) > 0.f ? t2[1][i] : 0.f;
                     dprv[e] = dpr;
-                    if (row0 + rl < a.R) {
-                        o_dpr[tl(i, t) * H + col] = dpr; cs_p += dpr;
-                        if (cb == 0 && (lane & 31) < EV) {
-                            const float ev = svx[ixx + (lane & 31)];
-                            o_dpv[tl(i, t) * EV + (lane & 31)] = ev > 0.f ? dev[i] : 0.f;
-                        }
+                    sc_p[i] = rok ? dpr : 0.f;
+                }
+                if (rok) {
+                    *reinterpret_cast<float4*>(o_dpr + (size_t)rt * H + c0 + 8 * q) = make_float4(dprv[0], dprv[1], dprv[2], dprv[3]);
+                    if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
+                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
+                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
+                            make_float4(ev4.x > 0.f ? dev[4 * q] : 0.f, ev4.y > 0.f ? dev[4 * q + 1] : 0.f, ev4.z > 0.f ? dev[4 * q + 2] : 0.f, ev4.w > 0.f ? dev[4 * q + 3] : 0.f);
                     }
                 }
-                put4(I3, LDB1, ILO1, col, q, dprv[0], dprv[1], dprv[2], dprv[3]);
+                put4(I3, LDB1, ILO1, c0 + 8 * q, dprv[0], dprv[1], dprv[2], dprv[3]);
             }
+            cs_p += colsum16(sc_p);
         }
         __syncthreads();
         // ---- social pooling backward ----
@@ -597,9 +637,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             {
                 f32x16 dpl[1] = {zero16()};
                 const uint4* bs[1] = {WsT + ((size_t)(b * NT + cb) * G16) * 64 + lane};
-                mmax_groups<1, 2>(dpl, a3_lane, ILO1, bs, PLS, G16);
+                mmax_groups<1, 2, true>(dpl, a3_lane, ILO1, bs, PLS, G16);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dp[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col] = dpl[0][i];
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dp + lr * LD1 + c0 + 8 * q) = make_float4(dpl[0][4 * q], dpl[0][4 * q + 1], dpl[0][4 * q + 2], dpl[0][4 * q + 3]);
             }
             __syncthreads();
             mask_t m2 = obs[r8 * B + b];
@@ -619,18 +660,30 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(NB + r8 * LD1 + q8 * 4 + c * 4 * TPR) = nb[c];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = dhp[i] + NB[(rofs + (i & 3) + 8 * (i >> 2)) * LD1 + col];
-    }
-    if (a.bias_part) {                                     // one part per tile: [da_r | da_u | da_c | dpre_r] column sums
-        cs_r += __shfl_xor(cs_r, 32); cs_u += __shfl_xor(cs_u, 32); cs_c += __shfl_xor(cs_c, 32); cs_p += __shfl_xor(cs_p, 32);
-        if (lane < 32) {
-            float* part = a.bias_part + (size_t)blockIdx.x * 4 * H;
-            part[col] = cs_r; part[H + col] = cs_u; part[2 * H + col] = cs_c; part[3 * H + col] = cs_p;
+        for (int q = 0; q < 4; ++q) {
+            const float4 n4 = *reinterpret_cast<const float4*>(NB + lr * LD1 + c0 + 8 * q);
+            dh[4 * q] = dhp[4 * q] + n4.x; dh[4 * q + 1] = dhp[4 * q + 1] + n4.y; dh[4 * q + 2] = dhp[4 * q + 2] + n4.z; dh[4 * q + 3] = dhp[4 * q + 3] + n4.w;
         }
     }
+    if (a.bias_part) {                                     // one part per tile: [da_r | da_u | da_c | dpre_r] column sums
+        // after the butterfly a lane holds the sum over ITS 16-lane row group of one accumulator element; the other row group is lane ^ 16
+        cs_r += __shfl_xor(cs_r, 16); cs_u += __shfl_xor(cs_u, 16); cs_c += __shfl_xor(cs_c, 16); cs_p += __shfl_xor(cs_p, 16);
+        if (!(lane & 16)) {
+            const int el = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);     // accumulator element this lane ended up with
+            const int colb = c0 + 8 * (el >> 2) + (el & 3);
+            float* part = a.bias_part + (size_t)blockIdx.x * 4 * H;
+            part[colb] = cs_r; part[H + colb] = cs_u; part[2 * H + colb] = cs_c; part[3 * H + colb] = cs_p;
+        }
+    }
+    if (rok) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (row0 + rofs + (i & 3) + 8 * (i >> 2) < a.R) a.dHx_rows[(size_t)rowi(i) * H + col] += dh[i];
+        for (int q = 0; q < 4; ++q) {
+            float4* d4 = reinterpret_cast<float4*>(a.dHx_rows + (size_t)(row0 + lr) * H + c0 + 8 * q);
+            float4 v = *d4;
+            v.x += dh[4 * q]; v.y += dh[4 * q + 1]; v.z += dh[4 * q + 2]; v.w += dh[4 * q + 3];
+            *d4 = v;
+        }
+    }
 }
 
 template <int H>

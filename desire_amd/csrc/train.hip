@@ -473,7 +473,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     b.dY0 = W(h, "dY0"); b.sv_r = W(h, "dec_sv_r"); b.sv_u = W(h, "dec_sv_u"); b.sv_c = W(h, "dec_sv_c"); b.sv_h = W(h, "dec_sv_h");
     b.Hx = W(h, "HxHy"); b.ldhx = 2 * H; b.w_head = D(h, "head/w");
     b.WcT_h = D4(h, "dec/WcT_h"); b.WgT_h = D4(h, "dec/WgT_h"); b.WgT_x = D4(h, "dec/WgT_x"); b.WcT_x = D4(h, "dec/WcT_x");
-    b.R = (int)R; b.K = d.K; b.mno = d.mno; b.T = T; b.H = H; b.legacy = (d.flags & DESIRE_FLAG_BPTT_LEGACY) ? 1 : 0;
+    b.R = (int)R; b.K = d.K; b.mno = d.mno; b.T = T; b.H = H;
     b.dag = W(h, "dec_dag"); b.dac = W(h, "dec_dac"); b.rh = W(h, "dec_rh"); b.hprev = W(h, "dec_hprev");
     b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = W(h, "dHx_rows");
     // bias gradients = column sums of the gate-gradient streams: summed per tile inside the BPTT kernels (no further pass over the streams)
@@ -689,7 +689,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         e.w_head = D(h, "head/w");
         if (head_loss && p == "enc_x") { e.dY0 = W(h, "head_dO"); e.w_head = D(h, "gauss_head/w"); e.nw = 5; }     // d L_head / d h_t = dO_t W5^T, every step
         e.WcT_h = D4(h, (p + "/WcT_h").c_str()); e.WgT_h = D4(h, (p + "/WgT_h").c_str());
-        e.R = A; e.K = 1; e.mno = d.mno; e.T = Te; e.H = H; e.legacy = (d.flags & DESIRE_FLAG_BPTT_LEGACY) ? 1 : 0;
+        e.R = A; e.K = 1; e.mno = d.mno; e.T = Te; e.H = H;
         e.dag = W(h, "enc_dag"); e.dac = W(h, "enc_dac"); e.rh = W(h, "enc_rh"); e.hprev = W(h, "enc_hprev");
         e.dh_init = W(h, "dHxHy") + col0; e.ld_init = 2 * H;
         launch_decoder_bwd(e, s);

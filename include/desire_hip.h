@@ -104,8 +104,6 @@ typedef struct desire_dims {
 #define DESIRE_IOC_X6_TILE32 13    /* dims.bf16 = 3: the 32-row / three-image six-product kernel whatever the launch size */
 #define DESIRE_IOC_X6_TILE64 14    /* dims.bf16 = 3: the 64-row six-product kernel whatever the launch size (default: launches of >= 256 tiles) */
 #define DESIRE_FLAG_NO_FUSE34 1    /* dims.bf16 = 1: deconv3 and deconv4 as separate kernels (default: fused, d3 never written) */
-#define DESIRE_FLAG_BPTT_LEGACY 2  /* training: the decoder / encoder BPTT kernel with row-major accumulators and 4-byte stream accesses
-                                      (default: transposed accumulators, 16-byte accesses; same arithmetic per element) */
 
 typedef struct desire_ctx desire_handle;
 
