@@ -26,8 +26,11 @@
 #endif
 // TPGT: tiles per group as a compile-time constant (2, 3, 4: the neighbour-chunk loops of the pooling chains are then branch-free), or 0 = read
 // it from the arguments
+#ifndef IOC16CL_OCC
+#define IOC16CL_OCC 2
+#endif
 template <int H, int EV, int C, bool SPLIT, int TPGT = 0>
-__global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? 2 : 1) void k_ioc_bf16_cl(IocArgs a, u16* __restrict__ hex16) {
+__global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) void k_ioc_bf16_cl(IocArgs a, u16* __restrict__ hex16) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
