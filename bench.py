@@ -586,10 +586,34 @@ def agent_sharded_comm(sharded, halves, fence, nrep, world, t_pred):
     no_comm = (time.perf_counter() - tc) / nrep
     for p, g in zip(sharded.parts, saved):
         p.gather = g
-    return {"bytes_sent_per_rank_per_ioc_step": sent, "bytes_received_per_rank_per_ioc_step": recv, "ioc_steps_per_pass": t_pred,
-            "ioc_ms_with_collectives": with_comm * 1e3, "ioc_ms_collectives_removed": no_comm * 1e3,
-            "exposed_comm_ms": max(0.0, (with_comm - no_comm) * 1e3),
-            "note": "two micro-batches per rank: the all-gather of one runs on a communication stream while the other computes its step"}
+    out = {"bytes_sent_per_rank_per_ioc_step": sent, "bytes_received_per_rank_per_ioc_step": recv, "ioc_steps_per_pass": t_pred,
+           "ioc_ms_with_collectives": with_comm * 1e3, "ioc_ms_collectives_removed": no_comm * 1e3,
+           "exposed_comm_ms": max(0.0, (with_comm - no_comm) * 1e3),
+           "note": "two micro-batches per rank: the all-gather of one runs on a communication stream while the other computes its step"}
+    # the same pass over PEER buffers (desire_peer_*: regions mapped through hipIpc, one call per pass, a one-wave wait kernel between the
+    # steps, no collective and no host in the step loop); the micro-batches run one after the other on the launch stream
+    try:
+        import torch
+        from desire_amd.dist import PeerShardedIoc
+        peers = [PeerShardedIoc(x["h"], p.rank, world) for x, p in zip(halves, sharded.parts)]
+        st = torch.cuda.current_stream().cuda_stream
+
+        def peer_only():              # one stream, the micro-batches one after the other: every rank issues them in the same order, and a
+            for pr, x in zip(peers, halves):      # pass's parked wait kernel can then never sit in front of work a peer is waiting for
+                pr.run(x["Y"], x["score"], st)
+        peer_only(); fence()
+        tc = time.perf_counter()
+        for _ in range(nrep):
+            peer_only()
+        fence()
+        out["peer_buffers"] = {"ioc_ms": (time.perf_counter() - tc) / nrep * 1e3,
+                               "note": "dist.PeerShardedIoc: hidden states read in place from the peers' exchange regions (hipIpc; xGMI between "
+                                       "GPUs), progress counters instead of collectives, %d launches per pass enqueued at once" % (3 * t_pred + 5)}
+        for pr in peers:
+            pr.close()
+    except Exception as exc:                                  # noqa: BLE001 -- the leg must not cost the line
+        out["peer_buffers"] = {"error": repr(exc)[:300]}
+    return out
 
 
 def self_spawn(n_gpus):

@@ -24,6 +24,7 @@ EXPORTS = [
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
     "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout", "desire_build_windows_la", "desire_adam_state",
     "desire_set_option", "desire_train_loss_async", "desire_set_head_loss",
+    "desire_peer_export", "desire_peer_open", "desire_ioc_peer_pass", "desire_peer_close", "desire_peer_region", "desire_peer_open_ptr",
 ]
 
 
@@ -96,6 +97,12 @@ def load() -> C.CDLL:
     lib.desire_train_loss.argtypes = [vp, f32p, C.POINTER(C.c_float), vp]
     lib.desire_train_loss_async.argtypes = [vp, f32p, f32p, vp]
     lib.desire_set_head_loss.argtypes = [vp, C.c_float]
+    lib.desire_peer_export.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t)]
+    lib.desire_peer_open.argtypes = [vp, i32, i32, i32, C.c_char_p]
+    lib.desire_ioc_peer_pass.argtypes = [vp, f32p, f32p, vp]
+    lib.desire_peer_close.argtypes = [vp]
+    lib.desire_peer_region.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.desire_peer_open_ptr.argtypes = [vp, i32, i32, i32, vp]
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     lib.desire_adam_state.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     lib.desire_get_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_size_t, vp]
@@ -280,6 +287,30 @@ class Handle:
         out = (C.c_float * 5)()
         _chk(self.lib.desire_train_loss(self._h, fut_ptr, out, stream or None))                 # (synchronises the stream)
         return self.loss_terms(self.read_buffer("loss_out", (8,), stream))                      # + the Gaussian-head term and the clip norm
+
+    def peer_export(self) -> bytes:
+        """This rank's exchange region as a 64-byte hipIpcMemHandle (allocated on the first call)."""
+        buf = C.create_string_buffer(64)
+        n = C.c_size_t(0)
+        _chk(self.lib.desire_peer_export(self._h, buf, C.byref(n)))
+        return bytes(buf.raw)
+
+    def peer_open(self, rank: int, nranks: int, peer: int, handle: bytes = None) -> None:
+        _chk(self.lib.desire_peer_open(self._h, rank, nranks, peer, None if peer == rank else bytes(handle)))
+
+    def peer_region(self) -> int:
+        p, n = C.c_void_p(), C.c_size_t(0)
+        _chk(self.lib.desire_peer_region(self._h, C.byref(p), C.byref(n)))
+        return int(p.value)
+
+    def peer_open_ptr(self, rank: int, nranks: int, peer: int, region_ptr: int = 0) -> None:
+        _chk(self.lib.desire_peer_open_ptr(self._h, rank, nranks, peer, region_ptr or None))
+
+    def ioc_peer_pass(self, y_ptr: int, score_ptr: int, stream: int = 0) -> None:
+        _chk(self.lib.desire_ioc_peer_pass(self._h, y_ptr, score_ptr, stream or None))
+
+    def peer_close(self) -> None:
+        _chk(self.lib.desire_peer_close(self._h))
 
     def set_head_loss(self, weight: float) -> None:
         """Weight of the reference's Gaussian-NLL term for the 5-wide output layer (model/model.py:494-550) in the training loss."""

@@ -60,3 +60,26 @@ __device__ __forceinline__ bool group_wait_wt(int* cnt, int target, int* err) {
     __syncthreads();
     return ok;
 }
+
+
+// SYSTEM-scope forms for memory another process / another GPU reads or writes (the peer exchange of k_ioc_step): relaxed atomic
+// 8-byte / 4-byte accesses are written through to memory and served from memory, whatever the allocation's caching attributes and
+// whatever cache maintenance the runtime does (or elides) between kernels of different queues.
+__device__ __forceinline__ void st_sys_u64(void* p, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint2 ld_sys_u64(const void* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+__device__ __forceinline__ float2 ld_sys_f2(const float* p) { const uint2 v = ld_sys_u64(p); return make_float2(__uint_as_float(v.x), __uint_as_float(v.y)); }
+__device__ __forceinline__ float4 ld_sys_f4(const float* p) {
+    const uint2 a = ld_sys_u64(p), b = ld_sys_u64(p + 2);
+    return make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x), __uint_as_float(b.y));
+}
+__device__ __forceinline__ unsigned ld_sys_u32(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys_f32(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

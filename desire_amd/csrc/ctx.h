@@ -60,6 +60,10 @@ struct desire_ctx {
     const float* grids = nullptr;
     bool grids_set = false;
     bool profiling = false;
+    // peer exchange of the agent-sharded IOC (desire_peer_*): this rank's region, the mapped regions of the others, a mapped host error word
+    void* peer_region = nullptr; size_t peer_bytes = 0; void* peer_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool peer_mapped[8] = {false, false, false, false, false, false, false, false}; int peer_rank = -1, peer_nranks = 0; bool peer_ready = false;
+    int* peer_err = nullptr;
     float head_loss_w = 0.f;                                 // desire_set_head_loss: weight of the Gaussian-head NLL term in the training loss
     int* host_err = nullptr;                                 // mapped host word the bin-split IOC's bounded spins report into (checked by the next call)
     std::vector<Prof> prof;

@@ -153,13 +153,27 @@ struct IocStepArgs {
     int t; int rank; int nranks; int m_loc; int n_scenes; int K; int R;       // R = local rows = n_scenes * K * m_loc
     int H; int T; int Gh; int Gw; int G; float nb_w, nb_h;
     const float* Yall; const float* plast_all; const uint8_t* valid_all; const float* Hall;
-    const float* st_h; float* st_h_out; float* st_score;
+    // peer form (desire_ioc_peer_pass): per-rank base pointers instead of one gathered array each -- device tables of nranks pointers to
+    // the rank's OWN block in the gathered layouts above (its exchange region, mapped through hipIpc when it lives in another process /
+    // on another GPU).  nullptr = the gathered arrays.
+    // (BY VALUE in the kernel arguments, not a table in device memory: a table rewritten by hipMemcpy for a new handle at a recycled
+    //  address was read stale by the next kernels -- the kernarg segment is fresh per dispatch)
+    int peer; const float* Yp[8]; const float* plp[8]; const uint8_t* vp[8]; const float* Hp[8];
+    const float* st_h; float* st_h_out; float* st_score; float* st_h_copy;
     const float* grids; const int32_t* grid_of_scene;
     const float* w_vel; const float* b_vel; const float4* Wsoc; const float* b_soc;
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c; const float* w_score;
     const float* bin_tab;
 };
 void launch_ioc_step(const IocStepArgs& a, hipStream_t s);
+// peer exchange (kernels_rnn.hip): progress counters in the ranks' exchange regions, written / polled with system-scope atomics
+struct PeerFlags { const unsigned* f[8]; };
+void launch_peer_wait(const PeerFlags& flags, int nranks, const unsigned* epoch, unsigned per_pass, unsigned stage, int* err, hipStream_t s);
+void launch_peer_set(unsigned* flag, const unsigned* epoch, unsigned per_pass, unsigned stage, hipStream_t s);
+void launch_peer_epoch(unsigned* epoch, hipStream_t s);
+// own block of the exchange region for one pass: presence flags, last observed positions, decoded positions, h_{-1} = Hx per row
+void launch_peer_publish(const uint8_t* valid, const float* p_last, const float* Y, const float* HxHy, int ldhx, uint8_t* o_valid,
+                         float* o_plast, float* o_Y, float* o_H, int n_scenes, int K, int mno, int T, int H, hipStream_t s);
 void launch_ioc_finish(float* Y, const float* dY, const float* st_score, const float* b_score, float* score, int R, int T, hipStream_t s);
 struct ConvArgs;
 void launch_deconv2_bf16(const ConvArgs& a, hipStream_t s);

@@ -1196,8 +1196,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     if (tid < 2) occ[tid] = 0;
     for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
-        *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
-            *reinterpret_cast<const float4*>(a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4);
+        const float* sp = a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4;
+        *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) = a.peer ? ld_sys_f4(sp) : *reinterpret_cast<const float4*>(sp);
     }
     const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
     const float* x_lane = XH + (lane & 31) * LDX + 4 * (lane >> 5);
@@ -1211,7 +1211,12 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     const int my_gslot = a.rank * a.m_loc + sl;
     auto pos_of = [&](int j, int t) {                    // position of global slot j of my group at step t (t = -1: last observed)
         const int rk = j / a.m_loc, s = j - rk * a.m_loc;
-        if (t < 0) return *reinterpret_cast<const float2*>(a.plast_all + ((size_t)(rk * a.n_scenes + scene) * a.m_loc + s) * 2);
+        // peer form: everything that lives in an exchange region is read with system-scope loads (cluster.h), never through a cache
+        if (t < 0) {
+            if (a.peer) return ld_sys_f2(a.plp[rk] + ((size_t)scene * a.m_loc + s) * 2);
+            return *reinterpret_cast<const float2*>(a.plast_all + ((size_t)(rk * a.n_scenes + scene) * a.m_loc + s) * 2);
+        }
+        if (a.peer) return ld_sys_f2(a.Yp[rk] + (((size_t)grp * a.m_loc + s) * a.T + t) * 2);
         return *reinterpret_cast<const float2*>(a.Yall + ((((size_t)rk * n_groups + grp) * a.m_loc + s) * a.T + t) * 2);
     };
     __syncthreads();
@@ -1239,7 +1244,10 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         }
         for (int j = q8; j < mall; j += TPR) {
             const int rk = j / a.m_loc, s = j - rk * a.m_loc;
-            if (j == my_gslot || !a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s]) continue;
+            bool there;
+            if (a.peer) { const size_t ix = (size_t)scene * a.m_loc + s; there = (ld_sys_u32(a.vp[rk] + (ix & ~(size_t)3)) >> (8 * (ix & 3))) & 0xffu; }
+            else there = a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s];
+            if (j == my_gslot || !there) continue;
             const float2 pj = pos_of(j, a.t);
             const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G, a.bin_tab);
             if (b >= 0) { atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
@@ -1257,10 +1265,11 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
                 const int j = wd * 64 + __ffsll((long long)m2) - 1;
                 m2 &= m2 - 1;
                 const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
-                const float* src = a.Hall + (((size_t)rk * n_groups + grp) * a.m_loc + sj) * H;
+                const float* hb = a.peer ? a.Hp[rk] : a.Hall + (size_t)rk * n_groups * a.m_loc * H;
+                const float* src = hb + ((size_t)grp * a.m_loc + sj) * H;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
+                    const float4 v = a.peer ? ld_sys_f4(src + q8 * 4 + c * 4 * TPR) : *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
                     s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
                 }
             }
@@ -1302,7 +1311,10 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     for (int i = 0; i < 16; ++i) {
         h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
         const int row = row0 + acc_row(i);
-        if (row < a.R) a.st_h_out[(size_t)row * H + col] = h[i];
+        if (row < a.R) {
+            if (a.peer) st_sys_f32(a.st_h_out + (size_t)row * H + col, h[i]); else a.st_h_out[(size_t)row * H + col] = h[i];
+            if (a.st_h_copy) a.st_h_copy[(size_t)row * H + col] = h[i];      // peer form, last step: h_T for the regression head, in ordinary memory
+        }
         float v = h[i] * wsc;
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
         if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
@@ -1326,6 +1338,61 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
     else if (a.H == 128) { allow_big_lds(k_ioc_step<128, 16, 32>); hipLaunchKernelGGL((k_ioc_step<128, 16, 32>), grid, block, lds, s, a); }
     else { allow_big_lds(k_ioc_step<64, 16, 32>); hipLaunchKernelGGL((k_ioc_step<64, 16, 32>), grid, block, lds, s, a); }
 }
+// ---- peer exchange: progress counters ------------------------------------------------------------------------------
+// Every rank owns one 32-bit counter in its exchange region; value = epoch * per_pass + stage, monotonic over the passes.  A rank's
+// kernels of stage s + 1 may start once every peer's counter has reached (epoch, s): k_peer_wait is ONE wave (lane = peer) polling with
+// relaxed system-scope loads and a bounded sleep loop, then a system-scope acquire; k_peer_set publishes with a system-scope release.
+// The kernels in between are ordinary launches -- nothing compute-sized ever spins, so two ranks that share a GPU (the one-box test)
+// cannot starve each other.  The epoch lives in device memory (k_peer_epoch bumps it) so that a captured pass can be replayed.
+__global__ void k_peer_wait(PeerFlags flags, int nranks, const unsigned* epoch, unsigned per_pass, unsigned stage, int* err) {
+    const int r = threadIdx.x;
+    if (r < nranks && !__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {      // (one time-out per pass, not one per step)
+        const unsigned target = ld_sys_u32(epoch) * per_pass + stage;
+        const unsigned* f = flags.f[r];
+        long spins = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > 2000000L) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // ~4 s
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+__global__ void k_peer_set(unsigned* flag, const unsigned* epoch, unsigned per_pass, unsigned stage) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(flag, ld_sys_u32(epoch) * per_pass + stage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_peer_epoch(unsigned* epoch) { __hip_atomic_store(epoch, ld_sys_u32(epoch) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+void launch_peer_wait(const PeerFlags& flags, int nranks, const unsigned* epoch, unsigned per_pass, unsigned stage, int* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, s, flags, nranks, epoch, per_pass, stage, err);
+}
+void launch_peer_set(unsigned* flag, const unsigned* epoch, unsigned per_pass, unsigned stage, hipStream_t s) {
+    hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(1), 0, s, flag, epoch, per_pass, stage);
+}
+void launch_peer_epoch(unsigned* epoch, hipStream_t s) { hipLaunchKernelGGL(k_peer_epoch, dim3(1), dim3(1), 0, s, epoch); }
+__global__ void k_peer_publish(const uint8_t* __restrict__ valid, const float* __restrict__ p_last, const float* __restrict__ Y,
+                               const float* __restrict__ HxHy, int ldhx, uint8_t* __restrict__ o_valid, float* __restrict__ o_plast,
+                               float* __restrict__ o_Y, float* __restrict__ o_H, int n_scenes, int K, int mno, int T, int H) {
+    const size_t A = (size_t)n_scenes * mno, R = A * K;
+    const size_t nY = R * T * 2, nH = R * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nY + nH; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nY) st_sys_f32(o_Y + i, Y[i]);
+        else {
+            const size_t j = i - nY, r = j / H, c = j - r * H;
+            st_sys_f32(o_H + j, HxHy[(size_t)agent_of_row((int)r, K, mno) * ldhx + c]);
+        }
+        if (i < (A + 3) / 4) {                                  // presence flags, four to a word (the region is zero-padded)
+            unsigned wv_ = 0;
+            for (int b = 0; b < 4; ++b) if (4 * i + b < A) wv_ |= (unsigned)valid[4 * i + b] << (8 * b);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(o_valid) + i, wv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (i < 2 * A) st_sys_f32(o_plast + i, p_last[i]);
+    }
+}
+void launch_peer_publish(const uint8_t* valid, const float* p_last, const float* Y, const float* HxHy, int ldhx, uint8_t* o_valid,
+                         float* o_plast, float* o_Y, float* o_H, int n_scenes, int K, int mno, int T, int H, hipStream_t s) {
+    hipLaunchKernelGGL(k_peer_publish, dim3(1024), dim3(256), 0, s, valid, p_last, Y, HxHy, ldhx, o_valid, o_plast, o_Y, o_H, n_scenes, K, mno, T, H);
+}
+
 // end of a pass: Y += dY (dY [R, 2T] from the regression GEMM), score = accumulated + T * b_score
 __global__ void k_ioc_finish(float* __restrict__ Y, const float* __restrict__ dY, const float* __restrict__ st_score,
                              const float* __restrict__ b_score, float* __restrict__ score, int R, int T2, int T) {

@@ -128,6 +128,40 @@ class ShardedIoc:
         return Y_loc, score_loc
 
 
+class PeerShardedIoc:
+    """Agent-sharded IOC over PEER buffers (include/desire_hip.h: desire_peer_*): the ranks map each other's exchange regions once
+    (hipIpc; xGMI between GPUs) and a pass is ONE call that enqueues every step -- the step kernels read the neighbours' hidden states in
+    place and a one-wave kernel waits on the peers' progress counters, so there is no collective and no host round trip per step (the
+    ShardedIoc loop above issues T_pred all-gathers from Python).  Bit-identical to ShardedIoc.  `exchange(obj) -> list` hands the 64-byte
+    handles round: default torch.distributed.all_gather_object (any backend); `barrier()` default torch.distributed.barrier."""
+
+    def __init__(self, handle, rank: int, nranks: int, exchange=None, barrier=None, group=None):
+        import torch.distributed as dist
+        self.h, self.rank, self.nranks = handle, int(rank), int(nranks)
+        if handle.dims.mno * nranks > 256:
+            raise ValueError("agent-sharded IOC: at most 256 agents per scene over all ranks")
+
+        def _exchange(obj):
+            out = [None] * nranks
+            dist.all_gather_object(out, obj, group=group)
+            return out
+        mine = handle.peer_export()
+        handles = (exchange or _exchange)(mine) if nranks > 1 else [mine]
+        for peer in range(nranks):
+            handle.peer_open(self.rank, self.nranks, peer, handles[peer])
+        if nranks > 1:
+            (barrier or (lambda: dist.barrier(group=group)))()       # every rank has mapped every region before anybody publishes
+
+    def run(self, Y_loc, score_loc, stream: int = 0):
+        """Y_loc [R_loc, T, 2] (in: decoded, out: refined), score_loc [R_loc]; all dims.iters passes, stream-ordered, no host sync."""
+        import torch
+        self.h.ioc_peer_pass(Y_loc.data_ptr(), score_loc.data_ptr(), stream or torch.cuda.current_stream().cuda_stream)
+        return Y_loc, score_loc
+
+    def close(self) -> None:
+        self.h.peer_close()
+
+
 class PipelinedShardedIoc:
     """The same agent-sharded IOC with the per-step neighbour all-gather HIDDEN behind compute ("overlap
     step-t all-gather with ... the local rows").  The rank's scenes are split into micro-batches (one ShardedIoc / handle each,

@@ -247,6 +247,28 @@ int desire_ioc_step(desire_handle* h, int32_t t, int32_t rank, int32_t nranks, c
                     float* dev_h_state, float* dev_score_state, void* stream);
 int desire_ioc_finish(desire_handle* h, const float* dev_h_state, const float* dev_score_state, float* dev_Y,
                       float* dev_score, void* stream);
+/* The same agent-sharded pass WITHOUT a collective and without the host in the step loop: every rank owns an exchange region (its
+ * blocks of the four gathered arrays above, two parities of hidden states, one progress counter), exported as a 64-byte
+ * hipIpcMemHandle by desire_peer_export and mapped by the other ranks with desire_peer_open(h, rank, nranks, peer, handle) -- over xGMI
+ * when the peer is another GPU, the same HBM when two ranks share a device.  How the handles travel is the caller's business
+ * (desire_amd/dist.py: PeerShardedIoc uses torch.distributed.all_gather_object once); open the own rank with a NULL handle.  After
+ * every rank has opened every peer (barrier), desire_ioc_peer_pass(h, dev_Y inout [R_loc, T_pred, 2], dev_score out [R_loc], stream)
+ * enqueues the whole refinement -- publish, then per step: one-wave wait on the peers' counters, the step kernel reading their hidden
+ * states IN PLACE, counter bump -- dims.iters times, with nothing but kernel launches (capturable by desire_graph_*).  A peer that
+ * never arrives makes the bounded wait give up (a few seconds); the NEXT call then fails with DESIRE_ERR_HIP.  Results are bit-identical to
+ * the desire_ioc_step loop.  desire_peer_close unmaps / frees (desire_destroy calls it). */
+int desire_peer_export(desire_handle* h, uint8_t* handle_out64, size_t* bytes_out);
+int desire_peer_open(desire_handle* h, int32_t rank, int32_t nranks, int32_t peer, const uint8_t* handle64);
+int desire_ioc_peer_pass(desire_handle* h, float* dev_Y, float* dev_score, void* stream);
+int desire_peer_close(desire_handle* h);
+/* Ranks inside ONE process (one process driving several devices with peer access enabled) attach each other's regions by device
+ * pointer: desire_peer_region gives a handle's own region, desire_peer_open_ptr takes the peer's (hipIpc handles cannot be opened by
+ * the process that exported them).  Every rank's pass must then run on a HARDWARE queue of its own: a pass parks a one-wave wait
+ * kernel on its stream until the peers catch up, and two streams that the runtime multiplexes onto one queue (it maps a process's
+ * streams of ONE device onto 4 queues) would wait for each other until the time-out.  Streams of different devices never share a
+ * queue; several ranks on one device belong in separate processes (tests/test_gpu_peer_ioc.py). */
+int desire_peer_region(desire_handle* h, void** dev_region, size_t* bytes);
+int desire_peer_open_ptr(desire_handle* h, int32_t rank, int32_t nranks, int32_t peer, void* dev_region);
 
 /* ---- training (the reference builds tf.gradients(cost) + Adam and never runs them: model/model.py:388-403) ----
  * desire_set_training(h,1) allocates the activation-save and gradient buffers; a desire_forward made afterwards keeps
