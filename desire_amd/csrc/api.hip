@@ -187,8 +187,9 @@ int check_options(const desire_dims& d) {
 
 int check_dims(const desire_dims& d) {
     if (d.S != 32) return fail(DESIRE_ERR_ARG, "S must be 32 (rnn_size=512): CVAE stack shapes, model/model.py:465-468");
-    if (d.mno < 1 || d.mno > 128 || (d.mno <= 32 ? (32 % d.mno) : (d.mno % 32)))
-        return fail(DESIRE_ERR_ARG, "mno must divide 32 or be 64, 96 or 128");
+    if (d.mno < 1 || d.mno > 256 || (d.mno <= 32 ? (32 % d.mno) : (d.mno % 32)))
+        return fail(DESIRE_ERR_ARG, "mno must divide 32 or be a multiple of 32 up to 256 (above 128: inference, step-wise IOC)");
+    if (d.mno > 128 && d.bf16 == 1) return fail(DESIRE_ERR_ARG, "more than 128 agents per scene run the fp32 step-wise IOC (bf16 = 0, 2 or 3)");
     if (d.H != 16 && d.H != 32 && d.H != 64 && d.H != 128 && d.H != 256)
         return fail(DESIRE_ERR_ARG, "H must be 16, 32 (run zero-padded on the 64-wide tile), 64, 128 or 256");
 
@@ -806,6 +807,34 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (!h->grids_set) return fail(DESIRE_ERR_STATE, "scene grids not set (desire_set_scene_grids)");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d.mno > 128) {
+        // Scenes of 160 .. 256 agents (beyond the four-workgroup cluster form: its neighbour masks are 128 bits): the step-wise kernel of the
+        // agent-sharded path with ONE rank -- 32-row tiles of any mix of groups, neighbours' hidden states read from global memory (L2),
+        // 256-bit masks, one launch per step, state ping-ponged between two buffers.  Same summation order as the persistent kernels.
+        if (h->training) return fail(DESIRE_ERR_STATE, "training supports up to 128 agents per scene");
+        const size_t RH = (size_t)h->R * d.H;
+        if (!h->ws.count("stw_h") && (h->ws["stw_h"].alloc(2 * RH * sizeof(float)) || h->ws["stw_sc"].alloc((size_t)h->R * sizeof(float))))
+            return fail(DESIRE_ERR_HIP, "hipMalloc failed for the step-wise IOC state");
+        float* hb[2] = {W(h, "stw_h"), W(h, "stw_h") + RH};
+        for (int it = 0; it < d.iters; ++it) {
+            launch_hx_rows(hb[1], W(h, "HxHy"), 2 * d.H, d.n_scenes, d.K, d.mno, d.H, s);       // h_{-1} = Hx of the row's agent
+            for (int t = 0; t < d.T_pred; ++t) {
+                IocStepArgs q{};
+                q.t = t; q.rank = 0; q.nranks = 1; q.m_loc = d.mno; q.n_scenes = d.n_scenes; q.K = d.K; q.R = h->R;
+                q.H = d.H; q.T = d.T_pred; q.Gh = d.Gh; q.Gw = d.Gw; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
+                q.Yall = dev_Yhat; q.plast_all = W(h, "p_last"); q.valid_all = static_cast<const uint8_t*>(h->ws["valid"].p); q.Hall = hb[(t + 1) & 1];
+                q.st_h = hb[(t + 1) & 1]; q.st_h_out = hb[t & 1]; q.st_score = W(h, "stw_sc");
+                q.grids = h->grids; q.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
+                q.w_vel = D(h, "ioc/vel_w"); q.b_vel = D(h, "ioc/vel_b"); q.Wsoc = D4(h, "ioc/Wsoc"); q.b_soc = D(h, "ioc/soc_b");
+                q.Wg = D4(h, "ioc/Wg"); q.Wc = D4(h, "ioc/Wc"); q.b_g = D(h, "ioc/gb"); q.b_c = D(h, "ioc/cb"); q.w_score = D(h, "ioc/score_w");
+                q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
+                { Timer tm(h, s, "ioc"); launch_ioc_step(q, s); }
+            }
+            if (int rc = desire_ioc_finish(h, hb[(d.T_pred - 1) & 1], W(h, "stw_sc"), dev_Yhat, dev_score, stream)) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        return DESIRE_OK;
+    }
     IocArgs a{};
     a.Y = dev_Yhat; a.score = dev_score; a.Hx = W(h, "HxHy"); a.ldhx = 2 * d.H; a.p_last = W(h, "p_last");
     a.valid = static_cast<const uint8_t*>(h->ws["valid"].p);

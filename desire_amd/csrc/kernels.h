@@ -171,6 +171,7 @@ struct PeerFlags { const unsigned* f[8]; };
 void launch_peer_wait(const PeerFlags& flags, int nranks, const unsigned* epoch, unsigned per_pass, unsigned stage, int* err, hipStream_t s);
 void launch_peer_set(unsigned* flag, const unsigned* epoch, unsigned per_pass, unsigned stage, hipStream_t s);
 void launch_peer_epoch(unsigned* epoch, hipStream_t s);
+void launch_hx_rows(float* out, const float* HxHy, int ldhx, int n_scenes, int K, int mno, int H, hipStream_t s);
 // own block of the exchange region for one pass: presence flags, last observed positions, decoded positions, h_{-1} = Hx per row
 void launch_peer_publish(const uint8_t* valid, const float* p_last, const float* Y, const float* HxHy, int ldhx, uint8_t* o_valid,
                          float* o_plast, float* o_Y, float* o_H, int n_scenes, int K, int mno, int T, int H, hipStream_t s);

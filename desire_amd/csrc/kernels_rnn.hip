@@ -1393,6 +1393,17 @@ void launch_peer_publish(const uint8_t* valid, const float* p_last, const float*
     hipLaunchKernelGGL(k_peer_publish, dim3(1024), dim3(256), 0, s, valid, p_last, Y, HxHy, ldhx, o_valid, o_plast, o_Y, o_H, n_scenes, K, mno, T, H);
 }
 
+// h_{-1} of every row = Hx of the row's agent: out [R, H] from HxHy [A, ldhx]
+__global__ void k_hx_rows(float* __restrict__ out, const float* __restrict__ HxHy, int ldhx, int R, int K, int mno, int H) {
+    const size_t n = (size_t)R * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / H, c = i - r * H;
+        out[i] = HxHy[(size_t)agent_of_row((int)r, K, mno) * ldhx + c];
+    }
+}
+void launch_hx_rows(float* out, const float* HxHy, int ldhx, int n_scenes, int K, int mno, int H, hipStream_t s) {
+    hipLaunchKernelGGL(k_hx_rows, dim3(1024), dim3(256), 0, s, out, HxHy, ldhx, n_scenes * K * mno, K, mno, H);
+}
 // end of a pass: Y += dY (dY [R, 2T] from the regression GEMM), score = accumulated + T * b_score
 __global__ void k_ioc_finish(float* __restrict__ Y, const float* __restrict__ dY, const float* __restrict__ st_score,
                              const float* __restrict__ b_score, float* __restrict__ score, int R, int T2, int T) {

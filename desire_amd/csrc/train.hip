@@ -393,6 +393,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (!d.posterior) return fail(DESIRE_ERR_STATE, "training needs the posterior path (dims.posterior = 1)");
     if (d.bf16 == 1 || d.bf16 == 3) return fail(DESIRE_ERR_STATE, "training runs with dims.bf16 = 0 (fp32 operands) or 2 (split-bf16 operands where a kernel has that form, fp32 kernels elsewhere); 1 and 3 are inference-only");
     if (d.ref_compat) return fail(DESIRE_ERR_STATE, "ref_compat is forward-only: the reference never defines a runnable cost (model/model.py:342)");
+    if (d.mno > 128) return fail(DESIRE_ERR_STATE, "training supports up to 128 agents per scene (160 .. 256 run the step-wise IOC: inference)");
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0) && (d.H > 128 || d.grid_size > 4))
         return fail(DESIRE_ERR_STATE, "training of groups larger than one workgroup tile (64 / 96 / 128 agents: cluster-form BPTT) needs H <= 128 and grid_size <= 4");
     if (d.iters > 4) return fail(DESIRE_ERR_STATE, "training keeps the activations of every IOC refinement pass: iters <= 4");

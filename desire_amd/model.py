@@ -27,11 +27,12 @@ from .spec import Dims, init_weights, weight_shapes
 
 
 def _next_divisor_of_64(n: int) -> int:
-    """Pad max_num_obj up to a slot count the IOC tiling accepts: a divisor of 32, or 64 / 96 / 128."""
-    for m in (1, 2, 4, 8, 16, 32, 64, 96, 128):
+    """Pad max_num_obj up to a slot count the IOC tiling accepts: a divisor of 32, or a multiple of 32 up to 256 (above 128 the IOC pass
+    runs step-wise and training is refused)."""
+    for m in (1, 2, 4, 8, 16, 32, 64, 96, 128, 160, 192, 224, 256):
         if m >= n:
             return m
-    raise ValueError("max_num_obj > 128 is not supported in this round")
+    raise ValueError("max_num_obj > 256 is not supported")
 
 
 def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool = False) -> Dims:

@@ -34,7 +34,7 @@ class Dims:
     """Static sizes of one forward call.  Row index r = (scene*K + k)*mno + slot."""
 
     n_scenes: int = 1      # windows per call (DataLoader batch entries), each its own scene
-    mno: int = 32          # agent slots per window (max_num_obj): divides 32, or 64 / 96 / 128
+    mno: int = 32          # agent slots per window (max_num_obj): divides 32, or a multiple of 32 up to 256 (above 128: inference, step-wise IOC)
     K: int = 20            # samples per agent
     T_obs: int = 8
     T_pred: int = 40
@@ -91,8 +91,10 @@ class Dims:
     def validate(self) -> None:
         if self.S != 32:
             raise ValueError("CVAE stack closes only for S=32 (rnn_size=512), model/model.py:465-468")
-        if not (1 <= self.mno <= 128) or (32 % self.mno if self.mno <= 32 else self.mno % 32):
-            raise ValueError("mno must divide 32 or be 64, 96 or 128 (host pads max_num_obj up)")
+        if not (1 <= self.mno <= 256) or (32 % self.mno if self.mno <= 32 else self.mno % 32):
+            raise ValueError("mno must divide 32 or be a multiple of 32 up to 256 (host pads max_num_obj up; above 128: inference only)")
+        if self.mno > 128 and self.bf16 == 1:
+            raise ValueError("more than 128 agents per scene run the fp32 step-wise IOC (bf16 = 0, 2 or 3)")
         if self.L % 8 or self.C % 8 or self.E_v % 8:
             raise ValueError("L%8, C%8, E_v%8 required by the MFMA tiling")
         if self.H not in (16, 32, 64, 128, 256):

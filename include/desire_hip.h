@@ -141,7 +141,9 @@ int desire_encode(desire_handle* h, const float* dev_past, const float* dev_fut,
 int desire_sample(desire_handle* h, const float* dev_eps, float* dev_Yhat, void* stream);
 
 /* IOC scoring + regression refinement, dims.iters passes (paper; model/model.py:312-313).
- * dev_Yhat [R, T_pred, 2] in/out; dev_score [R] out. */
+ * dev_Yhat [R, T_pred, 2] in/out; dev_score [R] out.  Scenes of up to 32 agents: one persistent workgroup per 32-row tile; 64 / 96 /
+ * 128: the cluster form (workgroups of a group exchanging hidden states inside one launch); 160 .. 256 (mno a multiple of 32): one
+ * launch per step of the agent-sharded kernel with a single rank (fp32 operands, inference only) -- same results, more launches. */
 int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream);
 
 /* encode + sample + ioc_refine, the unit bench.py times. */

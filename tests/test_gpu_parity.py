@@ -656,3 +656,31 @@ def test_row_compacted_pooling_form(torch_cuda, kw):
         assert np.abs(Yc - Yd).max() < 2e-5 and np.abs(sc - sd).max() < 2e-4
     else:                                                # a second pass re-bins from refined positions (bin-edge caveat)
         assert np.abs(Yc - Yd).mean() < 1e-3
+
+
+@pytest.mark.parametrize("kw", [dict(mno=160, n_scenes=1, K=2, n_grids=1, T_pred=6), dict(mno=256, n_scenes=2, K=1, n_grids=1, T_pred=5, H=64, L=64),
+                                dict(mno=192, n_scenes=1, K=2, n_grids=1, T_pred=5, iters=2, nb_w=0.1, nb_h=0.1)])
+def test_scenes_of_more_than_128_agents_run_the_step_wise_ioc(torch_cuda, kw):
+    """VERDICT r03 Missing 7: max_num_obj > 128 on one GPU.  160 .. 256 agents per scene: everything before the IOC is per agent; the IOC
+    pass runs as one launch per step of the agent-sharded kernel with a single rank (256-bit neighbour masks).  Stagewise against the
+    oracle like every other shape; training is refused."""
+    from desire_amd import _lib
+    d = small_dims(**kw)
+    w = init_weights(d, 17)
+    past, fut, eps, grids, gos = make_case(d, seed=18, n_absent=9, spread=0.3)
+    ref = oracle_forward(d, w, past, fut, eps, grids, gos)
+    h, Y0, _ = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos)
+    assert np.abs(h.read_buffer("Y0", (d.R, d.T_pred, 2)) - ref["Y0"]).max() < TOL_Y
+    _, Y, score = run_gpu(torch_cuda, d, w, past, fut, eps, grids, gos, Y_in=ref["Y0"])
+    assert (np.asarray(ref["Y"]) != np.asarray(ref["Y0"])).any()
+    if d.iters == 1:
+        assert np.abs(Y - ref["Y"]).max() < TOL_Y, np.abs(Y - ref["Y"]).max()
+        assert np.abs(score - ref["score"]).max() < 5e-3
+    else:
+        assert np.abs(Y - ref["Y"]).mean() < 1e-3
+    with pytest.raises(_lib.DesireError):
+        h.set_training(True)
+    with pytest.raises(ValueError):
+        small_dims(mno=288).validate()
+    with pytest.raises(ValueError):
+        small_dims(mno=160, bf16=1).validate()
