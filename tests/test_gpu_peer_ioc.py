@@ -65,3 +65,33 @@ def test_peer_api_refuses_out_of_order_use():
     with pytest.raises(_lib.DesireError):
         h.ioc_peer_pass(Y.data_ptr(), s.data_ptr())                       # rank 1 not attached yet
     h.peer_close()
+
+
+def test_peer_pass_replays_from_a_hipgraph():
+    """A pass is nothing but kernel launches (epoch bump, waits, publish, steps, counter bumps, finish): captured once with
+    desire_graph_begin / _end and replayed, it gives the same bits as the direct call -- the epoch lives in device memory, so every
+    replay is a new pass of the protocol."""
+    import torch
+    from desire_amd.dist import PeerShardedIoc
+    d = small_dims(K=3, T_pred=9)
+    w = init_weights(d, 23)
+    past, fut, eps, grids, gos = make_case(d, seed=24, n_absent=2)
+    h, keep = _setup_rank(torch, d, w, past, fut, eps, grids, gos)
+    Y0 = torch.as_tensor(h.read_buffer("Y0", (d.R, d.T_pred, 2)).copy(), device="cuda")
+    peer = PeerShardedIoc(h, 0, 1)
+    Ya, sa = Y0.clone(), torch.zeros(d.R, device="cuda")
+    peer.run(Ya, sa)                                                       # direct (also the warm-up: lazy allocations)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    Yb, sb = Y0.clone(), torch.zeros(d.R, device="cuda")
+    torch.cuda.synchronize()
+    h.graph_begin(side.cuda_stream)
+    peer.run(Yb, sb, side.cuda_stream)
+    gid = h.graph_end(side.cuda_stream)
+    for _ in range(3):
+        Yb.copy_(Y0); sb.zero_()
+        torch.cuda.synchronize()
+        h.graph_launch(gid, side.cuda_stream)
+        side.synchronize()
+        assert torch.equal(Yb, Ya) and torch.equal(sb, sa)
+    peer.close()
