@@ -439,6 +439,14 @@ int desire_pack_all(desire_ctx* h) {
             all.insert(all.end(), pv.begin(), pv.end());
         }
         bad |= up_split("ioc/Wsoc16", all);
+        if (d.mno > 128 || d.H == 256) {     // shapes served by the step-wise split kernel (k_ioc_step<.., NP>): the pooled operand is a plain
+            std::vector<float> alll;          // fp32 tile there, so the social weights are wanted in plain k order as well
+            for (int b = 0; b < B; ++b) {
+                const auto pv = pack_vals16(H, H, lin, [&](int k, int n) { return ws[((size_t)b * H + k) * H + n]; });
+                alll.insert(alll.end(), pv.begin(), pv.end());
+            }
+            bad |= up_split("ioc/Wsoc16l", alll);
+        }
         if (d.bf16 == 2) {   // training under dims.bf16 = 2: the two large data-gradient convolutions of the CVAE decoder (kernels_bwd_x3.hip)
             auto taps16 = [&](const std::vector<float>& wt, int CI, int CO) {       // as pack_taps(.., false): w[tap][ci][co]
                 std::vector<float> out;
@@ -807,17 +815,25 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (!h->grids_set) return fail(DESIRE_ERR_STATE, "scene grids not set (desire_set_scene_grids)");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (d.mno > 128) {
-        // Scenes of 160 .. 256 agents (beyond the four-workgroup cluster form: its neighbour masks are 128 bits): the step-wise kernel of the
-        // agent-sharded path with ONE rank -- 32-row tiles of any mix of groups, neighbours' hidden states read from global memory (L2),
-        // 256-bit masks, one launch per step, state ping-ponged between two buffers.  Same summation order as the persistent kernels.
+    // step-wise form (one launch of the agent-sharded kernel per step, a single rank): scenes of 160 .. 256 agents (beyond the cluster
+    // form's 128-bit neighbour masks) on any operands but plain bf16, and -- dims.bf16 = 2 / 3, inference -- H = 256 (BASELINE configs[3]:
+    // no persistent split kernel: the bin-split accumulators do not fit eight waves' registers) with split operands instead of the fp32
+    // fallback: 16.1 -> 9.1 ms (three products) / 12.7 ms (six) at configs[3]'s per-GPU shape.  (Groups of 96 / 128 agents at H <= 128
+    // were measured too: 34.4 vs 34.9 ms with three products, SLOWER with six -- they keep the fp32 cluster kernel.)
+    const int B_ = d.grid_size * d.grid_size;
+    const bool split_mode = (d.bf16 == 2 || d.bf16 == 3) && !h->training;
+    const bool split_served = ioc_x3_supported(d.mno, d.H, B_) || (d.mno == 64 && ioc_x6r2_supported(d.mno, d.H, B_));
+    const bool stepwise = d.mno > 128 || (split_mode && !split_served && d.H == 256 && d.ioc_form == DESIRE_IOC_AUTO);
+    if (stepwise) {
         if (h->training) return fail(DESIRE_ERR_STATE, "training supports up to 128 agents per scene");
         const size_t RH = (size_t)h->R * d.H;
         if (!h->ws.count("stw_h") && (h->ws["stw_h"].alloc(2 * RH * sizeof(float)) || h->ws["stw_sc"].alloc((size_t)h->R * sizeof(float))))
             return fail(DESIRE_ERR_HIP, "hipMalloc failed for the step-wise IOC state");
         float* hb[2] = {W(h, "stw_h"), W(h, "stw_h") + RH};
+        const int NTs = d.H / 32, KXs = d.E_v + d.C + 2 * d.H;
         for (int it = 0; it < d.iters; ++it) {
             launch_hx_rows(hb[1], W(h, "HxHy"), 2 * d.H, d.n_scenes, d.K, d.mno, d.H, s);       // h_{-1} = Hx of the row's agent
+            Timer tm(h, s, "ioc");                                                            // (one profile entry per pass, as for the persistent kernels)
             for (int t = 0; t < d.T_pred; ++t) {
                 IocStepArgs q{};
                 q.t = t; q.rank = 0; q.nranks = 1; q.m_loc = d.mno; q.n_scenes = d.n_scenes; q.K = d.K; q.R = h->R;
@@ -828,7 +844,12 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
                 q.w_vel = D(h, "ioc/vel_w"); q.b_vel = D(h, "ioc/vel_b"); q.Wsoc = D4(h, "ioc/Wsoc"); q.b_soc = D(h, "ioc/soc_b");
                 q.Wg = D4(h, "ioc/Wg"); q.Wc = D4(h, "ioc/Wc"); q.b_g = D(h, "ioc/gb"); q.b_c = D(h, "ioc/cb"); q.w_score = D(h, "ioc/score_w");
                 q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
-                { Timer tm(h, s, "ioc"); launch_ioc_step(q, s); }
+                if (split_mode) {
+                    q.np = d.bf16 == 3 ? 3 : 2;
+                    q.Wsoc = D4(h, "ioc/Wsoc16l"); q.Wg = D4(h, "ioc/Wg16"); q.Wc = D4(h, "ioc/Wc16");
+                    q.plo_soc = (size_t)B_ * NTs * (d.H / 16) * 64; q.plo_g = (size_t)2 * NTs * (KXs / 16) * 64; q.plo_c = (size_t)NTs * (KXs / 16) * 64;
+                }
+                launch_ioc_step(q, s);
             }
             if (int rc = desire_ioc_finish(h, hb[(d.T_pred - 1) & 1], W(h, "stw_sc"), dev_Yhat, dev_score, stream)) return rc;
         }

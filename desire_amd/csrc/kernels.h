@@ -164,6 +164,7 @@ struct IocStepArgs {
     const float* w_vel; const float* b_vel; const float4* Wsoc; const float* b_soc;
     const float4* Wg; const float4* Wc; const float* b_g; const float* b_c; const float* w_score;
     const float* bin_tab;
+    int np; size_t plo_soc, plo_g, plo_c;                  // np = 2 / 3: Wsoc / Wg / Wc are split packs (uint4 units between pieces), see k_ioc_step
 };
 void launch_ioc_step(const IocStepArgs& a, hipStream_t s);
 // peer exchange (kernels_rnn.hip): progress counters in the ranks' exchange regions, written / polled with system-scope atomics

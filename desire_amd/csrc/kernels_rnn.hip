@@ -359,6 +359,7 @@ void launch_decoder(const DecArgs& a, hipStream_t s) {
 // neighbour bit-masks: 32 bits are enough when the tile holds 32 rows (mno <= 32), which keeps a 36-bin tile under half
 // the LDS of a CU (two workgroups per CU); 64-row tiles use 64 bits
 #include "cluster.h"
+#include "split.h"
 template <int TM> struct MaskT { typedef unsigned long long type; };
 template <> struct MaskT<32> { typedef unsigned type; };
 __device__ __forceinline__ int ffs_(unsigned m) { return __ffs((int)m); }
@@ -1170,7 +1171,11 @@ void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
 // pooled operand is built from Hall in global memory (L2), neighbours in ascending global slot order -- the same
 // summation order as the single-GPU kernels, so the result is bit-identical to them.
 // ------------------------------------------------------------------------------------------------
-template <int H, int EV, int C>
+// NP = 0: fp32 operands on the fp32 matrix pipe.  NP = 2 / 3 (dims.bf16 = 2 / 3 at shapes the persistent split kernels do not serve:
+// groups of 96 .. 256 agents, H = 256): the same step with every contraction as three / six bf16 MFMAs per fp32 product -- A fragments
+// split on the fly out of the fp32 LDS tiles (split.h: mma6_groups), weights = the [hi | lo (| lo2)] packs in plain k order
+// ("ioc/Wg16", "ioc/Wc16", "ioc/Wsoc16l"); accumulators, state, gate math and layouts are the fp32 kernel's.
+template <int H, int EV, int C, int NP = 0>
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_step(IocStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, MW = 4;                      // MW 64-bit mask words: up to 256 agents per scene
@@ -1287,7 +1292,13 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         const int b = ffs_(om) - 1;
         om &= om - 1;
         if (om) build(ffs_(om) - 1, buf ^ 1);
-        mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+        if constexpr (NP == 0) mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
+        else {
+            f32x16 t1[1] = {soc};
+            const uint4* bl[1] = {reinterpret_cast<const uint4*>(a.Wsoc) + ((size_t)(b * NT + cb) * (H / 16)) * 64 + lane};
+            mma6_groups<1, NP>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), bl, a.plo_soc, H / 16);
+            soc = t1[0];
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -1295,8 +1306,16 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
     __syncthreads();
     f32x16 rh = zero16(), u = zero16();
-    mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
-    mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
+    if constexpr (NP == 0) {
+        mma1(rh, x_lane, a.Wg + ((size_t)cb * G8) * 64 + lane, G8);
+        mma1(u, x_lane, a.Wg + ((size_t)(cb + NT) * G8) * 64 + lane, G8);
+    } else {
+        f32x16 t2[2] = {rh, u};
+        const uint4* wg = reinterpret_cast<const uint4*>(a.Wg);
+        const uint4* bl[2] = {wg + ((size_t)cb * (KX / 16)) * 64 + lane, wg + ((size_t)(cb + NT) * (KX / 16)) * 64 + lane};
+        mma6_groups<2, NP>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), bl, a.plo_g, KX / 16);
+        rh = t2[0]; u = t2[1];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
 #pragma unroll
@@ -1305,8 +1324,18 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
     __syncthreads();
     f32x16 ac = zero16();
-    mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
-    mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
+    if constexpr (NP == 0) {
+        mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
+        mma1(ac, rh_lane, a.Wc + ((size_t)cb * G8 + GX) * 64 + lane, GH);
+    } else {
+        f32x16 t1[1] = {ac};
+        const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
+        const uint4* bx[1] = {wc + ((size_t)cb * (KX / 16)) * 64 + lane};
+        mma6_groups<1, NP>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), bx, a.plo_c, E / 16);
+        const uint4* bh[1] = {wc + ((size_t)cb * (KX / 16) + E / 16) * 64 + lane};
+        mma6_groups<1, NP>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), bh, a.plo_c, H / 16);
+        ac = t1[0];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
@@ -1334,9 +1363,11 @@ static size_t ioc_step_lds(const IocStepArgs& a) {
 void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 31) / 32), block((a.H / 32) * 64);
     const size_t lds = ioc_step_lds(a);
-    if (a.H == 256) { allow_big_lds(k_ioc_step<256, 16, 32>); hipLaunchKernelGGL((k_ioc_step<256, 16, 32>), grid, block, lds, s, a); }
-    else if (a.H == 128) { allow_big_lds(k_ioc_step<128, 16, 32>); hipLaunchKernelGGL((k_ioc_step<128, 16, 32>), grid, block, lds, s, a); }
-    else { allow_big_lds(k_ioc_step<64, 16, 32>); hipLaunchKernelGGL((k_ioc_step<64, 16, 32>), grid, block, lds, s, a); }
+#define STEP_LAUNCH(HH, NPP) { allow_big_lds(k_ioc_step<HH, 16, 32, NPP>); hipLaunchKernelGGL((k_ioc_step<HH, 16, 32, NPP>), grid, block, lds, s, a); }
+    if (a.np == 2) { if (a.H == 256) STEP_LAUNCH(256, 2) else if (a.H == 128) STEP_LAUNCH(128, 2) else STEP_LAUNCH(64, 2) return; }
+    if (a.np == 3) { if (a.H == 256) STEP_LAUNCH(256, 3) else if (a.H == 128) STEP_LAUNCH(128, 3) else STEP_LAUNCH(64, 3) return; }
+    if (a.H == 256) STEP_LAUNCH(256, 0) else if (a.H == 128) STEP_LAUNCH(128, 0) else STEP_LAUNCH(64, 0)
+#undef STEP_LAUNCH
 }
 // ---- peer exchange: progress counters ------------------------------------------------------------------------------
 // Every rank owns one 32-bit counter in its exchange region; value = epoch * per_pass + stage, monotonic over the passes.  A rank's

@@ -54,6 +54,9 @@ def test_default_contract_fields():
     assert wl["host_loader"]["next_batch_into_pinned_f32_windows_per_s"] > 0 and wl["host_loader"]["next_batch_windows_per_s"] > 0
     assert wl["device_builder"]["windows_per_s"] > 0 and wl["resident"]["value"] > 0
     assert 0.5 < wl["fed_by_host_loader"]["fraction_of_resident"] < 1.1 and 0.5 < wl["fed_by_device_builder"]["fraction_of_resident"] < 1.1
+    c3 = o["alt"]["config3_shape"]                            # BASELINE configs[3] per-GPU shape: fp32 and the step-wise split forms at H = 256
+    assert c3["fp32"]["ioc_ms"] > c3["split_bf16x3"]["ioc_ms"] > 0 and c3["split_bf16x6"]["ioc_ms"] > c3["split_bf16x3"]["ioc_ms"]
+    assert c3["split_bf16x3"]["ioc_max_abs_diff_vs_fp32_kernel"] < 1e-4 and c3["split_bf16x6"]["ioc_max_abs_diff_vs_fp32_kernel"] < 2e-6
     tr = o["alt"]["training_step"]                            # configs[4]'s per-GPU work, fp32 and split operands
     assert tr["fp32"]["value"] > 0 and tr["split_bf16x3"]["value"] > tr["fp32"]["value"] and np.isfinite(tr["split_bf16x3"]["loss"])
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class
