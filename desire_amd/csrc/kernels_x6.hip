@@ -22,7 +22,7 @@
 // three-piece packs.
 // ------------------------------------------------------------------------------------------------------------------
 template <int H, bool SAVE>           // SAVE: training-mode forward (gates / candidate / hidden states kept for BPTT, fp32)
-__global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_x6(DecArgs a) {
+__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decoder_x6(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, LDH = H + 4, LDB = H + 8, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
     constexpr int ILO = TM * LDB;                                      // bf16 elements from one piece's image to the next
@@ -164,9 +164,9 @@ static void launch_dec6(const DecArgs& a, hipStream_t s) {
     allow_big_lds(k_decoder_x6<H, false>);
     hipLaunchKernelGGL((k_decoder_x6<H, false>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }
-bool decoder_x6_supported(int H) { return H == 64 || H == 128; }
+bool decoder_x6_supported(int H) { return H == 64 || H == 128 || H == 256; }
 void launch_decoder_x6(const DecArgs& a, hipStream_t s) {
-    if (a.H == 128) launch_dec6<128>(a, s); else launch_dec6<64>(a, s);
+    if (a.H == 256) launch_dec6<256>(a, s); else if (a.H == 128) launch_dec6<128>(a, s); else launch_dec6<64>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -374,7 +374,7 @@ def test_six_product_form_refuses_training_and_falls_back_on_other_shapes(torch_
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(mno=16, n_scenes=3, K=5), dict(H=64, T_pred=7, K=3, L=64), dict(T_pred=40, K=2), dict(posterior=0, K=3),
-                                dict(H=16, T_pred=8, T_obs=8, K=2, mno=4, n_scenes=3)])
+                                dict(H=16, T_pred=8, T_obs=8, K=2, mno=4, n_scenes=3), dict(H=256, K=2, T_pred=9), dict(H=256, mno=64, n_scenes=1, K=2, n_grids=1, T_pred=40)])
 def test_six_product_sample_generation_stays_in_the_fp32_kernels_class(torch_cuda, kw):
     """dims.bf16 = 3 also runs the GRU decoder, deconv1-3 and the mask fc as six bf16 MFMAs per fp32 product (kernels_x6.hip).  Sample
     generation feeds a DISCONTINUOUS refinement (cells and bins are floors of the sampled positions), so the claim is strict: every stage
