@@ -16,7 +16,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(n):
-        mno = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 64, 96, 128]))
+        mno = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 64, 96, 128, 160, 256]))      # 160 / 256: the step-wise IOC (round 4)
         H = int(rng.choice([16, 32, 64, 128, 128, 256]))
         kw = dict(mno=mno, H=H, K=int(rng.integers(1, 6)), T_pred=int(rng.integers(1, 14)), T_obs=int(rng.integers(2, 9)),
                   n_scenes=int(rng.integers(1, 4)) if mno <= 32 else 1, grid_size=int(rng.integers(1, 7)),
@@ -27,7 +27,7 @@ def main():
             kw["grid_size"] = 4
         if rng.random() < 0.25:
             kw.update(bin_mode=1, nb_w=0.45, nb_h=0.04, grid_size=max(2, kw["grid_size"]))
-        bf16 = int(rng.random() < 0.3)                        # mno 96 / 128: the bf16 cluster form
+        bf16 = int(rng.random() < 0.3 and mno <= 128)         # mno 96 / 128: the bf16 cluster form (160+ agents: fp32 / split operands only)
         split = (not bf16) and rng.random() < 0.45            # dims.bf16 = 2 / 3: split operands (fp32 kernels where no split form exists)
         six = split and rng.random() < 0.5                    # three pieces, six products: the fp32 kernels' accuracy class (sample generation too)
         bn_mode = int(rng.choice([1, 2])) if (not bf16) and rng.random() < 0.25 else 0
