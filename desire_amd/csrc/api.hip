@@ -1118,9 +1118,10 @@ extern "C" int desire_peer_export(desire_handle* h, uint8_t* handle_out64, size_
             return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the peer error word");
         }
         *h->peer_err = 0;
+        for (const char* nm : {"peer_epoch", "peer_score", "peer_hT"}) h->ws[nm].release();          // (export after a close: no leak)
         if (h->ws["peer_epoch"].alloc(sizeof(unsigned)) || h->ws["peer_score"].alloc((size_t)h->R * sizeof(float)) ||
             h->ws["peer_hT"].alloc((size_t)h->R * h->d.H * sizeof(float)))
-            return fail(DESIRE_ERR_HIP, "hipMalloc failed for the peer tables");
+            return fail(DESIRE_ERR_HIP, "hipMalloc failed for the peer buffers");
         HIPCHK(hipMemset(h->ws["peer_epoch"].p, 0, sizeof(unsigned)));
     }
     hipIpcMemHandle_t hd;

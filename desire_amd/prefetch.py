@@ -122,9 +122,6 @@ class _FeederBase(object):
             self._copy_stream.wait_event(ev)             # the step that read this slot has finished with it (device-side wait)
         return slot
 
-    def _schedule(self):
-        raise NotImplementedError
-
     def _produce(self) -> None:
         raise NotImplementedError
 
