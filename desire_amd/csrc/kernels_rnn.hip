@@ -1178,7 +1178,9 @@ void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
 template <int H, int EV, int C, int NP = 0>
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_step(IocStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 32, MW = 4;                      // MW 64-bit mask words: up to 256 agents per scene
+    constexpr int TM = 32;
+    const int MW = (a.m_loc * a.nranks + 63) >> 6;      // 64-bit mask words per (row, bin): 1 .. 4 (up to 256 agents per scene) -- sized by the scene, so
+                                                        // that at H <= 128 and <= 64 agents the tile stays under 80 KB and two workgroups share a CU
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDX = KX + 4, LDB = H + 4;
     constexpr int NTHR = NT * 64, TPR = NTHR / TM;
     constexpr int G8 = KX >> 3, GH = H >> 3, GX = E >> 3;
@@ -1358,7 +1360,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
 }
 static size_t ioc_step_lds(const IocStepArgs& a) {
     const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G, TM = 32;
-    return ((size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * 4 * 2 + 3 * EV + NT * TM) * sizeof(float) + 64;
+    const int MW = (a.m_loc * a.nranks + 63) >> 6;
+    return ((size_t)TM * LDX + 2 * TM * LDB + (size_t)TM * B * MW * 2 + 3 * EV + NT * TM) * sizeof(float) + 64;
 }
 void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 31) / 32), block((a.H / 32) * 64);
