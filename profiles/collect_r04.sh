@@ -50,6 +50,9 @@ fi
 if want config3; then
   stats bench_config3_shape --mno 64 --H 256 --K 50 --windows 4 --steps 10 --warmup 3
   pmc   bench_config3_shape --mno 64 --H 256 --K 50 --windows 4
+  stats bench_config3_shape_split --mno 64 --H 256 --K 50 --windows 4 --split --steps 10 --warmup 3       # k_ioc_step<256, 16, 32, 2>: one launch per step
+  pmc   bench_config3_shape_split --mno 64 --H 256 --K 50 --windows 4 --split
+  stats bench_config3_shape_x6 --mno 64 --H 256 --K 50 --windows 4 --x6 --steps 10 --warmup 3
 fi
 if want train; then
   stats train --train --steps 5 --warmup 2
