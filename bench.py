@@ -1142,7 +1142,12 @@ def main():
         elif a.mno != 32 or a.H != 128 or a.K != 20 or a.grid != 4:
             out["config"]["workload"] = ("non-default shape: %d agent slots/window, K=%d, H=%d, social grid %dx%d, T_obs=8/T_pred=40, fp32; "
                                          "%d windows/step/GPU" % (d.mno, d.K, d.H, a.grid, a.grid, a.windows))
-            out["roofline"]["kernel"] = "k_ioc%s<%d,16,32>" % ("_cl" if d.mno > 64 else "", d.H)
+            if a.split or a.x6:      # H = 256 and scenes of more than 128 agents: the step-wise kernel, one launch per step
+                if d.H == 256 or d.mno > 128:
+                    out["roofline"]["kernel"] = "k_ioc_step<%d,16,32,%d>" % (d.H, 3 if a.x6 else 2)
+            else:
+                out["roofline"]["kernel"] = ("k_ioc_step<%d,16,32,0>" % d.H) if d.mno > 128 else \
+                                            ("k_ioc_cl<%d,16,32,false>" % d.H) if (d.mno > 64 or d.H == 256) else "k_ioc<%d,16,32,%d,false,false>" % (d.H, d.mno)
         if comm:
             out["comm"] = comm
         if a.bn == "per_object":

@@ -1176,7 +1176,7 @@ extern "C" int desire_peer_open_ptr(desire_handle* h, int32_t rank, int32_t nran
 }
 
 extern "C" int desire_peer_close(desire_handle* h) {
-    if (!h) return DESIRE_OK;
+    if (!h) return fail(DESIRE_ERR_ARG, "null handle");
     (void)hipDeviceSynchronize();
     for (int r = 0; r < 8; ++r) {
         if (h->peer_mapped[r] && h->peer_base[r]) (void)hipIpcCloseMemHandle(h->peer_base[r]);

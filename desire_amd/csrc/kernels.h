@@ -242,6 +242,7 @@ struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd
 struct ConvGather { int Cl, Pl, Ps, stride, pad; };
 void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n, hipStream_t s);       // kernels_bwd_x3.hip
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
+int gemm_tn_big_tiles(const TnArgs& a);                      // workgroups per slice of the 128 x 128 / 256 x 64 forms (0: another form)
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,
                      int Hl, int K, int mno, hipStream_t s);
@@ -267,6 +268,7 @@ struct IocBwdArgs {
     float* dHx_rows;
     const float* bin_tab;
     float* bias_part;                                      // optional [32-row blocks][4H]: column sums of da_r | da_u | da_c | dpre_r (32-row forms only)
+    long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);
 bool ioc_bwd_x3_supported(int mno, int H);                       // kernels_bwd_x3.hip: groups of up to 32 agents, H = 64 / 128

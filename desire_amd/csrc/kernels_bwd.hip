@@ -321,12 +321,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     __shared__ __attribute__((aligned(16))) float Gs[2][32 * BN];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int nbn = (a.N + BN - 1) / BN;
-    const int bk = (blockIdx.x / nbn) * BK, bn = (blockIdx.x % nbn) * BN;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int bk = (bx / nbn) * BK, bn = (bx % nbn) * BN;
     const int wk = w / WN, wn = w % WN;
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channels at the same time)
     const long m_hi = a.M, step = (long)a.nslices * 32;
-    const long m_lo = (long)blockIdx.y * 32;
+    const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
     f32x16 acc[2][2];
 #pragma unroll
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
         buf ^= 1;
         m0 = m1;
     }
-    float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
+    float* out = a.partial + (size_t)by * a.Kd * a.N;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -536,11 +537,19 @@ static bool skinny(const float* Wd, int ldw, int KW, const float* Nn, int ldn, i
     return true;
 }
 
+static bool tn_big(const TnArgs& a) {
+    return a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
+           !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);
+}
+// output tiles (= workgroups per slice) of the form launch_gemm_tn picks; 0: the 64 x 64 tiles of k_gemm_tn or a skinny form
+int gemm_tn_big_tiles(const TnArgs& a) {
+    if (!tn_big(a)) return 0;
+    return a.N <= 64 ? (a.Kd + 255) / 256 : ((a.Kd + 127) / 128) * ((a.N + 127) / 128);
+}
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s) {
     if (a.N <= 5 && a.Kd >= 16 && skinny(a.A, a.lda, a.Kd, a.G, a.ldg, a.N, a.M, a.partial, out, ldo, accumulate, false, s)) return;
     if (a.Kd <= 4 && a.N >= 16 && skinny(a.G, a.ldg, a.N, a.A, a.lda, a.Kd, a.M, a.partial, out, ldo, accumulate, true, s)) return;
-    const bool big = a.Kd >= 64 && a.N >= 64 && !(a.lda & 3) && !(a.ldg & 3) && !(a.Kd & 3) && !(a.N & 3) &&
-                     !(reinterpret_cast<uintptr_t>(a.A) & 15) && !(reinterpret_cast<uintptr_t>(a.G) & 15);
+    const bool big = tn_big(a);
     if (big) {
         if (a.np == 2) launch_gemm_tn2_split(a, nullptr, a.N <= 64, s);
         else if (a.N <= 64) {

@@ -64,12 +64,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     u16* Gs = As + 2 * NP * IA;                                     // [2][NP][BN][32]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int nbn = (a.N + BN - 1) / BN;
-    const int bk = (blockIdx.x / nbn) * BK, bn = (blockIdx.x % nbn) * BN;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int bk = (bx / nbn) * BK, bn = (bx % nbn) * BN;
     const int wk = w / WN, wn = w % WN;
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channel at the same time)
     const long m_hi = a.M, step = (long)a.nslices * 32;
-    const long m_lo = (long)blockIdx.y * 32;
+    const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
     f32x16 acc[2][2];
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
         if (mD < m_hi) gload(raA, rgA, mD);
         mA = mB; mB = mC; mC = mD;
     }
-    float* out = a.partial + (size_t)blockIdx.y * a.Kd * a.N;
+    float* out = a.partial + (size_t)by * a.Kd * a.N;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -359,8 +360,17 @@ __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v
 // the piece images take 8-byte writes, and the per-element stream offsets shrink to four per stream (the row-major kernel of round 3
 // spilled 54 dwords of them and took 4.3 ms longer per 81 920-row step).  Bias column sums by a butterfly over the rows (colsum16).
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef DESIRE_IOC_TIMING
+#define TICKB(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICKB(k)
+#endif
 template <int H, int EV, int C>
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32;
     constexpr int NT = H / 32, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
@@ -382,6 +392,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     float* wsc = dsc + TM;                    // [H]
     unsigned char* vld = reinterpret_cast<unsigned char*>(wsc + H);   // [32]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + TM);            // [2] bins that hold a neighbour anywhere in the tile
+    uint2* lut = reinterpret_cast<uint2*>(occ + 2);                   // [16] nibble -> 4 bf16 (0.0 / 1.0): A fragments of the scatter MFMAs
     float* DR = A2;                           // [32][LDR] regression-head operand (prologue only; 2T <= 2H assumed)
 
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
@@ -425,12 +436,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     const uint4* WcT = reinterpret_cast<const uint4*>(a.WcT_h);
     const uint4* WgT = reinterpret_cast<const uint4*>(a.WgT_h);
     const uint4* WsT = reinterpret_cast<const uint4*>(a.WsT);
-    constexpr size_t PLC = (size_t)(2 * NT + 1) * G16 * 64, PLG = (size_t)(2 * NT + 1) * G32 * 64;
-    const size_t PLS = (size_t)B * NT * G16 * 64;
     const uint4* bc2[2] = {WcT + ((size_t)cb * G16) * 64 + lane, WcT + ((size_t)(NT + cb) * G16) * 64 + lane};
     const uint4* bcv[1] = {WcT + ((size_t)(2 * NT) * G16) * 64 + lane};
     const uint4* bg2[2] = {WgT + ((size_t)cb * G32) * 64 + lane, WgT + ((size_t)(NT + cb) * G32) * 64 + lane};
     const uint4* bgv[1] = {WgT + ((size_t)(2 * NT) * G32) * 64 + lane};
+    constexpr size_t PLC = (size_t)(2 * NT + 1) * G16 * 64, PLG = (size_t)(2 * NT + 1) * G32 * 64;
+    const size_t PLS = (size_t)B * NT * G16 * 64;
     // saved activations / gradient streams are addressed as (uniform tile base) + (32-bit offset inside the tile)
     const int nloc = min(TM, a.R - row0);
     const bool rok = lr < nloc;                            // rows past R read the tile's last row; nothing of theirs is stored or summed
@@ -441,6 +452,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     float* o_dac = a.dac + tb * H; float* o_rh = a.rh + tb * H; float* o_hp = a.hprev + tb * H; float* o_dag = a.dag + tb * 2 * H;
     float* o_dpr = a.dpre_r + tb * H; float* o_dpv = a.dpre_v + tb * EV;
 
+    if (tid < 16) {
+        const unsigned lo = ((tid & 1) ? 0x3F80u : 0u) | ((tid & 2) ? 0x3F800000u : 0u);
+        const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
+        lut[tid] = make_uint2(lo, hi2);
+    }
+    const int gb31 = (lr / a.mno) * a.mno;                 // first tile row of the group this lane's row belongs to (obs bits are slots of the group)
     for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
     if (tid < TM) {
         const int row = min(row0 + tid, a.R - 1);
@@ -465,7 +482,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         int rc = rcl;
         asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
         const unsigned rt = (unsigned)(rc * a.T + t);
+        TICKB(0)
         __syncthreads();
+        TICKB(1)
         // ---- P0: positions, cleared masks, h_{t-1} tile ----
         if (tid < TM) {
             const int row = min(row0 + tid, a.R - 1);
@@ -488,7 +507,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             }
         };
         load_hprev();                                    // read by part 1 and by the pooled rebuild of this step
+        TICKB(2)
         __syncthreads();
+        TICKB(3)
         // ---- P1: neighbour / observer masks ----
         {
             const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
@@ -542,12 +563,19 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             put4(I2, LDB2, ILO2, H + c0 + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);      // (the dpool tiles that share A2 were last read before the step's barrier)
         }
         cs_c += colsum16(sc_c); cs_u += colsum16(sc_u);
+        TICKB(4)
         __syncthreads();
+        TICKB(5)
         f32x16 dev = zero16(), der;
         {
             f32x16 t2[2] = {zero16(), zero16()};                  // drh | de_r, one pass over the da_c fragments
-            mmax_groups<2, 2, true>(t2, a3_lane, ILO1, bc2, PLC, G16);
-            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2, true>(tv, a3_lane, ILO1, bcv, PLC, G16); dev = tv[0]; }
+            if (cb == 0) {                                        // (the e_v tile rides on the same fragment stream: one latency chain for this wave, not two)
+                f32x16 t3[3] = {t2[0], t2[1], dev};
+                const uint4* b3[3] = {bc2[0], bc2[1], bcv[0]};
+                mmax_groups<3, 2, true>(t3, a3_lane, ILO1, b3, PLC, G16);
+                t2[0] = t3[0]; t2[1] = t3[1]; dev = t3[2];
+            } else
+                mmax_groups<2, 2, true>(t2, a3_lane, ILO1, bc2, PLC, G16);
             der = t2[1];
             float sc_r[16];
 #pragma unroll
@@ -567,13 +595,20 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             }
             cs_r += colsum16(sc_r);
         }
+        TICKB(6)
         __syncthreads();
+        TICKB(5)
         // (h_{t-1} is still in its tile -- da_c went to the images, not over it as in the fp32 kernel -- so the pooled rebuild needs no reload);
         // da_c is consumed, its images take dpre_r
         {
             f32x16 t2[2] = {zero16(), der};                       // dh (gates) | de_r
-            mmax_groups<2, 2, true>(t2, a2_lane, ILO2, bg2, PLG, G32);
-            if (cb == 0) { f32x16 tv[1] = {dev}; mmax_groups<1, 2, true>(tv, a2_lane, ILO2, bgv, PLG, G32); dev = tv[0]; }
+            if (cb == 0) {
+                f32x16 t3[3] = {t2[0], t2[1], dev};
+                const uint4* b3[3] = {bg2[0], bg2[1], bgv[0]};
+                mmax_groups<3, 2, true>(t3, a2_lane, ILO2, b3, PLG, G32);
+                t2[0] = t3[0]; t2[1] = t3[1]; dev = t3[2];
+            } else
+                mmax_groups<2, 2, true>(t2, a2_lane, ILO2, bg2, PLG, G32);
             float sc_p[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -599,15 +634,18 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             }
             cs_p += colsum16(sc_p);
         }
+        TICKB(7)
         __syncthreads();
+        TICKB(5)
         // ---- social pooling backward ----
-        float4 nb[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) nb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // dh_j += sum_b sum_{i : j in bin b of i} dpool_b[i] = sum_b (M_b^T dpool_b)[j]: dpool_b comes out of its contraction UNtransposed (lane = hidden
+        // column, registers = rows), which is the B-operand layout of a second MFMA whose A operand is the 0/1 observer matrix (exact in bf16, built from
+        // the obs bit words through the nibble table): the scatter costs 4 MFMAs per bin and wave and no LDS tile, no barrier and no gather loop --
+        // the bin loop runs barrier-free, every wave on its own column block.  (dpool_b enters as its two bf16 pieces, like every operand of this kernel.)
+        f32x16 nbacc = zero16();
         // bins without a neighbour anywhere in the tile have dpool_b gathered by nobody: only their (zero) pooled rows are written
         unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
         om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
-        int buf = 0;
         for (int b = 0; b < B; ++b) {
             const bool live = (om >> b) & 1ull;
             {   // pooled_b[i] = sum_{j in bin b of i} h_{t-1}[j]  -> HBM (operand of the social-fc weight gradient)
@@ -631,34 +669,30 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(dst + c * 4 * TPR) = s[c];
                 }
             }
+            TICKB(8)
             if (!live) continue;
-            float* dp = DP + buf * TM * LD1;
-            buf ^= 1;
-            {
-                f32x16 dpl[1] = {zero16()};
-                const uint4* bs[1] = {WsT + ((size_t)(b * NT + cb) * G16) * 64 + lane};
-                mmax_groups<1, 2, true>(dpl, a3_lane, ILO1, bs, PLS, G16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dp + lr * LD1 + c0 + 8 * q) = make_float4(dpl[0][4 * q], dpl[0][4 * q + 1], dpl[0][4 * q + 2], dpl[0][4 * q + 3]);
-            }
-            __syncthreads();
-            mask_t m2 = obs[r8 * B + b];
-            while (m2) {
-                const int i2 = ffsm(m2) - 1;
-                m2 &= m2 - 1;
-                const int srow = grp_base + i2;
-                const float* src = dp + srow * LD1 + q8 * 4;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + c * 4 * TPR);
-                    nb[c].x += v.x; nb[c].y += v.y; nb[c].z += v.z; nb[c].w += v.w;
-                }
-            }
+            f32x16 dpl[1] = {zero16()};
+            const unsigned ts[1] = {(unsigned)((b * NT + cb) * G16 * 64)};
+            mmax_ring<1, 2, false, G16, G16>(dpl, a3_lane, ILO1, WsT, ts, (unsigned)PLS);
+            TICKB(9)
+            // accumulator elements 0..7 = rows 4 hi + {0..3, 8..11}, elements 8..15 = the same + 16: the k order of the two scatter MFMAs
+            const FragP<2> p0 = split8<2>(dpl[0][0], dpl[0][1], dpl[0][2], dpl[0][3], dpl[0][4], dpl[0][5], dpl[0][6], dpl[0][7]);
+            const FragP<2> p1 = split8<2>(dpl[0][8], dpl[0][9], dpl[0][10], dpl[0][11], dpl[0][12], dpl[0][13], dpl[0][14], dpl[0][15]);
+            const unsigned mo = ((unsigned)obs[lr * B + b] << gb31) >> (4 * hi);        // observers of row j = lr as tile rows, this half-wave's rows first
+            const uint2 l0 = lut[mo & 15u], l1 = lut[(mo >> 8) & 15u], l2 = lut[(mo >> 16) & 15u], l3 = lut[(mo >> 24) & 15u];
+            const uint4 m0 = make_uint4(l0.x, l0.y, l1.x, l1.y), m1 = make_uint4(l2.x, l2.y, l3.x, l3.y);
+            nbacc = mfma16(m0, p0.p[1], nbacc); nbacc = mfma16(m1, p1.p[1], nbacc);
+            nbacc = mfma16(m0, p0.p[0], nbacc); nbacc = mfma16(m1, p1.p[0], nbacc);
+            TICKB(11)
         }
+        TICKB(10)
+        __syncthreads();                                   // every wave is done with h_{t-1} (pooled rebuilds): its tile takes the neighbour gradient
+        TICKB(5)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(NB + r8 * LD1 + q8 * 4 + c * 4 * TPR) = nb[c];
+        for (int i = 0; i < 16; ++i) NB[(4 * hi + 8 * (i >> 2) + (i & 3)) * LD1 + cb * 32 + lr] = nbacc[i];
+        TICKB(11)
         __syncthreads();
+        TICKB(5)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 n4 = *reinterpret_cast<const float4*>(NB + lr * LD1 + c0 + 8 * q);
@@ -675,6 +709,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             part[colb] = cs_r; part[H + colb] = cs_u; part[2 * H + colb] = cs_c; part[3 * H + colb] = cs_p;
         }
     }
+#ifdef DESIRE_IOC_TIMING
+    if (a.dbg && blockIdx.x == 7 && tid == 0)
+        for (int k = 0; k < 12; ++k) a.dbg[k] = tacc[k];
+#endif
     if (rok) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -690,7 +728,7 @@ template <int H>
 void launch_ioc_bwd_x3_t(const IocBwdArgs& a, hipStream_t s) {
     const int B = a.G * a.G;
     const size_t lds = (size_t)(32 * (H + 4) * 3) * sizeof(float) + (size_t)2 * 32 * (H + 8) * sizeof(u16) + (size_t)2 * 32 * B * sizeof(unsigned)
-                       + (size_t)(32 * 2 + 32 + H) * sizeof(float) + 32 + 64;
+                       + (size_t)(32 * 2 + 32 + H) * sizeof(float) + 32 + 64 + 16 * sizeof(uint2);
     allow_big_lds(k_ioc_bwd_x3<H, 16, 32>);
     hipLaunchKernelGGL((k_ioc_bwd_x3<H, 16, 32>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }

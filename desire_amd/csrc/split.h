@@ -131,3 +131,42 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
     if (g < G) run(b0, g);
 }
 
+// The same contraction with D k-groups of pack fragments in flight (ring slot = g % D; G a multiple of D; the loop over rings stays ROLLED so that
+// the fragment addresses are formed per ring -- fully unrolled they are loop invariants of the caller's time loop, get hoisted and spill).
+// One group is only NB * (3 | 6) bf16 MFMAs -- 100 to 200 matrix-pipe cycles against the ~1000 cycles a fragment takes to arrive from L2 under
+// load -- so with ONE group ahead (mmax_groups) every group waits for its fragments: k_ioc_bwd_x3's per-bin contraction ran 8 groups in ~4000 cycles.
+// Fragment addresses are (uniform base in SGPRs) + (lane * 16 in one VGPR): W and the uint4 indices t0[nb] (group 0 of n-tile nb, piece 0) and
+// blo (piece stride) must be wave-uniform.  Per-lane 64-bit pointers per (n-tile, piece, ring slot) would be loop invariants of the caller's
+// time loop -- 2 VGPRs each, hoisted and spilled.
+template <int NB, int NP, bool SWAP, int G, int DW>
+__device__ __forceinline__ void mmax_ring(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* W, const unsigned (&t0)[NB], unsigned blo) {
+    constexpr int D = DW < G ? DW : G;
+    static_assert(G % D == 0, "whole rings");
+    uint4 b[D][NB][NP];
+    const unsigned lane16 = (unsigned)lane_id() * 16u;
+    auto ld = [&](uint4 (&bb)[NB][NP], int g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const char* base = reinterpret_cast<const char*>(W + ((size_t)t0[nb] + (size_t)i * blo + (size_t)g * 64));
+                bb[nb][i] = *reinterpret_cast<const uint4*>(base + lane16);
+            }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) ld(b[d], d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(disable)
+    for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            uint4 av[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + (g0 + d) * 16);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = SWAP ? mfma_xp<NP>(b[d][nb], av, acc[nb]) : mfma_xp<NP>(av, b[d][nb], acc[nb]);
+            if (g0 + D < G) ld(b[d], g0 + d + D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}

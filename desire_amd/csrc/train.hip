@@ -5,6 +5,7 @@
 #include "ctx.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace {
@@ -23,8 +24,12 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
     a.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
+    // slices: the large forms keep two workgroups per CU, and every workgroup walks its whole slice -- one full round of 512 (a second,
+    // partly filled round costs as much as a full one: 680 workgroups took 2.56 ms where 512 take 2.1)
+    const long big_tiles = gemm_tn_big_tiles(a);
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
-    long sl = 2048 / blocks; if (sl < 1) sl = 1; if (sl > 256) sl = 256;
+    long sl = big_tiles ? 512 / big_tiles : 2048 / blocks;
+    if (sl < 1) sl = 1; if (sl > 512) sl = 512;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
     while ((size_t)sl * Kd * N * sizeof(float) > h->ws["tn_partial"].bytes && sl > 1) sl /= 2;
     a.nslices = (int)sl; a.partial = W(h, "tn_partial");
@@ -543,7 +548,23 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                     return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
             } else if (d.bf16 == 2 && (train_x3_mask(h) & 4) && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
                 q.WcT_h = D4(h, "ioc/WcT16"); q.WgT_h = D4(h, "ioc/WgT16"); q.WsT = D4(h, "ioc/WsT16");
+#ifdef DESIRE_IOC_TIMING
+                if (!h->ws.count("dbgb")) { h->ws["dbgb"].alloc(12 * sizeof(long long)); }
+                q.dbg = static_cast<long long*>(h->ws["dbgb"].p);
+#endif
                 launch_ioc_bwd_x3(q, s);
+#ifdef DESIRE_IOC_TIMING
+                {
+                    long long host[12];
+                    (void)hipStreamSynchronize(s);
+                    (void)hipMemcpy(host, q.dbg, sizeof(host), hipMemcpyDeviceToHost);
+                    const char* nm[12] = {"loop tail (dh)", "bar top", "P0 pos/clear/load h", "bar P0", "P1 masks + part 1 (loads, stores, images)", "barriers after parts",
+                                          "t2 mma + dar", "gates mma + dpr", "pooled rebuild + store", "dpool mma + tile write", "bin barrier", "gather / NB"};
+                    long long tot = 0; for (int k = 0; k < 12; ++k) tot += host[k];
+                    fprintf(stderr, "k_ioc_bwd_x3 block 7 wave 0: total %lld cycles\n", tot);
+                    for (int k = 0; k < 12; ++k) fprintf(stderr, "  %-45s %12lld  %5.1f %%\n", nm[k], host[k], 100.0 * host[k] / (double)tot);
+                }
+#endif
             } else
             launch_ioc_bwd(q, s);
             tn(h, sv_h + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, acc, s);

@@ -209,8 +209,12 @@ class DataLoader(object):
             all_frame_data.append(arr)
             frame_list_data.append(fl)
             num_obj_data.append(no)
-        with open(data_file, "wb") as fh:
+        # written beside the target and renamed into place: several ranks preprocess the same directory at start-up
+        # (train.py under torchrun), and a reader must never see a half-written pickle
+        tmp = "%s.%d.tmp" % (data_file, os.getpid())
+        with open(tmp, "wb") as fh:
             pickle.dump((all_frame_data, frame_list_data, num_obj_data), fh, protocol=2)
+        os.replace(tmp, data_file)
 
     def load_preprocessed(self, data_file):
         with open(data_file, "rb") as fh:
