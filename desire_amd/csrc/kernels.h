@@ -237,11 +237,16 @@ struct TnArgs { const float* A; int lda; const float* G; int ldg; long M; int Kd
                 // optional block-sparsity of A: flags[m] bit b set <=> columns [b*fcols, (b+1)*fcols) of row m can be non-zero.  A 32-row
                 // chunk whose flags are clear over the workgroup's whole k-block is skipped (no loads, no MFMAs).
                 const unsigned long long* flags; int fcols;
-                int np; };                                  // 2: split-bf16 operands (hi + lo, three bf16 MFMAs per product) in the large forms; 0: fp32
+                int np;                                     // 2: split-bf16 operands (hi + lo, three bf16 MFMAs per product) in the large forms; 0: fp32
+                // optional ROW LISTS per column block of A (launch_bin_lists): the k-block b = bk / fcols (one output tile row = one block, fcols = 128)
+                // contracts only the rows rowlist[binbase[b] .. + bintotal[b]) -- those whose block b is non-zero -- instead of all M
+                const int* rowlist; const int* binbase; const int* bintotal; };
 // im2col view of a convolution's large-grid tensor as the A operand: column = tap*Cl + cl, row m = (sample, small-grid pixel)
 struct ConvGather { int Cl, Pl, Ps, stride, pad; };
 void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n, hipStream_t s);       // kernels_bwd_x3.hip
 void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStream_t s);
+// per-bin lists of the rows whose flag bit is set, in row order (deterministic): counts = scratch [ceil(M/2048)][B]; binbase [B+1]; bintotal [B]; rowlist [<= M*B]
+void launch_bin_lists(const unsigned long long* flags, long M, int B, int* counts, int* binbase, int* bintotal, int* rowlist, hipStream_t s);
 int gemm_tn_big_tiles(const TnArgs& a);                      // workgroups per slice of the 128 x 128 / 256 x 64 forms (0: another form)
 void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* partial, float* out, int accumulate, hipStream_t s);
 void launch_mask_bwd(const float* p, const float* dxz, const float* Hx, int ldhx, float* dq, float* dHx_rows, int R, int H,

@@ -326,7 +326,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int wk = w / WN, wn = w % WN;
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channels at the same time)
-    const long m_hi = a.M, step = (long)a.nslices * 32;
+    const int* rl = nullptr;                               // row lists (TnArgs::rowlist): this k-block's rows are list entries [0, bintotal[b])
+    long m_hi = a.M;
+    if (!CONV && a.rowlist) { const int b = bk / a.fcols; rl = a.rowlist + a.binbase[b]; m_hi = a.bintotal[b]; }
+    const long step = (long)a.nslices * 32;
     const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
     f32x16 acc[2][2];
@@ -342,6 +345,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int PP = cg.Ps * cg.Ps;
     const int ps_sh = (CONV && cg.Ps > 0 && (cg.Ps & (cg.Ps - 1)) == 0) ? __ffs(cg.Ps) - 1 : -1;
     float4 ra[PA], rg[PG];
+    int ia[PA], ig[PG];                                    // list mode: the next chunk's row indices, fetched one gload ahead
+    auto iload = [&](long m0) {
+        if (CONV || !rl) return;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) { const long m = m0 + ra0 + (256 / QA) * j; ia[j] = m < m_hi ? rl[m] : 0; }
+#pragma unroll
+        for (int j = 0; j < PG; ++j) { const long m = m0 + rg0 + (256 / QG) * j; ig[j] = m < m_hi ? rl[m] : 0; }
+    };
+    iload(m_lo);
     auto gload = [&](long m0) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
@@ -361,7 +373,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
                     if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
                 } else {
-                    v = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + kcol);
+                    const long mr = rl ? (long)ia[j] : m;
+                    v = *reinterpret_cast<const float4*>(a.A + (size_t)mr * a.lda + kcol);
                     // block-sparse A: a block whose flag is clear was never written by the producer (stale memory): read as zero
                     if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -371,8 +384,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const long m = m0 + rg0 + (256 / QG) * j;
-            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)m * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi && na) {
+                const long mr = (!CONV && rl) ? (long)ig[j] : m;
+                v = *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg);
+            }
+            rg[j] = v;
         }
+        iload(m0 + step);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -535,6 +554,81 @@ static bool skinny(const float* Wd, int ldw, int KW, const float* Nn, int ldn, i
     if (transpose_out) hipLaunchKernelGGL(k_reduce_slices_t, dim3((KW * NN + 255) / 256), dim3(256), 0, s, partial, ns, KW, NN, out, ldo, accumulate);
     else reduce_slices(partial, ns, KW, NN, out, ldo, accumulate, s);
     return true;
+}
+
+// ---- per-bin row lists of a block-sparse A operand (the pooled tensor of the social-fc weight gradient) ------------------------------
+// flags[m] bit b = block b of row m is non-zero.  Three passes: counts per (2048-row block, bin); one workgroup turns them into offsets and
+// the bins' bases; the rows are written in row order (so the reduction order -- and the result -- does not depend on scheduling).
+__global__ __launch_bounds__(256) void k_bin_count(const unsigned long long* __restrict__ flags, long M, int B, int* __restrict__ counts) {
+    __shared__ int red[4];
+    const long base = (long)blockIdx.x * 2048 + (long)threadIdx.x * 8;
+    unsigned long long f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (base + k < M) ? flags[base + k] : 0ull;
+    for (int b = 0; b < B; ++b) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += (int)((f[k] >> b) & 1ull);
+        for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[(size_t)blockIdx.x * B + b] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_scan(int* __restrict__ counts, int nblk, int B, int* __restrict__ binbase, int* __restrict__ bintotal) {
+    __shared__ int part[256];
+    const int per = (nblk + 255) / 256, lo = threadIdx.x * per, hi = min(nblk, lo + per);
+    for (int b = 0; b < B; ++b) {
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += counts[(size_t)i * B + b];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+            bintotal[b] = run;
+        }
+        __syncthreads();
+        int run = part[threadIdx.x];
+        for (int i = lo; i < hi; ++i) { const int v = counts[(size_t)i * B + b]; counts[(size_t)i * B + b] = run; run += v; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) { binbase[b] = run; run += bintotal[b]; }
+        binbase[B] = run;
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_fill(const unsigned long long* __restrict__ flags, long M, int B, const int* __restrict__ offs,
+                                                  const int* __restrict__ binbase, int* __restrict__ rowlist) {
+    __shared__ int wsum[4];
+    const long base = (long)blockIdx.x * 2048 + (long)threadIdx.x * 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (base + k < M) ? flags[base + k] : 0ull;
+    for (int b = 0; b < B; ++b) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += (int)((f[k] >> b) & 1ull);
+        int inc = c;                                        // inclusive scan over the wave
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int pos = binbase[b] + offs[(size_t)blockIdx.x * B + b] + (inc - c);
+        for (int i = 0; i < w; ++i) pos += wsum[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((f[k] >> b) & 1ull) rowlist[pos++] = (int)(base + k);
+        __syncthreads();
+    }
+}
+void launch_bin_lists(const unsigned long long* flags, long M, int B, int* counts, int* binbase, int* bintotal, int* rowlist, hipStream_t s) {
+    const int nblk = (int)((M + 2047) / 2048);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, s, flags, M, B, counts);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, s, counts, nblk, B, binbase, bintotal);
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, s, flags, M, B, static_cast<const int*>(counts), static_cast<const int*>(binbase), rowlist);
 }
 
 static bool tn_big(const TnArgs& a) {

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include "split.h"
+#include <cstdio>
 
 namespace {
 
@@ -54,9 +55,19 @@ __device__ __forceinline__ uint4 get_frag(const u16* img, int col, int slot) {
     return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + img_row<BC>(col) * 64 + ((slot ^ img_swz(col)) << 4));
 }
 
+#ifdef DESIRE_IOC_TIMING
+__device__ long long g_tn_ticks[8];
+#define TICKT(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
+#else
+#define TICKT(k)
+#endif
 // (WK*64) x (WN*64) output tile per workgroup, wave = 2x2 tiles of 32x32, 32-row chunks of m double-buffered in LDS as piece images
 template <int WK, int WN, bool CONV, int NP>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg) {
+#ifdef DESIRE_IOC_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#endif
     constexpr int BK = WK * 64, BN = WN * 64, QA = BK / 4, QG = BN / 4, PA = 32 / (256 / QA), PG = 32 / (256 / QG);
     constexpr int IA = BK * 32, IG = BN * 32;                       // bf16 elements of one piece image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
@@ -69,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     const int wk = w / WN, wn = w % WN;
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channel at the same time)
-    const long m_hi = a.M, step = (long)a.nslices * 32;
+    // row lists (TnArgs::rowlist): this k-block's rows are list entries [0, bintotal[b]) instead of all M rows
+    const bool lists = !CONV && a.rowlist != nullptr;
+    const int* const rl = lists ? a.rowlist + a.binbase[bk / a.fcols] : nullptr;
+    const long m_hi = lists ? (long)a.bintotal[bk / a.fcols] : a.M;
+    const long step = (long)a.nslices * 32;
     const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
     f32x16 acc[2][2];
@@ -87,7 +102,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     // two register stages: the chunk after next is already in flight while the current one is multiplied (the contraction is short
     // now -- 24 bf16 MFMAs per wave and chunk -- so one chunk in flight per workgroup left the kernel waiting on HBM latency)
     float4 raA[PA], rgA[PG], raB[PA], rgB[PG];
+    // list mode: the row indices of the chunk the NEXT gload takes (chunks follow each other at a fixed stride there) are fetched one gload ahead,
+    // so a chunk's row loads do not wait for their own indices
+    int ia[CONV ? 1 : PA], ig[CONV ? 1 : PG];
+    auto iload = [&](long m0) {
+        if constexpr (!CONV) {
+            if (!rl) return;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) { const long m = m0 + PA * ra0 + j; ia[j] = m < m_hi ? rl[m] : 0; }
+#pragma unroll
+            for (int j = 0; j < PG; ++j) { const long m = m0 + PG * rg0 + j; ig[j] = m < m_hi ? rl[m] : 0; }
+        }
+    };
+    iload(m_lo);
     auto gload = [&](float4 (&ra)[PA], float4 (&rg)[PG], long m0) {
+        // convolution layers whose small grid is PA pixels wide (every large one here: 8 x 8 with eight rows per thread, 4 x 4 with four): a thread's
+        // rows are ONE row of the grid -- one sample, one py, px = j -- so the eight gathers share a base address and differ by constant strides
+        // (the general form below forms eight 64-bit addresses out of shifts and masks and sat on the register limit: a spill inside this loop
+        // waits for vmcnt(0), i.e. for both prefetched chunks, and the deconv3 weight gradient swung between 5.2 and 8.3 ms with unrelated edits)
+        if (CONV && cg.Ps == PA && ps_sh >= 0) {
+            const long m = m0 + PA * ra0;
+            const long nn = m >> (2 * ps_sh);
+            const int py = (int)(m >> ps_sh) & (PA - 1);
+            const int qy = cg.stride * py + ky - cg.pad;
+            const bool rowok = m < m_hi && ka && qy >= 0 && qy < cg.Pl;
+            const float* base = a.A + (((size_t)nn * cg.Pl + (rowok ? qy : 0)) * cg.Pl) * cg.Cl + cl;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                const int qx = cg.stride * j + kx - cg.pad;
+                ra[j] = (rowok && qx >= 0 && qx < cg.Pl) ? *reinterpret_cast<const float4*>(base + qx * cg.Cl) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const long m = m0 + PA * ra0 + j;
@@ -101,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
                     if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
                 } else {
-                    v = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + kcol);
+                    const long mr = rl ? (long)ia[j] : m;
+                    v = *reinterpret_cast<const float4*>(a.A + (size_t)mr * a.lda + kcol);
                     if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -110,8 +156,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const long m = m0 + PG * rg0 + j;
-            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)m * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi && na) {
+                long mr = m;
+                if constexpr (!CONV) { if (rl) mr = (long)ig[j]; }
+                v = *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg);
+            }
+            rg[j] = v;
         }
+        iload(m0 + step);
     };
     auto lstore = [&](int buf, const float4 (&ra)[PA], const float4 (&rg)[PG]) {
         put_rows<BK, PA, NP>(As + buf * NP * IA, IA, 4 * qa, ra0, ra);
@@ -157,18 +210,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
         const u16* gb = Gs + buf * NP * IG;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            uint4 af[2][NP], gf[2][NP];
+            uint4 gf[2][NP];                                    // (the A fragments one 32-row block at a time: 8 registers fewer in flight)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    af[u][i] = get_frag<BK>(ab + i * IA, wk * 64 + 32 * u + c, 2 * kb + hi);
-                    gf[u][i] = get_frag<BN>(gb + i * IG, wn * 64 + 32 * u + c, 2 * kb + hi);
-                }
+                for (int i = 0; i < NP; ++i) gf[v][i] = get_frag<BN>(gb + i * IG, wn * 64 + 32 * v + c, 2 * kb + hi);
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                uint4 af[NP];
 #pragma unroll
-                for (int v = 0; v < 2; ++v) acc[u][v] = mfma_xp<NP>(af[u], gf[v], acc[u][v]);
+                for (int i = 0; i < NP; ++i) af[i] = get_frag<BK>(ab + i * IA, wk * 64 + 32 * u + c, 2 * kb + hi);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) acc[u][v] = mfma_xp<NP>(af, gf[v], acc[u][v]);
+            }
         }
     };
     // at the loop top: LDS[buf] holds chunk mA, stage B holds chunk mB, stage A holds chunk mC (each only if < m_hi)
@@ -181,23 +235,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     if (mC < m_hi) gload(raA, rgA, mC);
     __syncthreads();
     int buf = 0;
+    TICKT(0)
     while (mA < m_hi) {
         compute(buf);
+        TICKT(1)
         if (mB < m_hi) lstore(buf ^ 1, raB, rgB);
+        TICKT(2)
         __syncthreads();
+        TICKT(3)
         buf ^= 1;
         long mD = mC < m_hi ? next_live(mC + step) : m_hi;
         if (mD < m_hi) gload(raB, rgB, mD);
+        TICKT(4)
         mA = mB; mB = mC; mC = mD;
         if (!(mA < m_hi)) break;
         compute(buf);
+        TICKT(1)
         if (mB < m_hi) lstore(buf ^ 1, raA, rgA);
+        TICKT(2)
         __syncthreads();
+        TICKT(3)
         buf ^= 1;
         mD = mC < m_hi ? next_live(mC + step) : m_hi;
         if (mD < m_hi) gload(raA, rgA, mD);
+        TICKT(4)
         mA = mB; mB = mC; mC = mD;
     }
+#ifdef DESIRE_IOC_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 3 && tid == 0)
+        for (int k = 0; k < 8; ++k) g_tn_ticks[k] = tacc[k];
+#endif
     float* out = a.partial + (size_t)by * a.Kd * a.N;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -216,6 +283,17 @@ void launch_t(const TnArgs& a, const ConvGather& cg, int nblocks, hipStream_t s)
     const size_t lds = (size_t)2 * NP * (WK + WN) * 64 * 32 * sizeof(u16);
     allow_big_lds(k_gemm_tn2_xp<WK, WN, CONV, NP>);
     hipLaunchKernelGGL((k_gemm_tn2_xp<WK, WN, CONV, NP>), dim3(nblocks, a.nslices), dim3(256), lds, s, a, cg);
+#ifdef DESIRE_IOC_TIMING
+    if (a.M > 1000000 && !CONV && !a.flags) {
+        long long host[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn_ticks), sizeof(host));
+        const char* nm[5] = {"prologue", "compute (frag reads + mfma)", "lstore (split + LDS writes; waits for its loads)", "barrier", "next_live + gload issue"};
+        long long tot = 0; for (int k = 0; k < 5; ++k) tot += host[k];
+        fprintf(stderr, "k_gemm_tn2_xp<%d,%d> Kd=%d N=%d slices=%d: total %lld cycles\n", WK, WN, a.Kd, a.N, a.nslices, tot);
+        for (int k = 0; k < 5; ++k) fprintf(stderr, "  %-50s %12lld  %5.1f %%\n", nm[k], host[k], 100.0 * host[k] / (double)tot);
+    }
+#endif
 }
 
 }  // namespace

@@ -13,23 +13,31 @@ namespace {
 int ensure(desire_ctx* h, const char* name, size_t bytes) {
     if (h->ws.count(name) && h->ws[name].bytes >= bytes) return 0;
     if (h->ws.count(name)) h->ws[name].release();
+#ifdef DESIRE_WS_PAD
+    static size_t n_alloc = 0;
+    return h->ws[name].alloc(bytes, (++n_alloc * (size_t)DESIRE_WS_PAD) % ((size_t)1 << 20));
+#else
     return h->ws[name].alloc(bytes);
+#endif
 }
 
 float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slots.at(name).off; }
 
 // weight gradient block: out[Kd, N] = A^T G over M rows, written into a [.., ldo] matrix
 void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M, int Kd, int N, float* out, int ldo,
-        int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0) {
+        int accumulate, hipStream_t s, const unsigned long long* flags = nullptr, int fcols = 0,
+        const int* rowlist = nullptr, const int* binbase = nullptr, const int* bintotal = nullptr) {
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
+    a.rowlist = rowlist; a.binbase = binbase; a.bintotal = bintotal;
     a.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
-    // slices: the large forms keep two workgroups per CU, and every workgroup walks its whole slice -- one full round of 512 (a second,
-    // partly filled round costs as much as a full one: 680 workgroups took 2.56 ms where 512 take 2.1)
-    const long big_tiles = gemm_tn_big_tiles(a);
+    // slices.  Split operands: the large forms keep two workgroups per CU and a workgroup's time per chunk does not depend on its MFMA count
+    // (it waits for its operands), so ONE full round of 512 workgroups is best -- 680 took 2.56 ms where 512 take 1.87.  fp32 operands: the
+    // kernel is bound by the matrix pipe, tiles that hang over Kd / N finish early, and more workgroups than slots balance that (4.16 vs 5.22 ms)
+    const long big_tiles = a.np == 2 ? gemm_tn_big_tiles(a) : 0;
     const long blocks = ((Kd + 63) / 64) * ((N + 63) / 64);
     long sl = big_tiles ? 512 / big_tiles : 2048 / blocks;
-    if (sl < 1) sl = 1; if (sl > 512) sl = 512;
+    if (sl < 1) sl = 1; if (sl > (big_tiles ? 512 : 256)) sl = big_tiles ? 512 : 256;
     const long maxsl = (M + 63) / 64; if (sl > maxsl) sl = maxsl;
     while ((size_t)sl * Kd * N * sizeof(float) > h->ws["tn_partial"].bytes && sl > 1) sl /= 2;
     a.nslices = (int)sl; a.partial = W(h, "tn_partial");
@@ -430,6 +438,8 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dscoreT", R * T * f}, {"ioc_dag", R * T * 2 * H * f}, {"ioc_dac", R * T * H * f}, {"ioc_rh", R * T * H * f},
         {"ioc_hprev", R * T * H * f}, {"ioc_dpre_r", R * T * H * f}, {"ioc_dpre_v", R * T * d.E_v * f}, {"ioc_vel", R * T * 2 * f},
         {"ioc_pooled", R * T * (size_t)h->B * H * f}, {"ioc_pool_flags", R * T * sizeof(unsigned long long)},
+        {"bin_counts", ((R * T + 2047) / 2048) * (size_t)h->B * sizeof(int)}, {"bin_base", ((size_t)h->B + 1) * sizeof(int)},
+        {"bin_total", (size_t)h->B * sizeof(int)}, {"bin_list", H == 128 ? R * T * (size_t)h->B * sizeof(int) : 4},
         {"enc_dag", (size_t)h->A * Tm * 2 * H * f}, {"enc_dac", (size_t)h->A * Tm * H * f}, {"enc_rh", (size_t)h->A * Tm * H * f},
         {"enc_hprev", (size_t)h->A * Tm * H * f},
         {"ex_sv_r", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_u", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_c", (size_t)h->A * d.T_obs * H * f},
@@ -583,8 +593,17 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, acc, s);
             if (cl_bwd) colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
             else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 2 * H, H, G(h, "ioc/candidate/bias"), acc, s);
-            tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s,
-               static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p), H);     // empty (row, t, bin) blocks are skipped
+            const unsigned long long* pflags = static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p);
+            if (H == 128) {
+                // one output tile row = one bin (128 columns): each contracts only the (row, t) pairs that hold a neighbour in ITS bin, from
+                // per-bin row lists built out of the flags -- 23 % of the rows at the bench's density, where skipping whole 32-row chunks
+                // by their OR-ed flags still visited about half of them, zero rows and all
+                int* bl_counts = static_cast<int*>(h->ws["bin_counts"].p); int* bl_base = static_cast<int*>(h->ws["bin_base"].p);
+                int* bl_total = static_cast<int*>(h->ws["bin_total"].p); int* bl_list = static_cast<int*>(h->ws["bin_list"].p);
+                launch_bin_lists(pflags, RT, B, bl_counts, bl_base, bl_total, bl_list, s);
+                tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, nullptr, H, bl_list, bl_base, bl_total);
+            } else
+                tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, pflags, H);   // empty (row, t, bin) blocks are skipped
             if (cl_bwd) colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
             else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 3 * H, H, G(h, "ioc/social_fc/b"), acc, s);
             tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, acc, s);
