@@ -22,14 +22,13 @@ int desire_fail(int code, const std::string& msg);            // sets the thread
     } while (0)
 
 struct DevBuf {
-    void* p = nullptr; size_t bytes = 0; void* base = nullptr;
-    int alloc(size_t b, size_t off = 0) {                   // off: p starts that many bytes into the allocation (staggers the streams' bases)
+    void* p = nullptr; size_t bytes = 0;
+    int alloc(size_t b) {
         bytes = b;
-        hipError_t e = hipMalloc(&base, (b ? b : 4) + off);
-        p = e == hipSuccess ? static_cast<char*>(base) + off : nullptr;
+        hipError_t e = hipMalloc(&p, b ? b : 4);
         return e == hipSuccess ? 0 : -1;
     }
-    void release() { if (base) (void)hipFree(base); p = nullptr; base = nullptr; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
     float* f() const { return static_cast<float*>(p); }
 };
 

@@ -560,6 +560,14 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         int rc = rcl;
         asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
         const unsigned rt = (unsigned)(rc * a.T + t);
+        // this step's gate values are requested before anything else: they arrive while P0 / the mask search run (asked for where part 1
+        // uses them, behind two barriers the compiler does not move loads across, their HBM latency was exposed every step)
+        float4 pu[4], pcx[4], pr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned ix = rt * H + c0 + 8 * q;
+            pu[q] = *reinterpret_cast<const float4*>(svu + ix); pcx[q] = *reinterpret_cast<const float4*>(svc + ix); pr[q] = *reinterpret_cast<const float4*>(svr + ix);
+        }
         TICKB(0)
         __syncthreads();
         TICKB(1)
@@ -613,8 +621,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned ix = rt * H + c0 + 8 * q;
-            const float4 u4 = *reinterpret_cast<const float4*>(svu + ix), cc4 = *reinterpret_cast<const float4*>(svc + ix);
-            const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
+            const float4 u4 = pu[q], cc4 = pcx[q], r4 = pr[q];
             const float4 h4 = *reinterpret_cast<const float4*>(A1 + lr * LD1 + c0 + 8 * q);
             const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0 + 8 * q);
             float dacv[4], dauv[4], rhv[4];

@@ -13,12 +13,7 @@ namespace {
 int ensure(desire_ctx* h, const char* name, size_t bytes) {
     if (h->ws.count(name) && h->ws[name].bytes >= bytes) return 0;
     if (h->ws.count(name)) h->ws[name].release();
-#ifdef DESIRE_WS_PAD
-    static size_t n_alloc = 0;
-    return h->ws[name].alloc(bytes, (++n_alloc * (size_t)DESIRE_WS_PAD) % ((size_t)1 << 20));
-#else
     return h->ws[name].alloc(bytes);
-#endif
 }
 
 float* G(desire_ctx* h, const std::string& name) { return W(h, "Gflat") + h->slots.at(name).off; }
