@@ -314,7 +314,9 @@ __global__ void k_reduce_slices(const float* __restrict__ partial, int nslices, 
 // (the output index map absorbs the interleave).  Needs 16-byte aligned rows (lda, ldg, Kd, N multiples of 4).
 // CONV: the A operand is the im2col view of a convolution's large-grid tensor (ConvGather), column = tap*Cl + cl,
 // row m = (sample, small-grid pixel) -- the weight gradient of a (transposed) convolution as ONE [25*Cl] x [Cs] GEMM.
-template <int WK, int WN, bool CONV>
+// LISTS: the row-list form (TnArgs::rowlist) as an instantiation of its own -- as run-time branches inside the one kernel the list code made the
+// compiler wait for every row load separately (vmcnt(0) per element), and the plain dense calls took twice their time
+template <int WK, int WN, bool CONV, bool LISTS = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     constexpr int BK = WK * 64, BN = WN * 64, QA = BK / 4, QG = BN / 4, PA = 32 / (256 / QA), PG = 32 / (256 / QG);
     __shared__ __attribute__((aligned(16))) float As[2][32 * BK];
@@ -326,9 +328,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int wk = w / WN, wn = w % WN;
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channels at the same time)
-    const int* rl = nullptr;                               // row lists (TnArgs::rowlist): this k-block's rows are list entries [0, bintotal[b])
-    long m_hi = a.M;
-    if (!CONV && a.rowlist) { const int b = bk / a.fcols; rl = a.rowlist + a.binbase[b]; m_hi = a.bintotal[b]; }
+    const int* const rl = LISTS ? a.rowlist + a.binbase[bk / a.fcols] : nullptr;       // this k-block's rows are list entries [0, bintotal[b])
+    const long m_hi = LISTS ? (long)a.bintotal[bk / a.fcols] : a.M;
     const long step = (long)a.nslices * 32;
     const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
@@ -345,13 +346,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int PP = cg.Ps * cg.Ps;
     const int ps_sh = (CONV && cg.Ps > 0 && (cg.Ps & (cg.Ps - 1)) == 0) ? __ffs(cg.Ps) - 1 : -1;
     float4 ra[PA], rg[PG];
-    int ia[PA], ig[PG];                                    // list mode: the next chunk's row indices, fetched one gload ahead
+    int ia[LISTS ? PA : 1], ig[LISTS ? PG : 1];            // list mode: the next chunk's row indices, fetched one gload ahead
     auto iload = [&](long m0) {
-        if (CONV || !rl) return;
+        if constexpr (LISTS) {
 #pragma unroll
-        for (int j = 0; j < PA; ++j) { const long m = m0 + ra0 + (256 / QA) * j; ia[j] = m < m_hi ? rl[m] : 0; }
+            for (int j = 0; j < PA; ++j) { const long m = m0 + ra0 + (256 / QA) * j; ia[j] = m < m_hi ? rl[m] : 0; }
 #pragma unroll
-        for (int j = 0; j < PG; ++j) { const long m = m0 + rg0 + (256 / QG) * j; ig[j] = m < m_hi ? rl[m] : 0; }
+            for (int j = 0; j < PG; ++j) { const long m = m0 + rg0 + (256 / QG) * j; ig[j] = m < m_hi ? rl[m] : 0; }
+        }
     };
     iload(m_lo);
     auto gload = [&](long m0) {
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
                     if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
                 } else {
-                    const long mr = rl ? (long)ia[j] : m;
+                    long mr = m;
+                    if constexpr (LISTS) mr = (long)ia[j];
                     v = *reinterpret_cast<const float4*>(a.A + (size_t)mr * a.lda + kcol);
                     // block-sparse A: a block whose flag is clear was never written by the producer (stale memory): read as zero
                     if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -384,12 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const long m = m0 + rg0 + (256 / QG) * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_hi && na) {
-                const long mr = (!CONV && rl) ? (long)ig[j] : m;
-                v = *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg);
-            }
-            rg[j] = v;
+            long mr = m;
+            if constexpr (LISTS) mr = (long)ig[j];
+            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         iload(m0 + step);
     };
@@ -651,7 +651,8 @@ void launch_gemm_tn(const TnArgs& a, float* out, int ldo, int accumulate, hipStr
             hipLaunchKernelGGL((k_gemm_tn2<4, 1, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
         } else {
             const int nb = ((a.Kd + 127) / 128) * ((a.N + 127) / 128);
-            hipLaunchKernelGGL((k_gemm_tn2<2, 2, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
+            if (a.rowlist) hipLaunchKernelGGL((k_gemm_tn2<2, 2, false, true>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
+            else hipLaunchKernelGGL((k_gemm_tn2<2, 2, false>), dim3(nb, a.nslices), dim3(256), 0, s, a, ConvGather{});
         }
     } else {
         const int nb = ((a.Kd + 63) / 64) * ((a.N + 63) / 64);

@@ -62,7 +62,7 @@ __device__ long long g_tn_ticks[8];
 #define TICKT(k)
 #endif
 // (WK*64) x (WN*64) output tile per workgroup, wave = 2x2 tiles of 32x32, 32-row chunks of m double-buffered in LDS as piece images
-template <int WK, int WN, bool CONV, int NP>
+template <int WK, int WN, bool CONV, int NP, bool LISTS = false>      // LISTS: the row-list form (TnArgs::rowlist), an instantiation of its own
 __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -81,9 +81,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     // slice y takes the 32-row chunks y, y + nslices, y + 2 nslices, ..: the workgroups in flight read NEIGHBOURING chunks (contiguous
     // ranges per slice put every stream a multiple of megabytes apart -- the same HBM channel at the same time)
     // row lists (TnArgs::rowlist): this k-block's rows are list entries [0, bintotal[b]) instead of all M rows
-    const bool lists = !CONV && a.rowlist != nullptr;
-    const int* const rl = lists ? a.rowlist + a.binbase[bk / a.fcols] : nullptr;
-    const long m_hi = lists ? (long)a.bintotal[bk / a.fcols] : a.M;
+    const int* const rl = LISTS ? a.rowlist + a.binbase[bk / a.fcols] : nullptr;
+    const long m_hi = LISTS ? (long)a.bintotal[bk / a.fcols] : a.M;
     const long step = (long)a.nslices * 32;
     const long m_lo = (long)by * 32;
     const int hi = lane >> 5, c = lane & 31;
@@ -104,18 +103,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     float4 raA[PA], rgA[PG], raB[PA], rgB[PG];
     // list mode: the row indices of the chunk the NEXT gload takes (chunks follow each other at a fixed stride there) are fetched one gload ahead,
     // so a chunk's row loads do not wait for their own indices
-    int ia[CONV ? 1 : PA], ig[CONV ? 1 : PG];
-    auto iload = [&](long m0) {
-        if constexpr (!CONV) {
-            if (!rl) return;
+    // Two index sets, tied to the two register stages: a gload FIRST requests the indices of the next gload's chunk (into the other set), THEN its
+    // own rows -- so the wait for those indices (vmcnt = this chunk's row loads) leaves the rows in flight.  Requested after the rows, the indices
+    // were the youngest loads and waiting for them drained the whole prefetch (3.8 instead of 2.1 ms for the social-fc gradient).
+    constexpr int NI = LISTS ? PA : 1, NJ = LISTS ? PG : 1;
+    int iaA[NI], igA[NJ], iaB[NI], igB[NJ];
+    auto iload = [&](int (&ia)[NI], int (&ig)[NJ], long m0) {
+        if constexpr (LISTS) {
 #pragma unroll
             for (int j = 0; j < PA; ++j) { const long m = m0 + PA * ra0 + j; ia[j] = m < m_hi ? rl[m] : 0; }
 #pragma unroll
             for (int j = 0; j < PG; ++j) { const long m = m0 + PG * rg0 + j; ig[j] = m < m_hi ? rl[m] : 0; }
         }
     };
-    iload(m_lo);
-    auto gload = [&](float4 (&ra)[PA], float4 (&rg)[PG], long m0) {
+    iload(iaA, igA, m_lo);
+    auto gload = [&](float4 (&ra)[PA], float4 (&rg)[PG], long m0, int (&ia)[NI], int (&ig)[NJ], int (&ian)[NI], int (&ign)[NJ]) {
+        iload(ian, ign, m0 + step);
         // convolution layers whose small grid is PA pixels wide (every large one here: 8 x 8 with eight rows per thread, 4 x 4 with four): a thread's
         // rows are ONE row of the grid -- one sample, one py, px = j -- so the eight gathers share a base address and differ by constant strides
         // (the general form below forms eight 64-bit addresses out of shifts and masks and sat on the register limit: a spill inside this loop
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
                     if (qy >= 0 && qy < cg.Pl && qx >= 0 && qx < cg.Pl)
                         v = *reinterpret_cast<const float4*>(a.A + (((size_t)n * cg.Pl + qy) * cg.Pl + qx) * cg.Cl + cl);
                 } else {
-                    const long mr = rl ? (long)ia[j] : m;
+                    long mr = m;
+                    if constexpr (LISTS) mr = (long)ia[j];
                     v = *reinterpret_cast<const float4*>(a.A + (size_t)mr * a.lda + kcol);
                     if (a.flags && !((a.flags[m] >> (kcol / a.fcols)) & 1ull)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -156,15 +160,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const long m = m0 + PG * rg0 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_hi && na) {
-                long mr = m;
-                if constexpr (!CONV) { if (rl) mr = (long)ig[j]; }
-                v = *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg);
-            }
-            rg[j] = v;
+            long mr = m;
+            if constexpr (LISTS) mr = (long)ig[j];
+            rg[j] = (m < m_hi && na) ? *reinterpret_cast<const float4*>(a.G + (size_t)mr * a.ldg + bn + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        iload(m0 + step);
     };
     auto lstore = [&](int buf, const float4 (&ra)[PA], const float4 (&rg)[PG]) {
         put_rows<BK, PA, NP>(As + buf * NP * IA, IA, 4 * qa, ra0, ra);
@@ -227,12 +226,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
     };
     // at the loop top: LDS[buf] holds chunk mA, stage B holds chunk mB, stage A holds chunk mC (each only if < m_hi)
     long mA = next_live(m_lo);
-    if (mA < m_hi) gload(raA, rgA, mA);
+    if (mA < m_hi) gload(raA, rgA, mA, iaA, igA, iaB, igB);
     long mB = mA < m_hi ? next_live(mA + step) : m_hi;
-    if (mB < m_hi) gload(raB, rgB, mB);
+    if (mB < m_hi) gload(raB, rgB, mB, iaB, igB, iaA, igA);
     if (mA < m_hi) lstore(0, raA, rgA);
     long mC = mB < m_hi ? next_live(mB + step) : m_hi;
-    if (mC < m_hi) gload(raA, rgA, mC);
+    if (mC < m_hi) gload(raA, rgA, mC, iaA, igA, iaB, igB);
     __syncthreads();
     int buf = 0;
     TICKT(0)
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
         TICKT(3)
         buf ^= 1;
         long mD = mC < m_hi ? next_live(mC + step) : m_hi;
-        if (mD < m_hi) gload(raB, rgB, mD);
+        if (mD < m_hi) gload(raB, rgB, mD, iaB, igB, iaA, igA);
         TICKT(4)
         mA = mB; mB = mC; mC = mD;
         if (!(mA < m_hi)) break;
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
         TICKT(3)
         buf ^= 1;
         mD = mC < m_hi ? next_live(mC + step) : m_hi;
-        if (mD < m_hi) gload(raA, rgA, mD);
+        if (mD < m_hi) gload(raA, rgA, mD, iaA, igA, iaB, igB);
         TICKT(4)
         mA = mB; mB = mC; mC = mD;
     }
@@ -277,12 +276,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2_xp(TnArgs a, ConvGather cg)
             }
 }
 
-template <int WK, int WN, bool CONV>
+template <int WK, int WN, bool CONV, bool LISTS = false>
 void launch_t(const TnArgs& a, const ConvGather& cg, int nblocks, hipStream_t s) {
     constexpr int NP = 2;
     const size_t lds = (size_t)2 * NP * (WK + WN) * 64 * 32 * sizeof(u16);
-    allow_big_lds(k_gemm_tn2_xp<WK, WN, CONV, NP>);
-    hipLaunchKernelGGL((k_gemm_tn2_xp<WK, WN, CONV, NP>), dim3(nblocks, a.nslices), dim3(256), lds, s, a, cg);
+    allow_big_lds(k_gemm_tn2_xp<WK, WN, CONV, NP, LISTS>);
+    hipLaunchKernelGGL((k_gemm_tn2_xp<WK, WN, CONV, NP, LISTS>), dim3(nblocks, a.nslices), dim3(256), lds, s, a, cg);
 #ifdef DESIRE_IOC_TIMING
     if (a.M > 1000000 && !CONV && !a.flags) {
         long long host[8];
@@ -305,7 +304,9 @@ void launch_gemm_tn2_split(const TnArgs& a, const ConvGather* cg, bool narrow_n,
         if (cg) launch_t<4, 1, true>(a, *cg, nb, s); else launch_t<4, 1, false>(a, ConvGather{}, nb, s);
     } else {
         const int nb = ((a.Kd + 127) / 128) * ((a.N + 127) / 128);
-        if (cg) launch_t<2, 2, true>(a, *cg, nb, s); else launch_t<2, 2, false>(a, ConvGather{}, nb, s);
+        if (cg) launch_t<2, 2, true>(a, *cg, nb, s);
+        else if (a.rowlist) launch_t<2, 2, false, true>(a, ConvGather{}, nb, s);
+        else launch_t<2, 2, false>(a, ConvGather{}, nb, s);
     }
 }
 
