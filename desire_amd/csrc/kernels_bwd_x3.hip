@@ -366,32 +366,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_gather_x3(ConvArgs a) {
     const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
     constexpr size_t PLO = (size_t)25 * NT * G16 * 64;                 // uint4 from the hi pack to the lo pack
     const uint4* bl = Wp + ((size_t)nt * G16) * 64 + lane;
-    uint4 b[2][2];
-    b[0][0] = bl[0]; b[0][1] = bl[PLO];
+    // The 25 * G16 fragment pairs of this wave's n-tile are walked as ONE stream (tap-major): a ring of RD pairs in flight.  With one pair
+    // ahead -- MT * 3 MFMAs, 100 to 200 matrix cycles, against ~1000 cycles for a fragment to arrive from L2 -- every k-group waited for its
+    // fragments: 3.76 / 2.58 ms for the two layers where the MFMAs are 0.5 ms.
+    constexpr int NG = 25 * G16, RD = 10;
+    static_assert(NG % RD == 0 && (G16 & (G16 - 1)) == 0, "whole rings; power-of-two k-groups per tap");
+    uint4 b[RD][2];
+    auto frag_at = [&](int idx) { return bl + ((size_t)(idx / G16) * NT * G16 + (idx & (G16 - 1))) * 64; };     // packs are [tap][n-tile][k-group]
+#pragma unroll
+    for (int j = 0; j < RD; ++j) { const uint4* q = frag_at(j); b[j][0] = q[0]; b[j][1] = q[PLO]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const u16* ap[MT];
 #pragma unroll 1
-    for (int tap = 0; tap < 25; ++tap) {
-        const int ky = tap / 5, kx = tap - ky * 5;
-        const u16* ap[MT];
+    for (int c0 = 0; c0 < NG; c0 += RD) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
-            const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
-            ap[m] = img + (ok ? sm[m] * IW * IW + pos(iy, ix) : NPX) * LDB + 8 * hi;
-        }
+        for (int j = 0; j < RD; ++j) {
+            const int idx = c0 + j, tap = idx / G16, g = idx & (G16 - 1);
+            if (j == 0 || g == 0) {                            // (g == 0 is a compile-time test only when RD is a multiple of G16; cheap either way)
+                const int ky = tap / 5, kx = tap - ky * 5;
 #pragma unroll
-        for (int g = 0; g < G16; ++g) {
-            // next fragment pair in flight (the last one re-reads the first: harmless)
-            const int nx = (tap * G16 + g + 1 < 25 * G16) ? tap * G16 + g + 1 : 0;
-            const int ntap = nx / G16, ng = nx - ntap * G16;
-            const uint4* nb = bl + ((size_t)ntap * NT * G16 + ng) * 64;
-            b[(g + 1) & 1][0] = nb[0]; b[(g + 1) & 1][1] = nb[PLO];
+                for (int m = 0; m < MT; ++m) {
+                    const int iy = oy[m] * STRIDE + ky - PAD, ix = ox[m] * STRIDE + kx - PAD;
+                    const bool ok = iy >= 0 && iy < IW && ix >= 0 && ix < IW;
+                    ap[m] = img + (ok ? sm[m] * IW * IW + pos(iy, ix) : NPX) * LDB + 8 * hi;
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 uint4 av[2];
                 av[0] = *reinterpret_cast<const uint4*>(ap[m] + g * 16);
                 av[1] = *reinterpret_cast<const uint4*>(ap[m] + IMG + g * 16);
-                acc[m] = mfma_xp<2>(av, b[g & 1], acc[m]);
+                acc[m] = mfma_xp<2>(av, b[j], acc[m]);
             }
+            if (idx + RD < NG) { const uint4* q = frag_at(idx + RD); b[j][0] = q[0]; b[j][1] = q[PLO]; }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int co = nt * 32 + (lane & 31);
