@@ -51,14 +51,8 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     __syncthreads();
     // head weights of this thread's 16 columns in registers, walked from chunk hrot on (k_decoder: conflict-free 16-byte reads of h)
     const int hq = tid % TPR, hrot = TPR >= 8 ? (hq >> 2) * (TPR == 8 ? 2 : 1) : 0;
-    float hw0[16], hw1[16];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = hq * 16 + 4 * ((jj + hrot) & 3) + e;
-            hw0[4 * jj + e] = wo[c * 2]; hw1[4 * jj + e] = wo[c * 2 + 1];
-        }
+    // (the head weights are read from LDS every step: held in 32 registers they pushed the training-mode form into spills;
+    //  deeper fragment rings in the two contractions -- 4 / 8 k-groups in flight -- were measured with the room this makes: 8.75 - 8.95 vs 8.76 - 8.81 ms)
     float* my_h = hs + (4 * hi) * LDH + col;
     f32x16 xr[1] = {splat16h(a.b_g[col])}, xu[1] = {splat16h(a.b_g[H + col])}, xc[1] = {splat16h(a.b_c[col])};
     {
@@ -135,11 +129,13 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const float4 hv = *reinterpret_cast<const float4*>(hs + r * LDH + hq * 16 + 4 * ((jj + hrot) & 3));
-                s0 = fmaf(hv.x, hw0[4 * jj], s0); s1 = fmaf(hv.x, hw1[4 * jj], s1);
-                s0 = fmaf(hv.y, hw0[4 * jj + 1], s0); s1 = fmaf(hv.y, hw1[4 * jj + 1], s1);
-                s0 = fmaf(hv.z, hw0[4 * jj + 2], s0); s1 = fmaf(hv.z, hw1[4 * jj + 2], s1);
-                s0 = fmaf(hv.w, hw0[4 * jj + 3], s0); s1 = fmaf(hv.w, hw1[4 * jj + 3], s1);
+                const int c = hq * 16 + 4 * ((jj + hrot) & 3);
+                const float4 hv = *reinterpret_cast<const float4*>(hs + r * LDH + c);
+                const float4 wa = *reinterpret_cast<const float4*>(wo + 2 * c), wb = *reinterpret_cast<const float4*>(wo + 2 * c + 4);
+                s0 = fmaf(hv.x, wa.x, s0); s1 = fmaf(hv.x, wa.y, s1);
+                s0 = fmaf(hv.y, wa.z, s0); s1 = fmaf(hv.y, wa.w, s1);
+                s0 = fmaf(hv.z, wb.x, s0); s1 = fmaf(hv.z, wb.y, s1);
+                s0 = fmaf(hv.w, wb.z, s0); s1 = fmaf(hv.w, wb.w, s1);
             }
             const int q8 = hq;
             s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
