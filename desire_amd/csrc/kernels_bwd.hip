@@ -88,6 +88,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
     float* A2 = A1 + TM * LD1;           // [32][LD2]   da_r | da_u
     float* dy = A2 + TM * LD2;           // [32][NW]
     float* wo = dy + TM * NW;            // [NW][H] (transposed: a lane reads the head weights of its four columns as one float4)
+    float* A3 = wo + NW * H;             // [32][LD1]   r * h_{t-1}: staged only to leave as whole rows
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
     const int lr = lane & 31, hi = lane >> 5;
@@ -167,14 +168,23 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
             const float4 dac4 = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]), dau4 = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
             *reinterpret_cast<float4*>(my1 + 8 * q) = dac4;
             *reinterpret_cast<float4*>(my2 + H + 8 * q) = dau4;
-            if (rok) {
-                *reinterpret_cast<float4*>(o_dac + ix) = dac4;
-                *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
-                *reinterpret_cast<float4*>(o_hp + ix) = h4;
-                *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = dau4;
-            }
+            *reinterpret_cast<float4*>(A3 + lr * LD1 + c0 + 8 * q) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
         }
         __syncthreads();
+        // da_c leaves through its LDS tile (the next contraction's operand anyway), every thread one 16-byte piece of a row's 512 contiguous
+        // bytes: whole lines per store instruction.  Stored from the accumulator layout a lane writes 32 bytes of each of 32 different
+        // rows per instruction, and the memory system moved 1.6x the streams' bytes (13.2 GB written for 8.4).
+        // (r h_{t-1} the same way through a tile of its own; h_{t-1} -- the weight gradient's operand -- is a row-for-row copy of the saved states)
+        for (int i = tid; i < nloc * (H >> 2); i += NTHR) {
+            const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+            const size_t o = (size_t)(r * a.T + t) * H + c4 * 4;
+            *reinterpret_cast<float4*>(o_dac + o) = *reinterpret_cast<const float4*>(A1 + r * LD1 + c4 * 4);
+            *reinterpret_cast<float4*>(o_rh + o) = *reinterpret_cast<const float4*>(A3 + r * LD1 + c4 * 4);
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t > 0) hv = *reinterpret_cast<const float4*>(svh + o - H);
+            else if (a.Hx) hv = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(row0 + r, a.K, a.mno) * a.ldhx + c4 * 4);
+            *reinterpret_cast<float4*>(o_hp + o) = hv;
+        }
         f32x16 drh = zero16();
         mma1t(drh, a1_lane, a.WcT_h + ((size_t)cb * GH) * 64 + lane, GH);
 #pragma unroll
@@ -191,9 +201,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
             }
             const float4 dar4 = make_float4(darv[0], darv[1], darv[2], darv[3]);
             *reinterpret_cast<float4*>(my2 + 8 * q) = dar4;
-            if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = dar4;
         }
         __syncthreads();
+        for (int i = tid; i < nloc * (H >> 1); i += NTHR) {        // [da_r | da_u]: 2H contiguous floats per row
+            const int r = i / (H >> 1), c4 = i - r * (H >> 1);
+            *reinterpret_cast<float4*>(o_dag + (size_t)(r * a.T + t) * 2 * H + c4 * 4) = *reinterpret_cast<const float4*>(A2 + r * LD2 + c4 * 4);
+        }
         f32x16 dhg = zero16();
         mma1t(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
 #pragma unroll
@@ -240,7 +253,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_decoder_bwd(DecBwdArgs a) 
 }
 void launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
     const int H = a.H;
-    const size_t lds = (32 * (H + 4) + 32 * (2 * H + 4) + 32 * 5 + 5 * H) * sizeof(float);
+    const size_t lds = (2 * 32 * (H + 4) + 32 * (2 * H + 4) + 32 * 5 + 5 * H) * sizeof(float);
     const dim3 grid((a.R + 31) / 32);
     if (a.nw == 5) {                                      // the X encoder with the Gaussian head's per-step gradient (desire_set_head_loss)
         if (H == 256) { allow_big_lds(k_decoder_bwd<256, 5>); hipLaunchKernelGGL((k_decoder_bwd<256, 5>), grid, dim3(512), lds, s, a); }
