@@ -1146,6 +1146,17 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         }
         return v[0];
     };
+    // this wave's 32 x 32 block of an fp32 LDS tile (rows 32 mt .., columns col_t + 32 cb ..) leaves as whole 128-byte lines of a stream (see
+    // k_ioc_bwd_x3: from the accumulator layout a store instruction covers 32 bytes of 32 different rows, and the partial lines cost 1.6x the bytes)
+    auto flush32 = [&](const float* tile, int ld, int col_t, float* out, int wout, int col_out, int t) {
+        const int ch = lane & 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = mt * 32 + (lane >> 3) + 8 * k;
+            const float4 v = *reinterpret_cast<const float4*>(tile + r * ld + col_t + cb * 32 + 4 * ch);
+            if (r < nloc) *reinterpret_cast<float4*>(out + (size_t)(r * a.T + t) * wout + col_out + cb * 32 + 4 * ch) = v;
+        }
+    };
     const size_t tb = (size_t)row0 * a.T;
     const float* svu = a.sv_u + tb * H; const float* svc = a.sv_c + tb * H; const float* svr = a.sv_r + tb * H;
     const float* svx = a.sv_x + tb * E;
@@ -1185,16 +1196,18 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
         if (tid < 2) occ[tid] = 0;
         if (CPB && tid < B) rowbits[tid] = 0;
-        auto load_hprev = [&]() {                                              // h_{t-1} tile -> A1's space
+        auto load_hprev = [&](bool keep) {                                     // h_{t-1} tile -> A1's space (keep: and, as whole rows, to the weight gradient's operand stream)
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {
                 const int r = i / (H >> 2), c4 = i - r * (H >> 2);
                 const int row = min(row0 + r, a.R - 1);
                 const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
                                            : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
-                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+                const float4 hv = *reinterpret_cast<const float4*>(src + c4 * 4);
+                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = hv;
+                if (keep && r < nloc) *reinterpret_cast<float4*>(o_hp + (size_t)(r * a.T + t) * H + c4 * 4) = hv;
             }
         };
-        load_hprev();                                    // part 1 reads each element, then overwrites it with da_c
+        load_hprev(true);                                // part 1 reads each element, then overwrites it with da_c
         __syncthreads();
         // ---- P1: neighbour / observer masks ----
         {
@@ -1244,13 +1257,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 const float4 dac4 = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]), dau4 = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
                 *reinterpret_cast<float4*>(A1 + rl * LD1 + c0 + 8 * q) = dac4;
                 *reinterpret_cast<float4*>(A2 + rl * LD2 + H + c0 + 8 * q) = dau4;             // (the dpool tiles that share A2 were last read before the step's barrier)
-                if (rok) {
-                    *reinterpret_cast<float4*>(o_dac + ix) = dac4;
-                    *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
-                    *reinterpret_cast<float4*>(o_hp + ix) = h4;
-                    *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = dau4;
-                }
+                *reinterpret_cast<float4*>(A3 + rl * LD1 + c0 + 8 * q) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);    // r h_{t-1} borrows dpre_r's tile (written two phases on) on its way out
             }
+            flush32(A1, LD1, 0, o_dac, H, 0, t);
+            flush32(A2, LD2, H, o_dag, 2 * H, H, t);
+            flush32(A3, LD1, 0, o_rh, H, 0, t);
             cs_c += colsum16(sc_c); cs_u += colsum16(sc_u);
         }
         __syncthreads();
@@ -1274,13 +1285,13 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 }
                 const float4 dar4 = make_float4(darv[0], darv[1], darv[2], darv[3]);
                 *reinterpret_cast<float4*>(A2 + rl * LD2 + c0 + 8 * q) = dar4;
-                if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = dar4;
             }
+            flush32(A2, LD2, 0, o_dag, 2 * H, 0, t);
             cs_r += colsum16(sc_r);
         }
         __syncthreads();
         // da_c is consumed: its tile now takes h_{t-1} for the pooled rebuild (visible after the next barrier)
-        load_hprev();
+        load_hprev(false);
         {
             f32x16 dhg = zero16();
             mma1t(dhg, a2_lane, a.WgT_h + ((size_t)cb * G2) * 64 + lane, G2);
@@ -1302,7 +1313,6 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 const float4 dpr4 = make_float4(dprv[0], dprv[1], dprv[2], dprv[3]);
                 *reinterpret_cast<float4*>(A3 + rl * LD1 + c0 + 8 * q) = dpr4;
                 if (rok) {
-                    *reinterpret_cast<float4*>(o_dpr + (size_t)rt * H + c0 + 8 * q) = dpr4;
                     if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
                         const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
                         *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
@@ -1310,6 +1320,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     }
                 }
             }
+            flush32(A3, LD1, 0, o_dpr, H, 0, t);
             cs_p += colsum16(sc_p);
         }
         __syncthreads();

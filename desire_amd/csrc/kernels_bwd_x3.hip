@@ -501,6 +501,26 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         *reinterpret_cast<uint2*>(x) = make_uint2(pa[0], pb[0]);
         *reinterpret_cast<uint2*>(x + ilo) = make_uint2(pa[1], pb[1]);
     };
+    // This wave's 32 x 32 block of a [hi | lo] image pair leaves as WHOLE LINES of an fp32 stream: eight lanes per row read it back (its own
+    // columns, just written: LDS is in order within a wave, no barrier) and store 128 contiguous bytes per row.  Stored from the accumulator
+    // layout a lane writes 32 bytes of each of 32 rows per instruction, and the memory system then moves 1.6x the streams' bytes (partial
+    // lines are written back and fetched again: k_decoder_bwd 13.2 -> 8.4 GB written, 5.5 -> 3.6 GB fetched when it stopped doing that).
+    // The stream holds hi + lo, i.e. the value the split weight-gradient kernels would split it into anyway (exact to 2^-17).
+    auto flush32 = [&](const u16* img, int ld, int ilo, int col_img, float* out, int wout, int col_out, int t, int nloc) {
+        const int ch = lane & 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (lane >> 3) + 8 * k;
+            const u16* p = img + r * ld + col_img + cb * 32 + 4 * ch;
+            const uint2 vh = *reinterpret_cast<const uint2*>(p), vl = *reinterpret_cast<const uint2*>(p + ilo);
+            float4 v;
+            v.x = __uint_as_float(vh.x << 16) + __uint_as_float(vl.x << 16);
+            v.y = __uint_as_float(vh.x & 0xffff0000u) + __uint_as_float(vl.x & 0xffff0000u);
+            v.z = __uint_as_float(vh.y << 16) + __uint_as_float(vl.y << 16);
+            v.w = __uint_as_float(vh.y & 0xffff0000u) + __uint_as_float(vl.y & 0xffff0000u);
+            if (r < nloc) *reinterpret_cast<float4*>(out + (size_t)(r * a.T + t) * wout + col_out + cb * 32 + 4 * ch) = v;
+        }
+    };
     // column sums over the tile's rows without 16 accumulators per tensor: a butterfly reduce-scatter over the 16 lanes that share
     // bits 0..3 of the row (15 exchanges): lane bits (b0 b1 b2 b3) end up with the sum of accumulator element 8 b0 + 4 b1 + 2 b2 + b3
     auto colsum16 = [&](const float (&x)[16]) {
@@ -598,7 +618,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 const int row = min(row0 + r, a.R - 1);
                 const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
                                            : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
-                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+                const float4 hv = *reinterpret_cast<const float4*>(src + c4 * 4);
+                *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = hv;
+                if (r < nloc) *reinterpret_cast<float4*>(o_hp + (size_t)(r * a.T + t) * H + c4 * 4) = hv;      // the weight gradient's h_{t-1} operand, whole rows
             }
         };
         load_hprev();                                    // read by part 1 and by the pooled rebuild of this step
@@ -647,15 +669,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 sc_c[i] = rok ? dac : 0.f; sc_u[i] = rok ? dau : 0.f;
                 rr[i] = r; hp[i] = hprev;
             }
-            if (rok) {
-                *reinterpret_cast<float4*>(o_dac + ix) = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]);
-                *reinterpret_cast<float4*>(o_rh + ix) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);
-                *reinterpret_cast<float4*>(o_hp + ix) = h4;
-                *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + H + c0 + 8 * q) = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
-            }
             put4(I3, LDB1, ILO1, c0 + 8 * q, dacv[0], dacv[1], dacv[2], dacv[3]);
-            put4(I2, LDB2, ILO2, H + c0 + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);      // (the dpool tiles that share A2 were last read before the step's barrier)
+            put4(I2, LDB2, ILO2, H + c0 + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);
+            put4(I2, LDB2, ILO2, c0 + 8 * q, rhv[0], rhv[1], rhv[2], rhv[3]);              // r h_{t-1} borrows da_r's slot (written after the next contraction) on its way out
         }
+        flush32(I3, LDB1, ILO1, 0, o_dac, H, 0, t, nloc);
+        flush32(I2, LDB2, ILO2, H, o_dag, 2 * H, H, t, nloc);
+        flush32(I2, LDB2, ILO2, 0, o_rh, H, 0, t, nloc);
         cs_c += colsum16(sc_c); cs_u += colsum16(sc_u);
         TICKB(4)
         __syncthreads();
@@ -684,9 +704,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                     darv[e] = dar;
                     sc_r[i] = rok ? dar : 0.f;
                 }
-                if (rok) *reinterpret_cast<float4*>(o_dag + (size_t)rt * 2 * H + c0 + 8 * q) = make_float4(darv[0], darv[1], darv[2], darv[3]);
                 put4(I2, LDB2, ILO2, c0 + 8 * q, darv[0], darv[1], darv[2], darv[3]);
             }
+            flush32(I2, LDB2, ILO2, 0, o_dag, 2 * H, 0, t, nloc);
             cs_r += colsum16(sc_r);
         }
         TICKB(6)
@@ -717,7 +737,6 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                     sc_p[i] = rok ? dpr : 0.f;
                 }
                 if (rok) {
-                    *reinterpret_cast<float4*>(o_dpr + (size_t)rt * H + c0 + 8 * q) = make_float4(dprv[0], dprv[1], dprv[2], dprv[3]);
                     if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
                         const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
                         *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
@@ -726,6 +745,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 }
                 put4(I3, LDB1, ILO1, c0 + 8 * q, dprv[0], dprv[1], dprv[2], dprv[3]);
             }
+            flush32(I3, LDB1, ILO1, 0, o_dpr, H, 0, t, nloc);
             cs_p += colsum16(sc_p);
         }
         TICKB(7)
