@@ -359,20 +359,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     const int PP = cg.Ps * cg.Ps;
     const int ps_sh = (CONV && cg.Ps > 0 && (cg.Ps & (cg.Ps - 1)) == 0) ? __ffs(cg.Ps) - 1 : -1;
     float4 ra[PA], rg[PG];
+    auto arow = [&](int j) { return CONV ? PA * ra0 + j : ra0 + (256 / QA) * j; };      // chunk row of this thread's j-th A row (convolutions: consecutive = one grid row)
     int ia[LISTS ? PA : 1], ig[LISTS ? PG : 1];            // list mode: the next chunk's row indices, fetched one gload ahead
     auto iload = [&](long m0) {
         if constexpr (LISTS) {
 #pragma unroll
-            for (int j = 0; j < PA; ++j) { const long m = m0 + ra0 + (256 / QA) * j; ia[j] = m < m_hi ? rl[m] : 0; }
+            for (int j = 0; j < PA; ++j) { const long m = m0 + arow(j); ia[j] = m < m_hi ? rl[m] : 0; }
 #pragma unroll
             for (int j = 0; j < PG; ++j) { const long m = m0 + rg0 + (256 / QG) * j; ig[j] = m < m_hi ? rl[m] : 0; }
         }
     };
     iload(m_lo);
     auto gload = [&](long m0) {
+        // convolution layers whose small grid is PA pixels wide: a thread's rows are one row of the grid (one sample, one py, px = j), the
+        // gathers share a base address and differ by constant strides (kernels_bwd_x3.hip: k_gemm_tn2_xp)
+        if (CONV && cg.Ps == PA && ps_sh >= 0) {
+            const long m = m0 + PA * ra0;
+            const long nn = m >> (2 * ps_sh);
+            const int py = (int)(m >> ps_sh) & (PA - 1);
+            const int qy = cg.stride * py + ky - cg.pad;
+            const bool rowok = m < m_hi && ka && qy >= 0 && qy < cg.Pl;
+            const float* base = a.A + (((size_t)nn * cg.Pl + (rowok ? qy : 0)) * cg.Pl) * cg.Cl + cl;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                const int qx = cg.stride * j + kx - cg.pad;
+                ra[j] = (rowok && qx >= 0 && qx < cg.Pl) ? *reinterpret_cast<const float4*>(base + qx * cg.Cl) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const long m = m0 + ra0 + (256 / QA) * j;
+            const long m = m0 + arow(j);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < m_hi && ka) {
                 if (CONV) {
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn2(TnArgs a, ConvGather cg) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < PA; ++j) *reinterpret_cast<float4*>(&As[buf][(ra0 + (256 / QA) * j) * BK + 4 * qa]) = ra[j];
+        for (int j = 0; j < PA; ++j) *reinterpret_cast<float4*>(&As[buf][arow(j) * BK + 4 * qa]) = ra[j];
 #pragma unroll
         for (int j = 0; j < PG; ++j) *reinterpret_cast<float4*>(&Gs[buf][(rg0 + (256 / QG) * j) * BN + 4 * qg]) = rg[j];
     };
