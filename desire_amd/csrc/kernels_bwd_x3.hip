@@ -493,11 +493,14 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     const u16* a2_lane = I2 + (lane & 31) * LDB2 + 8 * (lane >> 5);
     const u16* a3_lane = I3 + (lane & 31) * LDB1 + 8 * (lane >> 5);
     // four consecutive columns c..c+3 of this lane's row -> both piece images of a row-major bf16 tile: one 8-byte LDS write per piece
+    // step-local copies of the lane's coordinates, re-derived from an opaque copy of the lane id at the top of every step: the LDS / stream
+    // addresses built on them are then re-formed where they are used (a few VALU operations) instead of sitting, hoisted, in spilled registers
+    int lr_s = lr, hi_s = hi, c0_s = c0;
     auto put4 = [&](u16* img, int ld, int ilo, int c, float v0, float v1, float v2, float v3) {
         unsigned pa[2], pb[2];
         splitp<2>(v0, v1, pa);
         splitp<2>(v2, v3, pb);
-        u16* x = img + lr * ld + c;
+        u16* x = img + lr_s * ld + c;
         *reinterpret_cast<uint2*>(x) = make_uint2(pa[0], pb[0]);
         *reinterpret_cast<uint2*>(x + ilo) = make_uint2(pa[1], pb[1]);
     };
@@ -507,10 +510,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     // lines are written back and fetched again: k_decoder_bwd 13.2 -> 8.4 GB written, 5.5 -> 3.6 GB fetched when it stopped doing that).
     // The stream holds hi + lo, i.e. the value the split weight-gradient kernels would split it into anyway (exact to 2^-17).
     auto flush32 = [&](const u16* img, int ld, int ilo, int col_img, float* out, int wout, int col_out, int t, int nloc) {
-        const int ch = lane & 7;
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));      // opaque per call: the twenty-odd addresses below are re-formed, not hoisted out of the time loop and spilled
+        const int ch = ln & 7;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int r = (lane >> 3) + 8 * k;
+            const int r = (ln >> 3) + 8 * k;
             const u16* p = img + r * ld + col_img + cb * 32 + 4 * ch;
             const uint2 vh = *reinterpret_cast<const uint2*>(p), vl = *reinterpret_cast<const uint2*>(p + ilo);
             float4 v;
@@ -588,13 +593,18 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     for (int t = a.T - 1; t >= 0; --t) {
         int rc = rcl;
         asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
+        {
+            int ls;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ls) : "v"(lane));
+            lr_s = ls & 31; hi_s = ls >> 5; c0_s = cb * 32 + 4 * hi_s;
+        }
         const unsigned rt = (unsigned)(rc * a.T + t);
         // this step's gate values are requested before anything else: they arrive while P0 / the mask search run (asked for where part 1
         // uses them, behind two barriers the compiler does not move loads across, their HBM latency was exposed every step)
         float4 pu[4], pcx[4], pr[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const unsigned ix = rt * H + c0 + 8 * q;
+            const unsigned ix = rt * H + c0_s + 8 * q;
             pu[q] = *reinterpret_cast<const float4*>(svu + ix); pcx[q] = *reinterpret_cast<const float4*>(svc + ix); pr[q] = *reinterpret_cast<const float4*>(svr + ix);
         }
         TICKB(0)
@@ -646,15 +656,15 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             for (int b = 0; b < B; ++b) fl |= (unsigned long long)(masks[r8 * B + b] != 0) << b;
             a.pool_flags[(size_t)my_row * a.T + t] = fl;
         }
-        f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
+        f32x16 dhp, rr;                              // what part 2 needs: r (h_{t-1} is re-read from its tile; everything else is stored at once)
         float sc_c[16], sc_u[16];
-        const float dscv = dsc[lr];
+        const float dscv = dsc[lr_s];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const unsigned ix = rt * H + c0 + 8 * q;
+            const unsigned ix = rt * H + c0_s + 8 * q;
             const float4 u4 = pu[q], cc4 = pcx[q], r4 = pr[q];
-            const float4 h4 = *reinterpret_cast<const float4*>(A1 + lr * LD1 + c0 + 8 * q);
-            const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0 + 8 * q);
+            const float4 h4 = *reinterpret_cast<const float4*>(A1 + lr_s * LD1 + c0_s + 8 * q);
+            const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0_s + 8 * q);
             float dacv[4], dauv[4], rhv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -667,11 +677,11 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 const float dac = dc * (1.0f - c * c);
                 dacv[e] = dac; dauv[e] = dau; rhv[e] = r * hprev;
                 sc_c[i] = rok ? dac : 0.f; sc_u[i] = rok ? dau : 0.f;
-                rr[i] = r; hp[i] = hprev;
+                rr[i] = r;
             }
-            put4(I3, LDB1, ILO1, c0 + 8 * q, dacv[0], dacv[1], dacv[2], dacv[3]);
-            put4(I2, LDB2, ILO2, H + c0 + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);
-            put4(I2, LDB2, ILO2, c0 + 8 * q, rhv[0], rhv[1], rhv[2], rhv[3]);              // r h_{t-1} borrows da_r's slot (written after the next contraction) on its way out
+            put4(I3, LDB1, ILO1, c0_s + 8 * q, dacv[0], dacv[1], dacv[2], dacv[3]);
+            put4(I2, LDB2, ILO2, H + c0_s + 8 * q, dauv[0], dauv[1], dauv[2], dauv[3]);
+            put4(I2, LDB2, ILO2, c0_s + 8 * q, rhv[0], rhv[1], rhv[2], rhv[3]);              // r h_{t-1} borrows da_r's slot (written after the next contraction) on its way out
         }
         flush32(I3, LDB1, ILO1, 0, o_dac, H, 0, t, nloc);
         flush32(I2, LDB2, ILO2, H, o_dag, 2 * H, H, t, nloc);
@@ -695,16 +705,17 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float darv[4];
+                const float4 h4 = *reinterpret_cast<const float4*>(A1 + lr_s * LD1 + c0_s + 8 * q);      // h_{t-1}, still in its tile (not carried in registers across the contraction)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q + e;
-                    const float dr = t2[0][i] * hp[i];
+                    const float dr = t2[0][i] * f4e(h4, e);
                     dhp[i] += t2[0][i] * rr[i];
                     const float dar = dr * rr[i] * (1.0f - rr[i]);
                     darv[e] = dar;
                     sc_r[i] = rok ? dar : 0.f;
                 }
-                put4(I2, LDB2, ILO2, c0 + 8 * q, darv[0], darv[1], darv[2], darv[3]);
+                put4(I2, LDB2, ILO2, c0_s + 8 * q, darv[0], darv[1], darv[2], darv[3]);
             }
             flush32(I2, LDB2, ILO2, 0, o_dag, 2 * H, 0, t, nloc);
             cs_r += colsum16(sc_r);
@@ -726,7 +737,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             float sc_p[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0 + 8 * q);
+                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0_s + 8 * q);
                 float dprv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -738,12 +749,12 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
                 }
                 if (rok) {
                     if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
-                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
-                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
+                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi_s + 8 * q);
+                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi_s + 8 * q) =
                             make_float4(ev4.x > 0.f ? dev[4 * q] : 0.f, ev4.y > 0.f ? dev[4 * q + 1] : 0.f, ev4.z > 0.f ? dev[4 * q + 2] : 0.f, ev4.w > 0.f ? dev[4 * q + 3] : 0.f);
                     }
                 }
-                put4(I3, LDB1, ILO1, c0 + 8 * q, dprv[0], dprv[1], dprv[2], dprv[3]);
+                put4(I3, LDB1, ILO1, c0_s + 8 * q, dprv[0], dprv[1], dprv[2], dprv[3]);
             }
             flush32(I3, LDB1, ILO1, 0, o_dpr, H, 0, t, nloc);
             cs_p += colsum16(sc_p);
@@ -792,7 +803,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             // accumulator elements 0..7 = rows 4 hi + {0..3, 8..11}, elements 8..15 = the same + 16: the k order of the two scatter MFMAs
             const FragP<2> p0 = split8<2>(dpl[0][0], dpl[0][1], dpl[0][2], dpl[0][3], dpl[0][4], dpl[0][5], dpl[0][6], dpl[0][7]);
             const FragP<2> p1 = split8<2>(dpl[0][8], dpl[0][9], dpl[0][10], dpl[0][11], dpl[0][12], dpl[0][13], dpl[0][14], dpl[0][15]);
-            const unsigned mo = ((unsigned)obs[lr * B + b] << gb31) >> (4 * hi);        // observers of row j = lr as tile rows, this half-wave's rows first
+            const unsigned mo = ((unsigned)obs[lr_s * B + b] << gb31) >> (4 * hi_s);        // observers of row j = lr as tile rows, this half-wave's rows first
             const uint2 l0 = lut[mo & 15u], l1 = lut[(mo >> 8) & 15u], l2 = lut[(mo >> 16) & 15u], l3 = lut[(mo >> 24) & 15u];
             const uint4 m0 = make_uint4(l0.x, l0.y, l1.x, l1.y), m1 = make_uint4(l2.x, l2.y, l3.x, l3.y);
             nbacc = mfma16(m0, p0.p[1], nbacc); nbacc = mfma16(m1, p1.p[1], nbacc);
@@ -803,13 +814,13 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         __syncthreads();                                   // every wave is done with h_{t-1} (pooled rebuilds): its tile takes the neighbour gradient
         TICKB(5)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) NB[(4 * hi + 8 * (i >> 2) + (i & 3)) * LD1 + cb * 32 + lr] = nbacc[i];
+        for (int i = 0; i < 16; ++i) NB[(4 * hi_s + 8 * (i >> 2) + (i & 3)) * LD1 + cb * 32 + lr_s] = nbacc[i];
         TICKB(11)
         __syncthreads();
         TICKB(5)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 n4 = *reinterpret_cast<const float4*>(NB + lr * LD1 + c0 + 8 * q);
+            const float4 n4 = *reinterpret_cast<const float4*>(NB + lr_s * LD1 + c0_s + 8 * q);
             dh[4 * q] = dhp[4 * q] + n4.x; dh[4 * q + 1] = dhp[4 * q + 1] + n4.y; dh[4 * q + 2] = dhp[4 * q + 2] + n4.z; dh[4 * q + 3] = dhp[4 * q + 3] + n4.w;
         }
     }
