@@ -1165,10 +1165,12 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     // this wave's 32 x 32 block of an fp32 LDS tile (rows 32 mt .., columns col_t + 32 cb ..) leaves as whole 128-byte lines of a stream (see
     // k_ioc_bwd_x3: from the accumulator layout a store instruction covers 32 bytes of 32 different rows, and the partial lines cost 1.6x the bytes)
     auto flush32 = [&](const float* tile, int ld, int col_t, float* out, int wout, int col_out, int t) {
-        const int ch = lane & 7;
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));      // opaque per call: the addresses below are re-formed, not hoisted out of the time loop and spilled
+        const int ch = ln & 7;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int r = mt * 32 + (lane >> 3) + 8 * k;
+            const int r = mt * 32 + (ln >> 3) + 8 * k;
             const float4 v = *reinterpret_cast<const float4*>(tile + r * ld + col_t + cb * 32 + 4 * ch);
             if (r < nloc) *reinterpret_cast<float4*>(out + (size_t)(r * a.T + t) * wout + col_out + cb * 32 + 4 * ch) = v;
         }
@@ -1190,6 +1192,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         DR[r * LDR + c] = (c < 2 * a.T && row0 + r < a.R) ? a.dYr[(size_t)(row0 + r) * 2 * a.T + c] : 0.f;
     }
     __syncthreads();
+    int rl_s = rl, hi_s = hi, c0_s = c0;
     float cs_r = 0.f, cs_u = 0.f, cs_c = 0.f, cs_p = 0.f;   // this lane's column sums of da_r, da_u, da_c, dpre_r over its rows and all steps
     f32x16 dh = zero16();
     mma1t(dh, DR + rl * LDR + 4 * hi, a.WrT + ((size_t)cb * (KR / 8)) * 64 + lane, KR / 8);
@@ -1197,6 +1200,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     for (int t = a.T - 1; t >= 0; --t) {
         int rc = rcl;
         asm volatile("v_mov_b32 %0, %1" : "=v"(rc) : "v"(rcl));     // opaque per step: stream offsets are re-formed, not hoisted and spilled
+        {   // the lane's coordinates as step-local values off an opaque lane id: the addresses built on them are re-formed where used (k_ioc_bwd_x3)
+            int ls;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ls) : "v"(lane));
+            hi_s = ls >> 5; rl_s = mt * 32 + (ls & 31); c0_s = cb * 32 + 4 * hi_s;
+        }
         const unsigned rt = (unsigned)(rc * a.T + t);
         __syncthreads();
         // ---- P0: positions, cleared masks, h_{t-1} tile ----
@@ -1248,14 +1256,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         f32x16 dhp, rr, hp;                          // what part 2 needs: r and h_{t-1} (everything else is stored at once)
         {
             float sc_c[16], sc_u[16];
-            const float dscv = dsc[rl];
+            const float dscv = dsc[rl_s];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned ix = rt * H + c0 + 8 * q;
+                const unsigned ix = rt * H + c0_s + 8 * q;
                 const float4 u4 = *reinterpret_cast<const float4*>(svu + ix), cc4 = *reinterpret_cast<const float4*>(svc + ix);
                 const float4 r4 = *reinterpret_cast<const float4*>(svr + ix);
-                const float4 h4 = *reinterpret_cast<const float4*>(A1 + rl * LD1 + c0 + 8 * q);
-                const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0 + 8 * q);
+                const float4 h4 = *reinterpret_cast<const float4*>(A1 + rl_s * LD1 + c0_s + 8 * q);
+                const float4 w4 = *reinterpret_cast<const float4*>(wsc + c0_s + 8 * q);
                 float dacv[4], dauv[4], rhv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1271,9 +1279,9 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     rr[i] = r; hp[i] = hprev;
                 }
                 const float4 dac4 = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]), dau4 = make_float4(dauv[0], dauv[1], dauv[2], dauv[3]);
-                *reinterpret_cast<float4*>(A1 + rl * LD1 + c0 + 8 * q) = dac4;
-                *reinterpret_cast<float4*>(A2 + rl * LD2 + H + c0 + 8 * q) = dau4;             // (the dpool tiles that share A2 were last read before the step's barrier)
-                *reinterpret_cast<float4*>(A3 + rl * LD1 + c0 + 8 * q) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);    // r h_{t-1} borrows dpre_r's tile (written two phases on) on its way out
+                *reinterpret_cast<float4*>(A1 + rl_s * LD1 + c0_s + 8 * q) = dac4;
+                *reinterpret_cast<float4*>(A2 + rl_s * LD2 + H + c0_s + 8 * q) = dau4;             // (the dpool tiles that share A2 were last read before the step's barrier)
+                *reinterpret_cast<float4*>(A3 + rl_s * LD1 + c0_s + 8 * q) = make_float4(rhv[0], rhv[1], rhv[2], rhv[3]);    // r h_{t-1} borrows dpre_r's tile (written two phases on) on its way out
             }
             flush32(A1, LD1, 0, o_dac, H, 0, t);
             flush32(A2, LD2, H, o_dag, 2 * H, H, t);
@@ -1300,7 +1308,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     sc_r[i] = rok ? dar : 0.f;
                 }
                 const float4 dar4 = make_float4(darv[0], darv[1], darv[2], darv[3]);
-                *reinterpret_cast<float4*>(A2 + rl * LD2 + c0 + 8 * q) = dar4;
+                *reinterpret_cast<float4*>(A2 + rl_s * LD2 + c0_s + 8 * q) = dar4;
             }
             flush32(A2, LD2, 0, o_dag, 2 * H, 0, t);
             cs_r += colsum16(sc_r);
@@ -1316,7 +1324,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             float sc_p[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0 + 8 * q);
+                const float4 er4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + EV + C + c0_s + 8 * q);
                 float dprv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1327,11 +1335,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     sc_p[i] = rok ? dpr : 0.f;
                 }
                 const float4 dpr4 = make_float4(dprv[0], dprv[1], dprv[2], dprv[3]);
-                *reinterpret_cast<float4*>(A3 + rl * LD1 + c0 + 8 * q) = dpr4;
+                *reinterpret_cast<float4*>(A3 + rl_s * LD1 + c0_s + 8 * q) = dpr4;
                 if (rok) {
                     if (cb == 0 && q < EV / 8) {                  // the e_v tile: columns 4 hi + 8 q + e < EV
-                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi + 8 * q);
-                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi + 8 * q) =
+                        const float4 ev4 = *reinterpret_cast<const float4*>(svx + (size_t)rt * E + 4 * hi_s + 8 * q);
+                        *reinterpret_cast<float4*>(o_dpv + (size_t)rt * EV + 4 * hi_s + 8 * q) =
                             make_float4(ev4.x > 0.f ? dev[4 * q] : 0.f, ev4.y > 0.f ? dev[4 * q + 1] : 0.f, ev4.z > 0.f ? dev[4 * q + 2] : 0.f, ev4.w > 0.f ? dev[4 * q + 3] : 0.f);
                     }
                 }
@@ -1411,7 +1419,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 mma1t(dpl, a3_lane, a.WsT + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dp + rl * LD1 + c0 + 8 * q) = make_float4(dpl[4 * q], dpl[4 * q + 1], dpl[4 * q + 2], dpl[4 * q + 3]);
+                    *reinterpret_cast<float4*>(dp + rl_s * LD1 + c0_s + 8 * q) = make_float4(dpl[4 * q], dpl[4 * q + 1], dpl[4 * q + 2], dpl[4 * q + 3]);
             }
             __syncthreads();
             mask_t m2 = obs[r8 * B + b];
@@ -1433,7 +1441,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 n4 = *reinterpret_cast<const float4*>(NB + rl * LD1 + c0 + 8 * q);
+            const float4 n4 = *reinterpret_cast<const float4*>(NB + rl_s * LD1 + c0_s + 8 * q);
             dh[4 * q] = dhp[4 * q] + n4.x; dh[4 * q + 1] = dhp[4 * q + 1] + n4.y; dh[4 * q + 2] = dhp[4 * q + 2] + n4.z; dh[4 * q + 3] = dhp[4 * q + 3] + n4.w;
         }
     }
