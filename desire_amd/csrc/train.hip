@@ -589,7 +589,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             if (cl_bwd) colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
             else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 2 * H, H, G(h, "ioc/candidate/bias"), acc, s);
             const unsigned long long* pflags = static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p);
-            if (H == 128) {
+            if (H == 128 && (size_t)RT * (size_t)B < ((size_t)1 << 31)) {      // (list positions are ints)
                 // one output tile row = one bin (128 columns): each contracts only the (row, t) pairs that hold a neighbour in ITS bin, from
                 // per-bin row lists built out of the flags -- 23 % of the rows at the bench's density, where skipping whole 32-row chunks
                 // by their OR-ed flags still visited about half of them, zero rows and all
