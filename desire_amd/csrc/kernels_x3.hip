@@ -151,6 +151,7 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                     splitp<NP>(e0, e1, ep);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<unsigned*>(Xb + i * XLO + r8 * LDXB + j) = ep[i];
+                    if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float2*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + j)) = make_float2(e0, e1);
                 }
                 int cy, cx;
                 scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
@@ -161,6 +162,7 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                     splitp<NP>(g4.x, g4.y, ga); splitp<NP>(g4.z, g4.w, gb);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(Xb + i * XLO + r8 * LDXB + EV + j) = make_uint2(ga[i], gb[i]);
+                    if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + EV + j)) = g4;
                 }
                 for (int j = q8; j < a.mno; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
@@ -327,6 +329,12 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (TRAIN) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (sv_ok(4 * q + e))
+                                sv_x_t[(unsigned)(((arow + e + 8 * q) * a.T + t) * E + EV + C + col)] = fmaxf(soc[0][4 * q + e] + bso, 0.f);
+                    }
                     unsigned pa[NP], pb[NP];
                     put4(Xb + (arow + 8 * q) * LDXB + EV + C + col, LDXB, XLO, fmaxf(soc[0][4 * q] + bso, 0.f), fmaxf(soc[0][4 * q + 1] + bso, 0.f),
                          fmaxf(soc[0][4 * q + 2] + bso, 0.f), fmaxf(soc[0][4 * q + 3] + bso, 0.f), pa, pb);
@@ -335,26 +343,6 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
             TICKX(4)
             __syncthreads();
             TICKX(5)
-            if (TRAIN) {
-                // x_t = [e_v | e_s | e_r] leaves as whole rows out of its (now complete) images, 16 bytes per thread along the row -- hi + lo, the value
-                // the split weight-gradient kernels would split it into anyway; the signs the backward pass tests are those of hi.  Stored element by
-                // element where it was produced (a row's e_r starts mid-line, 192 bytes in; 16 four-byte stores per lane with a bounds test each), the
-                // save cost this phase 3.4x its inference time.
-                constexpr int Q4 = E >> 2;
-                for (int i = tid; i < TM * Q4; i += NTHR) {
-                    const int r = i / Q4, c4 = i - r * Q4;
-                    if (row0 + r < a.R) {
-                        const u16* px = Xb + r * LDXB + 4 * c4;
-                        const uint2 vh = *reinterpret_cast<const uint2*>(px), vl = *reinterpret_cast<const uint2*>(px + XLO);
-                        float4 v;
-                        v.x = __uint_as_float(vh.x << 16) + __uint_as_float(vl.x << 16);
-                        v.y = __uint_as_float(vh.x & 0xffff0000u) + __uint_as_float(vl.x & 0xffff0000u);
-                        v.z = __uint_as_float(vh.y << 16) + __uint_as_float(vl.y << 16);
-                        v.w = __uint_as_float(vh.y & 0xffff0000u) + __uint_as_float(vl.y & 0xffff0000u);
-                        *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r * a.T + t) * E + 4 * c4)) = v;
-                    }
-                }
-            }
             // ---- P4: gates over [x | h], and the candidate's x part (same A fragments: three n-tiles per LDS read) ----
             // B fragments run through a ring of RD4 k-groups, requested RD4 groups (~ 850 matrix cycles) before their use
             f32x16 u, ac = zero16();
