@@ -25,6 +25,9 @@ void tn(desire_ctx* h, const float* A, int lda, const float* Gm, int ldg, long M
     TnArgs a{};
     a.A = A; a.lda = lda; a.G = Gm; a.ldg = ldg; a.M = M; a.Kd = Kd; a.N = N; a.flags = flags; a.fcols = fcols;
     a.rowlist = rowlist; a.binbase = binbase; a.bintotal = bintotal;
+    // row lists serve the 128 x 128 tile form only (one tile row = one flag block of 128 columns); anything else keeps the flag words
+    if (rowlist && !(fcols == 128 && N > 64 && gemm_tn_big_tiles(a) > 0)) a.rowlist = nullptr;
+    if (a.rowlist) a.flags = nullptr;
     a.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
     // slices.  Split operands: the large forms keep two workgroups per CU and a workgroup's time per chunk does not depend on its MFMA count
     // (it waits for its operands), so ONE full round of 512 workgroups is best -- 680 took 2.56 ms where 512 take 1.87.  fp32 operands: the
@@ -596,7 +599,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                 int* bl_counts = static_cast<int*>(h->ws["bin_counts"].p); int* bl_base = static_cast<int*>(h->ws["bin_base"].p);
                 int* bl_total = static_cast<int*>(h->ws["bin_total"].p); int* bl_list = static_cast<int*>(h->ws["bin_list"].p);
                 launch_bin_lists(pflags, RT, B, bl_counts, bl_base, bl_total, bl_list, s);
-                tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, nullptr, H, bl_list, bl_base, bl_total);
+                tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, pflags, H, bl_list, bl_base, bl_total);
             } else
                 tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, pflags, H);   // empty (row, t, bin) blocks are skipped
             if (cl_bwd) colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
