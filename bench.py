@@ -563,8 +563,10 @@ def training_step_leg(d_full, seed, dev, steps):
     p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
     stream = torch.cuda.current_stream().cuda_stream
     Y = torch.zeros((dt_.R, dt_.T_pred, 2), device=dev); sc = torch.zeros((dt_.R,), device=dev)
-    for tag, mode in (("fp32", 0), ("split_bf16x3", 2)):
-        h = _lib.Handle(dt_.replace(bf16=mode))
+    # third entry: dims.flags = DESIRE_FLAG_TRAIN_FWD_3P -- the forward's sample generation with two-piece operands too (gradients within 5e-4
+    # of float64 autograd instead of 2e-4: include/desire_hip.h)
+    for tag, mode, flags in (("fp32", 0, 0), ("split_bf16x3", 2, 0), ("split_bf16x3_two_piece_forward", 2, 2)):
+        h = _lib.Handle(dt_.replace(bf16=mode, flags=flags))
         h.set_weights(w)
         h.set_scene_grids(g_t.data_ptr(), gos)
         h.set_training(True)

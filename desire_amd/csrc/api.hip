@@ -181,7 +181,7 @@ int check_options(const desire_dims& d) {
     }
     if (d.ioc_split < 0 || d.ioc_split > 4) return fail(DESIRE_ERR_ARG, "ioc_split must be 0 (auto), 1 (never split: batch-size invariant results) or 2..4 (cap)");
     if (d.train_fp32_mask < 0 || d.train_fp32_mask > 15) return fail(DESIRE_ERR_ARG, "train_fp32_mask is a mask of bits 1, 2, 4, 8");
-    if (d.flags & ~DESIRE_FLAG_NO_FUSE34) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_TRAIN_FWD_3P)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
     return 0;
 }
 
@@ -754,7 +754,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = D(h, "vae_dec/deconv2/shift");
     // dims.bf16 = 3: six-product forms of the two large transposed convolutions and of the decoder (frozen batch-norm, inference)
     if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv2/W16"); Timer t(h, s, "deconv2"); launch_deconv2_bf16(c, s); }
-    else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s); }
+    else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv2/W6"); Timer t(h, s, "deconv2"); launch_deconv2_x6(c, s, (h->training && (d.flags & DESIRE_FLAG_TRAIN_FWD_3P)) ? 2 : 3); }
     else { Timer t(h, s, "deconv2"); launch_deconv2(c, s);
            if (pobn) normd("vae_dec/deconv2", W(h, "d2"), 64, 64, 0); }
     c.in = W(h, "d2"); c.out = W(h, "d3"); c.Wp = D4(h, "vae_dec/deconv3/W");
@@ -768,7 +768,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         launch_deconv34_bf16(c, D(h, "vae_dec/deconv4/scale"), D(h, "vae_dec/deconv4/shift"), s);
     } else {
         if (d.bf16 == 1) { c.Wp = D4(h, "vae_dec/deconv3/W16"); Timer t(h, s, "deconv3"); launch_deconv3_bf16(c, s); }
-        else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv3/W6"); Timer t(h, s, "deconv3"); launch_deconv3_x6(c, s); }
+        else if (x6gen) { c.Wp = D4(h, "vae_dec/deconv3/W6"); Timer t(h, s, "deconv3"); launch_deconv3_x6(c, s, (h->training && (d.flags & DESIRE_FLAG_TRAIN_FWD_3P)) ? 2 : 3); }
         else { Timer t(h, s, "deconv3"); launch_deconv3(c, s);
                if (pobn) normd("vae_dec/deconv3", W(h, "d3"), 256, 32, 0); }
         c.in = W(h, "d3"); c.out = W(h, "xhat"); c.w_raw = D(h, "vae_dec/deconv4/raw");
@@ -797,7 +797,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     } else
     if (x6gen && decoder_x6_supported(H)) {
         a.Whg = D4(h, "dec/Whg6"); a.Whc = D4(h, "dec/Whc6");
-        Timer t(h, s, "decoder"); launch_decoder_x6(a, s);
+        Timer t(h, s, "decoder"); launch_decoder_x6(a, s, (h->training && (d.flags & DESIRE_FLAG_TRAIN_FWD_3P)) ? 2 : 3);
     } else
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
     if (d.ref_compat)      // model/model.py:286-289: each state [H] re-read as T_obs points (x, y) -> [A, n_dec, T_obs, 2]

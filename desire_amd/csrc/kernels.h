@@ -144,9 +144,9 @@ void launch_ioc_x6r2(const IocArgs& a, hipStream_t s);
 void launch_ioc_x3r2(const IocArgs& a, hipStream_t s);             // ... with two-piece operands (dims.bf16 = 2)
 // sample generation with three-piece operands (kernels_x6.hip, dims.bf16 = 3)
 bool decoder_x6_supported(int H);
-void launch_decoder_x6(const DecArgs& a, hipStream_t s);
-void launch_deconv2_x6(const ConvArgs& a, hipStream_t s);
-void launch_deconv3_x6(const ConvArgs& a, hipStream_t s);
+void launch_decoder_x6(const DecArgs& a, hipStream_t s, int np = 3);      // np = 2 (training-mode form only): two-piece operands
+void launch_deconv2_x6(const ConvArgs& a, hipStream_t s, int np = 3);      // np = 2: the first two pieces of the packs, three products (training-mode forward)
+void launch_deconv3_x6(const ConvArgs& a, hipStream_t s, int np = 3);
             // three bf16 pieces per operand, six products (dims.bf16 = 3)
 // agent-sharded IOC, one step per launch (kernels_rnn.hip: k_ioc_step)
 struct IocStepArgs {

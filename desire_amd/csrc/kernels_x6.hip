@@ -21,7 +21,7 @@
 // wave that owns the columns (splitting the fp32 tile on the fly in every wave: 8.9 ms per 327 680 samples; the images: 8.6 ms).  a.Whg / a.Whc point at the
 // three-piece packs.
 // ------------------------------------------------------------------------------------------------------------------
-template <int H, bool SAVE>           // SAVE: training-mode forward (gates / candidate / hidden states kept for BPTT, fp32)
+template <int H, bool SAVE, int NP = 3>      // NP = 2: three products per fp32 product (the training-mode forward: the first two pieces of the same packs)           // SAVE: training-mode forward (gates / candidate / hidden states kept for BPTT, fp32)
 __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decoder_x6(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32, LDH = H + 4, LDB = H + 8, NT = H >> 5, G = H >> 3, GH16 = H >> 4, NTHR = NT * 64, TPR = NTHR / TM;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     float* wo = hs + TM * LDH;              // [H][2] head weights
     float* pl = wo + 2 * H;                 // [32][2] last observed position
     u16* hb = reinterpret_cast<u16*>(pl + TM * 2);     // [3][32][LDB]  the three bf16 pieces of h      (A operand of the gates)
-    u16* rb = hb + 3 * ILO;                            // [3][32][LDB]  ... of r*h                        (A operand of the candidate)
+    u16* rb = hb + NP * ILO;                            // [3][32][LDB]  ... of r*h                        (A operand of the candidate)
     float* xs = reinterpret_cast<float*>(hb);          // [32][LDH]  x_z tile: prologue only, in the space the images take afterwards
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
@@ -67,12 +67,12 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     __syncthreads();                                   // every wave is done with the x_z tile: its space now carries the images
     // four values of one accumulator column run (rows 4hi + 8q + 0..3) -> every piece's image of a row-major bf16 tile
     auto put4 = [&](u16* img, int q, float v0, float v1, float v2, float v3) {
-        unsigned pa[3], pb[3];
-        splitp<3>(v0, v1, pa);
-        splitp<3>(v2, v3, pb);
+        unsigned pa[NP], pb[NP];
+        splitp<NP>(v0, v1, pa);
+        splitp<NP>(v2, v3, pb);
         u16* x = img + (4 * hi + 8 * q) * LDB + col;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NP; ++i) {
             x[i * ILO] = (u16)pa[i]; x[i * ILO + LDB] = (u16)(pa[i] >> 16); x[i * ILO + 2 * LDB] = (u16)pb[i]; x[i * ILO + 3 * LDB] = (u16)(pb[i] >> 16);
         }
     };
@@ -89,7 +89,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     const float bh0 = a.b_head[0], bh1 = a.b_head[1];
     for (int t = 0; t < a.T; ++t) {
         f32x16 g2[2] = {xr[0], xu[0]};
-        mmax_groups<2, 3>(g2, a8, ILO, bg, PLG, GH16);
+        mmax_groups<2, NP>(g2, a8, ILO, bg, PLG, GH16);
         f32x16 u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
         }
         __syncthreads();
         f32x16 ac[1] = {xc[0]};
-        mmax_groups<1, 3>(ac, r8p, ILO, bc, PLC, GH16);
+        mmax_groups<1, NP>(ac, r8p, ILO, bc, PLC, GH16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float c = tanhf_(ac[0][i]);
@@ -150,8 +150,14 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     }
 }
 template <int H>
-static void launch_dec6(const DecArgs& a, hipStream_t s) {
+static void launch_dec6(const DecArgs& a, hipStream_t s, int np) {
     const size_t lds = (size_t)(32 * (H + 4) + 2 * H + 64) * sizeof(float) + (size_t)6 * 32 * (H + 8) * sizeof(u16);
+    if (a.sv_r && np == 2) {                                   // training-mode forward with two-piece operands (DESIRE_FLAG_TRAIN_FWD_3P)
+        const size_t lds2 = (size_t)(32 * (H + 4) + 2 * H + 64) * sizeof(float) + (size_t)4 * 32 * (H + 8) * sizeof(u16);
+        allow_big_lds(k_decoder_x6<H, true, 2>);
+        hipLaunchKernelGGL((k_decoder_x6<H, true, 2>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds2, s, a);
+        return;
+    }
     if (a.sv_r) {                                              // training-mode forward (api.hip sets all four save streams together)
         allow_big_lds(k_decoder_x6<H, true>);
         hipLaunchKernelGGL((k_decoder_x6<H, true>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
@@ -161,8 +167,8 @@ static void launch_dec6(const DecArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_decoder_x6<H, false>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }
 bool decoder_x6_supported(int H) { return H == 64 || H == 128 || H == 256; }
-void launch_decoder_x6(const DecArgs& a, hipStream_t s) {
-    if (a.H == 256) launch_dec6<256>(a, s); else if (a.H == 128) launch_dec6<128>(a, s); else launch_dec6<64>(a, s);
+void launch_decoder_x6(const DecArgs& a, hipStream_t s, int np) {
+    if (a.H == 256) launch_dec6<256>(a, s, np); else if (a.H == 128) launch_dec6<128>(a, s, np); else launch_dec6<64>(a, s, np);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -170,6 +176,7 @@ void launch_decoder_x6(const DecArgs& a, hipStream_t s) {
 // (sample, input pixel).  A (K = 128) is split ONCE into 3 x 8 register fragments; the B fragments of all 25 taps x 8 k-groups run
 // through one ring RD k-groups deep; 48 MFMAs per tap in two interleaved accumulator chains, then the plain LDS scatter.
 // ------------------------------------------------------------------------------------------------------------------
+template <int NP>                                        // 3: six products (inference), 2: three (the training-mode forward)
 __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo) {
     extern __shared__ __attribute__((aligned(16))) float out_s6[];    // [4][64 px][64 co]
     constexpr int RD = 4;
@@ -180,24 +187,24 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo)
     float* my = out_s6 + (sp * 2) * 4096;
     const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
     for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 af[8][3];
+    uint4 af[8][NP];
     {
         const int row = lane & 31;
         const int smp = min(s0 + (row >> 4), a.n - 1);
         const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const FragP<3> f = frag6(src + g * 16);
+            const FragP<NP> f = fragp<NP>(src + g * 16);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) af[g][i] = f.p[i];
+            for (int i = 0; i < NP; ++i) af[g][i] = f.p[i];
         }
     }
     const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    uint4 rb[RD][3];
+    uint4 rb[RD][NP];
     auto req = [&](int tap, int g) {                       // g: compile-time after unrolling; the slot is g % RD (8 % RD == 0)
         const uint4* bp = Wp + ((size_t)(min(tap, 24) * 2 + hf) * 8 + g) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rb[g % RD][i] = bp[i * plo];
+        for (int i = 0; i < NP; ++i) rb[g % RD][i] = bp[i * plo];
     };
 #pragma unroll
     for (int g = 0; g < RD; ++g) req(0, g);
@@ -209,9 +216,9 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo)
         for (int g = 0; g < 8; ++g) {
             const int sl = g % RD;
 #pragma unroll
-            for (int pr = 0; pr < 6; pr += 2) {
-                accA = mfma16(af[g][Pairs<3>::A[pr]], rb[sl][Pairs<3>::B[pr]], accA);
-                accB = mfma16(af[g][Pairs<3>::A[pr + 1]], rb[sl][Pairs<3>::B[pr + 1]], accB);
+            for (int pr = 0; pr < Pairs<NP>::N; ++pr) {             // two accumulator chains, alternating
+                if (pr & 1) accB = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accB);
+                else accA = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accA);
             }
             if (g + RD < 8) req(tap, g + RD); else req(tap + 1, g + RD - 8);
             __builtin_amdgcn_sched_barrier(0);
@@ -244,10 +251,15 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo)
         }
     }
 }
-void launch_deconv2_x6(const ConvArgs& a, hipStream_t s) {
-    allow_big_lds(k_deconv2_x6);
+void launch_deconv2_x6(const ConvArgs& a, hipStream_t s, int np) {
     const size_t plo = (size_t)25 * 2 * 8 * 64;                        // uint4 per piece: 25 taps x 2 n-tiles x 8 k-groups x 64 lanes
-    hipLaunchKernelGGL(k_deconv2_x6, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
+    if (np == 2) {
+        allow_big_lds(k_deconv2_x6<2>);
+        hipLaunchKernelGGL(k_deconv2_x6<2>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
+        return;
+    }
+    allow_big_lds(k_deconv2_x6<3>);
+    hipLaunchKernelGGL(k_deconv2_x6<3>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -259,6 +271,7 @@ void launch_deconv2_x6(const ConvArgs& a, hipStream_t s) {
 // samples per workgroup, two waves per sample -- wave (sample, half) owns the output parity classes {(0,0), (1,1)} (4 + 9 taps) or
 // {(0,1), (1,0)} (6 + 6) -- so that the images (56 KB) still leave two workgroups per CU.
 // ------------------------------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo) {
     // bf16 elements per piece image: 128 pixels, then 384 bytes of zeros for the taps outside.  A lane whose tap is outside reads the
     // zeros at the byte offset (mod 256) its pixel WOULD have had: ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row,
@@ -269,16 +282,16 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
     u16* img = reinterpret_cast<u16*>(smem);                           // [3][NPX + 1][LDB]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * 2;
-    for (int i = tid; i < 3 * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
+    for (int i = tid; i < NP * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
     for (int i = tid; i < NPX * 16; i += DS_WG) {
         const int pix = i >> 4, c4 = i & 15;
         const int smp = s0 + (pix >> 6);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
-        unsigned p0[3], p1[3];
-        splitp<3>(v.x, v.y, p0); splitp<3>(v.z, v.w, p1);
+        unsigned p0[NP], p1[NP];
+        splitp<NP>(v.x, v.y, p0); splitp<NP>(v.z, v.w, p1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
     }
     __syncthreads();
     const int ls = w >> 1, half = w & 1, smp = s0 + ls;
@@ -298,15 +311,15 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
         f32x16 acc[2] = {zero16(), zero16()};
         const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
         auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
-        uint4 bc[4][3], bn[4][3];
-        auto ldw = [&](uint4 (&b)[4][3], int tap) {
+        uint4 bc[4][NP], bn[4][NP];
+        auto ldw = [&](uint4 (&b)[4][NP], int tap) {
             const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) b[g][i] = bp[i * plo + g * 64];
+                for (int i = 0; i < NP; ++i) b[g][i] = bp[i * plo + g * 64];
         };
-        auto run = [&](const uint4 (&b)[4][3], int t) {
+        auto run = [&](const uint4 (&b)[4][NP], int t) {
             const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
             const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
             const u16* xp[2];
@@ -318,16 +331,16 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint4 f0[3], f1[3];
+                uint4 f0[NP], f1[NP];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < NP; ++i) {
                     f0[i] = *reinterpret_cast<const uint4*>(xp[0] + i * IMG + 16 * g);
                     f1[i] = *reinterpret_cast<const uint4*>(xp[1] + i * IMG + 16 * g);
                 }
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {                       // D[co][pixel]: the two row blocks alternate on the pipe
-                    acc[0] = mfma16(b[g][Pairs<3>::B[pr]], f0[Pairs<3>::A[pr]], acc[0]);
-                    acc[1] = mfma16(b[g][Pairs<3>::B[pr]], f1[Pairs<3>::A[pr]], acc[1]);
+                for (int pr = 0; pr < Pairs<NP>::N; ++pr) {            // D[co][pixel]: the two row blocks alternate on the pipe
+                    acc[0] = mfma16(b[g][Pairs<NP>::B[pr]], f0[Pairs<NP>::A[pr]], acc[0]);
+                    acc[1] = mfma16(b[g][Pairs<NP>::B[pr]], f1[Pairs<NP>::A[pr]], acc[1]);
                 }
             }
         };
@@ -362,10 +375,17 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
         }
     }
 }
-void launch_deconv3_x6(const ConvArgs& a, hipStream_t s) {
+void launch_deconv3_x6(const ConvArgs& a, hipStream_t s, int np) {
+    const size_t plo = (size_t)25 * 1 * 4 * 64;                       // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
+    if (np == 2) {
+        const size_t ldsi = (size_t)2 * (2 * 64 * 72 + 192) * sizeof(u16);
+        allow_big_lds(k_deconv3_x6i<2>);
+        hipLaunchKernelGGL(k_deconv3_x6i<2>, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
+        return;
+    }
     const size_t ldsi = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16);
-    allow_big_lds(k_deconv3_x6i);
-    hipLaunchKernelGGL(k_deconv3_x6i, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, (size_t)25 * 1 * 4 * 64);     // uint4 per piece: 25 taps x 1 n-tile x 4 k-groups x 64 lanes
+    allow_big_lds(k_deconv3_x6i<3>);
+    hipLaunchKernelGGL(k_deconv3_x6i<3>, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

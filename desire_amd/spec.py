@@ -27,6 +27,7 @@ BN_EPS = 1e-3  # variance_epsilon, model/model.py:460,479
 
 IOC_AUTO, IOC_TILE64, IOC_CLUSTER, IOC_CLUSTER_BINS, IOC_COMPACT, IOC_TRAIN_DENSE, IOC_X6_TILE32, IOC_X6_TILE64 = 0, 2, 4, 6, 8, 9, 13, 14   # desire_hip.h: DESIRE_IOC_*
 FLAG_NO_FUSE34 = 1
+FLAG_TRAIN_FWD_3P = 2     # dims.bf16 = 2 training: two-piece operands in the forward's sample generation (include/desire_hip.h)
 
 
 @dataclass(frozen=True)
@@ -65,7 +66,7 @@ class Dims:
     ioc_split: int = 0     # bin-split regime of the fp32 inference IOC kernel: 0 auto (a window's result then depends on the batch it is in, <= 2e-6),
                            #    1 never (bit-identical across batch sizes), 2..4 cap on the workgroups per tile
     train_fp32_mask: int = 0   # dims.bf16 = 2 training: parts kept on fp32 operands (1 weight gradients, 2 data-gradient convs, 4 IOC BPTT, 8 sample generation)
-    flags: int = 0         # FLAG_NO_FUSE34 = 1: bf16 deconv3 / deconv4 as separate kernels
+    flags: int = 0         # FLAG_NO_FUSE34 = 1: bf16 deconv3 / deconv4 as separate kernels; FLAG_TRAIN_FWD_3P = 2: see the header
 
     @property
     def A(self) -> int:

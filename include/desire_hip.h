@@ -104,6 +104,10 @@ typedef struct desire_dims {
 #define DESIRE_IOC_X6_TILE32 13    /* dims.bf16 = 3: the 32-row / three-image six-product kernel whatever the launch size */
 #define DESIRE_IOC_X6_TILE64 14    /* dims.bf16 = 3: the 64-row six-product kernel whatever the launch size (default: launches of >= 256 tiles) */
 #define DESIRE_FLAG_NO_FUSE34 1    /* dims.bf16 = 1: deconv3 and deconv4 as separate kernels (default: fused, d3 never written) */
+#define DESIRE_FLAG_TRAIN_FWD_3P 2 /* dims.bf16 = 2, training mode: the forward pass's sample generation (GRU decoder, deconv2, deconv3) with TWO-piece
+                                      operands (three bf16 products per fp32 product, the first two pieces of the same packs) instead of three pieces /
+                                      six products: 67.6 instead of 70.0 ms per 81 920-sample step, every weight gradient within 5e-4 of float64
+                                      autograd instead of 2e-4 (Y0 moves by ~1e-5, and the step's rounding class becomes that of the IOC kernels) */
 
 typedef struct desire_ctx desire_handle;
 

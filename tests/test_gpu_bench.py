@@ -59,6 +59,8 @@ def test_default_contract_fields():
     assert c3["split_bf16x3"]["ioc_max_abs_diff_vs_fp32_kernel"] < 1e-4 and c3["split_bf16x6"]["ioc_max_abs_diff_vs_fp32_kernel"] < 2e-6
     tr = o["alt"]["training_step"]                            # configs[4]'s per-GPU work, fp32 and split operands
     assert tr["fp32"]["value"] > 0 and tr["split_bf16x3"]["value"] > tr["fp32"]["value"] and np.isfinite(tr["split_bf16x3"]["loss"])
+    tp = tr["split_bf16x3_two_piece_forward"]                 # DESIRE_FLAG_TRAIN_FWD_3P: faster, and the same loss to the step's rounding
+    assert tp["value"] > tr["split_bf16x3"]["value"] and abs(tp["loss"] - tr["split_bf16x3"]["loss"]) < 1e-3 * abs(tr["split_bf16x3"]["loss"])
     assert o["accuracy"]["x6_max_abs_err_Y0"] < 2e-6 and o["accuracy"]["x6_max_abs_err_Y"] < 2e-6       # the fp32 kernels' own class
     v64 = o["accuracy"]["vs_float64_oracle"]                  # against exact (float64) arithmetic: not further than the fp32 implementations
     for key in ("Y0", "Y"):
