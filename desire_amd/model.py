@@ -57,7 +57,8 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
         posterior=int(posterior), nb_w=nb / w_img, nb_h=nb / h_img, sx=1.0 / w_img, sy=1.0 / h_img,
         bin_mode=int(getattr(args, "social_layout", "rect") == "logpolar"),
         bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")],
-        bf16=_operand_mode(getattr(args, "bf16", False)))
+        bf16=_operand_mode(getattr(args, "bf16", False)),
+        flags=int(getattr(args, "dims_flags", 0)))             # DESIRE_FLAG_* bits (train.py --two_piece_forward)
 
 
 def _operand_mode(v) -> int:

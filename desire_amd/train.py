@@ -62,6 +62,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="matrix operands of the training step: fp32 (default) or x3 = split-bf16 (hi + lo, three bf16 MFMAs per product) in the IOC "
                         "forward / BPTT, the weight-gradient reductions and the large data-gradient convolutions; gradients stay within the fp32 "
                         "path's tolerance of float64 autograd")
+    p.add_argument("--two_piece_forward", action="store_true",
+                   help="with --bf16 x3: two-piece operands in the forward pass's sample generation too (DESIRE_FLAG_TRAIN_FWD_3P: ~4 %% faster "
+                        "steps, gradients within 5e-4 instead of 2e-4 of float64 autograd)")
     p.add_argument("--head_loss_weight", type=float, default=0.0,
                    help="weight of the reference's own loss for the 5-wide Gaussian output layer (model/model.py:494-550: -log N(next position | "
                         "mux, muy, sx, sy, rho), teacher-forced over the observed frames) added to the training loss; > 0 trains gauss_head/w|b "
@@ -224,6 +227,9 @@ def _train_overlapped(args, data_loader, model, log, rank, world, t_obs, t_pred,
 
 def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
+    if args.two_piece_forward:
+        from desire_amd.spec import FLAG_TRAIN_FWD_3P
+        args.dims_flags = FLAG_TRAIN_FWD_3P
     import torch
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
