@@ -763,6 +763,14 @@ void launch_colsum(const float* G, int ldg, long M, int N, int nslices, float* p
         reduce_slices(partial, nb, 1, 1, out, 1, accumulate, s);
         return;
     }
+    if (N == 2 && ldg == 2 && !(M & 1) && !(reinterpret_cast<uintptr_t>(G) & 15) && M >= 4096) {
+        // two-column sums (the 2-d head's bias gradient over rows x steps): two rows are one float4, and the four column sums of that view fold
+        // pairwise when the partials are read as twice as many slices of width two.  (Through k_colsum two lanes of a wave did the work: 0.43 ms.)
+        long sl = (M / 2) / 256; if (sl < 1) sl = 1; if (sl > 2048) sl = 2048;
+        hipLaunchKernelGGL(k_colsum4, dim3((int)sl), dim3(256), 0, s, G, 4, M / 2, 4, (int)sl, partial);
+        reduce_slices(partial, 2 * (int)sl, 1, 2, out, 2, accumulate, s);
+        return;
+    }
     const int VN = N >> 2;
     const bool vec = !(N & 3) && VN >= 1 && VN <= 256 && !(VN & (VN - 1)) && !(ldg & 3) && !(reinterpret_cast<uintptr_t>(G) & 15);
     if (vec) {
