@@ -501,7 +501,10 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ 
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + c;
     float sacc = 0.f;
-    if (n < N) for (int pth = g; pth < nparts; pth += 8) sacc += part[(size_t)pth * ld + off + n];
+    if (n < N) {                                           // (unrolled: the loads of eight parts are in flight together -- one at a time the 2 560 tiles' parts took 0.13 ms per call)
+#pragma unroll 8
+        for (int pth = g; pth < nparts; pth += 8) sacc += part[(size_t)pth * ld + off + n];
+    }
     red[g][c] = sacc;
     __syncthreads();
     if (g == 0 && n < N) {
@@ -563,6 +566,7 @@ __global__ void k_reduce_slices_t(const float* __restrict__ partial, int nslices
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= KW * NN) return;
     float s = 0.f;
+#pragma unroll 8
     for (int sl = 0; sl < nslices; ++sl) s += partial[(size_t)sl * KW * NN + i];
     float* o = out + (size_t)(i % NN) * ldo + (i / NN);
     *o = accumulate ? (*o + s) : s;
