@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256) void k_reduce_slices8(const float* __restrict_
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
     float s = 0.f;
-    if (i < Kd * N) for (int sl = g; sl < nslices; sl += 8) s += partial[(size_t)sl * Kd * N + i];
+    if (i < Kd * N) {
+#pragma unroll 8
+        for (int sl = g; sl < nslices; sl += 8) s += partial[(size_t)sl * Kd * N + i];
+    }
     red[g][c] = s;
     __syncthreads();
     if (g == 0 && i < Kd * N) {
@@ -609,33 +612,34 @@ __global__ __launch_bounds__(256) void k_bin_count(const unsigned long long* __r
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k_bin_scan(int* __restrict__ counts, int nblk, int B, int* __restrict__ binbase, int* __restrict__ bintotal) {
+__global__ __launch_bounds__(256) void k_bin_scan(int* __restrict__ counts, int nblk, int B, int* __restrict__ bintotal) {      // one workgroup per bin
     __shared__ int part[256];
     const int per = (nblk + 255) / 256, lo = threadIdx.x * per, hi = min(nblk, lo + per);
-    for (int b = 0; b < B; ++b) {
-        int sum = 0;
-        for (int i = lo; i < hi; ++i) sum += counts[(size_t)i * B + b];
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-            bintotal[b] = run;
-        }
-        __syncthreads();
-        int run = part[threadIdx.x];
-        for (int i = lo; i < hi; ++i) { const int v = counts[(size_t)i * B + b]; counts[(size_t)i * B + b] = run; run += v; }
-        __syncthreads();
-    }
+    const int b = blockIdx.x;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[(size_t)i * B + b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int b = 0; b < B; ++b) { binbase[b] = run; run += bintotal[b]; }
-        binbase[B] = run;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        bintotal[b] = run;
     }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = counts[(size_t)i * B + b]; counts[(size_t)i * B + b] = run; run += v; }
 }
 __global__ __launch_bounds__(256) void k_bin_fill(const unsigned long long* __restrict__ flags, long M, int B, const int* __restrict__ offs,
-                                                  const int* __restrict__ binbase, int* __restrict__ rowlist) {
+                                                  const int* __restrict__ bintotal, int* __restrict__ binbase, int* __restrict__ rowlist) {
     __shared__ int wsum[4];
+    __shared__ int sbase[65];                              // the bins' bases: prefix sums of their totals (every workgroup forms them; workgroup 0 publishes them)
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) { sbase[b] = run; run += bintotal[b]; }
+        sbase[B] = run;
+        if (blockIdx.x == 0) for (int b = 0; b <= B; ++b) binbase[b] = sbase[b];
+    }
+    __syncthreads();
     const long base = (long)blockIdx.x * 2048 + (long)threadIdx.x * 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long f[8];
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(const unsigned long long* __re
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
-        int pos = binbase[b] + offs[(size_t)blockIdx.x * B + b] + (inc - c);
+        int pos = sbase[b] + offs[(size_t)blockIdx.x * B + b] + (inc - c);
         for (int i = 0; i < w; ++i) pos += wsum[i];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -660,8 +664,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(const unsigned long long* __re
 void launch_bin_lists(const unsigned long long* flags, long M, int B, int* counts, int* binbase, int* bintotal, int* rowlist, hipStream_t s) {
     const int nblk = (int)((M + 2047) / 2048);
     hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, s, flags, M, B, counts);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, s, counts, nblk, B, binbase, bintotal);
-    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, s, flags, M, B, static_cast<const int*>(counts), static_cast<const int*>(binbase), rowlist);
+    hipLaunchKernelGGL(k_bin_scan, dim3(B), dim3(256), 0, s, counts, nblk, B, bintotal);
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, s, flags, M, B, static_cast<const int*>(counts), static_cast<const int*>(bintotal), binbase, rowlist);
 }
 
 static bool tn_big(const TnArgs& a) {
@@ -1052,7 +1056,8 @@ void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes,
 // IOC loss gradients w.r.t. the scores:  CE(P, softmax_k(score)) with P = softmax_k(-max_t ||Y_gt - Y0_k||)
 //   dscore_k = valid / N * (softmax_k(score) - P_k);  dscoreT[r, t] = dscore[r] (broadcast used by the tn reductions)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_score_grad(const float* __restrict__ Y0, const float* __restrict__ fut, const float* __restrict__ score,
+// (one thread per agent: the form for more than 64 samples per agent)
+__global__ void k_score_grad_serial(const float* __restrict__ Y0, const float* __restrict__ fut, const float* __restrict__ score,
                              const uint8_t* __restrict__ valid, const float* __restrict__ nvalid, float* __restrict__ dscore,
                              float* __restrict__ dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1084,10 +1089,50 @@ __global__ void k_score_grad(const float* __restrict__ Y0, const float* __restri
         for (int t = 0; t < T; ++t) dscoreT[r * T + t] = g;
     }
 }
+// one thread per (agent, sample k): 32 k-lanes x 4 agents per workgroup; the softmax sums run over k in index order in every lane, so the
+// result does not depend on the lane that forms it.  (One thread per agent walked K x T positions alone: 0.33 ms on 64 workgroups.)
+__global__ __launch_bounds__(128) void k_score_grad(const float* __restrict__ Y0, const float* __restrict__ fut, const float* __restrict__ score,
+                             const uint8_t* __restrict__ valid, const float* __restrict__ nvalid, float* __restrict__ dscore,
+                             float* __restrict__ dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy) {
+    __shared__ float dmx[4][64], scr[4][64];
+    const int ai = threadIdx.x >> 5, kl = threadIdx.x & 31;
+    const int a = blockIdx.x * 4 + ai;
+    const bool live = a < n_scenes * mno;
+    const int sc = live ? a / mno : 0, slot = live ? a - sc * mno : 0;
+    for (int k = kl; k < K && live; k += 32) {             // this lane's samples: d_max and the score
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        float dm = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float* f = fut + (((size_t)sc * T + t) * mno + slot) * 3;
+            if (f[0] == 0.f) continue;                   // frames without the object carry no ground truth
+            const float dx = Y0[(r * T + t) * 2] - __fmul_rn(f[1], sx), dy = Y0[(r * T + t) * 2 + 1] - __fmul_rn(f[2], sy);
+            dm = fmaxf(dm, sqrtf(dx * dx + dy * dy));
+        }
+        dmx[ai][k] = dm; scr[ai][k] = score[r];
+    }
+    __syncthreads();
+    if (!live) return;
+    float m1 = -3.0e38f, m2 = -3.0e38f;
+    for (int k = 0; k < K; ++k) { m1 = fmaxf(m1, -dmx[ai][k]); m2 = fmaxf(m2, scr[ai][k]); }
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < K; ++k) { s1 += expf(-dmx[ai][k] - m1); s2 += expf(scr[ai][k] - m2); }
+    const float wv = valid[a] ? 1.0f / nvalid[0] : 0.f;
+    for (int k = kl; k < K; k += 32) {
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        const float g = wv * (expf(scr[ai][k] - m2) / s2 - expf(-dmx[ai][k] - m1) / s1);
+        dscore[r] = g;
+        for (int t = 0; t < T; ++t) dscoreT[r * T + t] = g;
+    }
+}
 void launch_score_grad(const float* Y0, const float* fut, const float* score, const uint8_t* valid, const float* nvalid,
                        float* dscore, float* dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s) {
     const int A = n_scenes * mno;
-    hipLaunchKernelGGL(k_score_grad, dim3((A + 63) / 64), dim3(64), 0, s, Y0, fut, score, valid, nvalid, dscore, dscoreT,
+    if (K > 64) {
+        hipLaunchKernelGGL(k_score_grad_serial, dim3((A + 63) / 64), dim3(64), 0, s, Y0, fut, score, valid, nvalid, dscore, dscoreT,
+                           n_scenes, mno, K, T, sx, sy);
+        return;
+    }
+    hipLaunchKernelGGL(k_score_grad, dim3((A + 3) / 4), dim3(128), 0, s, Y0, fut, score, valid, nvalid, dscore, dscoreT,
                        n_scenes, mno, K, T, sx, sy);
 }
 
