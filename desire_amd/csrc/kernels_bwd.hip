@@ -317,6 +317,7 @@ __global__ void k_reduce_slices(const float* __restrict__ partial, int nslices, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Kd * N) return;
     float s = 0.f;
+#pragma unroll 8
     for (int sl = 0; sl < nslices; ++sl) s += partial[(size_t)sl * Kd * N + i];
     float* o = out + (size_t)(i / N) * ldo + (i % N);
     *o = accumulate ? (*o + s) : s;
