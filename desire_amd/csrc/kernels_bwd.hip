@@ -974,21 +974,22 @@ __global__ __launch_bounds__(256) void k_w1ch_grad(const float* __restrict__ Lg,
         __syncthreads();
         for (int i = tid; i < 1024; i += 256) lg[((i >> 5) + 1) * 40 + (i & 31) + 1] = Lg[(size_t)smp * 1024 + i];
         __syncthreads();
-        for (int p = pg; p < 256; p += 8) {
-            const float sv = S[((size_t)smp * 256 + p) * 32 + c];
-            const int py = p >> 4, px = p & 15;
-            const int base = (2 * px) & ~3;                  // padded column of tap kx = 2 px + kx; its 8-float aligned window
-            const bool odd = px & 1;                         // 2 px - base = 0 (even px) or 2 (odd px); uniform in the wave
+        // a pixel PAIR (even px, px + 1) per pass: both read the same 8-float aligned window of a padded row -- taps base + 0..4 for the even
+        // pixel, base + 2..6 for the odd one -- so two 16-byte reads serve ten products and nothing is selected per lane
+        for (int q = pg; q < 128; q += 8) {
+            const int py = q >> 3, px = 2 * (q & 7);
+            const float* sp = S + ((size_t)smp * 256 + py * 16 + px) * 32 + c;
+            const float s0 = sp[0], s1 = sp[32];
+            const int base = 2 * px;                         // (even px: a multiple of 4)
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
                 const float* row = lg + (2 * py + ky) * 40 + base;
                 const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
-                const float t0 = odd ? v0.z : v0.x, t1 = odd ? v0.w : v0.y, t2 = odd ? v1.x : v0.z, t3 = odd ? v1.y : v0.w, t4 = odd ? v1.z : v1.x;
-                acc[ky * 5 + 0] = fmaf(t0, sv, acc[ky * 5 + 0]);
-                acc[ky * 5 + 1] = fmaf(t1, sv, acc[ky * 5 + 1]);
-                acc[ky * 5 + 2] = fmaf(t2, sv, acc[ky * 5 + 2]);
-                acc[ky * 5 + 3] = fmaf(t3, sv, acc[ky * 5 + 3]);
-                acc[ky * 5 + 4] = fmaf(t4, sv, acc[ky * 5 + 4]);
+                acc[ky * 5 + 0] = fmaf(v0.x, s0, acc[ky * 5 + 0]); acc[ky * 5 + 0] = fmaf(v0.z, s1, acc[ky * 5 + 0]);
+                acc[ky * 5 + 1] = fmaf(v0.y, s0, acc[ky * 5 + 1]); acc[ky * 5 + 1] = fmaf(v0.w, s1, acc[ky * 5 + 1]);
+                acc[ky * 5 + 2] = fmaf(v0.z, s0, acc[ky * 5 + 2]); acc[ky * 5 + 2] = fmaf(v1.x, s1, acc[ky * 5 + 2]);
+                acc[ky * 5 + 3] = fmaf(v0.w, s0, acc[ky * 5 + 3]); acc[ky * 5 + 3] = fmaf(v1.y, s1, acc[ky * 5 + 3]);
+                acc[ky * 5 + 4] = fmaf(v1.x, s0, acc[ky * 5 + 4]); acc[ky * 5 + 4] = fmaf(v1.z, s1, acc[ky * 5 + 4]);
             }
         }
     }
