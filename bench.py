@@ -1050,6 +1050,33 @@ def main():
                        "workload the headline and its roofline are quoted on"}
         assert bool(torch.isfinite(Y).all())
         h2.close()
+        # the same windows with DESIRE_FLAG_COMPACT_ROWS: the per-row sample-generation stages on the rows of present agents only
+        h3 = _lib.Handle(d2.replace(flags=d2.flags | 4))
+        h3.set_weights(w)
+        h3.set_scene_grids(grids_t.data_ptr(), gos)
+        Yc = torch.zeros_like(Y)
+        for _ in range(2):
+            h3.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yc.data_ptr(), score.data_ptr(), stream)
+        torch.cuda.synchronize()
+        h3.set_profiling(True)
+        ts = time.perf_counter()
+        for _ in range(n2):
+            h3.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yc.data_ptr(), score.data_ptr(), stream)
+        torch.cuda.synchronize()
+        c_dt = (time.perf_counter() - ts) / n2
+        h3.set_profiling(False)
+        k3 = {}
+        for name, ms in h3.get_profile():
+            k3.setdefault(name, []).append(ms)
+        rows_present = torch.as_tensor(np.repeat((p2[:, -1, :, 0] != 0)[:, None, :], d.K, axis=1).reshape(-1), device=dev)
+        sdd["compact_rows"] = {"ms_per_step": c_dt * 1e3, "value_present_agents_only": present * d.K * d.n_scenes / c_dt,
+                               "ioc_ms": float(np.mean(k3["ioc"])) if "ioc" in k3 else None,
+                               "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in k3.items()},
+                               "present_rows_bit_identical_to_uncompacted": bool((Yc[rows_present] == Y[rows_present]).all()),
+                               "note": "dims.flags = DESIRE_FLAG_COMPACT_ROWS: reparam .. GRU decoder run on the K rows of present agents only; "
+                                       "IOC tiles stay scene-shaped"}
+        sdd["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in k2.items()}
+        h3.close()
 
     per_kernel = {}
     for name, ms in prof:

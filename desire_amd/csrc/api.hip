@@ -181,7 +181,9 @@ int check_options(const desire_dims& d) {
     }
     if (d.ioc_split < 0 || d.ioc_split > 4) return fail(DESIRE_ERR_ARG, "ioc_split must be 0 (auto), 1 (never split: batch-size invariant results) or 2..4 (cap)");
     if (d.train_fp32_mask < 0 || d.train_fp32_mask > 15) return fail(DESIRE_ERR_ARG, "train_fp32_mask is a mask of bits 1, 2, 4, 8");
-    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_TRAIN_FWD_3P)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_TRAIN_FWD_3P | DESIRE_FLAG_COMPACT_ROWS)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if ((d.flags & DESIRE_FLAG_COMPACT_ROWS) && (d.bn_mode == 2 || d.ref_compat))
+        return fail(DESIRE_ERR_ARG, "DESIRE_FLAG_COMPACT_ROWS: not with bn_mode = 2 (whole-batch statistics depend on the padding rows) or ref_compat");
     return 0;
 }
 
@@ -303,6 +305,8 @@ extern "C" int desire_peer_close(desire_handle* h);
 extern "C" int desire_destroy(desire_handle* h) {
     if (!h) return DESIRE_OK;
     if (h->host_err) { (void)hipHostFree(h->host_err); h->host_err = nullptr; }
+    if (h->cp_host) { (void)hipHostFree(h->cp_host); h->cp_host = nullptr; }
+    if (h->cp_ev) { (void)hipEventDestroy(h->cp_ev); h->cp_ev = nullptr; }
     (void)desire_peer_close(h);
     for (auto& kv : h->dev) kv.second.release();
     for (auto& kv : h->ws) kv.second.release();
@@ -652,6 +656,26 @@ int desire_ready(desire_handle* h) {
     return 0;
 }
 
+// DESIRE_FLAG_COMPACT_ROWS: the per-row sample-generation stages run on the rows of present agents only (kernels_compact.hip)
+bool compact_rows(const desire_ctx* h) { return (h->d.flags & DESIRE_FLAG_COMPACT_ROWS) != 0; }
+int compact_setup(desire_ctx* h) {
+    if (h->cp_host) return DESIRE_OK;
+    const desire_dims& d = h->d;
+    const size_t A = h->A, R = h->R, f = sizeof(float);
+    struct WS { const char* n; size_t bytes; };
+    const WS list[] = {{"cp_amap", A * sizeof(int32_t)}, {"cp_inv", A * sizeof(int32_t)}, {"cp_count", sizeof(int32_t)}, {"cp_HxHy", A * 2 * d.H * f},
+                       {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f}};
+    for (const WS& w : list)
+        if (!h->ws[w.n].p && h->ws[w.n].alloc(w.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n);
+    if (!h->cp_ev) HIPCHK(hipEventCreateWithFlags(&h->cp_ev, hipEventDisableTiming));
+    int32_t* p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(int32_t), hipHostMallocMapped) != hipSuccess || !p)
+        return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the present-agent count word");
+    *p = 0;
+    h->cp_host = p;
+    return DESIRE_OK;
+}
+
 extern "C" int desire_encode(desire_handle* h, const float* dev_past, const float* dev_fut, void* stream) {
     if (int rc = desire_ready(h)) return rc;
     const desire_dims& d = h->d;
@@ -682,6 +706,16 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     } else if (d.posterior) {      // the two encoders are independent and latency-bound: one launch
         Timer t(h, s, "encoder_xy"); launch_encoder_pair(ex, e, s);
     } else { Timer t(h, s, "encoder_x"); launch_encoder(ex, s); }
+    if (compact_rows(h)) {
+        // present-row compaction (DESIRE_FLAG_COMPACT_ROWS): the map of the agents present at the last observed frame, built right behind the
+        // encoder that writes `valid`; its size reaches the host through a mapped word while the CVAE encoder below keeps the device busy, and
+        // desire_sample waits on the event before it sizes its launches.
+        if (int rc = compact_setup(h)) return rc;
+        launch_present_scan(static_cast<const uint8_t*>(h->ws["valid"].p), A, static_cast<int32_t*>(h->ws["cp_amap"].p), static_cast<int32_t*>(h->ws["cp_inv"].p),
+                            static_cast<int32_t*>(h->ws["cp_count"].p), h->cp_host, s);
+        HIPCHK(hipEventRecord(h->cp_ev, s));
+        h->cp_pending = true;
+    }
     if (d.posterior) {
         GemmArgs g{};
         g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
@@ -723,8 +757,37 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     if (!dev_eps || !dev_Yhat) return fail(DESIRE_ERR_ARG, "null argument");
     const desire_dims& d = h->d;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int H = d.H, R = h->R;
-    { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
+    const int H = d.H;
+    // per-row stages: all R = A*K rows, or (DESIRE_FLAG_COMPACT_ROWS) the K*P rows of the P present agents laid out as one pseudo-scene of P
+    // slots (kernels_compact.hip) -- the kernels below are the same either way, they only see (R, K, mno) and the agent-level inputs
+    int R = h->R, mno = d.mno;
+    const float* HxS = W(h, "HxHy"); const float* plS = W(h, "p_last"); float* Yout = W(h, "Y0");
+    const bool compact = compact_rows(h);
+    if (compact) {
+        if (!h->cp_pending) return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_ROWS: desire_encode comes first (it builds the present-agent map)");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_ROWS reads the present-agent count back: not capturable in a hipGraph");
+        HIPCHK(hipEventSynchronize(h->cp_ev));
+        const int P = *static_cast<volatile int32_t*>(h->cp_host);
+        if (P < 0 || P > h->A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
+        h->cp_P = P;
+        R = P * d.K; mno = P;
+        const size_t RT2 = (size_t)h->R * d.T_pred * 2;
+        if (P == 0) {       // nothing present: every row is padding
+            launch_fill_f32(W(h, "Y0"), RT2, 0.f, s); launch_fill_f32(dev_Yhat, RT2, 0.f, s);
+            HIPCHK(hipGetLastError());
+            return DESIRE_OK;
+        }
+        const int32_t* amap = static_cast<const int32_t*>(h->ws["cp_amap"].p);
+        Timer t(h, s, "compact_gather");
+        launch_gather_agents(W(h, "HxHy"), W(h, "cp_HxHy"), amap, P, 2 * H, s);
+        launch_gather_agents(W(h, "p_last"), W(h, "cp_plast"), amap, P, 2, s);
+        if (d.posterior) launch_gather_agents(W(h, "params"), W(h, "cp_params"), amap, P, 2 * d.L, s);
+        HxS = W(h, "cp_HxHy"); plS = W(h, "cp_plast"); Yout = W(h, "cp_Y0");
+    }
+    if (compact) { Timer t(h, s, "reparam"); launch_reparam_c(W(h, "cp_params"), dev_eps, W(h, "z"), static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.L, d.posterior, s); }
+    else { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
     auto normd = [&](const char* layer, float* x, int P, int C, int sig) {          // batch statistics of the decoder layers (see desire_encode)
         const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
         if (h->training)
@@ -777,18 +840,18 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
           if (pobn) normd("vae_dec/deconv4", W(h, "xhat"), 1024, 1, 1); }
     }
     MaskArgs m{};
-    m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = d.mno;
-    m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = W(h, "HxHy"); m.ldhx = 2 * H; m.xz = W(h, "xz");
+    m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = mno;
+    m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = HxS; m.ldhx = 2 * H; m.xz = W(h, "xz");
     if (h->training) m.sv_p = W(h, "mask_sv_p");
     if (d.bf16 == 1) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
     else if (x6gen && (H == 64 || H == 128) && h->V % 128 == 0) { m.Wp = D4(h, "mask/W6"); Timer t(h, s, "mask_fc"); launch_mask_x6(m, s); }
     else { Timer t(h, s, "mask_fc"); launch_mask(m, s); }
     DecArgs a{};
-    a.xz = W(h, "xz"); a.Hx = W(h, "HxHy"); a.ldhx = 2 * H; a.p_last = W(h, "p_last");
-    a.R = R; a.K = d.K; a.mno = d.mno; a.H = H; a.T = d.T_pred;
+    a.xz = W(h, "xz"); a.Hx = HxS; a.ldhx = 2 * H; a.p_last = plS;
+    a.R = R; a.K = d.K; a.mno = mno; a.H = H; a.T = d.T_pred;
     a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
-    a.Y = W(h, "Y0"); a.hdump = nullptr;
+    a.Y = Yout; a.hdump = nullptr;
     if (d.ref_compat) { a.T = d.n_dec; a.hdump = W(h, "dec_states"); }       // model/model.py:280-285: 7 steps, the states are the output
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
     if (d.bf16 == 1) {
@@ -802,7 +865,12 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     { Timer t(h, s, "decoder"); launch_decoder(a, s); }
     if (d.ref_compat)      // model/model.py:286-289: each state [H] re-read as T_obs points (x, y) -> [A, n_dec, T_obs, 2]
         launch_copy_cols(dev_Yhat, W(h, "dec_states"), (size_t)R * d.n_dec, h->Hl, H, s);
-    else
+    else if (compact) {     // back to the caller's row layout; rows of absent agents are zeros (the cost masks them, model/model.py:351-366)
+        Timer t(h, s, "compact_scatter");
+        const size_t RT2 = (size_t)h->R * d.T_pred * 2;
+        launch_fill_f32(W(h, "Y0"), RT2, 0.f, s); launch_fill_f32(dev_Yhat, RT2, 0.f, s);
+        launch_scatter_rows(Yout, W(h, "Y0"), dev_Yhat, static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.T_pred * 2, s);
+    } else
         launch_copy_f32(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2, s);
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
@@ -827,7 +895,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
     if (stepwise) {
         if (h->training) return fail(DESIRE_ERR_STATE, "training supports up to 128 agents per scene");
         const size_t RH = (size_t)h->R * d.H;
-        if (!h->ws.count("stw_h") && (h->ws["stw_h"].alloc(2 * RH * sizeof(float)) || h->ws["stw_sc"].alloc((size_t)h->R * sizeof(float))))
+        if ((!h->ws.count("stw_h") || !h->ws["stw_h"].p || !h->ws["stw_sc"].p) &&
+            ((!h->ws["stw_h"].p && h->ws["stw_h"].alloc(2 * RH * sizeof(float))) || (!h->ws["stw_sc"].p && h->ws["stw_sc"].alloc((size_t)h->R * sizeof(float)))))
             return fail(DESIRE_ERR_HIP, "hipMalloc failed for the step-wise IOC state");
         float* hb[2] = {W(h, "stw_h"), W(h, "stw_h") + RH};
         const int NTs = d.H / 32, KXs = d.E_v + d.C + 2 * d.H;
@@ -1177,6 +1246,9 @@ extern "C" int desire_peer_open_ptr(desire_handle* h, int32_t rank, int32_t nran
 
 extern "C" int desire_peer_close(desire_handle* h) {
     if (!h) return fail(DESIRE_ERR_ARG, "null handle");
+    bool any = h->peer_region != nullptr || h->peer_err != nullptr;
+    for (int r = 0; r < 8; ++r) any = any || h->peer_base[r] != nullptr;
+    if (!any) return DESIRE_OK;          // a handle that never used peer buffers: nothing to wait for (no device-wide stall in desire_destroy)
     (void)hipDeviceSynchronize();
     for (int r = 0; r < 8; ++r) {
         if (h->peer_mapped[r] && h->peer_base[r]) (void)hipIpcCloseMemHandle(h->peer_base[r]);

@@ -66,6 +66,9 @@ struct desire_ctx {
     int* peer_err = nullptr;
     float head_loss_w = 0.f;                                 // desire_set_head_loss: weight of the Gaussian-head NLL term in the training loss
     int* host_err = nullptr;                                 // mapped host word the bin-split IOC's bounded spins report into (checked by the next call)
+    // present-row compaction (DESIRE_FLAG_COMPACT_ROWS, kernels_compact.hip): mapped host word the scan kernel reports the present-agent count
+    // into, the event behind it, the count of the last desire_sample (-1: none yet)
+    int32_t* cp_host = nullptr; hipEvent_t cp_ev = nullptr; bool cp_pending = false; int cp_P = -1;
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;
     // ---- training (train.hip) ----
@@ -120,4 +123,6 @@ std::vector<float> desire_embed(const desire_ctx* h, const std::string& name, co
 void desire_extract(const desire_ctx* h, const std::string& name, const float* phys, float* user);
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v);
 int desire_ready(desire_handle* h);
+bool compact_rows(const desire_ctx* h);                        // DESIRE_FLAG_COMPACT_ROWS set
+int compact_setup(desire_ctx* h);                              // its buffers, event and mapped count word (idempotent)
 int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

@@ -280,3 +280,11 @@ bool ioc_bwd_x3_supported(int mno, int H);                       // kernels_bwd_
 void launch_ioc_bwd_x3(const IocBwdArgs& a, hipStream_t s);      // a.WcT_h / a.WgT_h / a.WsT = the [hi | lo] packs "ioc/W?T16"
 // cluster form (kernels_bwd_cl.hip): groups of 64 / 96 / 128 agents, H <= 128, <= 16 bins; grp_cnt zeroed per launch; != 0: shape not served
 int launch_ioc_bwd_cluster(const IocBwdArgs& a, int* grp_cnt, int* err, hipStream_t s);
+
+// ---- present-row compaction (kernels_compact.hip; DESIRE_FLAG_COMPACT_ROWS) ----
+void launch_present_scan(const uint8_t* valid, int A, int32_t* amap, int32_t* inv, int32_t* count_dev, int32_t* count_host, hipStream_t s);
+void launch_gather_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s);
+void launch_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* amap, int P, int n, hipStream_t s);
+void launch_reparam_c(const float* params_c, const float* eps, float* z, const int32_t* amap, int P, int K, int mno, int L, int posterior, hipStream_t s);
+void launch_scatter_rows(const float* comp, float* full0, float* full1, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);
+void launch_gather_rows(const float* full, float* comp, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);

@@ -109,6 +109,17 @@ typedef struct desire_dims {
                                       six products: 67.6 instead of 70.0 ms per 81 920-sample step, every weight gradient within 5e-4 of float64
                                       autograd instead of 2e-4 (Y0 moves by ~1e-5, and the step's rounding class becomes that of the IOC kernels) */
 
+#define DESIRE_FLAG_COMPACT_ROWS 4  /* PRESENT-ROW COMPACTION.  The loader pads every window to max_num_obj slots (utils/data_loader.py:209-229) and the reference
+                                      masks id-0 objects in the cost only (model/model.py:351-366); with this bit the per-row sample-generation stages
+                                      (reparameterisation, deconv1..4, mask fc, GRU decoder -- and in training their saves and their whole backward) run on
+                                      the K rows of the agents PRESENT at the last observed frame only.  Rows of present agents are bit-identical to the
+                                      uncompacted path (every stage is row-independent); rows of absent agents come back as zeros in dev_Yhat / "Y0" instead
+                                      of the decode of an all-zero track.  The IOC stage keeps its scene-shaped tiles.  Costs one host wait per desire_sample
+                                      (the present count is read back through a mapped word, overlapped with the CVAE encoder), so a compacted
+                                      desire_sample / desire_forward cannot be captured in a hipGraph.  Not with bn_mode = 2 (whole-batch statistics would
+                                      change) or ref_compat.  The intermediates "z", "d1".."d3", "xhat", "xz" of desire_read_buffer are then in the COMPACT
+                                      row order r' = k*P + a' (P = present agents, a' = rank of the agent among them). */
+
 typedef struct desire_ctx desire_handle;
 
 const char* desire_last_error(void);

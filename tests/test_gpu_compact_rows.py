@@ -1,0 +1,163 @@
+"""Present-row compaction (dims.flags = DESIRE_FLAG_COMPACT_ROWS, include/desire_hip.h; csrc/kernels_compact.hip).
+
+The loader pads every window to max_num_obj slots (utils/data_loader.py:209-229) and the reference masks id-0 objects in the cost only
+(model/model.py:351-366).  With the flag the per-row sample-generation stages run on the rows of present agents only.  Contract tested here:
+  * rows of present agents: BIT-IDENTICAL to the uncompacted HIP path (every operand mode, both frozen and per-object batch-norm) and
+    within 1e-3 of the CPU oracle (normalised coordinates) on the committed real-SDD goldens;
+  * rows of absent agents: zeros in "Y0" (the sample-generation output);
+  * edge cases: nothing present, everything present, a single agent, prior sampling (no posterior);
+  * the flag is refused where it would change results (bn_mode = 2) and under hipGraph capture."""
+import numpy as np
+import pytest
+
+from desire_amd.spec import FLAG_COMPACT_ROWS, init_weights
+from tests.helpers import make_case, small_dims
+from tests.test_golden_e2e import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch
+
+
+def ragged_case(d, seed, keep=0.35):
+    """make_case windows with most slots absent, SDD-like: each slot is kept with probability `keep` (at least one window keeps none of
+    its slots when n_scenes >= 3, one keeps all); a kept slot may still be absent from some TARGET frames."""
+    past, fut, eps, grids, gos = make_case(d, seed=seed, n_absent=0)
+    rng = np.random.default_rng(seed + 100)
+    keep_m = rng.uniform(size=(d.n_scenes, d.mno)) < keep
+    if d.n_scenes >= 3:
+        keep_m[1] = False
+        keep_m[2] = True
+    past[~keep_m[:, None, :].repeat(d.T_obs, 1)] = 0
+    fut[~keep_m[:, None, :].repeat(d.T_pred, 1)] = 0
+    gone = rng.uniform(size=fut.shape[:3]) < 0.1                 # objects leaving the scene mid-target
+    fut[gone] = 0
+    return past, fut, eps, grids, gos, keep_m
+
+
+def run(torch, d, w, past, fut, eps, grids, gos):
+    from desire_amd import _lib
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.full((d.R, d.T_pred, 2), 7.0, device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    h.forward(past_t.data_ptr(), fut_t.data_ptr() if d.posterior else 0, eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), s)
+    torch.cuda.synchronize()
+    Y0 = h.read_buffer("Y0", (d.R, d.T_pred, 2))
+    h.close()
+    return Y0, Y.cpu().numpy(), score.cpu().numpy()
+
+
+def row_mask(d, present):
+    return np.repeat(present[:, None, :], d.K, axis=1).reshape(-1)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                          # fp32 operands
+    dict(bf16=2),                                    # split operands: six-product sample generation, three-product IOC
+    dict(bf16=3),
+    dict(bf16=1),                                    # plain bf16 operands (fused deconv3+4)
+    dict(bn_mode=1),                                 # per-object batch statistics (the reference graph's batch of one)
+    dict(H=64, K=3, mno=16),
+    dict(mno=8, K=5, n_scenes=6),
+    dict(posterior=0),                               # z ~ N(0, I): no CVAE encoder behind the scan
+    dict(mno=64, n_scenes=3, K=2),                   # groups larger than a tile (cluster-form IOC)
+], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
+def test_present_rows_are_bit_identical_and_absent_rows_zero(torch_cuda, kw):
+    d = small_dims(**{**dict(n_scenes=4, K=4, T_pred=12), **kw})
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos, keep = ragged_case(d, seed=11)
+    Y0a, Ya, sa = run(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0b, Yb, sb = run(torch_cuda, d.replace(flags=FLAG_COMPACT_ROWS), w, past, fut, eps, grids, gos)
+    m = row_mask(d, keep)
+    assert m.any() and (~m).any()
+    np.testing.assert_array_equal(Y0b[m], Y0a[m])
+    assert not Y0b[~m].any()
+    assert np.isfinite(Yb).all() and np.isfinite(sb).all()
+    # the IOC pass pools present agents only, so their refined rows do not depend on what the absent rows hold either
+    np.testing.assert_array_equal(Yb[m], Ya[m])
+    np.testing.assert_array_equal(sb[m], sa[m])
+
+
+@pytest.mark.parametrize("which", ["none", "all", "one"])
+def test_edge_counts(torch_cuda, which):
+    d = small_dims(n_scenes=2, K=3, T_pred=8, mno=16)
+    w = init_weights(d, 5)
+    past, fut, eps, grids, gos = make_case(d, seed=2, n_absent=0)
+    keep = np.ones((d.n_scenes, d.mno), bool)
+    if which == "none":
+        keep[:] = False
+    elif which == "one":
+        keep[:] = False
+        keep[1, 5] = True
+    past[~keep[:, None, :].repeat(d.T_obs, 1)] = 0
+    fut[~keep[:, None, :].repeat(d.T_pred, 1)] = 0
+    Y0a, Ya, sa = run(torch_cuda, d, w, past, fut, eps, grids, gos)
+    Y0b, Yb, sb = run(torch_cuda, d.replace(flags=FLAG_COMPACT_ROWS), w, past, fut, eps, grids, gos)
+    m = row_mask(d, keep)
+    np.testing.assert_array_equal(Y0b[m], Y0a[m])
+    np.testing.assert_array_equal(Yb[m], Ya[m])
+    assert not Y0b[~m].any()
+    assert np.isfinite(Yb).all() and np.isfinite(sb).all()
+
+
+@pytest.mark.parametrize("tag", ["cfg0", "cfg1"])
+def test_compacted_path_reproduces_the_sdd_goldens(torch_cuda, tag):
+    """Real SDD bookstore windows (9 of 32 slots present at cfg1): the compacted path against the ORACLE's goldens, present rows."""
+    d, g, eps, grids, gos, w = load_case(tag)
+    Y0, Y, score = run(torch_cuda, d.replace(flags=FLAG_COMPACT_ROWS), w, g["past"], g["fut"], eps, grids, gos)
+    present = g["past"][:, -1, :, 0] != 0
+    m = row_mask(d, present)
+    assert np.abs(Y0 - g["Y0"])[m].max() < 1e-3
+    assert not Y0[~m].any()
+    err = np.abs(Y - g["Y"]).reshape(d.R, -1).max(1)[m]
+    flipped = err > 1e-3                                  # (the un-anchored statistic of test_golden_e2e.py: a 1e-7 move may cross a bin edge)
+    assert flipped.mean() < 0.01
+    assert err[~flipped].max() < 1e-3
+    assert np.abs(score - g["score"])[m][~flipped].max() < 5e-3
+
+
+def test_flag_is_refused_where_it_would_change_results(torch_cuda):
+    from desire_amd import _lib
+    d = small_dims(n_scenes=1, K=2, T_pred=8)
+    with pytest.raises(_lib.DesireError, match="COMPACT_ROWS"):
+        _lib.Handle(d.replace(flags=FLAG_COMPACT_ROWS, bn_mode=2))
+    h = _lib.Handle(d)
+    with pytest.raises(_lib.DesireError):
+        h.set_option("flags", 64)
+    h.set_option("flags", FLAG_COMPACT_ROWS)               # on a live handle
+    w = init_weights(d, 0)
+    h.set_weights(w)
+    torch = torch_cuda
+    dev = torch.device("cuda")
+    past, fut, eps, grids, gos = make_case(d, seed=1)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    with pytest.raises(_lib.DesireError, match="desire_encode comes first"):
+        h.sample(eps_t.data_ptr(), Y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        h.encode(past_t.data_ptr(), fut_t.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        h.graph_begin(side.cuda_stream)
+        try:
+            with pytest.raises(_lib.DesireError, match="not capturable"):
+                h.sample(eps_t.data_ptr(), Y.data_ptr(), side.cuda_stream)
+        finally:
+            try:
+                h.graph_end(side.cuda_stream)
+            except _lib.DesireError:
+                pass
+    h.close()
