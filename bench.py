@@ -592,6 +592,44 @@ def training_step_leg(d_full, seed, dev, steps):
         del h
         torch.cuda.empty_cache()
     out["note"] = "128 windows per step (a training step keeps ~0.5 GB of activations per window); lr 1e-4, clip 10; synthetic windows"
+    # the same step on REAL SDD bookstore windows (9 of 32 slots present), without and with DESIRE_FLAG_COMPACT_ROWS: the per-row stages, their saves
+    # and their whole backward on the rows of present agents only
+    if dt_.mno >= 32:
+        W_IMG, H_IMG = 1424.0, 1088.0
+        ds = dt_.replace(nb_w=32.0 / W_IMG, nb_h=32.0 / H_IMG, sx=1.0 / W_IMG, sy=1.0 / H_IMG)
+        p2, f2, n_real = sdd_windows(ds.n_scenes, ds.mno)
+        present = float((p2[:, -1, :, 0] != 0).sum()) / p2.shape[0]
+        p_t, f_t = t(p2), t(f2)
+        sd = {}
+        for tag, mode, flags in (("fp32", 0, 0), ("fp32_compact_rows", 0, 4), ("split_bf16x3", 2, 0), ("split_bf16x3_compact_rows", 2, 4)):
+            h = _lib.Handle(ds.replace(bf16=mode, flags=flags))
+            h.set_weights(w)
+            h.set_scene_grids(g_t.data_ptr(), gos)
+            h.set_training(True)
+
+            def one():
+                h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+                h.backward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), stream)
+                h.clip_grads(10.0, stream=stream)
+                h.adam_step(1e-4, stream=stream)
+            for _ in range(2):
+                one()
+            torch.cuda.synchronize()
+            n2 = max(3, min(steps, 8))
+            t0 = time.perf_counter()
+            for _ in range(n2):
+                one()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / n2
+            terms = h.train_loss(f_t.data_ptr(), stream)
+            assert all(np.isfinite(float(v)) for v in terms.values()), terms
+            sd[tag] = {"ms_per_step": dts * 1e3, "value_present_agents_only": present * ds.K * ds.n_scenes / dts, "unit": "samples/s trained (present agents x K)",
+                       "loss": float(terms["loss"])}
+            h.close()
+            del h
+            torch.cuda.empty_cache()
+        sd["data"] = "SDD bookstore/video6 windows (%d distinct, tiled to %d), %.1f of %d slots present" % (n_real, ds.n_scenes, present, ds.mno)
+        out["sdd"] = sd
     return out
 
 

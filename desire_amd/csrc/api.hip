@@ -763,6 +763,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     int R = h->R, mno = d.mno;
     const float* HxS = W(h, "HxHy"); const float* plS = W(h, "p_last"); float* Yout = W(h, "Y0");
     const bool compact = compact_rows(h);
+    h->cp_last = compact;
     if (compact) {
         if (!h->cp_pending) return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_ROWS: desire_encode comes first (it builds the present-agent map)");
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -69,6 +69,7 @@ struct desire_ctx {
     // present-row compaction (DESIRE_FLAG_COMPACT_ROWS, kernels_compact.hip): mapped host word the scan kernel reports the present-agent count
     // into, the event behind it, the count of the last desire_sample (-1: none yet)
     int32_t* cp_host = nullptr; hipEvent_t cp_ev = nullptr; bool cp_pending = false; int cp_P = -1;
+    bool cp_last = false;                                    // the last desire_sample ran compacted (desire_backward follows it, not the flag)
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;
     // ---- training (train.hip) ----

@@ -255,7 +255,7 @@ struct ConvWgradArgs { const float* S; int Cs; int Ps; const float* Lg; int Cl; 
 void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStream_t s);
 void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s);
 void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
-                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s);
+                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s, const int32_t* inv = nullptr, int P = 0);
 void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s);
 void launch_score_grad(const float* Y0, const float* fut, const float* score, const uint8_t* valid, const float* nvalid,
                        float* dscore, float* dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s);

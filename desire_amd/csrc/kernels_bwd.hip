@@ -1013,7 +1013,7 @@ void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float
 //   kld = -0.5 sum(1 + ls - mu^2 - exp(ls)), weight valid/N  =>  dmu += w mu ; dls += w (-0.5)(1 - exp(ls))
 __global__ void k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ eps, const float* __restrict__ params,
                               const uint8_t* __restrict__ valid, const float* __restrict__ nvalid, float* __restrict__ dparams,
-                              int n_scenes, int mno, int K, int L) {
+                              int n_scenes, int mno, int K, int L, const int32_t* __restrict__ inv, int P) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int A = n_scenes * mno;
     if (i >= A * L) return;
@@ -1022,21 +1022,24 @@ __global__ void k_reparam_bwd(const float* __restrict__ dz, const float* __restr
     const float mu = params[(size_t)a * 2 * L + l], ls = params[(size_t)a * 2 * L + L + l];
     const float sd = sqrtf(expf(ls));
     float dmu = 0.f, dls = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const size_t r = ((size_t)sc * K + k) * mno + slot;
-        const float g = dz[r * L + l];
-        dmu += g;
-        dls += g * eps[r * L + l];
-    }
+    // inv != nullptr: dz lives in the compact row order of kernels_compact.hip (r' = k*P + inv[a]; absent agents have no rows and no gradient)
+    const int ip = inv ? inv[a] : 0;
+    if (ip >= 0)
+        for (int k = 0; k < K; ++k) {
+            const size_t r = ((size_t)sc * K + k) * mno + slot;
+            const float g = dz[(inv ? (size_t)k * P + ip : r) * L + l];
+            dmu += g;
+            dls += g * eps[r * L + l];
+        }
     dls *= 0.5f * sd;
     const float wv = valid[a] ? 1.0f / nvalid[0] : 0.f;
     dparams[(size_t)a * 2 * L + l] = dmu + wv * mu;
     dparams[(size_t)a * 2 * L + L + l] = dls + wv * (-0.5f) * (1.0f - expf(ls));
 }
 void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
-                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s) {
+                        float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s, const int32_t* inv, int P) {
     const int n = n_scenes * mno * L;
-    hipLaunchKernelGGL(k_reparam_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, eps, params, valid, nvalid, dparams, n_scenes, mno, K, L);
+    hipLaunchKernelGGL(k_reparam_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, eps, params, valid, nvalid, dparams, n_scenes, mno, K, L, inv, P);
 }
 
 // ---- dHx[a] (+)= sum_k dHx_rows[(scene,k,slot)] --------------------------------------------------------------------------

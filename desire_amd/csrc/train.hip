@@ -474,6 +474,20 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = d.H, T = d.T_pred;
     const long R = h->R;
+    // DESIRE_FLAG_COMPACT_ROWS: the training-mode forward ran the per-row sample-generation stages on the K*P rows of the P present agents
+    // (compact row order r' = k*P + a', one pseudo-scene of P slots: kernels_compact.hip) and left every save of those stages in that order;
+    // their whole backward runs on the same rows.  Rs / mnos / ns_s are the (rows, slots, scenes) those stages see; the IOC module and the
+    // encoders keep the caller's layout.  A gradient enters the compact domain once (dY0) and leaves it twice (dparams, dHx).
+    const bool compact = h->cp_last;
+    const int P = compact ? h->cp_P : 0;
+    const long Rs = compact ? (long)P * d.K : R;
+    const int mnos = compact ? P : d.mno, ns_s = compact ? 1 : d.n_scenes;
+    if (compact && (ensure(h, "cp_dY0", (size_t)R * T * 2 * sizeof(float)) || ensure(h, "cp_dHx_rows", (size_t)R * H * sizeof(float)) ||
+                    ensure(h, "cp_dHx", (size_t)h->A * H * sizeof(float))))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the compact-row gradient buffers");
+    const int32_t* amap = compact ? static_cast<const int32_t*>(h->ws["cp_amap"].p) : nullptr;
+    const float* HxS = compact ? W(h, "cp_HxHy") : W(h, "HxHy");
+    float* dHxS = compact ? W(h, "cp_dHx_rows") : W(h, "dHx_rows");
     launch_fill_f32(W(h, "Gflat"), h->n_params, 0.f, s);
     // loss mask: present at the last observed frame and in at least one target frame; every loss term below is masked per
     // target frame (model/model.py:351-366).  `valid` (presence at the last observed frame) stays what social pooling uses.
@@ -483,30 +497,35 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     launch_count_valid(valid, h->A, W(h, "nvalid"), s);
     // ---- sample-generation module ----
     launch_loss_grad_y(W(h, "Y0"), dev_fut, valid, W(h, "nfut"), W(h, "nvalid"), W(h, "dY0"), d.n_scenes, d.mno, d.K, T, d.sx, d.sy, s);
+    if (compact) launch_gather_rows(W(h, "dY0"), W(h, "cp_dY0"), amap, P, d.K, d.mno, T * 2, s);
+    const float* dY0s = compact ? W(h, "cp_dY0") : W(h, "dY0");
+    const int n_tiles32 = (int)((R + 31) / 32), n_tiles32s = (int)((Rs + 31) / 32);
+    if (Rs > 0) {
     DecBwdArgs b{};
-    b.dY0 = W(h, "dY0"); b.sv_r = W(h, "dec_sv_r"); b.sv_u = W(h, "dec_sv_u"); b.sv_c = W(h, "dec_sv_c"); b.sv_h = W(h, "dec_sv_h");
-    b.Hx = W(h, "HxHy"); b.ldhx = 2 * H; b.w_head = D(h, "head/w");
+    b.dY0 = dY0s; b.sv_r = W(h, "dec_sv_r"); b.sv_u = W(h, "dec_sv_u"); b.sv_c = W(h, "dec_sv_c"); b.sv_h = W(h, "dec_sv_h");
+    b.Hx = HxS; b.ldhx = 2 * H; b.w_head = D(h, "head/w");
     b.WcT_h = D4(h, "dec/WcT_h"); b.WgT_h = D4(h, "dec/WgT_h"); b.WgT_x = D4(h, "dec/WgT_x"); b.WcT_x = D4(h, "dec/WcT_x");
-    b.R = (int)R; b.K = d.K; b.mno = d.mno; b.T = T; b.H = H;
+    b.R = (int)Rs; b.K = d.K; b.mno = mnos; b.T = T; b.H = H;
     b.dag = W(h, "dec_dag"); b.dac = W(h, "dec_dac"); b.rh = W(h, "dec_rh"); b.hprev = W(h, "dec_hprev");
-    b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = W(h, "dHx_rows");
+    b.dxg = W(h, "dec_dxg"); b.dxc = W(h, "dec_dxc"); b.dxz = W(h, "dxz"); b.dHx_rows = dHxS;
     // bias gradients = column sums of the gate-gradient streams: summed per tile inside the BPTT kernels (no further pass over the streams)
-    const int n_tiles32 = (int)((R + 31) / 32);
     b.bias_part = W(h, "bias_part");                            // (allocated by desire_set_training: no hipMalloc inside a call that may be under stream capture)
     { Timer t(h, s, "bwd_decoder"); launch_decoder_bwd(b, s); }
-    launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 0, 2 * H, G(h, "dec/gates/bias"), 0, s);
-    launch_reduce_parts(b.bias_part, n_tiles32, 3 * H, 2 * H, H, G(h, "dec/candidate/bias"), 0, s);
+    launch_reduce_parts(b.bias_part, n_tiles32s, 3 * H, 0, 2 * H, G(h, "dec/gates/bias"), 0, s);
+    launch_reduce_parts(b.bias_part, n_tiles32s, 3 * H, 2 * H, H, G(h, "dec/candidate/bias"), 0, s);
     {
         Timer t(h, s, "bwd_decoder_wgrad");
-        tn(h, W(h, "dec_sv_h"), H, W(h, "dY0"), 2, R * T, H, 2, G(h, "head/w"), 2, 0, s);
-        colsum(h, W(h, "dY0"), 2, R * T, 2, G(h, "head/b"), 0, s);
+        tn(h, W(h, "dec_sv_h"), H, dY0s, 2, Rs * T, H, 2, G(h, "head/w"), 2, 0, s);
+        colsum(h, dY0s, 2, Rs * T, 2, G(h, "head/b"), 0, s);
         float* gk = G(h, "dec/gates/kernel");        // [(H+H), 2H]
-        tn(h, W(h, "xz"), H, W(h, "dec_dxg"), 2 * H, R, H, 2 * H, gk, 2 * H, 0, s);
-        tn(h, W(h, "dec_hprev"), H, W(h, "dec_dag"), 2 * H, R * T, H, 2 * H, gk + (size_t)H * 2 * H, 2 * H, 0, s);
+        tn(h, W(h, "xz"), H, W(h, "dec_dxg"), 2 * H, Rs, H, 2 * H, gk, 2 * H, 0, s);
+        tn(h, W(h, "dec_hprev"), H, W(h, "dec_dag"), 2 * H, Rs * T, H, 2 * H, gk + (size_t)H * 2 * H, 2 * H, 0, s);
         float* ck = G(h, "dec/candidate/kernel");    // [(H+H), H]
-        tn(h, W(h, "xz"), H, W(h, "dec_dxc"), H, R, H, H, ck, H, 0, s);
-        tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, R * T, H, H, ck + (size_t)H * H, H, 0, s);
+        tn(h, W(h, "xz"), H, W(h, "dec_dxc"), H, Rs, H, H, ck, H, 0, s);
+        tn(h, W(h, "dec_rh"), H, W(h, "dec_dac"), H, Rs * T, H, H, ck + (size_t)H * H, H, 0, s);
     }
+    }       // Rs > 0
+    if (compact) launch_fill_f32(W(h, "dHx_rows"), (size_t)R * H, 0.f, s);      // the IOC module accumulates into it; the decoder no longer initialises it
     const int V = h->V, L = d.L, A = h->A;
     const bool bn1 = d.bn_mode != 0;                       // batch statistics -- per object (mode 1, the reference graph's batch of one) or over
                                                            // the whole batch (mode 2): the conv data-gradient kernels run with a linear epilogue and
@@ -609,61 +628,62 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         }
     }
     // ---- mask fc ----
-    {
+    if (Rs > 0) {
         Timer t(h, s, "bwd_mask");
-        launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), W(h, "HxHy"), 2 * H, W(h, "dq_mask"), W(h, "dHx_rows"), (int)R, H, h->Hl, d.K, d.mno, s);
-        colsum(h, W(h, "dq_mask"), H, R, H, G(h, "mask_fc/b"), 0, s);
-        tn(h, W(h, "xhat"), V, W(h, "dq_mask"), H, R, V, H, G(h, "mask_fc/w"), H, 0, s);
+        launch_mask_bwd(W(h, "mask_sv_p"), W(h, "dxz"), HxS, 2 * H, W(h, "dq_mask"), dHxS, (int)Rs, H, h->Hl, d.K, mnos, s);
+        colsum(h, W(h, "dq_mask"), H, Rs, H, G(h, "mask_fc/b"), 0, s);
+        tn(h, W(h, "xhat"), V, W(h, "dq_mask"), H, Rs, V, H, G(h, "mask_fc/w"), H, 0, s);
         GemmArgs g{};
-        g.A = W(h, "dq_mask"); g.lda = H; g.M = (int)R; g.K = H; g.Bp = D4(h, "mask/WT"); g.G = H / 8; g.NT = V / 32;
+        g.A = W(h, "dq_mask"); g.lda = H; g.M = (int)Rs; g.K = H; g.Bp = D4(h, "mask/WT"); g.G = H / 8; g.NT = V / 32;
         g.out = W(h, "dconv4"); g.ldo = V; g.N = V; g.p0 = D(h, "vae_dec/deconv4/scale"); g.chmod = 1; g.aux = W(h, "xhat");
         if (bn1) {          // per-object batch-norm: gradient w.r.t. the layer OUTPUT first, then through activation + instance norm
             launch_gemm_rows(g, EPI_NONE, s);
-            norm_bwd(W(h, "dconv4"), W(h, "deconv4_pre"), W(h, "xhat"), (int)R, 1024, 1, D(h, "vae_dec/deconv4/gamma"), 1);
+            norm_bwd(W(h, "dconv4"), W(h, "deconv4_pre"), W(h, "xhat"), (int)Rs, 1024, 1, D(h, "vae_dec/deconv4/gamma"), 1);
         } else
         launch_gemm_rows(g, EPI_SIGGRAD, s);
     }
     // ---- CVAE decoder (each data gradient = the forward kernel of the mirrored layer with a gradient epilogue) ----
-    {
+    if (Rs > 0) {
         Timer t(h, s, "bwd_cvae_dec");
         const int NSL = 78;
-        launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)R, R < 2048 ? (int)R : 2048, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
-        if (!bn1) colsum(h, W(h, "dconv4"), 1, R * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
+        launch_w1ch_grad(W(h, "dconv4"), W(h, "d3"), (int)Rs, Rs < 2048 ? (int)Rs : 2048, W(h, "tn_partial"), G(h, "vae_dec/deconv4/w"), s);
+        if (!bn1) colsum(h, W(h, "dconv4"), 1, Rs * 1024, 1, G(h, "vae_dec/deconv4/b"), 0, s);
         ConvArgs c{};
-        c.n = (int)R;
+        c.n = (int)Rs;
         c.in = W(h, "dconv4"); c.out = W(h, "dconv3"); c.w_raw = D(h, "vae_dec/deconv4/raw");
         c.scale = D(h, "vae_dec/deconv3/scale"); c.shift = c.scale; c.mode = bn1 ? 3 : 1; c.yprev = W(h, "d3");
         launch_conv1(c, s);
-        if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)R, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
+        if (bn1) norm_bwd(W(h, "dconv3"), W(h, "deconv3_pre"), W(h, "d3"), (int)Rs, 256, 32, D(h, "vae_dec/deconv3/gamma"), 0);
         ConvWgradArgs wg{};
         wg.np = (h->d.bf16 == 2 && (train_x3_mask(h) & 1)) ? 2 : 0;
         wg.S = W(h, "d2"); wg.Cs = 64; wg.Ps = 8; wg.Lg = W(h, "dconv3"); wg.Cl = 32; wg.Pl = 16; wg.stride = 2; wg.pad = 1;
-        wg.n = (int)R; wg.partial = W(h, "tn_partial");
+        wg.n = (int)Rs; wg.partial = W(h, "tn_partial");
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv3/w"), s);
-        if (!bn1) colsum(h, W(h, "dconv3"), 32, R * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv3"), 32, Rs * 256, 32, G(h, "vae_dec/deconv3/b"), 0, s);
         const bool x3 = h->d.bf16 == 2 && (train_x3_mask(h) & 2);                  // split-bf16 operands in the two large data-gradient convolutions
         c.in = W(h, "dconv3"); c.out = W(h, "dconv2"); c.Wp = D4(h, x3 ? "vae_dec/deconv3/Wbwd16" : "vae_dec/deconv3/Wbwd");
         c.scale = D(h, "vae_dec/deconv2/scale"); c.shift = c.scale; c.yprev = W(h, "d2");
         if (x3) launch_conv2_x3(c, s); else launch_conv2(c, s);
-        if (bn1) norm_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)R, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0);
+        if (bn1) norm_bwd(W(h, "dconv2"), W(h, "deconv2_pre"), W(h, "d2"), (int)Rs, 64, 64, D(h, "vae_dec/deconv2/gamma"), 0);
         wg.S = W(h, "d1"); wg.Cs = 128; wg.Ps = 4; wg.Lg = W(h, "dconv2"); wg.Cl = 64; wg.Pl = 8; wg.stride = 1; wg.pad = 0;
         launch_conv_wgrad(wg, NSL, G(h, "vae_dec/deconv2/w"), s);
-        if (!bn1) colsum(h, W(h, "dconv2"), 64, R * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
+        if (!bn1) colsum(h, W(h, "dconv2"), 64, Rs * 64, 64, G(h, "vae_dec/deconv2/b"), 0, s);
         c.in = W(h, "dconv2"); c.out = W(h, "dconv1"); c.Wp = D4(h, x3 ? "vae_dec/deconv2/Wbwd16" : "vae_dec/deconv2/Wbwd");
         c.scale = D(h, "vae_dec/deconv1/scale"); c.shift = c.scale; c.yprev = W(h, "d1");
         if (x3) launch_conv3_x3(c, s); else launch_conv3(c, s);
-        if (bn1) norm_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)R, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0);
-        tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, R, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
-        if (!bn1) colsum(h, W(h, "dconv1"), 128, R * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
+        if (bn1) norm_bwd(W(h, "dconv1"), W(h, "deconv1_pre"), W(h, "d1"), (int)Rs, 16, 128, D(h, "vae_dec/deconv1/gamma"), 0);
+        tn(h, W(h, "dconv1"), 2048, W(h, "z"), L, Rs, 2048, L, G(h, "vae_dec/deconv1/w"), L, 0, s);
+        if (!bn1) colsum(h, W(h, "dconv1"), 128, Rs * 16, 128, G(h, "vae_dec/deconv1/b"), 0, s);
         GemmArgs g{};
-        g.A = W(h, "dconv1"); g.lda = 2048; g.M = (int)R; g.K = 2048; g.Bp = D4(h, "vae_dec/deconv1/WT"); g.G = 2048 / 8;
+        g.A = W(h, "dconv1"); g.lda = 2048; g.M = (int)Rs; g.K = 2048; g.Bp = D4(h, "vae_dec/deconv1/WT"); g.G = 2048 / 8;
         g.NT = (L + 31) / 32; g.out = W(h, "dz"); g.ldo = L; g.N = L;
         launch_gemm_rows(g, EPI_NONE, s);
     }
     // ---- latent + CVAE encoder + fc_c ----
     {
         Timer t(h, s, "bwd_cvae_enc");
-        launch_reparam_bwd(W(h, "dz"), dev_eps, W(h, "params"), valid, W(h, "nvalid"), W(h, "dparams"), d.n_scenes, d.mno, d.K, L, s);
+        launch_reparam_bwd(W(h, "dz"), dev_eps, W(h, "params"), valid, W(h, "nvalid"), W(h, "dparams"), d.n_scenes, d.mno, d.K, L, s,
+                           compact ? static_cast<const int32_t*>(h->ws["cp_inv"].p) : nullptr, P);
         tn(h, W(h, "c3"), 2048, W(h, "dparams"), 2 * L, A, 2048, 2 * L, G(h, "vae_enc/fc/w"), 2 * L, 0, s);
         colsum(h, W(h, "dparams"), 2 * L, A, 2 * L, G(h, "vae_enc/fc/b"), 0, s);
         GemmArgs g{};
@@ -705,6 +725,11 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         g.out = W(h, "dHxHy"); g.ldo = 2 * H; g.N = 2 * H;
         launch_gemm_rows(g, EPI_NONE, s);
         launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
+        if (compact && P > 0) {         // the compact stages' share of d loss / d Hx: rows -> compact agents -> agents
+            launch_fill_f32(W(h, "cp_dHx"), (size_t)P * H, 0.f, s);
+            launch_rows_to_agents(dHxS, W(h, "cp_dHx"), H, 1, P, d.K, H, s);
+            launch_scatter_add_agents(W(h, "cp_dHx"), H, W(h, "dHxHy"), 2 * H, amap, P, H, s);
+        }
     }
     // ---- encoders: BPTT from the final state (Hx / Hy), zero initial state ----
     const bool head_loss = h->head_loss_w > 0.f;

@@ -161,3 +161,74 @@ def test_flag_is_refused_where_it_would_change_results(torch_cuda):
             except _lib.DesireError:
                 pass
     h.close()
+
+
+# ---- training: the per-row stages' saves and their whole backward on the compact rows --------------------------------------------------
+def _train_step(torch, d, w, past, fut, eps, grids, gos):
+    from desire_amd import _lib
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    h.set_training(True)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.zeros((d.R, d.T_pred, 2), device=dev)
+    score = torch.zeros((d.R,), device=dev)
+    h.forward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr(), Y.data_ptr(), score.data_ptr())
+    h.backward(past_t.data_ptr(), fut_t.data_ptr(), eps_t.data_ptr())
+    torch.cuda.synchronize()
+    loss = h.train_loss(fut_t.data_ptr())
+    grads = {k: h.get_grad(k, w[k].shape) for k in w if not k.startswith("gauss_head/") and "/moving_" not in k and "/gamma" not in k and "/beta" not in k}
+    h.close()
+    return loss, grads
+
+
+def _spread(w):
+    for k in w:                                  # as tests/test_gpu_train.py: spread the K samples so that the ranking gradients do not vanish
+        if k.startswith("vae_dec/") and k.endswith("/w"):
+            w[k] = w[k] * 3
+    w["mask_fc/w"] = w["mask_fc/w"] * 20
+    w["head/w"] = w["head/w"] * 4
+    w["ioc/score/w"] = w["ioc/score/w"] * 3
+    return w
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(bf16=2), dict(bn_mode=1), dict(mno=16, H=64, K=2)], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
+def test_training_step_on_compact_rows_matches_the_uncompacted_one(torch_cuda, kw):
+    """Loss terms and every weight gradient of the compacted step against the uncompacted step: the same sums over the same present rows in a
+    different order (absent rows contribute exact zeros to the uncompacted sums), so they agree to fp32 reduction noise."""
+    d = small_dims(**{**dict(n_scenes=4, K=3, T_obs=6, T_pred=7, n_grids=1), **kw})
+    w = _spread(init_weights(d, 41))
+    past, fut, eps, grids, gos, keep = ragged_case(d, seed=42)
+    la, ga = _train_step(torch_cuda, d, w, past, fut, eps, grids, gos)
+    lb, gb = _train_step(torch_cuda, d.replace(flags=FLAG_COMPACT_ROWS), w, past, fut, eps, grids, gos)
+    for key in ("recon", "kld", "ce", "reg", "loss"):
+        assert abs(la[key] - lb[key]) <= 1e-6 * max(1.0, abs(la[key])), (key, la[key], lb[key])
+    assert la["n_present"] == lb["n_present"] > 0
+    worst = ("", 0.0)
+    for k in ga:
+        ref = np.abs(ga[k]).max()
+        err = float(np.abs(ga[k] - gb[k]).max() / (ref + 1e-12)) if ref > 1e-9 else float(np.abs(gb[k]).max())
+        if err > worst[1]:
+            worst = (k, err)
+        assert np.isfinite(gb[k]).all()
+    print("compact vs uncompacted training step: worst relative gradient difference %.2e (%s)" % (worst[1], worst[0]))
+    assert worst[1] < (5e-5 if kw.get("bf16") else 2e-5), worst
+
+
+def test_training_gradients_on_compact_rows_match_float64_autograd(torch_cuda):
+    """The compacted training step against the float64 autograd oracle (oracle/desire_torch.py), the bar of tests/test_gpu_train.py."""
+    from oracle import desire_torch as OT
+    from tests.helpers import to_oracle_layout
+    d = small_dims(n_scenes=2, mno=32, K=3, T_obs=6, T_pred=7, n_grids=1)
+    w = _spread(init_weights(d, 41))
+    past, fut, eps, grids, gos, keep = ragged_case(d, seed=43, keep=0.4)
+    vals, ref = OT.loss_and_grads(to_oracle_layout(past), to_oracle_layout(fut), eps, grids, gos, w, d)
+    loss, g = _train_step(torch_cuda, d.replace(flags=FLAG_COMPACT_ROWS), w, past, fut, eps, grids, gos)
+    assert abs(loss["loss"] - float(vals["loss"])) < 1e-4 * max(1.0, abs(float(vals["loss"])))
+    for k in g:
+        if k not in ref or k == "ioc/score/b":
+            continue
+        rel = float(np.abs(g[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-12))
+        assert rel < 2e-4, (k, rel)
