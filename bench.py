@@ -1115,6 +1115,31 @@ def main():
                                        "IOC tiles stay scene-shaped"}
         sdd["kernel_ms"] = {k: round(float(np.mean(v)), 4) for k, v in k2.items()}
         h3.close()
+        # ... and with DESIRE_FLAG_COMPACT_IOC on top: the IOC stage on slot classes (a window with 9 present agents runs in 16 slots, not 32)
+        h4 = _lib.Handle(d2.replace(flags=d2.flags | 4 | 8))
+        h4.set_weights(w)
+        h4.set_scene_grids(grids_t.data_ptr(), gos)
+        Yi = torch.zeros_like(Y)
+        sci = torch.zeros_like(score)
+        for _ in range(2):
+            h4.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yi.data_ptr(), sci.data_ptr(), stream)
+        torch.cuda.synchronize()
+        h4.set_profiling(True)
+        ts = time.perf_counter()
+        for _ in range(n2):
+            h4.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yi.data_ptr(), sci.data_ptr(), stream)
+        torch.cuda.synchronize()
+        i_dt = (time.perf_counter() - ts) / n2
+        h4.set_profiling(False)
+        k4 = {}
+        for name, ms in h4.get_profile():
+            k4.setdefault(name, []).append(ms)
+        sdd["compact_rows_and_ioc"] = {"ms_per_step": i_dt * 1e3, "value_present_agents_only": present * d.K * d.n_scenes / i_dt,
+                                       "kernel_ms_per_step": {k: round(float(np.sum(v)) / n2, 4) for k, v in k4.items()},
+                                       "max_abs_diff_present_rows_vs_uncompacted": float((Yi[rows_present] - Y[rows_present]).abs().max()),
+                                       "note": "dims.flags = DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC; kernel_ms_per_step sums the launches of one "
+                                               "step (one IOC launch per slot class)"}
+        h4.close()
 
     per_kernel = {}
     for name, ms in prof:

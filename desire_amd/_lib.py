@@ -14,7 +14,7 @@ from .spec import Dims
 LIB_PATH = os.environ.get("DESIRE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdesire_hip.so")
 
 EXPORTS = [
-    "desire_last_error", "desire_version", "desire_create", "desire_destroy", "desire_set_weight",
+    "desire_last_error", "desire_version", "desire_dims_size", "desire_create", "desire_destroy", "desire_set_weight",
     "desire_finalize_weights", "desire_set_scene_grids", "desire_encode", "desire_sample",
     "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
     "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
@@ -119,6 +119,9 @@ def load() -> C.CDLL:
     for n in EXPORTS:
         if n != "desire_last_error":
             getattr(lib, n).restype = C.c_int
+    if lib.desire_dims_size() != C.sizeof(DesireDims):          # this binding and the library disagree about desire_dims: refuse to run
+        raise DesireError("libdesire_hip.so was built with sizeof(desire_dims) = %d, this binding has %d: rebuild (python -c 'import "
+                          "__graft_entry__ as g; g.build()')" % (lib.desire_dims_size(), C.sizeof(DesireDims)))
     _lib = lib
     return lib
 
@@ -153,7 +156,8 @@ class Handle:
     def set_option(self, name: str, value: int) -> None:
         """One of the behavioural switches of desire_dims ("ioc_form", "ioc_split", "train_fp32_mask", "flags") on the live handle."""
         _chk(self.lib.desire_set_option(self._h, name.encode(), int(value)))
-        self.dims = self.dims.replace(**{name: int(value)})
+        if hasattr(self.dims, name):                      # ("compact_min_rows" is a handle option, not a desire_dims field)
+            self.dims = self.dims.replace(**{name: int(value)})
 
     def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
         for name, arr in weights.items():

@@ -11,7 +11,8 @@ static thread_local std::string g_err;
 int desire_fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* desire_last_error(void) { return g_err.c_str(); }
-extern "C" int desire_version(void) { return 1; }
+extern "C" int desire_version(void) { return 5; }
+extern "C" int desire_dims_size(void) { return (int)sizeof(desire_dims); }
 
 // Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
 std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at) {
@@ -181,7 +182,8 @@ int check_options(const desire_dims& d) {
     }
     if (d.ioc_split < 0 || d.ioc_split > 4) return fail(DESIRE_ERR_ARG, "ioc_split must be 0 (auto), 1 (never split: batch-size invariant results) or 2..4 (cap)");
     if (d.train_fp32_mask < 0 || d.train_fp32_mask > 15) return fail(DESIRE_ERR_ARG, "train_fp32_mask is a mask of bits 1, 2, 4, 8");
-    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_TRAIN_FWD_3P | DESIRE_FLAG_COMPACT_ROWS)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if (d.flags & ~(DESIRE_FLAG_NO_FUSE34 | DESIRE_FLAG_TRAIN_FWD_3P | DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC)) return fail(DESIRE_ERR_ARG, "unknown bit in flags (DESIRE_FLAG_*)");
+    if ((d.flags & DESIRE_FLAG_COMPACT_IOC) && d.ref_compat) return fail(DESIRE_ERR_ARG, "DESIRE_FLAG_COMPACT_IOC: ref_compat has no IOC stage");
     if ((d.flags & DESIRE_FLAG_COMPACT_ROWS) && (d.bn_mode == 2 || d.ref_compat))
         return fail(DESIRE_ERR_ARG, "DESIRE_FLAG_COMPACT_ROWS: not with bn_mode = 2 (whole-batch statistics depend on the padding rows) or ref_compat");
     return 0;
@@ -230,7 +232,12 @@ extern "C" int desire_set_option(desire_handle* h, const char* name, int32_t val
     else if (nm == "ioc_split") d.ioc_split = value;
     else if (nm == "train_fp32_mask") d.train_fp32_mask = value;
     else if (nm == "flags") d.flags = value;
-    else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags)");
+    else if (nm == "compact_min_rows") {       // DESIRE_FLAG_COMPACT_IOC: a slot class with fewer rows than this is folded into the next larger one (default 8192)
+        if (value < 0) return fail(DESIRE_ERR_ARG, "compact_min_rows must be >= 0");
+        h->ci_min_rows = value;
+        return DESIRE_OK;
+    }
+    else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags, compact_min_rows)");
     if (int rc = check_options(d)) return rc;
     h->d = d;
     return DESIRE_OK;
@@ -658,21 +665,53 @@ int desire_ready(desire_handle* h) {
 
 // DESIRE_FLAG_COMPACT_ROWS: the per-row sample-generation stages run on the rows of present agents only (kernels_compact.hip)
 bool compact_rows(const desire_ctx* h) { return (h->d.flags & DESIRE_FLAG_COMPACT_ROWS) != 0; }
+// DESIRE_FLAG_COMPACT_IOC: windows re-seated in the smallest slot class that holds their present agents (kernels_compact.hip).  Shapes served by the
+// step-wise IOC (more than 128 slots, or split operands at H = 256) keep their own layout.
+bool compact_ioc(const desire_ctx* h) {
+    const desire_dims& d = h->d;
+    if (!(d.flags & DESIRE_FLAG_COMPACT_IOC) || d.mno > 128 || h->training) return false;
+    const int B_ = d.grid_size * d.grid_size;
+    const bool split_mode = (d.bf16 == 2 || d.bf16 == 3) && !h->training;
+    const bool split_served = ioc_x3_supported(d.mno, d.H, B_) || (d.mno == 64 && ioc_x6r2_supported(d.mno, d.H, B_));
+    return !(split_mode && !split_served && d.H == 256 && d.ioc_form == DESIRE_IOC_AUTO);
+}
+int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: 8, 16, 32 below the handle's own mno, then mno itself
+    int n = 0;
+    for (int m : {8, 16, 32}) if (m < h->d.mno) m4[n++] = m;
+    m4[n++] = h->d.mno;
+    for (int i = n; i < 4; ++i) m4[i] = h->d.mno;
+    return n;
+}
 int compact_setup(desire_ctx* h) {
-    if (h->cp_host) return DESIRE_OK;
     const desire_dims& d = h->d;
     const size_t A = h->A, R = h->R, f = sizeof(float);
     struct WS { const char* n; size_t bytes; };
-    const WS list[] = {{"cp_amap", A * sizeof(int32_t)}, {"cp_inv", A * sizeof(int32_t)}, {"cp_count", sizeof(int32_t)}, {"cp_HxHy", A * 2 * d.H * f},
+    const WS list[] = {{"cp_amap", A * sizeof(int32_t)}, {"cp_inv", A * sizeof(int32_t)}, {"cp_count", 8 * sizeof(int32_t)}, {"cp_HxHy", A * 2 * d.H * f},
                        {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f}};
+    const WS list_ioc[] = {{"ci_win", 4 * (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_map", 4 * A * sizeof(int32_t)}, {"ci_Hx", A * 2 * d.H * f}, {"ci_pl", A * 2 * f},
+                           {"ci_valid", A}, {"ci_gos", (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_Y", R * (size_t)d.T_pred * 2 * f}, {"ci_score", R * f}};
     for (const WS& w : list)
         if (!h->ws[w.n].p && h->ws[w.n].alloc(w.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n);
+    if (h->d.flags & DESIRE_FLAG_COMPACT_IOC)
+        for (const WS& w : list_ioc)
+            if (!h->ws[w.n].p && h->ws[w.n].alloc(w.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n);
     if (!h->cp_ev) HIPCHK(hipEventCreateWithFlags(&h->cp_ev, hipEventDisableTiming));
-    int32_t* p = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(int32_t), hipHostMallocMapped) != hipSuccess || !p)
-        return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the present-agent count word");
-    *p = 0;
-    h->cp_host = p;
+    if (!h->cp_host) {
+        int32_t* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), 8 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess || !p)
+            return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the present-agent count words");
+        for (int i = 0; i < 8; ++i) p[i] = 0;
+        h->cp_host = p;
+    }
+    return DESIRE_OK;
+}
+// waits (once per desire_encode) for the scans' counts to reach the host
+static int compact_wait(desire_ctx* h, hipStream_t s) {
+    if (!h->cp_pending) return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_*: desire_encode comes first (it builds the present-agent maps)");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_* read the present-agent counts back: not capturable in a hipGraph");
+    HIPCHK(hipEventSynchronize(h->cp_ev));
     return DESIRE_OK;
 }
 
@@ -706,13 +745,19 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     } else if (d.posterior) {      // the two encoders are independent and latency-bound: one launch
         Timer t(h, s, "encoder_xy"); launch_encoder_pair(ex, e, s);
     } else { Timer t(h, s, "encoder_x"); launch_encoder(ex, s); }
-    if (compact_rows(h)) {
+    if (compact_rows(h) || compact_ioc(h)) {
         // present-row compaction (DESIRE_FLAG_COMPACT_ROWS): the map of the agents present at the last observed frame, built right behind the
         // encoder that writes `valid`; its size reaches the host through a mapped word while the CVAE encoder below keeps the device busy, and
         // desire_sample waits on the event before it sizes its launches.
         if (int rc = compact_setup(h)) return rc;
         launch_present_scan(static_cast<const uint8_t*>(h->ws["valid"].p), A, static_cast<int32_t*>(h->ws["cp_amap"].p), static_cast<int32_t*>(h->ws["cp_inv"].p),
                             static_cast<int32_t*>(h->ws["cp_count"].p), h->cp_host, s);
+        if (compact_ioc(h)) {
+            int m4[4];
+            const int n_cls = compact_classes(h, m4);
+            launch_class_scan(static_cast<const uint8_t*>(h->ws["valid"].p), d.n_scenes, d.mno, n_cls, m4, d.K, h->ci_min_rows, static_cast<int32_t*>(h->ws["ci_win"].p),
+                              static_cast<int32_t*>(h->ws["ci_map"].p), static_cast<int32_t*>(h->ws["cp_count"].p) + 4, h->cp_host + 4, s);
+        }
         HIPCHK(hipEventRecord(h->cp_ev, s));
         h->cp_pending = true;
     }
@@ -765,11 +810,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     const bool compact = compact_rows(h);
     h->cp_last = compact;
     if (compact) {
-        if (!h->cp_pending) return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_ROWS: desire_encode comes first (it builds the present-agent map)");
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_ROWS reads the present-agent count back: not capturable in a hipGraph");
-        HIPCHK(hipEventSynchronize(h->cp_ev));
+        if (int rc = compact_wait(h, s)) return rc;
         const int P = *static_cast<volatile int32_t*>(h->cp_host);
         if (P < 0 || P > h->A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
         h->cp_P = P;
@@ -877,6 +918,145 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     return DESIRE_OK;
 }
 
+// One IOC launch sequence over a VIEW of the handle's rows: the handle's own shape (row_off 0), or one slot class of DESIRE_FLAG_COMPACT_IOC --
+// n_scenes windows of mno slots each with their own agent-level inputs; training-mode saves go to the view's row offset in the shared buffers.
+struct IocView {
+    int R, mno, n_scenes; float* Y; float* score; const float* Hx; int ldhx; const float* p_last; const uint8_t* valid; const int32_t* gos; size_t row_off;
+};
+static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
+    const desire_dims& d = h->d;
+    IocArgs a{};
+    a.Y = v.Y; a.score = v.score; a.Hx = v.Hx; a.ldhx = v.ldhx; a.p_last = v.p_last;
+    a.valid = v.valid;
+    a.R = v.R; a.K = d.K; a.mno = v.mno; a.H = d.H; a.T = d.T_pred; a.iters = d.iters;
+    a.C = d.C; a.Gh = d.Gh; a.Gw = d.Gw; a.E_v = d.E_v; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;
+    a.grids = h->grids; a.grid_of_scene = v.gos;
+    a.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
+    a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b");
+    a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b"); a.Wsoc_c = D4(h, "ioc/Wsoc_c");
+    a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
+    a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
+    a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
+    a.variant = d.ioc_form;
+    // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
+    // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
+    // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
+    const bool wide64 = v.mno == 64 && !h->training && ioc_x6r2_supported(v.mno, d.H, d.grid_size * d.grid_size);
+    const bool x3 = d.bf16 == 2 && (ioc_x3_supported(v.mno, d.H, d.grid_size * d.grid_size) || wide64);
+    const bool x6 = d.bf16 == 3 && (ioc_x3_supported(v.mno, d.H, d.grid_size * d.grid_size) || wide64);     // six-product form: inference only
+    const bool cluster = d.bf16 == 1 ? (v.mno > 64 || (v.mno == 64 && (a.variant == 4 || a.variant == 6)))
+                                : (!(x3 || x6) || h->training) && ioc_uses_cluster(v.mno, d.H, d.grid_size * d.grid_size, a.variant);
+    if (cluster) {
+        const size_t n_groups = (size_t)v.R / v.mno;
+        if (!h->ws.count("hex")) {          // (sized for the handle's own shape: every view of it -- DESIRE_FLAG_COMPACT_IOC classes -- is smaller)
+            if (h->ws["hex"].alloc((size_t)2 * h->R * d.H * sizeof(float)) || h->ws["grp_cnt"].alloc(((size_t)h->R / 32 + 1) * sizeof(int)) ||
+                h->ws["ioc_err"].alloc(sizeof(int)))
+                return fail(DESIRE_ERR_HIP, "hipMalloc failed for the cluster exchange buffers");
+        }
+        HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
+        HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
+        a.hex = W(h, "hex"); a.grp_cnt = static_cast<int*>(h->ws["grp_cnt"].p); a.err = static_cast<int*>(h->ws["ioc_err"].p);
+    }
+    // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; dims.ioc_split = 1: off).
+    // The members of a tile wait for each other, so the split is taken only when the whole launch is co-resident on THIS device
+    // (occupancy x compute units, not a constant: a partition with fewer CUs falls back to the plain form).
+    if (!cluster && d.bf16 == 0 && !h->training && d.ioc_split != 1 && a.variant == 0) {
+        int nspl = ioc_bin_split(v.R, v.mno, d.H, d.grid_size * d.grid_size, d.iters);
+        if (nspl > 1 && d.ioc_split > 1) nspl = std::min(nspl, d.ioc_split);
+        const size_t tiles = ((size_t)v.R + 31) / 32, tiles_max = ((size_t)h->R + 31) / 32;
+        while (nspl > 1 && (size_t)ioc_bin_split_capacity(a, nspl) < tiles * nspl) --nspl;
+        if (nspl > 1) {
+            if (!h->ws.count("hex_s") || !h->ws["hex_s"].p || !h->ws["cnt_s"].p) {
+                if (h->ws["hex_s"].alloc(tiles_max * 2 * 4 * 32 * d.H * sizeof(float)) || h->ws["cnt_s"].alloc(tiles_max * sizeof(int)))
+                    return fail(DESIRE_ERR_HIP, "hipMalloc failed for the bin-split exchange buffers");
+            }
+            // the error word is mapped host memory: no read-back (and no stream synchronisation) per call; a timed-out hand-off is
+            // reported by the NEXT call on this handle.  Allocated and checked on its own (a failure here must not leave a later call
+            // with exchange buffers and a null word); the kernels write it with system-scope atomics.
+            if (!h->host_err) {
+                if (hipHostMalloc(reinterpret_cast<void**>(&h->host_err), sizeof(int), hipHostMallocMapped) != hipSuccess || !h->host_err) {
+                    h->host_err = nullptr;
+                    return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the bin-split error word");
+                }
+                *h->host_err = 0;
+            }
+            if (*static_cast<volatile int*>(h->host_err)) {
+                *h->host_err = 0;
+                return fail(DESIRE_ERR_HIP, "bin-split IOC hand-off timed out in an earlier call (workgroups of a tile were not co-resident)");
+            }
+            // (a fill KERNEL, not hipMemsetAsync: memset nodes of a captured graph were seen to run out of order on replay -- section 6a --
+            //  and a counter that still holds the previous pass's arrivals lets every member read its peers' slots before they are written)
+            launch_fill_f32(W(h, "cnt_s"), tiles, 0.f, s);
+            a.hex = W(h, "hex_s"); a.grp_cnt = static_cast<int*>(h->ws["cnt_s"].p); a.err = h->host_err;
+            a.nspl = nspl;
+        }
+    }
+#ifdef DESIRE_IOC_TIMING
+    if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
+    a.dbg = static_cast<long long*>(h->ws["dbg"].p);
+#endif
+    if (h->training && d.bf16 != 1) {
+        // training-mode forward: one launch per refinement pass, each keeping its own activations and the positions it ran on
+        // (the pass's input is DETACHED where it enters the features -- cells, bins, velocity embedding -- and Y_p = Y_{p-1} + dY_p
+        // carries the gradient: DESIGN.md section 8)
+        const size_t RT = (size_t)v.R * d.T_pred, RTf = (size_t)h->R * d.T_pred, ro = v.row_off * d.T_pred;     // a view's saves sit at its row offset
+        a.iters = 1;
+        for (int p = 0; p < d.iters; ++p) {
+            const size_t po = (size_t)p * RTf + ro;
+            launch_copy_f32(W(h, "ioc_Yin") + po * 2, v.Y, RT * 2, s);
+            a.sv_x = W(h, "ioc_sv_x") + po * h->E; a.sv_r = W(h, "ioc_sv_r") + po * d.H;
+            a.sv_u = W(h, "ioc_sv_u") + po * d.H; a.sv_c = W(h, "ioc_sv_c") + po * d.H;
+            a.sv_h = W(h, "ioc_sv_h") + po * d.H;
+            if (cluster && p > 0) HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, ((size_t)v.R / v.mno) * sizeof(int), s));
+            if (x3) {       // split-bf16 operands; the saves are fp32 and the backward pass is the fp32 one
+                a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+                Timer t(h, s, "ioc"); launch_ioc_x3(a, s);
+            } else
+            { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+        }
+    } else
+    if (x3 || x6) {   // split-bf16 operands: fp32-equivalent results on the bf16 matrix pipe (shapes without that form run the fp32 kernels)
+        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+        Timer t(h, s, "ioc");
+        if (x6) launch_ioc_x6(a, s); else launch_ioc_x3(a, s);
+    } else
+    if (d.bf16 == 1) {
+        if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
+        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
+        Timer t(h, s, "ioc");
+        if (cluster) { if (launch_ioc_bf16_cluster(a, s)) return fail(DESIRE_ERR_HIP, "bf16 cluster IOC: no resident grid for this shape"); }
+        else launch_ioc_bf16(a, s);
+    } else
+    { Timer t(h, s, "ioc"); launch_ioc(a, s); }
+#ifdef DESIRE_IOC_TIMING
+    {
+        long long host[10];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
+        const char* n32[10] = {"P0 pos+clear", "P1 ev/es/masks", "build0+bar", "build(b+1)", "mma bin", "bin barrier",
+                               "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
+        const char* n16[10] = {"loop top", "P1 ev/es/masks", "barrier 1", "P2 pooling chain + e_r", "barrier 2", "P4 gates + r*h",
+                               "barrier 3", "P5 cand + publish", "barrier 4", ""};
+        const char* nx3[10] = {"step top (bar 4 wait)", "P1 ev/es/masks", "barrier 1", "P2 pooling chain", "exchange + e_r", "barrier 2",
+                               "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
+        const char* ncl[10] = {"step top: positions + clear + bar", "P1 ev/es/masks", "wait for the peers", "copy peers' Ht + bar", "P2 pooling chains",
+                               "exchange + e_r", "barrier 2", "P4 gates + r*h + cand frags", "bar 3 + P5 cand + publish stores", "drain + arrive + bar"};
+        const char** names = (x3 || x6) ? nx3 : d.bf16 == 1 ? (cluster ? ncl : n16) : n32;
+        const int nk = (x3 || x6 || (d.bf16 == 1 && cluster)) ? 10 : 9;
+        long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
+        for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
+    }
+#endif
+    HIPCHK(hipGetLastError());
+    if (cluster) {
+        int err = 0;
+        HIPCHK(hipMemcpyAsync(&err, h->ws["ioc_err"].p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (err) return fail(DESIRE_ERR_HIP, "IOC cluster hand-off timed out (workgroups of a group were not co-resident)");
+    }
+    return DESIRE_OK;
+}
+
 extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_score, void* stream) {
     if (int rc = desire_ready(h)) return rc;
     if (!dev_Yhat || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
@@ -926,135 +1106,56 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         HIPCHK(hipGetLastError());
         return DESIRE_OK;
     }
-    IocArgs a{};
-    a.Y = dev_Yhat; a.score = dev_score; a.Hx = W(h, "HxHy"); a.ldhx = 2 * d.H; a.p_last = W(h, "p_last");
-    a.valid = static_cast<const uint8_t*>(h->ws["valid"].p);
-    a.R = h->R; a.K = d.K; a.mno = d.mno; a.H = d.H; a.T = d.T_pred; a.iters = d.iters;
-    a.C = d.C; a.Gh = d.Gh; a.Gw = d.Gw; a.E_v = d.E_v; a.G = d.grid_size; a.nb_w = d.nb_w; a.nb_h = d.nb_h;
-    a.grids = h->grids; a.grid_of_scene = static_cast<const int32_t*>(h->ws["grid_of_scene"].p);
-    a.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
-    a.w_vel = D(h, "ioc/vel_w"); a.b_vel = D(h, "ioc/vel_b");
-    a.Wsoc = D4(h, "ioc/Wsoc"); a.b_soc = D(h, "ioc/soc_b"); a.Wsoc_c = D4(h, "ioc/Wsoc_c");
-    a.Wg = D4(h, "ioc/Wg"); a.Wc = D4(h, "ioc/Wc"); a.b_g = D(h, "ioc/gb"); a.b_c = D(h, "ioc/cb");
-    a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
-    a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
-    a.variant = d.ioc_form;
-    // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
-    // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
-    // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
-    const bool wide64 = d.mno == 64 && !h->training && ioc_x6r2_supported(d.mno, d.H, d.grid_size * d.grid_size);
-    const bool x3 = d.bf16 == 2 && (ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size) || wide64);
-    const bool x6 = d.bf16 == 3 && (ioc_x3_supported(d.mno, d.H, d.grid_size * d.grid_size) || wide64);     // six-product form: inference only
-    const bool cluster = d.bf16 == 1 ? (d.mno > 64 || (d.mno == 64 && (a.variant == 4 || a.variant == 6)))
-                                : (!(x3 || x6) || h->training) && ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, a.variant);
-    if (cluster) {
-        const size_t n_groups = (size_t)h->R / d.mno;
-        if (!h->ws.count("hex")) {
-            if (h->ws["hex"].alloc((size_t)2 * h->R * d.H * sizeof(float)) || h->ws["grp_cnt"].alloc(n_groups * sizeof(int)) ||
-                h->ws["ioc_err"].alloc(sizeof(int)))
-                return fail(DESIRE_ERR_HIP, "hipMalloc failed for the cluster exchange buffers");
+    if (compact_ioc(h)) {
+        // DESIRE_FLAG_COMPACT_IOC: one launch sequence per slot class over the windows seated in it; windows without a present agent are not run
+        // (their rows keep the Y they came with and score 0)
+        if (int rc = compact_wait(h, s)) return rc;
+        int m4[4];
+        const int n_cls = compact_classes(h, m4);
+        const int32_t* cnt = h->cp_host + 4;
+        size_t aoff = 0, roff = 0, woff = 0;
+        const size_t T2 = (size_t)d.T_pred * 2;
+        launch_fill_f32(dev_score, (size_t)h->R, 0.f, s);
+        h->ci_n = 0;
+        for (int c = 0; c < n_cls; ++c) {
+            const int n_c = static_cast<volatile const int32_t*>(cnt)[c], m_c = m4[c];
+            if (n_c < 0 || n_c > d.n_scenes) return fail(DESIRE_ERR_HIP, "slot-class scan returned a count out of range");
+            if (n_c == 0) continue;
+            const int32_t* cmap = static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A;
+            const int32_t* win = static_cast<const int32_t*>(h->ws["ci_win"].p) + (size_t)c * d.n_scenes;
+            const int R_c = n_c * d.K * m_c;
+            IocView v{R_c, m_c, n_c, W(h, "ci_Y") + roff * T2, W(h, "ci_score") + roff, W(h, "ci_Hx") + aoff * 2 * d.H, 2 * d.H, W(h, "ci_pl") + aoff * 2,
+                      static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, static_cast<const int32_t*>(h->ws["ci_gos"].p) + woff, roff};
+            {
+                Timer t(h, s, "ioc_repack");
+                launch_cls_gather_agents(W(h, "HxHy"), 2 * d.H, W(h, "p_last"), static_cast<const int32_t*>(h->ws["grid_of_scene"].p), cmap, win, n_c, m_c,
+                                         const_cast<float*>(v.Hx), const_cast<float*>(v.p_last), const_cast<uint8_t*>(v.valid), const_cast<int32_t*>(v.gos), s);
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 0, s);
+            }
+            if (int rc = ioc_core(h, v, s)) return rc;
+            {
+                Timer t(h, s, "ioc_repack");
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 1, s);
+                launch_cls_rows(dev_score, v.score, cmap, n_c, m_c, d.K, d.mno, 1, 1, s);
+            }
+            h->ci_cls[h->ci_n] = c; h->ci_cnt[h->ci_n] = n_c; ++h->ci_n;
+            aoff += (size_t)n_c * m_c; roff += (size_t)R_c; woff += (size_t)n_c;
         }
-        HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
-        HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
-        a.hex = W(h, "hex"); a.grp_cnt = static_cast<int*>(h->ws["grp_cnt"].p); a.err = static_cast<int*>(h->ws["ioc_err"].p);
-    }
-    // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; dims.ioc_split = 1: off).
-    // The members of a tile wait for each other, so the split is taken only when the whole launch is co-resident on THIS device
-    // (occupancy x compute units, not a constant: a partition with fewer CUs falls back to the plain form).
-    if (!cluster && d.bf16 == 0 && !h->training && d.ioc_split != 1 && a.variant == 0) {
-        int nspl = ioc_bin_split(h->R, d.mno, d.H, d.grid_size * d.grid_size, d.iters);
-        if (nspl > 1 && d.ioc_split > 1) nspl = std::min(nspl, d.ioc_split);
-        const size_t tiles = ((size_t)h->R + 31) / 32;
-        while (nspl > 1 && (size_t)ioc_bin_split_capacity(a, nspl) < tiles * nspl) --nspl;
-        if (nspl > 1) {
-            if (!h->ws.count("hex_s") || !h->ws["hex_s"].p || !h->ws["cnt_s"].p) {
-                if (h->ws["hex_s"].alloc(tiles * 2 * 4 * 32 * d.H * sizeof(float)) || h->ws["cnt_s"].alloc(tiles * sizeof(int)))
-                    return fail(DESIRE_ERR_HIP, "hipMalloc failed for the bin-split exchange buffers");
-            }
-            // the error word is mapped host memory: no read-back (and no stream synchronisation) per call; a timed-out hand-off is
-            // reported by the NEXT call on this handle.  Allocated and checked on its own (a failure here must not leave a later call
-            // with exchange buffers and a null word); the kernels write it with system-scope atomics.
-            if (!h->host_err) {
-                if (hipHostMalloc(reinterpret_cast<void**>(&h->host_err), sizeof(int), hipHostMallocMapped) != hipSuccess || !h->host_err) {
-                    h->host_err = nullptr;
-                    return fail(DESIRE_ERR_HIP, "hipHostMalloc failed for the bin-split error word");
-                }
-                *h->host_err = 0;
-            }
-            if (*static_cast<volatile int*>(h->host_err)) {
-                *h->host_err = 0;
-                return fail(DESIRE_ERR_HIP, "bin-split IOC hand-off timed out in an earlier call (workgroups of a tile were not co-resident)");
-            }
-            // (a fill KERNEL, not hipMemsetAsync: memset nodes of a captured graph were seen to run out of order on replay -- section 6a --
-            //  and a counter that still holds the previous pass's arrivals lets every member read its peers' slots before they are written)
-            launch_fill_f32(W(h, "cnt_s"), tiles, 0.f, s);
-            a.hex = W(h, "hex_s"); a.grp_cnt = static_cast<int*>(h->ws["cnt_s"].p); a.err = h->host_err;
-            a.nspl = nspl;
+        h->ci_last = true;
+        if (h->training && d.bf16 != 1) {
+            launch_copy_f32(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2, s);
+            launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
         }
+        HIPCHK(hipGetLastError());
+        return DESIRE_OK;
     }
-#ifdef DESIRE_IOC_TIMING
-    if (!h->ws.count("dbg")) { h->ws["dbg"].alloc(10 * sizeof(long long)); }
-    a.dbg = static_cast<long long*>(h->ws["dbg"].p);
-#endif
+    h->ci_last = false;
+    IocView full{h->R, d.mno, d.n_scenes, dev_Yhat, dev_score, W(h, "HxHy"), 2 * d.H, W(h, "p_last"), static_cast<const uint8_t*>(h->ws["valid"].p),
+                 static_cast<const int32_t*>(h->ws["grid_of_scene"].p), 0};
+    if (int rc = ioc_core(h, full, s)) return rc;
     if (h->training && d.bf16 != 1) {
-        // training-mode forward: one launch per refinement pass, each keeping its own activations and the positions it ran on
-        // (the pass's input is DETACHED where it enters the features -- cells, bins, velocity embedding -- and Y_p = Y_{p-1} + dY_p
-        // carries the gradient: DESIGN.md section 8)
-        const size_t RT = (size_t)h->R * d.T_pred;
-        a.iters = 1;
-        for (int p = 0; p < d.iters; ++p) {
-            launch_copy_f32(W(h, "ioc_Yin") + (size_t)p * RT * 2, dev_Yhat, RT * 2, s);
-            a.sv_x = W(h, "ioc_sv_x") + (size_t)p * RT * h->E; a.sv_r = W(h, "ioc_sv_r") + (size_t)p * RT * d.H;
-            a.sv_u = W(h, "ioc_sv_u") + (size_t)p * RT * d.H; a.sv_c = W(h, "ioc_sv_c") + (size_t)p * RT * d.H;
-            a.sv_h = W(h, "ioc_sv_h") + (size_t)p * RT * d.H;
-            if (cluster && p > 0) HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, ((size_t)h->R / d.mno) * sizeof(int), s));
-            if (x3) {       // split-bf16 operands; the saves are fp32 and the backward pass is the fp32 one
-                a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
-                Timer t(h, s, "ioc"); launch_ioc_x3(a, s);
-            } else
-            { Timer t(h, s, "ioc"); launch_ioc(a, s); }
-        }
-        launch_copy_f32(W(h, "Y_ref"), dev_Yhat, RT * 2, s);
+        launch_copy_f32(W(h, "Y_ref"), dev_Yhat, (size_t)h->R * d.T_pred * 2, s);
         launch_copy_f32(W(h, "score_sv"), dev_score, (size_t)h->R, s);
-    } else
-    if (x3 || x6) {   // split-bf16 operands: fp32-equivalent results on the bf16 matrix pipe (shapes without that form run the fp32 kernels)
-        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
-        Timer t(h, s, "ioc");
-        if (x6) launch_ioc_x6(a, s); else launch_ioc_x3(a, s);
-    } else
-    if (d.bf16 == 1) {
-        if (h->training) return fail(DESIRE_ERR_STATE, "bf16 operands are inference-only");
-        a.Wsoc = D4(h, "ioc/Wsoc16"); a.Wg = D4(h, "ioc/Wg16"); a.Wc = D4(h, "ioc/Wc16"); a.Wreg = D4(h, "ioc/Wreg16");
-        Timer t(h, s, "ioc");
-        if (cluster) { if (launch_ioc_bf16_cluster(a, s)) return fail(DESIRE_ERR_HIP, "bf16 cluster IOC: no resident grid for this shape"); }
-        else launch_ioc_bf16(a, s);
-    } else
-    { Timer t(h, s, "ioc"); launch_ioc(a, s); }
-#ifdef DESIRE_IOC_TIMING
-    {
-        long long host[10];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
-        const char* n32[10] = {"P0 pos+clear", "P1 ev/es/masks", "build0+bar", "build(b+1)", "mma bin", "bin barrier",
-                               "P3 e_r+bar", "P4 gates(2 mma)+ep+2bar", "P5 cand+ep+2bar", ""};
-        const char* n16[10] = {"loop top", "P1 ev/es/masks", "barrier 1", "P2 pooling chain + e_r", "barrier 2", "P4 gates + r*h",
-                               "barrier 3", "P5 cand + publish", "barrier 4", ""};
-        const char* nx3[10] = {"step top (bar 4 wait)", "P1 ev/es/masks", "barrier 1", "P2 pooling chain", "exchange + e_r", "barrier 2",
-                               "P4 gates + r*h", "barrier 3", "P5 cand + publish", "barrier 4"};
-        const char* ncl[10] = {"step top: positions + clear + bar", "P1 ev/es/masks", "wait for the peers", "copy peers' Ht + bar", "P2 pooling chains",
-                               "exchange + e_r", "barrier 2", "P4 gates + r*h + cand frags", "bar 3 + P5 cand + publish stores", "drain + arrive + bar"};
-        const char** names = (x3 || x6) ? nx3 : d.bf16 == 1 ? (cluster ? ncl : n16) : n32;
-        const int nk = (x3 || x6 || (d.bf16 == 1 && cluster)) ? 10 : 9;
-        long long tot = 0; for (int k = 0; k < nk; ++k) tot += host[k];
-        for (int k = 0; k < nk; ++k) fprintf(stderr, "[ioc timing] %-26s %12lld cyc  %5.1f%%\n", names[k], host[k], 100.0 * host[k] / (double)tot);
-    }
-#endif
-    HIPCHK(hipGetLastError());
-    if (cluster) {
-        int err = 0;
-        HIPCHK(hipMemcpyAsync(&err, h->ws["ioc_err"].p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (err) return fail(DESIRE_ERR_HIP, "IOC cluster hand-off timed out (workgroups of a group were not co-resident)");
     }
     return DESIRE_OK;
 }

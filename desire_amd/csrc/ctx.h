@@ -69,6 +69,7 @@ struct desire_ctx {
     // present-row compaction (DESIRE_FLAG_COMPACT_ROWS, kernels_compact.hip): mapped host word the scan kernel reports the present-agent count
     // into, the event behind it, the count of the last desire_sample (-1: none yet)
     int32_t* cp_host = nullptr; hipEvent_t cp_ev = nullptr; bool cp_pending = false; int cp_P = -1;
+    int ci_n = 0, ci_cls[4] = {0, 0, 0, 0}, ci_cnt[4] = {0, 0, 0, 0}; bool ci_last = false; int ci_min_rows = 8192;     // DESIRE_FLAG_COMPACT_IOC: the classes the last IOC stage ran (class index, windows)
     bool cp_last = false;                                    // the last desire_sample ran compacted (desire_backward follows it, not the flag)
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;
@@ -125,5 +126,7 @@ void desire_extract(const desire_ctx* h, const std::string& name, const float* p
 int desire_upload(desire_ctx* h, const std::string& name, const std::vector<float>& v);
 int desire_ready(desire_handle* h);
 bool compact_rows(const desire_ctx* h);                        // DESIRE_FLAG_COMPACT_ROWS set
+bool compact_ioc(const desire_ctx* h);                         // DESIRE_FLAG_COMPACT_IOC set and the shape is served
+int compact_classes(const desire_ctx* h, int* m4);             // its slot classes (ascending, the handle's mno last): returns how many
 int compact_setup(desire_ctx* h);                              // its buffers, event and mapped count word (idempotent)
 int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

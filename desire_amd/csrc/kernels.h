@@ -288,3 +288,9 @@ void launch_scatter_add_agents(const float* in, int ldi, float* out, int ldo, co
 void launch_reparam_c(const float* params_c, const float* eps, float* z, const int32_t* amap, int P, int K, int mno, int L, int posterior, hipStream_t s);
 void launch_scatter_rows(const float* comp, float* full0, float* full1, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);
 void launch_gather_rows(const float* full, float* comp, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);
+// IOC class repacking (DESIRE_FLAG_COMPACT_IOC)
+void launch_class_scan(const uint8_t* valid, int n_scenes, int mno, int n_cls, const int* m4, int K, int min_rows, int32_t* cls_win, int32_t* cmap,
+                       int32_t* cnt_dev, int32_t* cnt_host, hipStream_t s);
+void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
+                              float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s);
+void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s);

@@ -128,3 +128,122 @@ void launch_gather_rows(const float* full, float* comp, const int32_t* amap, int
     if (t <= 0) return;
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, amap, P, K, mno, n);
 }
+
+// =====================================================================================================================================
+// IOC class repacking (dims.flags & DESIRE_FLAG_COMPACT_IOC).  The IOC kernels tile rows by whole (scene, k) groups of mno slots; a window
+// with c present agents still occupies mno rows per sample.  Here every window is re-seated in the smallest slot class m in {8, 16, 32, ...,
+// mno} that holds its present agents (compacted to the front, order kept; padding slots absent), windows of one class form a pseudo-batch
+// (n_c windows x m_c slots) that the SAME kernels run on, and windows without any present agent are not run at all.
+//     class agent  i = w'*m_c + j   <->  full agent cmap[i] (or -1: padding);   class row (w'*K + k)*m_c + j  <->  full row of (cmap[i], k)
+// =====================================================================================================================================
+// one workgroup: windows in order; cnt[c] windows per class (device + mapped host copy), cls_win[c][w'] = window, cmap[c][w'*m_c + j].
+// A class whose launch would be smaller than min_rows rows (K * m_c * its windows) is folded into the next larger one: a launch of the
+// persistent kernel costs T steps of latency whatever its size, more than the padding rows saved.
+__global__ __launch_bounds__(1024) void k_class_scan(const uint8_t* __restrict__ valid, int n_scenes, int mno, int n_cls, int4 msz, int K, int min_rows,
+                                                     int32_t* __restrict__ cls_win, int32_t* __restrict__ cmap, int32_t* __restrict__ cnt_dev,
+                                                     volatile int32_t* cnt_host) {
+    __shared__ int wsum[4][16];
+    __shared__ int base_s[4];
+    __shared__ int tot_s[4];
+    __shared__ int remap_s[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int A = n_scenes * mno;
+    const int m[4] = {msz.x, msz.y, msz.z, msz.w};
+    auto class_of = [&](int w) {
+        int c = 0;
+        for (int j = 0; j < mno; ++j) c += valid[(size_t)w * mno + j] ? 1 : 0;
+        if (c == 0) return -1;
+        int cls = 0;
+        while (cls < n_cls - 1 && c > m[cls]) ++cls;
+        return cls;
+    };
+    if (tid < 4) { base_s[tid] = 0; tot_s[tid] = 0; }
+    __syncthreads();
+    for (int w = tid; w < n_scenes; w += 1024) { const int cls = class_of(w); if (cls >= 0) atomicAdd(&tot_s[cls], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int carry = 0;
+        for (int q = 0; q < 4; ++q) remap_s[q] = q;
+        for (int q = 0; q < n_cls - 1; ++q) {
+            const int n = tot_s[q] + carry;
+            if (n > 0 && (long)n * K * m[q] < (long)min_rows) { carry = n; for (int x = 0; x <= q; ++x) if (remap_s[x] == q) remap_s[x] = q + 1; }
+            else carry = 0;
+        }
+    }
+    __syncthreads();
+    for (int w0 = 0; w0 < n_scenes; w0 += 1024) {
+        const int w = w0 + tid;
+        int cls = w < n_scenes ? class_of(w) : -1;
+        if (cls >= 0) cls = remap_s[cls];
+        int pos = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long b = __ballot(cls == q);
+            if (cls == q) pos = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[q][wv] = __popcll(b);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int off = base_s[cls];
+            for (int x = 0; x < wv; ++x) off += wsum[cls][x];
+            const int wp = off + pos;
+            cls_win[(size_t)cls * n_scenes + wp] = w;
+            int32_t* dst = cmap + (size_t)cls * A + (size_t)wp * m[cls];
+            int j2 = 0;
+            for (int j = 0; j < mno; ++j) if (valid[(size_t)w * mno + j]) dst[j2++] = w * mno + j;
+            for (; j2 < m[cls]; ++j2) dst[j2] = -1;
+        }
+        __syncthreads();
+        if (tid < 4) { int t = 0; for (int x = 0; x < 16; ++x) t += wsum[tid][x]; base_s[tid] += t; }
+        __syncthreads();
+    }
+    if (tid < 4) { cnt_dev[tid] = base_s[tid]; cnt_host[tid] = base_s[tid]; }
+    __threadfence_system();
+}
+void launch_class_scan(const uint8_t* valid, int n_scenes, int mno, int n_cls, const int* m4, int K, int min_rows, int32_t* cls_win, int32_t* cmap,
+                       int32_t* cnt_dev, int32_t* cnt_host, hipStream_t s) {
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, s, valid, n_scenes, mno, n_cls, make_int4(m4[0], m4[1], m4[2], m4[3]), K, min_rows, cls_win, cmap,
+                       cnt_dev, cnt_host);
+}
+
+// agent-level inputs of one class: Hx (ld floats per agent, zeros for padding), p_last, valid, grid of the window
+__global__ void k_cls_gather_agents(const float* __restrict__ Hx, int ld, const float* __restrict__ p_last, const int32_t* __restrict__ gos,
+                                    const int32_t* __restrict__ cmap, const int32_t* __restrict__ win, int n_c, int m_c,
+                                    float* __restrict__ Hx_c, float* __restrict__ p_c, uint8_t* __restrict__ valid_c, int32_t* __restrict__ gos_c) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long NA = (long)n_c * m_c;
+    if (i < n_c) gos_c[i] = gos[win[i]];
+    if (i < NA) {
+        const int a = cmap[i];
+        valid_c[i] = a >= 0 ? 1 : 0;
+        p_c[2 * i] = a >= 0 ? p_last[2 * (size_t)a] : 0.f;
+        p_c[2 * i + 1] = a >= 0 ? p_last[2 * (size_t)a + 1] : 0.f;
+    }
+    if (i >= NA * ld) return;
+    const long ia = i / ld; const int c = (int)(i - ia * ld);
+    const int a = cmap[ia];
+    Hx_c[i] = a >= 0 ? Hx[(size_t)a * ld + c] : 0.f;
+}
+void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
+                              float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s) {
+    const long n = (long)n_c * m_c * ld;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cls_gather_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Hx, ld, p_last, gos, cmap, win, n_c, m_c, Hx_c, p_c, valid_c, gos_c);
+}
+// rows: dir = 0 gather  comp[(w'*K + k)*m_c + j, :] = full[row(cmap, k), :] (zeros for padding);  dir = 1 scatter back (padding rows dropped)
+__global__ void k_cls_rows(float* __restrict__ full, float* __restrict__ comp, const int32_t* __restrict__ cmap, int n_c, int m_c, int K, int mno, int n, int dir) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_c * K * m_c * n) return;
+    const long rc = i / n; const int c = (int)(i - rc * n);
+    const int j = (int)(rc % m_c); const long g = rc / m_c; const int k = (int)(g % K); const int wp = (int)(g / K);
+    const int a = cmap[(size_t)wp * m_c + j];
+    if (a < 0) { if (!dir) comp[i] = 0.f; return; }
+    const int sc = a / mno, slot = a - sc * mno;
+    const size_t r = ((size_t)sc * K + k) * mno + slot;
+    if (dir) full[r * n + c] = comp[i]; else comp[i] = full[r * n + c];
+}
+void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s) {
+    const long t = (long)n_c * K * m_c * n;
+    if (t <= 0) return;
+    hipLaunchKernelGGL(k_cls_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir);
+}

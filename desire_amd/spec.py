@@ -28,6 +28,7 @@ BN_EPS = 1e-3  # variance_epsilon, model/model.py:460,479
 IOC_AUTO, IOC_TILE64, IOC_CLUSTER, IOC_CLUSTER_BINS, IOC_COMPACT, IOC_TRAIN_DENSE, IOC_X6_TILE32, IOC_X6_TILE64 = 0, 2, 4, 6, 8, 9, 13, 14   # desire_hip.h: DESIRE_IOC_*
 FLAG_NO_FUSE34 = 1
 FLAG_COMPACT_ROWS = 4     # per-row sample-generation stages on the rows of present agents only (include/desire_hip.h)
+FLAG_COMPACT_IOC = 8      # IOC stage on slot classes: windows re-seated in the smallest of {8, 16, 32, mno} slots that holds their present agents
 FLAG_TRAIN_FWD_3P = 2     # dims.bf16 = 2 training: two-piece operands in the forward's sample generation (include/desire_hip.h)
 
 

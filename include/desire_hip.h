@@ -120,12 +120,27 @@ typedef struct desire_dims {
                                       change) or ref_compat.  The intermediates "z", "d1".."d3", "xhat", "xz" of desire_read_buffer are then in the COMPACT
                                       row order r' = k*P + a' (P = present agents, a' = rank of the agent among them). */
 
+#define DESIRE_FLAG_COMPACT_IOC 8   /* IOC SLOT CLASSES.  The IOC kernels tile rows by whole (scene, k) groups of mno slots, so a window with 9 of 32 slots present
+                                      still costs 32 rows per sample.  With this bit every window is re-seated in the smallest slot class m in {8, 16, 32, mno}
+                                      that holds its present agents (compacted to the front, order kept), the windows of a class run as one pseudo-batch on the
+                                      same kernels, and windows without a present agent are not run (their dev_Yhat rows are left as they came, score 0); rows of
+                                      absent agents inside a window likewise keep their incoming dev_Yhat and get score 0.  A class too small to fill the device
+                                      (< 8192 rows) is folded into the next larger one, so -- like dims.ioc_split -- the summation order of a window's social
+                                      pooling, i.e. the last bits of its result (<= 2e-6 on trajectories), depends on what else is in the batch.  Same host wait
+                                      and hipGraph restriction as DESIRE_FLAG_COMPACT_ROWS; shapes on the step-wise IOC (mno > 128; split operands at H = 256)
+                                      ignore the bit. */
+
 typedef struct desire_ctx desire_handle;
 
 const char* desire_last_error(void);
 int desire_version(void);
+/* sizeof(desire_dims) as THIS library was built: a host compiled against another revision of this header (the struct has grown by appending
+ * fields) compares it with its own sizeof before the first desire_create and refuses to run on a mismatch. */
+int desire_dims_size(void);
 /* Changes one of the behavioural switches of desire_dims on a live handle: name = "ioc_form", "ioc_split", "train_fp32_mask" or
- * "flags"; takes effect at the next call.  Unknown name or value out of range: DESIRE_ERR_ARG. */
+ * "flags"; takes effect at the next call (a flag that changes what desire_encode prepares -- DESIRE_FLAG_COMPACT_* -- at the next
+ * desire_encode).  "compact_min_rows" (not a desire_dims field): the fold threshold of DESIRE_FLAG_COMPACT_IOC.  Unknown name or value
+ * out of range: DESIRE_ERR_ARG. */
 int desire_set_option(desire_handle* h, const char* name, int32_t value);
 
 /* Replaces DESIREModel.__init__/build_model graph construction (model/model.py:36-77). */

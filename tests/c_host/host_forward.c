@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     CHECK(f != NULL);
     desire_dims d;
+    CHECK(desire_dims_size() == (int)sizeof(desire_dims));     /* this host and the library agree about the struct */
     CHECK(fread(&d, sizeof(d), 1, f) == 1);
     desire_handle* h = NULL;
     CHECK(desire_create(&d, &h) == DESIRE_OK);

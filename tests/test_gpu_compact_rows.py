@@ -232,3 +232,85 @@ def test_training_gradients_on_compact_rows_match_float64_autograd(torch_cuda):
             continue
         rel = float(np.abs(g[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-12))
         assert rel < 2e-4, (k, rel)
+
+
+# ---- IOC slot classes (DESIRE_FLAG_COMPACT_IOC) --------------------------------------------------------------------------------------------
+def run_opts(torch, d, w, past, fut, eps, grids, gos, min_rows=None, Y_in=None):
+    from desire_amd import _lib
+    h = _lib.Handle(d)
+    h.set_weights(w)
+    if min_rows is not None:
+        h.set_option("compact_min_rows", min_rows)
+    dev = torch.device("cuda")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    past_t, fut_t, eps_t, grids_t = t(past), t(fut), t(eps), t(grids)
+    h.set_scene_grids(grids_t.data_ptr(), gos)
+    Y = torch.full((d.R, d.T_pred, 2), 7.0, device=dev)
+    score = torch.full((d.R,), 3.0, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    if Y_in is None:
+        h.forward(past_t.data_ptr(), fut_t.data_ptr() if d.posterior else 0, eps_t.data_ptr(), Y.data_ptr(), score.data_ptr(), s)
+    else:
+        h.encode(past_t.data_ptr(), fut_t.data_ptr() if d.posterior else 0, s)
+        Y.copy_(t(Y_in))
+        h.ioc_refine(Y.data_ptr(), score.data_ptr(), s)
+    torch.cuda.synchronize()
+    prof_names = None
+    h.close()
+    return Y.cpu().numpy(), score.cpu().numpy()
+
+
+def ragged_counts(d, seed, counts):
+    """make_case windows where window i keeps its first... no: a random subset of counts[i] slots (so every slot class gets windows)."""
+    past, fut, eps, grids, gos = make_case(d, seed=seed, n_absent=0)
+    rng = np.random.default_rng(seed + 7)
+    keep = np.zeros((d.n_scenes, d.mno), bool)
+    for i in range(d.n_scenes):
+        keep[i, rng.permutation(d.mno)[: counts[i % len(counts)]]] = True
+    past[~keep[:, None, :].repeat(d.T_obs, 1)] = 0
+    fut[~keep[:, None, :].repeat(d.T_pred, 1)] = 0
+    return past, fut, eps, grids, gos, keep
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(bf16=2),
+    dict(bf16=3),
+    dict(bf16=1),
+    dict(mno=64, n_scenes=6, K=2),                   # top class = the cluster / 64-row forms, lower classes the 32-row tile
+    dict(mno=16, H=64, K=3),
+    dict(bin_mode=1, grid_size=4, nb_h=0.02, nb_w=0.3),
+    dict(iters=2),
+], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
+@pytest.mark.parametrize("rows_too", [False, True], ids=["ioc_only", "rows+ioc"])
+def test_slot_classes_reproduce_the_scene_shaped_ioc(torch_cuda, kw, rows_too):
+    """Every window re-seated in its slot class (fold threshold 0: every class that has windows runs on its own) against the scene-shaped
+    pass on the SAME decoded positions: identical neighbour sets and cells, sums regrouped -> 1e-5 on trajectories (normalised units)."""
+    from desire_amd.spec import FLAG_COMPACT_IOC
+    d = small_dims(**{**dict(n_scenes=8, K=4, T_pred=12), **kw})
+    w = init_weights(d, 3)
+    past, fut, eps, grids, gos, keep = ragged_counts(d, seed=21, counts=[3, 9, 0, 14, 8, d.mno, 1, 20])
+    Ya, sa = run_opts(torch_cuda, d, w, past, fut, eps, grids, gos)
+    flags = FLAG_COMPACT_IOC | (FLAG_COMPACT_ROWS if rows_too else 0)
+    Yb, sb = run_opts(torch_cuda, d.replace(flags=flags), w, past, fut, eps, grids, gos, min_rows=0)
+    m = row_mask(d, keep)
+    tolY, tolS = (2e-3, 2e-2) if kw.get("bf16") == 1 else (1e-5, 1e-4)
+    assert np.isfinite(Yb).all() and np.isfinite(sb).all()
+    assert np.abs(Yb - Ya)[m].max() < tolY, np.abs(Yb - Ya)[m].max()
+    assert np.abs(sb - sa)[m].max() < tolS, np.abs(sb - sa)[m].max()
+    assert not sb[~m].any()                                # rows that were not run: score 0
+    # default fold threshold (everything here is far below it): one class, the handle's own -> the scene-shaped result up to row order
+    Yc, sc_ = run_opts(torch_cuda, d.replace(flags=flags), w, past, fut, eps, grids, gos)
+    assert np.abs(Yc - Ya)[m].max() < tolY and np.abs(sc_ - sa)[m].max() < tolS
+
+
+@pytest.mark.parametrize("tag", ["cfg0", "cfg1"])
+def test_slot_classes_on_the_sdd_goldens(torch_cuda, tag):
+    """IOC on the ORACLE's decoder output (bins identical by construction), windows seated in their slot classes: every present row within 1e-3."""
+    from desire_amd.spec import FLAG_COMPACT_IOC
+    d, g, eps, grids, gos, w = load_case(tag)
+    present = g["past"][:, -1, :, 0] != 0
+    m = row_mask(d, present)
+    Y, score = run_opts(torch_cuda, d.replace(flags=FLAG_COMPACT_IOC | FLAG_COMPACT_ROWS), w, g["past"], g["fut"], eps, grids, gos, min_rows=0, Y_in=g["Y0"])
+    assert np.abs(Y - g["Y"])[m].max() < 1e-3
+    assert np.abs(score - g["score"])[m].max() < 5e-3
