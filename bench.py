@@ -601,7 +601,8 @@ def training_step_leg(d_full, seed, dev, steps):
         present = float((p2[:, -1, :, 0] != 0).sum()) / p2.shape[0]
         p_t, f_t = t(p2), t(f2)
         sd = {}
-        for tag, mode, flags in (("fp32", 0, 0), ("fp32_compact_rows", 0, 4), ("split_bf16x3", 2, 0), ("split_bf16x3_compact_rows", 2, 4)):
+        for tag, mode, flags in (("fp32", 0, 0), ("fp32_compact_rows", 0, 4), ("fp32_compact_rows_and_ioc", 0, 12), ("split_bf16x3", 2, 0),
+                                 ("split_bf16x3_compact_rows", 2, 4), ("split_bf16x3_compact_rows_and_ioc", 2, 12)):
             h = _lib.Handle(ds.replace(bf16=mode, flags=flags))
             h.set_weights(w)
             h.set_scene_grids(g_t.data_ptr(), gos)

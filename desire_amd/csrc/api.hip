@@ -669,7 +669,7 @@ bool compact_rows(const desire_ctx* h) { return (h->d.flags & DESIRE_FLAG_COMPAC
 // step-wise IOC (more than 128 slots, or split operands at H = 256) keep their own layout.
 bool compact_ioc(const desire_ctx* h) {
     const desire_dims& d = h->d;
-    if (!(d.flags & DESIRE_FLAG_COMPACT_IOC) || d.mno > 128 || h->training) return false;
+    if (!(d.flags & DESIRE_FLAG_COMPACT_IOC) || d.mno > 128) return false;
     const int B_ = d.grid_size * d.grid_size;
     const bool split_mode = (d.bf16 == 2 || d.bf16 == 3) && !h->training;
     const bool split_served = ioc_x3_supported(d.mno, d.H, B_) || (d.mno == 64 && ioc_x6r2_supported(d.mno, d.H, B_));

@@ -294,3 +294,4 @@ void launch_class_scan(const uint8_t* valid, int n_scenes, int mno, int n_cls, c
 void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
                               float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s);
 void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s);
+void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* cmap, int NA, int n, hipStream_t s);

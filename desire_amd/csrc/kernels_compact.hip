@@ -247,3 +247,16 @@ void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int
     if (t <= 0) return;
     hipLaunchKernelGGL(k_cls_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir);
 }
+// out[cmap[i], c] += in[i, c] for the seated agents of a class (cmap[i] >= 0; one writer per element: an agent sits in exactly one class slot)
+__global__ void k_cls_scatter_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ cmap, int NA, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)NA * n) return;
+    const int ia = (int)(i / n), c = (int)(i - (long)ia * n);
+    const int a = cmap[ia];
+    if (a >= 0) out[(size_t)a * ldo + c] += in[(size_t)ia * ldi + c];
+}
+void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* cmap, int NA, int n, hipStream_t s) {
+    const long t = (long)NA * n;
+    if (t <= 0) return;
+    hipLaunchKernelGGL(k_cls_scatter_add_agents, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, cmap, NA, n);
+}

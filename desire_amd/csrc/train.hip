@@ -545,35 +545,72 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                           d.mno, d.K, T, d.sx, d.sy, s);
         // one BPTT per refinement pass, last pass first: Y_final = Y0 + sum_p dY_p, so every pass's regression head sees the same
         // dL/dY_final; only the last pass's scores enter the loss.  Weight gradients of the passes accumulate.
-        const long RT = R * T;
+        // DESIRE_FLAG_COMPACT_IOC: the forward ran one launch sequence per slot class (api.hip: IocView) and left each class's saves at its row
+        // offset; the BPTT and every weight-gradient reduction below run per class on the same views, accumulating.  Otherwise: one view, the
+        // handle's own shape.
+        struct BView { long R; int mno, n_scenes; const float* Hx; const float* p_last; const uint8_t* valid; size_t row_off; const int32_t* cmap; };
+        std::vector<BView> views;
+        if (h->ci_last) {
+            if (ensure(h, "ci_dYr", (size_t)R * T * 2 * sizeof(float)) || ensure(h, "ci_dscore", (size_t)R * sizeof(float)) || ensure(h, "ci_dscoreT", (size_t)R * T * sizeof(float)) ||
+                ensure(h, "ci_dHx_rows", (size_t)R * H * sizeof(float)) || ensure(h, "ci_dHx", (size_t)h->A * H * sizeof(float)) || ensure(h, "dHxHy_ioc", (size_t)h->A * H * sizeof(float)))
+                return fail(DESIRE_ERR_HIP, "hipMalloc failed for the slot-class gradient buffers");
+            launch_fill_f32(W(h, "dHxHy_ioc"), (size_t)h->A * H, 0.f, s);
+            int m4[4];
+            compact_classes(h, m4);
+            size_t aoff = 0, roff = 0;
+            for (int i = 0; i < h->ci_n; ++i) {
+                const int c = h->ci_cls[i], n_c = h->ci_cnt[i], m_c = m4[c];
+                views.push_back(BView{(long)n_c * d.K * m_c, m_c, n_c, W(h, "ci_Hx") + aoff * 2 * H, W(h, "ci_pl") + aoff * 2,
+                                      static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, roff, static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A});
+                aoff += (size_t)n_c * m_c; roff += (size_t)n_c * d.K * m_c;
+            }
+        } else
+            views.push_back(BView{R, d.mno, d.n_scenes, W(h, "HxHy"), W(h, "p_last"), static_cast<const uint8_t*>(h->ws["valid"].p), 0, nullptr});
+        const long RTf = R * T;
         launch_fill_f32(W(h, "dscore0"), (size_t)R, 0.f, s);
+        bool first = true;                          // the first launch sequence writes the weight gradients, the others accumulate
+        for (size_t vi = 0; vi < views.size(); ++vi) {
+        const BView& v = views[vi];
+        const long Rv = v.R, RT = Rv * T;
+        const int n_tiles32v = (int)((Rv + 31) / 32);
+        float* dYr_v = W(h, "dYr"); float* dscore_v = W(h, "dscore"); float* dscoreT_v = W(h, "dscoreT"); float* dHx_v = W(h, "dHx_rows");
+        if (v.cmap) {          // the class's rows of the loss gradients; its own d loss / d Hx rows
+            dYr_v = W(h, "ci_dYr"); dscore_v = W(h, "ci_dscore"); dscoreT_v = W(h, "ci_dscoreT"); dHx_v = W(h, "ci_dHx_rows");
+            launch_cls_rows(W(h, "dYr"), dYr_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 2 * T, 0, s);
+            launch_cls_rows(W(h, "dscore"), dscore_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 1, 0, s);
+            launch_cls_rows(W(h, "dscoreT"), dscoreT_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, T, 0, s);
+            launch_fill_f32(dHx_v, (size_t)Rv * H, 0.f, s);
+        }
         for (int p = d.iters - 1; p >= 0; --p) {
-            const int acc = (p != d.iters - 1) ? 1 : 0;
-            const size_t po = (size_t)p * RT;
+            const bool last_pass = p == d.iters - 1;
+            const int acc = first ? 0 : 1;
+            const int acc_s = vi > 0 ? 1 : 0;         // (score weights: the last pass of every view)
+            first = false;
+            const size_t po = (size_t)p * RTf + v.row_off * T;
             const float* sv_h = W(h, "ioc_sv_h") + po * H;
             const float* sv_x = W(h, "ioc_sv_x") + po * E;
             IocBwdArgs q{};
-            q.Y0 = W(h, "ioc_Yin") + po * 2; q.p_last = W(h, "p_last"); q.valid = static_cast<const uint8_t*>(h->ws["valid"].p); q.Hx = W(h, "HxHy"); q.ldhx = 2 * H;
-            q.dYr = W(h, "dYr"); q.dscore = acc ? W(h, "dscore0") : W(h, "dscore");
+            q.Y0 = W(h, "ioc_Yin") + po * 2; q.p_last = v.p_last; q.valid = v.valid; q.Hx = v.Hx; q.ldhx = 2 * H;
+            q.dYr = dYr_v; q.dscore = last_pass ? dscore_v : W(h, "dscore0");
             q.sv_x = sv_x; q.sv_r = W(h, "ioc_sv_r") + po * H; q.sv_u = W(h, "ioc_sv_u") + po * H; q.sv_c = W(h, "ioc_sv_c") + po * H; q.sv_h = sv_h;
             q.w_score = D(h, "ioc/score_w");
-            q.R = (int)R; q.K = d.K; q.mno = d.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
+            q.R = (int)Rv; q.K = d.K; q.mno = v.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
             q.WrT = D4(h, "ioc/WrT"); q.WcT_h = D4(h, "ioc/WcT_h"); q.WcT_er = D4(h, "ioc/WcT_er"); q.WcT_ev = D4(h, "ioc/WcT_ev");
             q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT"); q.WsT_c = D4(h, "ioc/WsT_c");
             q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
             q.dpre_r = W(h, "ioc_dpre_r"); q.dpre_v = W(h, "ioc_dpre_v"); q.vel = W(h, "ioc_vel"); q.pooled = W(h, "ioc_pooled");
             q.pool_flags = static_cast<unsigned long long*>(h->ws["ioc_pool_flags"].p);
-            q.dHx_rows = W(h, "dHx_rows");
+            q.dHx_rows = dHx_v;
             q.bin_tab = d.bin_mode == 1 ? W(h, "bin_tab") : nullptr;
-            const bool cl_bwd = ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0);
+            const bool cl_bwd = ioc_uses_cluster(v.mno, d.H, d.grid_size * d.grid_size, 0);
             q.bias_part = cl_bwd ? nullptr : W(h, "bias_part");           // (the cluster form keeps the separate column-sum passes)
             if (cl_bwd) {
-                const size_t n_groups = (size_t)h->R / d.mno;
+                const size_t n_groups = (size_t)Rv / v.mno;
                 HIPCHK(hipMemsetAsync(h->ws["grp_cnt"].p, 0, n_groups * sizeof(int), s));
-                if (!acc) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
+                if (vi == 0 && last_pass) HIPCHK(hipMemsetAsync(h->ws["ioc_err"].p, 0, sizeof(int), s));
                 if (launch_ioc_bwd_cluster(q, static_cast<int*>(h->ws["grp_cnt"].p), static_cast<int*>(h->ws["ioc_err"].p), s))
                     return fail(DESIRE_ERR_STATE, "cluster-form IOC backward does not serve this shape");
-            } else if (d.bf16 == 2 && (train_x3_mask(h) & 4) && ioc_bwd_x3_supported(d.mno, H)) {      // split-bf16 operands in the data-gradient contractions
+            } else if (d.bf16 == 2 && (train_x3_mask(h) & 4) && ioc_bwd_x3_supported(v.mno, H)) {      // split-bf16 operands in the data-gradient contractions
                 q.WcT_h = D4(h, "ioc/WcT16"); q.WgT_h = D4(h, "ioc/WgT16"); q.WsT = D4(h, "ioc/WsT16");
 #ifdef DESIRE_IOC_TIMING
                 if (!h->ws.count("dbgb")) { h->ws["dbgb"].alloc(12 * sizeof(long long)); }
@@ -594,22 +631,22 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
 #endif
             } else
             launch_ioc_bwd(q, s);
-            tn(h, sv_h + (size_t)(T - 1) * H, T * H, W(h, "dYr"), 2 * T, R, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, acc, s);
-            colsum(h, W(h, "dYr"), 2 * T, R, 2 * T, G(h, "ioc/reg/b"), acc, s);
-            if (!acc) {
-                tn(h, sv_h, H, W(h, "dscoreT"), 1, RT, H, 1, G(h, "ioc/score/w"), 1, 0, s);
-                colsum(h, W(h, "dscoreT"), 1, RT, 1, G(h, "ioc/score/b"), 0, s);
+            tn(h, sv_h + (size_t)(T - 1) * H, T * H, dYr_v, 2 * T, Rv, H, 2 * T, G(h, "ioc/reg/w"), 2 * T, acc, s);
+            colsum(h, dYr_v, 2 * T, Rv, 2 * T, G(h, "ioc/reg/b"), acc, s);
+            if (last_pass) {
+                tn(h, sv_h, H, dscoreT_v, 1, RT, H, 1, G(h, "ioc/score/w"), 1, acc_s, s);
+                colsum(h, dscoreT_v, 1, RT, 1, G(h, "ioc/score/b"), acc_s, s);
             }
             float* gk = G(h, "ioc/gates/kernel");            // [(E+H), 2H]
             tn(h, sv_x, E, W(h, "ioc_dag"), 2 * H, RT, E, 2 * H, gk, 2 * H, acc, s);
             tn(h, W(h, "ioc_hprev"), H, W(h, "ioc_dag"), 2 * H, RT, H, 2 * H, gk + (size_t)E * 2 * H, 2 * H, acc, s);
             if (cl_bwd) colsum(h, W(h, "ioc_dag"), 2 * H, RT, 2 * H, G(h, "ioc/gates/bias"), acc, s);
-            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 0, 2 * H, G(h, "ioc/gates/bias"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32v, 4 * H, 0, 2 * H, G(h, "ioc/gates/bias"), acc, s);
             float* ck = G(h, "ioc/candidate/kernel");        // [(E+H), H]
             tn(h, sv_x, E, W(h, "ioc_dac"), H, RT, E, H, ck, H, acc, s);
             tn(h, W(h, "ioc_rh"), H, W(h, "ioc_dac"), H, RT, H, H, ck + (size_t)E * H, H, acc, s);
             if (cl_bwd) colsum(h, W(h, "ioc_dac"), H, RT, H, G(h, "ioc/candidate/bias"), acc, s);
-            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 2 * H, H, G(h, "ioc/candidate/bias"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32v, 4 * H, 2 * H, H, G(h, "ioc/candidate/bias"), acc, s);
             const unsigned long long* pflags = static_cast<const unsigned long long*>(h->ws["ioc_pool_flags"].p);
             if (H == 128 && (size_t)RT * (size_t)B < ((size_t)1 << 31)) {      // (list positions are ints)
                 // one output tile row = one bin (128 columns): each contracts only the (row, t) pairs that hold a neighbour in ITS bin, from
@@ -622,10 +659,16 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             } else
                 tn(h, W(h, "ioc_pooled"), B * H, W(h, "ioc_dpre_r"), H, RT, B * H, H, G(h, "ioc/social_fc/w"), H, acc, s, pflags, H);   // empty (row, t, bin) blocks are skipped
             if (cl_bwd) colsum(h, W(h, "ioc_dpre_r"), H, RT, H, G(h, "ioc/social_fc/b"), acc, s);
-            else launch_reduce_parts(q.bias_part, n_tiles32, 4 * H, 3 * H, H, G(h, "ioc/social_fc/b"), acc, s);
+            else launch_reduce_parts(q.bias_part, n_tiles32v, 4 * H, 3 * H, H, G(h, "ioc/social_fc/b"), acc, s);
             tn(h, W(h, "ioc_vel"), 2, W(h, "ioc_dpre_v"), d.E_v, RT, 2, d.E_v, G(h, "ioc/vel_fc/w"), d.E_v, acc, s);
             colsum(h, W(h, "ioc_dpre_v"), d.E_v, RT, d.E_v, G(h, "ioc/vel_fc/b"), acc, s);
         }
+        if (v.cmap) {          // the class's share of d loss / d Hx: rows -> class agents -> agents (padding slots dropped)
+            launch_fill_f32(W(h, "ci_dHx"), (size_t)v.n_scenes * v.mno * H, 0.f, s);
+            launch_rows_to_agents(dHx_v, W(h, "ci_dHx"), H, v.n_scenes, v.mno, d.K, H, s);
+            launch_cls_scatter_add_agents(W(h, "ci_dHx"), H, W(h, "dHxHy_ioc"), H, v.cmap, v.n_scenes * v.mno, H, s);
+        }
+        }       // views
     }
     // ---- mask fc ----
     if (Rs > 0) {
@@ -725,6 +768,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         g.out = W(h, "dHxHy"); g.ldo = 2 * H; g.N = 2 * H;
         launch_gemm_rows(g, EPI_NONE, s);
         launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
+        if (h->ci_last) launch_rows_to_agents(W(h, "dHxHy_ioc"), W(h, "dHxHy"), 2 * H, h->A, 1, 1, H, s);       // + the slot classes' share (one "row" per agent)
         if (compact && P > 0) {         // the compact stages' share of d loss / d Hx: rows -> compact agents -> agents
             launch_fill_f32(W(h, "cp_dHx"), (size_t)P * H, 0.f, s);
             launch_rows_to_agents(dHxS, W(h, "cp_dHx"), H, 1, P, d.K, H, s);
