@@ -24,7 +24,7 @@ EXPORTS = [
     "desire_device_buffer", "desire_ioc_step", "desire_ioc_finish", "desire_get_bin_table",
     "desire_graph_begin", "desire_graph_end", "desire_graph_launch", "desire_rollout", "desire_build_windows_la", "desire_adam_state",
     "desire_set_option", "desire_train_loss_async", "desire_set_head_loss",
-    "desire_peer_export", "desire_peer_open", "desire_ioc_peer_pass", "desire_peer_close", "desire_peer_region", "desire_peer_open_ptr",
+    "desire_peer_export", "desire_peer_open", "desire_ioc_peer_pass", "desire_peer_close", "desire_peer_region", "desire_peer_open_ptr", "desire_peer_status",
 ]
 
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.desire_peer_open.argtypes = [vp, i32, i32, i32, C.c_char_p]
     lib.desire_ioc_peer_pass.argtypes = [vp, f32p, f32p, vp]
     lib.desire_peer_close.argtypes = [vp]
+    lib.desire_peer_status.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.desire_peer_region.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.desire_peer_open_ptr.argtypes = [vp, i32, i32, i32, vp]
     lib.desire_adam_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
@@ -312,6 +313,12 @@ class Handle:
 
     def ioc_peer_pass(self, y_ptr: int, score_ptr: int, stream: int = 0) -> None:
         _chk(self.lib.desire_ioc_peer_pass(self._h, y_ptr, score_ptr, stream or None))
+
+    def peer_timed_out(self) -> bool:
+        """After synchronising the stream a peer pass ran on: did one of its bounded waits give up (results unusable)?"""
+        v = C.c_int32(0)
+        _chk(self.lib.desire_peer_status(self._h, C.byref(v)))
+        return bool(v.value)
 
     def peer_close(self) -> None:
         _chk(self.lib.desire_peer_close(self._h))

@@ -278,6 +278,9 @@ extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
         {"dec_states", d.ref_compat ? R * (size_t)d.n_dec * d.H * f : 0},
         {"bn_part", d.bn_mode == 2 ? (size_t)512 * 128 * f : 0}, {"bn_stat", d.bn_mode == 2 ? (size_t)2 * 128 * f : 0},
         {"grid_of_scene", (size_t)d.n_scenes * sizeof(int32_t)},
+        // desire_build_windows*: allocated here, not lazily, because a feeder thread may call the builder while the owner thread runs a forward on
+        // the same handle (desire_amd/prefetch.py: DeviceWindowFeeder) -- the builder then touches these two buffers and nothing else of the handle
+        {"bw_starts", (size_t)d.n_scenes * sizeof(int32_t)}, {"bw_err", sizeof(int32_t)},
     };
     for (const WS& w : list) {
         if (h->ws[w.n].alloc(w.bytes)) { desire_destroy(h); return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n); }
@@ -1362,6 +1365,15 @@ extern "C" int desire_peer_close(desire_handle* h) {
     return DESIRE_OK;
 }
 
+// The mapped error word of the peer exchange, for a caller that HAS synchronised the stream its pass ran on: 0 = every wait of the passes
+// enqueued so far was satisfied, 1 = a bounded wait gave up (the results of that pass are not to be used).  Reading clears nothing: the next
+// desire_ioc_peer_pass still fails with DESIRE_ERR_HIP and resets the word.
+extern "C" int desire_peer_status(desire_handle* h, int32_t* timed_out) {
+    if (!h || !timed_out) return fail(DESIRE_ERR_ARG, "null argument");
+    *timed_out = h->peer_err ? (*static_cast<volatile int*>(h->peer_err) != 0 ? 1 : 0) : 0;
+    return DESIRE_OK;
+}
+
 extern "C" int desire_ioc_peer_pass(desire_handle* h, float* dev_Y, float* dev_score, void* stream) {
     if (int rc = desire_ready(h)) return rc;
     if (!dev_Y || !dev_score) return fail(DESIRE_ERR_ARG, "null argument");
@@ -1547,16 +1559,13 @@ extern "C" int desire_build_windows_la(desire_handle* h, const float* dev_frames
         if (host_starts[i] < 0 || host_starts[i] + d.T_obs + d.T_pred > n_frames)
             return fail(DESIRE_ERR_ARG, "window start out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!h->ws.count("bw_starts")) {
-        if (h->ws["bw_starts"].alloc((size_t)d.n_scenes * sizeof(int32_t)) || h->ws["bw_err"].alloc(sizeof(int32_t)))
-            return fail(DESIRE_ERR_HIP, "hipMalloc failed");
-    }
-    HIPCHK(hipMemcpyAsync(h->ws["bw_starts"].p, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->ws["bw_err"].p, 0, sizeof(int32_t), s));
-    launch_build_windows(dev_frames, n_frames, mno_in, static_cast<const int32_t*>(h->ws["bw_starts"].p), n_windows, d.T_obs,
-                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws["bw_err"].p), lookahead, s);
+    // (ws.at, not ws[]: no insertion into the handle's map from this call -- it may run on a feeder thread, see desire_create)
+    HIPCHK(hipMemcpyAsync(h->ws.at("bw_starts").p, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->ws.at("bw_err").p, 0, sizeof(int32_t), s));
+    launch_build_windows(dev_frames, n_frames, mno_in, static_cast<const int32_t*>(h->ws.at("bw_starts").p), n_windows, d.T_obs,
+                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws.at("bw_err").p), lookahead, s);
     int32_t err = 0;
-    HIPCHK(hipMemcpyAsync(&err, h->ws["bw_err"].p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&err, h->ws.at("bw_err").p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (err & 2) return fail(DESIRE_ERR_ARG, "a window holds more unique ids than max_num_obj slots (utils/data_loader.py:227 IndexError)");
     if (err & 4) return fail(DESIRE_ERR_ARG, "a track id occurs twice in one frame of a window (utils/data_loader.py:224-229 ValueError)");

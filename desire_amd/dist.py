@@ -152,10 +152,17 @@ class PeerShardedIoc:
         if nranks > 1:
             (barrier or (lambda: dist.barrier(group=group)))()       # every rank has mapped every region before anybody publishes
 
-    def run(self, Y_loc, score_loc, stream: int = 0):
-        """Y_loc [R_loc, T, 2] (in: decoded, out: refined), score_loc [R_loc]; all dims.iters passes, stream-ordered, no host sync."""
+    def run(self, Y_loc, score_loc, stream: int = 0, sync: bool = False):
+        """Y_loc [R_loc, T, 2] (in: decoded, out: refined), score_loc [R_loc]; all dims.iters passes, stream-ordered, no host sync.
+        sync=True: wait for the pass and raise if one of its bounded peer waits gave up (desire_peer_status) -- without it a timed-out pass
+        is only reported by the NEXT run."""
         import torch
-        self.h.ioc_peer_pass(Y_loc.data_ptr(), score_loc.data_ptr(), stream or torch.cuda.current_stream().cuda_stream)
+        st = stream or torch.cuda.current_stream().cuda_stream
+        self.h.ioc_peer_pass(Y_loc.data_ptr(), score_loc.data_ptr(), st)
+        if sync:
+            torch.cuda.synchronize()
+            if self.h.peer_timed_out():
+                raise RuntimeError("peer-buffer IOC pass: a peer never arrived (bounded wait gave up); Y / score of this pass are invalid")
         return Y_loc, score_loc
 
     def close(self) -> None:

@@ -380,6 +380,9 @@ class DESIREModel(object):
         if self._weights is None:
             raise ValueError("no weights yet: run forward() once or pass weights=")
         blob = dict(self.sync_weights())
+        # whether gauss_head/* holds trained (or caller-supplied) values rather than the random init: an archive always carries the head, so
+        # key presence says nothing -- restore() reads this marker to pick sample()'s default mode
+        blob["meta/head_trained"] = np.asarray([1.0 if getattr(self, "_head_given", False) else 0.0], np.float32)
         h = getattr(self, "_trained", None)
         if h is not None:                             # the reference's Saver keeps the optimiser slots too (train.py:114)
             for k, v in h.opt_state().items():
@@ -391,6 +394,8 @@ class DESIREModel(object):
         from .formats import load_weights
         blob = load_weights(path)
         opt = {k[4:]: blob.pop(k) for k in list(blob) if k.startswith("opt/")}
+        meta = {k[5:]: blob.pop(k) for k in list(blob) if k.startswith("meta/")}
+        head_trained = bool(float(np.asarray(meta["head_trained"]).reshape(-1)[0])) if "head_trained" in meta else False     # (older archives: unknown = not trained)
         # archives written before an auxiliary weight existed (the sample() head "gauss_head/*" came with round 2): complete them
         # with the values init_weights draws, so an older checkpoint still loads
         d0 = dims_from_args(args, 1, True)
@@ -405,8 +410,7 @@ class DESIREModel(object):
             if opt:                                   # moments of the flat buffer no longer line up: Adam restarts from zero
                 opt = {}
         m = cls(args, weights=blob)
-        if missing:
-            m._head_given = False
+        m._head_given = head_trained and not missing      # NOT key presence: save() writes the head whether or not anything ever trained it
         if opt:
             m._opt_pending = opt                      # applied when training starts (the moments live in the training handle)
         return m

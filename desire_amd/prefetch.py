@@ -149,6 +149,7 @@ class WindowFeeder(_FeederBase):
         self.lo, self.hi = shard_windows(n, rank, world)
         k = self.hi - self.lo
         self._stage, self._full, self._past, self._fut = [], [], [], []
+        self._staged_ready = [None] * (self.depth + 1)   # per slot: the event behind the last copy out of its pinned staging buffer
         for _ in range(self.depth + 1):
             st = torch.zeros((n, T, m_in, 3), dtype=torch.float32)
             if self._cuda:
@@ -173,6 +174,11 @@ class WindowFeeder(_FeederBase):
                 if slot is None:
                     return
                 st = self._stage[slot]
+                # the H2D copy that last read this staging buffer may still be queued (the consumer's release only makes the COPY STREAM wait; a
+                # consumer that never host-syncs can run ahead of the GPU): the host must not rewrite the buffer before that copy has finished
+                prev = self._staged_ready[slot]
+                if prev is not None:
+                    prev.synchronize()
                 d = self.loader.next_batch_into(st.numpy(), False, self.random_update)
                 ready = None
                 if self._cuda:
@@ -182,6 +188,7 @@ class WindowFeeder(_FeederBase):
                         self._fut[slot][:, :, :m_in].copy_(self._full[slot][:, self.t_obs:])
                         ready = torch.cuda.Event()
                         ready.record(self._copy_stream)
+                        self._staged_ready[slot] = ready
                 else:                                    # CPU (tests of the schedule and of the batches; no GPU here)
                     self._past[slot][:, :, :m_in].copy_(st[self.lo:self.hi, :self.t_obs])
                     self._fut[slot][:, :, :m_in].copy_(st[self.lo:self.hi, self.t_obs:])

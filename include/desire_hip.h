@@ -293,6 +293,10 @@ int desire_peer_export(desire_handle* h, uint8_t* handle_out64, size_t* bytes_ou
 int desire_peer_open(desire_handle* h, int32_t rank, int32_t nranks, int32_t peer, const uint8_t* handle64);
 int desire_ioc_peer_pass(desire_handle* h, float* dev_Y, float* dev_score, void* stream);
 int desire_peer_close(desire_handle* h);
+/* Whether a bounded wait of the passes enqueued so far has given up (*timed_out = 1): meaningful once the caller has synchronised the stream
+ * the pass ran on -- a pass is stream-ordered, so this is the earliest point at which ITS outcome is known; without the query a caller only
+ * learns of a timed-out pass from the next desire_ioc_peer_pass.  Does not clear the condition. */
+int desire_peer_status(desire_handle* h, int32_t* timed_out);
 /* Ranks inside ONE process (one process driving several devices with peer access enabled) attach each other's regions by device
  * pointer: desire_peer_region gives a handle's own region, desire_peer_open_ptr takes the peer's (hipIpc handles cannot be opened by
  * the process that exported them).  Every rank's pass must then run on a HARDWARE queue of its own: a pass parks a one-wave wait

@@ -56,6 +56,10 @@ def main():
         peer.run(Yb, sb)
         outs.append((Yb, sb))
     torch.cuda.synchronize()
+    assert not h.peer_timed_out()                                         # desire_peer_status: the passes this rank has waited for all completed
+    Yc, sc = Y0.clone(), torch.zeros(d_loc.R, device="cuda")
+    peer.run(Yc, sc, sync=True)                                           # the checked form: raises if a bounded wait had given up
+    outs.append((Yc, sc))
     dist.barrier()
     ok = all(torch.equal(Yb, Ya) and torch.equal(sb, sa) for Yb, sb in outs) and bool(torch.isfinite(Ya).all()) and float((Ya - Y0).abs().max()) > 0
     peer.close()

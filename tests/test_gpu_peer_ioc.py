@@ -29,7 +29,8 @@ def test_single_rank_peer_pass_equals_ioc_refine():
     Ya = torch.as_tensor(Y0.copy(), device="cuda"); sa = torch.zeros(d.R, device="cuda")
     h.ioc_refine(Ya.data_ptr(), sa.data_ptr())
     Yb = torch.as_tensor(Y0.copy(), device="cuda"); sb = torch.zeros(d.R, device="cuda")
-    PeerShardedIoc(h, 0, 1).run(Yb, sb)
+    PeerShardedIoc(h, 0, 1).run(Yb, sb, sync=True)
+    assert not h.peer_timed_out()
     torch.cuda.synchronize()
     assert float((Ya - Yb).abs().max()) < 2e-6 and float((sa - sb).abs().max()) < 2e-5
 

@@ -170,15 +170,29 @@ def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
         m2 = DESIREModel.restore(args, os.path.join(td, "old.npz"))
         c = m2.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="ioc", seed=3)
         np.testing.assert_allclose(c, a, atol=1e-3)
-        m3 = DESIREModel.restore(args, os.path.join(td, "new.npz"))          # a head that came with the weights: no warning
+        # save() always writes gauss_head/*, so an archive of an UNTRAINED head must not flip sample()'s default to the rollout:
+        # the archive carries an explicit marker (meta/head_trained), and this model never trained or received a head
+        assert float(blob["meta/head_trained"][0]) == 0.0
+        m3 = DESIREModel.restore(args, os.path.join(td, "new.npz"))
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
+            e = m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, seed=3)
             m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
+        assert any("mode='ioc'" in str(r.message) for r in rec) and any("random initial values" in str(r.message) for r in rec)
+        np.testing.assert_allclose(e, a, atol=1e-3)                           # the same default as before the save / restore round trip
+        # a head that CAME WITH the weights (caller-supplied): the marker is set, survives save -> restore, and the reference-compatible rollout is the default
+        given = {k: v for k, v in blob.items() if not k.startswith(("opt/", "meta/"))}
+        m4 = DESIREModel(args, weights=given)
+        m4.save(os.path.join(td, "given.npz"))
+        assert float(load_weights(os.path.join(td, "given.npz"))["meta/head_trained"][0]) == 1.0
+        m5 = DESIREModel.restore(args, os.path.join(td, "given.npz"))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
         assert not any("gauss_head" in str(r.message) for r in rec)
-        # ... and for such a model the reference-compatible rollout IS the default
         nrm = np.random.default_rng(1).standard_normal((6, 16, 2)).astype(np.float32)
-        np.testing.assert_array_equal(m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, normals=nrm),
-                                      m3.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=nrm))
+        np.testing.assert_array_equal(m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, normals=nrm),
+                                      m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=nrm))
 
 
 def test_ref_compat_handle_with_its_own_prediction_length():
