@@ -2,6 +2,7 @@
 library is a plain C-ABI shared object (include/desire_hip.h) loaded through ctypes."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,36 +16,65 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 FLAGS += os.environ.get("DESIRE_HIPCC_FLAGS", "").split()      # e.g. -DDESIRE_IOC_TIMING for the per-phase cycle counters (build_lib(force=True))
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "desire_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(paths, extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "desire_hip.h")]
+
+
+def source_hash() -> str:
+    """sha256 over every file of csrc/, the public header and the compile flags: what libdesire_hip.so was built FROM.  build_lib compiles its first
+    16 hex digits into the library (desire_build_hash()), so `the tested .so == the tree` is checkable (tests/test_abi.py) instead of trusted to
+    file times -- built objects travel to the GPU box with the snapshot, git-ignored but not gpurun-ignored."""
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return _sha(srcs + _headers(), " ".join(FLAGS))[:16]
+
+
+def _read(path: str) -> str:
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+    """Content-addressed incremental build: an object is reused only if the hash of (its source, every header, the flags) equals the stamp written
+    next to it when it was compiled; the library is relinked whenever the tree's source_hash differs from the one stamped beside the .so."""
+    want = source_hash()
+    objdir = os.path.join(HERE, "build")
+    lib_stamp = os.path.join(objdir, "lib.stamp")
+    if not force and os.path.exists(LIB) and _read(lib_stamp) == want:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libdesire_hip.so")
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-
-    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "desire_hip.h")), os.path.getmtime(__file__))
+    hdrs = _headers()
 
     def cc(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
-            return obj                       # object newer than its source and every header: keep it
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        flags = list(FLAGS)
+        if src == "api.hip":                      # the library reports the tree it was built from
+            flags.append('-DDESIRE_SRC_HASH="%s"' % want)
+        key = _sha([os.path.join(CSRC, src)] + hdrs, " ".join(flags))
+        if not force and os.path.exists(obj) and _read(obj + ".stamp") == key:
+            return obj
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
         if verbose and r.stderr:
             print(r.stderr)
+        with open(obj + ".stamp", "w") as fh:
+            fh.write(key)
         return obj
 
     with ThreadPoolExecutor(len(SOURCES)) as ex:
@@ -53,6 +83,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(lib_stamp, "w") as fh:
+        fh.write(want)
     return LIB
 
 

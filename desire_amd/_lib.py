@@ -14,7 +14,7 @@ from .spec import Dims
 LIB_PATH = os.environ.get("DESIRE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdesire_hip.so")
 
 EXPORTS = [
-    "desire_last_error", "desire_version", "desire_dims_size", "desire_create", "desire_destroy", "desire_set_weight",
+    "desire_last_error", "desire_version", "desire_dims_size", "desire_build_hash", "desire_create", "desire_destroy", "desire_set_weight",
     "desire_finalize_weights", "desire_set_scene_grids", "desire_encode", "desire_sample",
     "desire_ioc_refine", "desire_forward", "desire_read_buffer", "desire_neighbor_bins",
     "desire_scene_cells", "desire_set_profiling", "desire_get_profile", "desire_scene_cnn", "desire_losses",
@@ -68,6 +68,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
     lib.desire_last_error.restype = C.c_char_p
+    lib.desire_build_hash.restype = C.c_char_p
     lib.desire_create.argtypes = [C.POINTER(DesireDims), C.POINTER(vp)]
     lib.desire_destroy.argtypes = [vp]
     lib.desire_set_option.argtypes = [vp, C.c_char_p, i32]
@@ -118,7 +119,7 @@ def load() -> C.CDLL:
     lib.desire_set_profiling.argtypes = [vp, C.c_int]
     lib.desire_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     for n in EXPORTS:
-        if n != "desire_last_error":
+        if n not in ("desire_last_error", "desire_build_hash"):
             getattr(lib, n).restype = C.c_int
     if lib.desire_dims_size() != C.sizeof(DesireDims):          # this binding and the library disagree about desire_dims: refuse to run
         raise DesireError("libdesire_hip.so was built with sizeof(desire_dims) = %d, this binding has %d: rebuild (python -c 'import "

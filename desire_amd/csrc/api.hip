@@ -13,6 +13,10 @@ int desire_fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" const char* desire_last_error(void) { return g_err.c_str(); }
 extern "C" int desire_version(void) { return 5; }
 extern "C" int desire_dims_size(void) { return (int)sizeof(desire_dims); }
+#ifndef DESIRE_SRC_HASH
+#define DESIRE_SRC_HASH "unstamped"
+#endif
+extern "C" const char* desire_build_hash(void) { return DESIRE_SRC_HASH; }
 
 // Packed fragment order: out[((nt*G + g)*64 + lane)*4 + i] = W(k = 8g + 4*(lane>>5) + i, n = nt*32 + (lane&31))
 std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& at) {

@@ -37,6 +37,14 @@ def test_dims_struct_matches_header():
     assert ctypes.sizeof(DesireDims) == 4 * len(names)
 
 
+def test_loaded_library_is_the_trees_code(lib):
+    """built objects travel to the GPU box next to the sources (git-ignored, not gpurun-ignored); the build is content-hashed
+    and the library carries the hash of the tree it was built from, so a stale .so cannot pass for the tree's code."""
+    from desire_amd._build import source_hash
+    assert lib.desire_build_hash().decode() == source_hash()
+    assert lib.desire_dims_size() == ctypes.sizeof(__import__("desire_amd._lib", fromlist=["DesireDims"]).DesireDims)
+
+
 def test_create_validates_dims_and_needs_a_gpu(lib):
     import torch
     from desire_amd import _lib
