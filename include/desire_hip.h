@@ -137,7 +137,7 @@ int desire_version(void);
 /* sizeof(desire_dims) as THIS library was built: a host compiled against another revision of this header (the struct has grown by appending
  * fields) compares it with its own sizeof before the first desire_create and refuses to run on a mismatch. */
 int desire_dims_size(void);
-/* First 16 hex digits of the sha256 over csrc/*, this header and the compile flags the library was built from (desire_amd/_build.py:
+/* First 16 hex digits of the sha256 over every source file under csrc, this header and the compile flags the library was built from (desire_amd/_build.py:
  * source_hash): equal to the tree's value <=> the loaded .so is the tree's code.  "unstamped" for a build that bypassed _build.py. */
 const char* desire_build_hash(void);
 /* Changes one of the behavioural switches of desire_dims on a live handle: name = "ioc_form", "ioc_split", "train_fp32_mask" or
