@@ -24,7 +24,7 @@ SCRIPT = textwrap.dedent('''
     z = torch.zeros(1 << 20, device="cuda")
     n_calls = 0
     for name, args in protos:
-        if name in ("desire_create", "desire_destroy", "desire_version"):
+        if name in ("desire_create", "desire_destroy", "desire_version", "desire_dims_size"):
             continue
         fn = getattr(lib, name)
         params = [a.strip() for a in args.replace("\\n", " ").split(",")]

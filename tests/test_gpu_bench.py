@@ -112,6 +112,42 @@ def test_two_ranks_on_one_gpu(extra):
         assert abs(o["value"] - 2 * o["config"]["rows_per_gpu"] * 2 / (o["ms_per_step"] * 2e-3)) < 1e-6 * o["value"]
 
 
+def _check_multi_rank_legs(o, world):
+    """the plain `bench.py --gpus N` line carries the peer-buffer pass (on by default), BASELINE configs[3] at its named shape
+    (32 scenes x 64 agents sharded 64/N per rank, K = 50, H = 256, fp32 and split) and configs[4] (512 agents per step over the ranks, training)."""
+    pb = o["agent_sharded"]["peer_buffers"]
+    assert "error" not in pb and "skipped" not in pb and pb["ioc_ms"] > 0, pb
+    c3 = o["alt"]["config3"]
+    assert "error" not in c3, c3
+    assert ("%d slots per rank over %d ranks" % (64 // world, world)) in c3["shape"]
+    for tag in ("fp32", "split_bf16x3"):
+        assert c3[tag]["finite"] and c3[tag]["ms_per_step"] > 0 and c3[tag]["exposed_comm_ms"] >= 0, c3[tag]
+        assert c3[tag]["peer_buffers"]["ioc_ms"] > 0, c3[tag]
+    c4 = o["alt"]["config4_train"]
+    assert "error" not in c4, c4
+    for tag in ("fp32", "split_bf16x3"):
+        assert c4[tag]["finite"] and c4[tag]["ms_per_step"] > 0 and c4[tag]["allreduce_ms"] > 0 and c4[tag]["allreduce_bytes"] > 4_000_000, c4[tag]
+    assert abs(c4["fp32"]["loss"] - c4["split_bf16x3"]["loss"]) < 1e-3 * abs(c4["fp32"]["loss"])
+
+
+def test_eight_ranks_on_one_gpu_carry_every_leg():
+    """The driver's SCALE command at N = 8, all ranks sharing this box's GPU over gloo (DESIRE_BENCH_ONE_GPU): 8 slots per rank of 64-agent scenes
+    at configs[3], 2 windows per rank at configs[4]."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DESIRE_BENCH_ONE_GPU"] = "1"
+    env["DESIRE_BENCH_LEG_TIMEOUT"] = "600"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--windows", "8"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    o = _last_json(p.stdout)
+    assert o["n_gpus"] == 8 and o["value"] > 0
+    assert "error" not in o["agent_sharded"], o["agent_sharded"]
+    _check_multi_rank_legs(o, 8)
+
+
 def test_gpus_flag_starts_its_own_ranks():
     """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must not die on plumbing -- it re-executes
     itself under torch.distributed.run, keeps the one-JSON-line contract, reports the rank count the collective library saw and
@@ -130,6 +166,7 @@ def test_gpus_flag_starts_its_own_ranks():
     assert "error" not in leg, leg
     assert leg["finite"] and leg["agents_per_scene_over_all_ranks"] == 64 and leg["bytes_received_per_rank_per_ioc_step"] == 2 * leg["bytes_sent_per_rank_per_ioc_step"]
     assert leg["ioc_ms_with_collectives"] > 0 and leg["exposed_comm_ms"] >= 0
+    _check_multi_rank_legs(o, 2)
     # asking for more GPUs than the node has is an error message, not a hang (without the one-GPU test switch)
     env.pop("DESIRE_BENCH_ONE_GPU")
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "64"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
