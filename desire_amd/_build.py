@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdesire_hip.so")
-SOURCES = ["api.hip", "kernels_gemm.hip", "kernels_conv.hip", "kernels_rnn.hip", "kernels_aux.hip", "kernels_compact.hip", "kernels_bwd.hip", "kernels_bwd_x3.hip", "kernels_bwd_cl.hip", "kernels_bf16.hip", "kernels_bf16_cl.hip", "kernels_x3.hip", "kernels_x6.hip", "kernels_x6r2.hip", "train.hip"]
+SOURCES = ["api.hip", "api_pack.hip", "api_forward.hip", "api_peer.hip", "api_ops.hip", "kernels_gemm.hip", "kernels_conv.hip", "kernels_rnn.hip", "kernels_aux.hip", "kernels_compact.hip", "kernels_bwd.hip", "kernels_bwd_x3.hip", "kernels_bwd_cl.hip", "kernels_bf16.hip", "kernels_bf16_cl.hip", "kernels_x3.hip", "kernels_x6.hip", "kernels_x6r2.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 FLAGS += os.environ.get("DESIRE_HIPCC_FLAGS", "").split()      # e.g. -DDESIRE_IOC_TIMING for the per-phase cycle counters (build_lib(force=True))
 
