@@ -126,6 +126,43 @@ def multi_rank_legs(out, a, d, w, grids_t, rank, world, dev, stream, fence, emit
     wd = threading.Timer(float(budget), bail)
     wd.daemon = True
     wd.start()
+    # a rank that DIES in one of these legs (a GPU fault across xGMI is an abort, not an exception) makes the launcher send SIGTERM to the others:
+    # rank 0 then still owes the driver its line.  The main thread may sit in a C call (a synchronise that will never return), where a Python signal
+    # handler cannot run, so the signal is routed to a wake-up pipe and a helper thread prints the line with the legs that did finish.
+    if rank == 0:
+        import signal
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        try:
+            signal.set_wakeup_fd(wfd)
+            signal.signal(signal.SIGTERM, lambda *_: None)
+
+            def on_term():
+                os.read(rfd, 1)
+                if done.is_set():
+                    return
+                out.setdefault("alt", {})
+                tgt = out if state["leg"] == "agent_sharded" else out["alt"]
+                tgt[state["leg"]] = {"error": "terminated by the launcher while this leg ran (another rank died); the scene-sharded headline above is unaffected"}
+                emit()
+                os._exit(0)
+            threading.Thread(target=on_term, daemon=True).start()
+        except ValueError:                                        # not the main thread (bench.py imported and driven from elsewhere): no handler
+            pass
+    fault_at = os.environ.get("DESIRE_BENCH_FAULT_AT")              # test hook: the LAST rank kills itself when that leg starts (tests/test_gpu_bench.py)
+
+    def maybe_fault(name):
+        if fault_at == name and rank == world - 1:
+            os.kill(os.getpid(), 9)
+
+    broken = {"v": False}
+
+    def leg_fence():
+        """barrier + synchronise between legs; a peer that has died turns it into an exception: no further legs then, the line goes out as it is"""
+        try:
+            fence()
+        except Exception:                                         # noqa: BLE001
+            broken["v"] = True
 
     def put(name, val, top=False):
         if rank == 0:
@@ -136,6 +173,7 @@ def multi_rank_legs(out, a, d, w, grids_t, rank, world, dev, stream, fence, emit
 
     # ---- (1) agent-sharded IOC at configs[1] dims --------------------------------------------------------------------------------------
     if d.mno * world <= 256 and os.environ.get("DESIRE_BENCH_NO_AGENT_LEG") != "1":
+        maybe_fault("agent_sharded")
         try:
             da = d.replace(n_scenes=32)
             past_a, fut_a, eps_a, _, gos_a = make_case(da, seed=a.seed + 101 + rank, n_absent=0)
@@ -152,11 +190,12 @@ def multi_rank_legs(out, a, d, w, grids_t, rank, world, dev, stream, fence, emit
                 x["h"].close()
         except Exception as exc:                                  # noqa: BLE001 -- the headline must survive a failure of an extra leg
             put("agent_sharded", {"error": repr(exc)[:300]}, top=True)
-        fence()
+        leg_fence()
 
     # ---- (2) BASELINE configs[3]: 32 scenes x 64 agents, K = 50, H = 256, agents sharded over the ranks --------------------------------------
     state["leg"] = "config3"
-    if 64 % world == 0 and os.environ.get("DESIRE_BENCH_NO_CONFIG3_LEG") != "1":
+    if not broken["v"] and 64 % world == 0 and os.environ.get("DESIRE_BENCH_NO_CONFIG3_LEG") != "1":
+        maybe_fault("config3")
         res = {}
         try:
             m_loc = 64 // world
@@ -197,11 +236,12 @@ def multi_rank_legs(out, a, d, w, grids_t, rank, world, dev, stream, fence, emit
         except Exception as exc:                                  # noqa: BLE001
             res["error"] = repr(exc)[:300]
         put("config3", res)
-        fence()
+        leg_fence()
 
     # ---- (3) BASELINE configs[4]: training, 512 agents per step over the ranks -----------------------------------------------------------------
     state["leg"] = "config4_train"
-    if os.environ.get("DESIRE_BENCH_NO_CONFIG4_LEG") != "1":
+    if not broken["v"] and os.environ.get("DESIRE_BENCH_NO_CONFIG4_LEG") != "1":
+        maybe_fault("config4_train")
         res = {}
         try:
             n_win = max(1, 16 // world)                               # 16 windows x 32 slots = 512 agents per step
@@ -246,6 +286,6 @@ def multi_rank_legs(out, a, d, w, grids_t, rank, world, dev, stream, fence, emit
         except Exception as exc:                                  # noqa: BLE001
             res["error"] = repr(exc)[:300]
         put("config4_train", res)
-        fence()
+        leg_fence()
     done.set()
     wd.cancel()

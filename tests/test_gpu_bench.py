@@ -148,6 +148,23 @@ def test_eight_ranks_on_one_gpu_carry_every_leg():
     _check_multi_rank_legs(o, 8)
 
 
+def test_a_rank_dying_in_an_extra_leg_does_not_cost_the_line():
+    """A GPU fault in one of the multi-rank legs is an abort of that rank, and the launcher then SIGTERMs the others: rank 0 must still print the
+    line with the headline and the legs that had finished (benchlib/legs_dist.py: wake-up pipe + helper thread)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DESIRE_BENCH_ONE_GPU"] = "1"
+    env["DESIRE_BENCH_FAULT_AT"] = "config3"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "8"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    o = _last_json(p.stdout)
+    assert o["n_gpus"] == 2 and o["value"] > 0
+    assert "error" not in o["agent_sharded"] and o["agent_sharded"]["finite"]
+    assert "error" in o["alt"]["config3"] and "config4_train" not in o["alt"]
+
+
 def test_gpus_flag_starts_its_own_ranks():
     """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must not die on plumbing -- it re-executes
     itself under torch.distributed.run, keeps the one-JSON-line contract, reports the rank count the collective library saw and
