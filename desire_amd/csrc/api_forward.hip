@@ -19,9 +19,11 @@ bool compact_ioc(const desire_ctx* h) {
     const bool split_served = ioc_x3_supported(d.mno, d.H, B_) || (d.mno == 64 && ioc_x6r2_supported(d.mno, d.H, B_));
     return !(split_mode && !split_served && d.H == 256 && d.ioc_form == DESIRE_IOC_AUTO);
 }
-int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: 8, 16, 32 below the handle's own mno, then mno itself
+int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: the three largest of 8, 16, 32, 64, 96 below the handle's own mno, then mno itself
+    int cand[5], nc = 0;
+    for (int m : {8, 16, 32, 64, 96}) if (m < h->d.mno) cand[nc++] = m;
     int n = 0;
-    for (int m : {8, 16, 32}) if (m < h->d.mno) m4[n++] = m;
+    for (int i = nc > 3 ? nc - 3 : 0; i < nc; ++i) m4[n++] = cand[i];
     m4[n++] = h->d.mno;
     for (int i = n; i < 4; ++i) m4[i] = h->d.mno;
     return n;

@@ -283,18 +283,21 @@ def ragged_counts(d, seed, counts):
     dict(bf16=3),
     dict(bf16=1),
     dict(mno=64, n_scenes=6, K=2),                   # top class = the cluster / 64-row forms, lower classes the 32-row tile
+    dict(mno=128, n_scenes=8, K=2, counts=[3, 40, 70, 100, 128, 0, 33, 64]),      # classes 32 / 64 / 96 / 128 (deathCircle-sized scenes)
     dict(mno=16, H=64, K=3),
     dict(bin_mode=1, grid_size=4, nb_h=0.02, nb_w=0.3),
     dict(iters=2),
-], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
+], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items() if kv[0] != "counts") or "fp32")
 @pytest.mark.parametrize("rows_too", [False, True], ids=["ioc_only", "rows+ioc"])
 def test_slot_classes_reproduce_the_scene_shaped_ioc(torch_cuda, kw, rows_too):
     """Every window re-seated in its slot class (fold threshold 0: every class that has windows runs on its own) against the scene-shaped
     pass on the SAME decoded positions: identical neighbour sets and cells, sums regrouped -> 1e-5 on trajectories (normalised units)."""
     from desire_amd.spec import FLAG_COMPACT_IOC
+    kw = dict(kw)
+    counts = kw.pop("counts", None)
     d = small_dims(**{**dict(n_scenes=8, K=4, T_pred=12), **kw})
     w = init_weights(d, 3)
-    past, fut, eps, grids, gos, keep = ragged_counts(d, seed=21, counts=[3, 9, 0, 14, 8, d.mno, 1, 20])
+    past, fut, eps, grids, gos, keep = ragged_counts(d, seed=21, counts=counts or [3, 9, 0, 14, 8, d.mno, 1, 20])
     Ya, sa = run_opts(torch_cuda, d, w, past, fut, eps, grids, gos)
     flags = FLAG_COMPACT_IOC | (FLAG_COMPACT_ROWS if rows_too else 0)
     Yb, sb = run_opts(torch_cuda, d.replace(flags=flags), w, past, fut, eps, grids, gos, min_rows=0)
@@ -345,3 +348,30 @@ def test_training_step_on_slot_classes_matches_the_uncompacted_one(torch_cuda, k
         assert np.isfinite(gb[k]).all()
     print("slot classes vs uncompacted training step: worst relative gradient difference %.2e (%s)" % (worst[1], worst[0]))
     assert worst[1] < (1e-4 if kw.get("bf16") else 3e-5), worst
+
+
+def test_model_api_with_skip_padding(torch_cuda):
+    """The Python surface: DESIREModel(args with dims_flags = COMPACT_ROWS | COMPACT_IOC).forward on loader-shaped windows equals the padded model on
+    present agents, and a compacted train_step moves the same loss."""
+    import argparse
+    from desire_amd.model import DESIREModel
+    from desire_amd.spec import FLAG_COMPACT_IOC
+    from desire_amd.train import build_parser
+    def mk(flags):
+        a = build_parser().parse_args(["--d_dim", "64", "--seq_length", "8", "--pred_length", "12", "--max_num_obj", "32", "--batch_size", "4"])
+        a.dims_flags = flags
+        a.num_samples = 4
+        return a
+    d = small_dims(n_scenes=4, K=4, T_obs=8, T_pred=12, H=64)
+    past, fut, eps, grids, gos, keep = ragged_counts(d, seed=5, counts=[9, 3, 0, 14])
+    x = [p.astype(np.float64) for p in past]; y = [f.astype(np.float64) for f in fut]
+    m0 = DESIREModel(mk(0), seed=3)
+    m1 = DESIREModel(mk(FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC), seed=3)
+    Y0, s0 = m0.forward(x, y, seed=1)
+    Y1, s1 = m1.forward(x, y, seed=1)
+    torch_cuda.cuda.synchronize()
+    k = torch_cuda.as_tensor(keep, device=Y0.device)[:, None, :].expand(-1, Y0.shape[1], -1)
+    assert float((Y0 - Y1).abs()[k].max()) < 1e-5 and float((s0 - s1).abs()[k].max()) < 1e-4
+    assert abs(float(m0.cost) - float(m1.cost)) < 1e-6 * max(1.0, abs(float(m0.cost)))
+    l0 = m0.train_step(x, y, seed=2); l1 = m1.train_step(x, y, seed=2)
+    assert abs(float(l0["loss"]) - float(l1["loss"])) < 1e-5 * max(1.0, abs(float(l0["loss"])))
