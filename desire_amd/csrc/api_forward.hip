@@ -33,7 +33,8 @@ int compact_setup(desire_ctx* h) {
     const size_t A = h->A, R = h->R, f = sizeof(float);
     struct WS { const char* n; size_t bytes; };
     const WS list[] = {{"cp_amap", A * sizeof(int32_t)}, {"cp_inv", A * sizeof(int32_t)}, {"cp_count", 8 * sizeof(int32_t)}, {"cp_HxHy", A * 2 * d.H * f},
-                       {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f}};
+                       {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f},
+                       {"cp_past", A * (size_t)d.T_obs * 3 * f}, {"cp_fut", A * (size_t)d.T_pred * 3 * f}, {"cp_valid2", A}};
     const WS list_ioc[] = {{"ci_win", 4 * (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_map", 4 * A * sizeof(int32_t)}, {"ci_Hx", A * 2 * d.H * f}, {"ci_pl", A * 2 * f},
                            {"ci_valid", A}, {"ci_gos", (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_Y", R * (size_t)d.T_pred * 2 * f}, {"ci_score", R * f}};
     for (const WS& w : list)
@@ -49,6 +50,21 @@ int compact_setup(desire_ctx* h) {
         for (int i = 0; i < 8; ++i) p[i] = 0;
         h->cp_host = p;
     }
+    return DESIRE_OK;
+}
+// the present-agent scan (+ the slot-class scan) over `valid`, and the event desire_sample / desire_ioc_refine wait on
+static int compact_scans(desire_ctx* h, hipStream_t s) {
+    const desire_dims& d = h->d;
+    launch_present_scan(static_cast<const uint8_t*>(h->ws["valid"].p), h->A, static_cast<int32_t*>(h->ws["cp_amap"].p), static_cast<int32_t*>(h->ws["cp_inv"].p),
+                        static_cast<int32_t*>(h->ws["cp_count"].p), h->cp_host, s);
+    if (compact_ioc(h)) {
+        int m4[4];
+        const int n_cls = compact_classes(h, m4);
+        launch_class_scan(static_cast<const uint8_t*>(h->ws["valid"].p), d.n_scenes, d.mno, n_cls, m4, d.K, h->ci_min_rows, static_cast<int32_t*>(h->ws["ci_win"].p),
+                          static_cast<int32_t*>(h->ws["ci_map"].p), static_cast<int32_t*>(h->ws["cp_count"].p) + 4, h->cp_host + 4, s);
+    }
+    HIPCHK(hipEventRecord(h->cp_ev, s));
+    h->cp_pending = true;
     return DESIRE_OK;
 }
 // waits (once per desire_encode) for the scans' counts to reach the host
@@ -68,19 +84,48 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     if (d.posterior && !dev_fut) return fail(DESIRE_ERR_ARG, "dims.posterior=1 needs dev_fut");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = d.H, A = h->A;
+    // DESIRE_FLAG_COMPACT_ROWS: the encoder stack is per-agent as well.  `valid` is read off the last observed frame first, the scans run, the host
+    // learns P, and the GRU encoders + CVAE encoder run on the P present agents as ONE pseudo-scene of P slots (frames gathered to [1, T, P, 3]);
+    // HxHy / p_last / params are scattered back for the stages that keep the caller's layout (IOC, losses).  Ae = agents the stack runs on.
+    // (not while the Gaussian-head loss is on: that term counts every (object, observed frame) pair, including objects that have left by the last
+    //  observed frame, which the present-agent map does not hold)
+    const bool enc_c = compact_rows(h) && !(h->training && h->head_loss_w > 0.f);
+    h->cp_enc = false;
+    int Ae = A;
+    const float* pastE = dev_past; const float* futE = dev_fut;
+    float* HxE = W(h, "HxHy"); float* plE = W(h, "p_last"); uint8_t* validE = static_cast<uint8_t*>(h->ws["valid"].p);
+    float* paramsE = W(h, "params");
+    const int32_t* amap = nullptr;
+    if (enc_c) {
+        if (int rc = compact_setup(h)) return rc;
+        launch_valid_from_frames(dev_past, d.n_scenes, d.T_obs, d.mno, validE, s);
+        if (int rc = compact_scans(h, s)) return rc;
+        if (int rc = compact_wait(h, s)) return rc;
+        const int P = *static_cast<volatile int32_t*>(h->cp_host);
+        if (P < 0 || P > A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
+        h->cp_P = P; h->cp_enc = true; Ae = P;
+        launch_fill_f32(W(h, "HxHy"), (size_t)A * 2 * H, 0.f, s); launch_fill_f32(W(h, "p_last"), (size_t)A * 2, 0.f, s);
+        if (d.posterior) launch_fill_f32(W(h, "params"), (size_t)A * 2 * d.L, 0.f, s);
+        if (P == 0) { HIPCHK(hipGetLastError()); return DESIRE_OK; }
+        amap = static_cast<const int32_t*>(h->ws["cp_amap"].p);
+        launch_gather_frames(dev_past, W(h, "cp_past"), amap, P, d.T_obs, d.mno, s);
+        if (d.posterior) launch_gather_frames(dev_fut, W(h, "cp_fut"), amap, P, d.T_pred, d.mno, s);
+        pastE = W(h, "cp_past"); futE = W(h, "cp_fut");
+        HxE = W(h, "cp_HxHy"); plE = W(h, "cp_plast"); validE = static_cast<uint8_t*>(h->ws["cp_valid2"].p); paramsE = W(h, "cp_params");
+    }
     EncArgs e{};
-    e.n_scenes = d.n_scenes; e.mno = d.mno; e.sx = d.sx; e.sy = d.sy; e.H = H;
-    e.frames = dev_past; e.T = d.T_obs;
+    e.n_scenes = enc_c ? 1 : d.n_scenes; e.mno = enc_c ? Ae : d.mno; e.sx = d.sx; e.sy = d.sy; e.H = H;
+    e.frames = pastE; e.T = d.T_obs;
     e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
-    e.out = W(h, "HxHy"); e.ldo = 2 * H; e.p_last = W(h, "p_last"); e.valid = static_cast<uint8_t*>(h->ws["valid"].p);
+    e.out = HxE; e.ldo = 2 * H; e.p_last = plE; e.valid = validE;
     if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
     const EncArgs ex = e;
     if (d.posterior) {
-        e.frames = dev_fut; e.T = d.T_pred;
+        e.frames = futE; e.T = d.T_pred;
         e.wx_g = D(h, "enc_y/gk"); e.b_g = D(h, "enc_y/gb"); e.wx_c = D(h, "enc_y/ck"); e.b_c = D(h, "enc_y/cb");
         e.Whg = D4(h, "enc_y/Whg"); e.Whc = D4(h, "enc_y/Whc");
-        e.out = W(h, "HxHy") + H; e.p_last = nullptr; e.valid = nullptr;
+        e.out = HxE + H; e.p_last = nullptr; e.valid = nullptr;
         if (h->training) { e.sv_r = W(h, "ey_sv_r"); e.sv_u = W(h, "ey_sv_u"); e.sv_c = W(h, "ey_sv_c"); e.sv_h = W(h, "ey_sv_h"); e.sv_x = W(h, "ey_sv_x"); }
     }
     if (d.bf16 == 1) {
@@ -91,29 +136,22 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     } else if (d.posterior) {      // the two encoders are independent and latency-bound: one launch
         Timer t(h, s, "encoder_xy"); launch_encoder_pair(ex, e, s);
     } else { Timer t(h, s, "encoder_x"); launch_encoder(ex, s); }
-    if (compact_rows(h) || compact_ioc(h)) {
-        // present-row compaction (DESIRE_FLAG_COMPACT_ROWS): the map of the agents present at the last observed frame, built right behind the
-        // encoder that writes `valid`; its size reaches the host through a mapped word while the CVAE encoder below keeps the device busy, and
-        // desire_sample waits on the event before it sizes its launches.
+    if (enc_c) {          // back to the caller's layout for the IOC stage (absent agents: zeros, filled above)
+        launch_scatter_agents(HxE, W(h, "HxHy"), amap, Ae, 2 * H, s);
+        launch_scatter_agents(plE, W(h, "p_last"), amap, Ae, 2, s);
+    } else if (compact_rows(h) || compact_ioc(h)) {
+        // DESIRE_FLAG_COMPACT_IOC alone: the slot-class maps are built behind the encoder that writes `valid`; their sizes reach the host through a
+        // mapped word while the CVAE encoder below keeps the device busy, and desire_ioc_refine waits on the event before it sizes its launches
         if (int rc = compact_setup(h)) return rc;
-        launch_present_scan(static_cast<const uint8_t*>(h->ws["valid"].p), A, static_cast<int32_t*>(h->ws["cp_amap"].p), static_cast<int32_t*>(h->ws["cp_inv"].p),
-                            static_cast<int32_t*>(h->ws["cp_count"].p), h->cp_host, s);
-        if (compact_ioc(h)) {
-            int m4[4];
-            const int n_cls = compact_classes(h, m4);
-            launch_class_scan(static_cast<const uint8_t*>(h->ws["valid"].p), d.n_scenes, d.mno, n_cls, m4, d.K, h->ci_min_rows, static_cast<int32_t*>(h->ws["ci_win"].p),
-                              static_cast<int32_t*>(h->ws["ci_map"].p), static_cast<int32_t*>(h->ws["cp_count"].p) + 4, h->cp_host + 4, s);
-        }
-        HIPCHK(hipEventRecord(h->cp_ev, s));
-        h->cp_pending = true;
+        if (int rc = compact_scans(h, s)) return rc;
     }
     if (d.posterior) {
         GemmArgs g{};
-        g.A = W(h, "HxHy"); g.lda = 2 * H; g.M = A; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
+        g.A = HxE; g.lda = 2 * H; g.M = Ae; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
         g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");
         { Timer t(h, s, "fc_c"); launch_gemm_rows(g, EPI_BIAS_RELU, s); }
         ConvArgs c{};
-        c.n = A;
+        c.n = Ae;
         c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
         const bool pobn = d.bn_mode != 0;                 // batch statistics: linear conv epilogue, then a normalise + activate pass per layer
@@ -125,19 +163,20 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
             else launch_instnorm_act(x, n, P, C, ga, be, sig, s);
         };
         if (pobn) c.mode = 3;
-        { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), A, 256, 32, 0); }
+        { Timer t(h, s, "conv1"); launch_conv1(c, s); if (pobn) norm("vae_enc/conv1", W(h, "c1"), Ae, 256, 32, 0); }
         c.in = W(h, "c1"); c.out = W(h, "c2"); c.Wp = D4(h, "vae_enc/conv2/W");
         c.scale = D(h, "vae_enc/conv2/scale"); c.shift = D(h, "vae_enc/conv2/shift");
         if (d.bf16 == 1) { c.Wp = D4(h, "vae_enc/conv2/W16"); Timer t(h, s, "conv2"); launch_conv2_bf16(c, s); }
-        else { Timer t(h, s, "conv2"); launch_conv2(c, s); if (pobn) norm("vae_enc/conv2", W(h, "c2"), A, 64, 64, 0); }
+        else { Timer t(h, s, "conv2"); launch_conv2(c, s); if (pobn) norm("vae_enc/conv2", W(h, "c2"), Ae, 64, 64, 0); }
         c.in = W(h, "c2"); c.out = W(h, "c3"); c.Wp = D4(h, "vae_enc/conv3/W");
         c.scale = D(h, "vae_enc/conv3/scale"); c.shift = D(h, "vae_enc/conv3/shift");
         if (d.bf16 == 1) { c.Wp = D4(h, "vae_enc/conv3/W16"); Timer t(h, s, "conv3"); launch_conv3_bf16(c, s); }
-        else { Timer t(h, s, "conv3"); launch_conv3(c, s); if (pobn) norm("vae_enc/conv3", W(h, "c3"), A, 16, 128, 0); }
+        else { Timer t(h, s, "conv3"); launch_conv3(c, s); if (pobn) norm("vae_enc/conv3", W(h, "c3"), Ae, 16, 128, 0); }
         g = GemmArgs{};
-        g.A = W(h, "c3"); g.lda = 2048; g.M = A; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
-        g.NT = (2 * d.L + 31) / 32; g.out = W(h, "params"); g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
+        g.A = W(h, "c3"); g.lda = 2048; g.M = Ae; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
+        g.NT = (2 * d.L + 31) / 32; g.out = paramsE; g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
         { Timer t(h, s, "vae_enc_fc"); launch_gemm_rows(g, EPI_BIAS, s); }
+        if (enc_c) launch_scatter_agents(paramsE, W(h, "params"), amap, Ae, 2 * d.L, s);       // desire_losses / the reparam backward read them per agent
     }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
@@ -169,9 +208,11 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         }
         const int32_t* amap = static_cast<const int32_t*>(h->ws["cp_amap"].p);
         Timer t(h, s, "compact_gather");
-        launch_gather_agents(W(h, "HxHy"), W(h, "cp_HxHy"), amap, P, 2 * H, s);
-        launch_gather_agents(W(h, "p_last"), W(h, "cp_plast"), amap, P, 2, s);
-        if (d.posterior) launch_gather_agents(W(h, "params"), W(h, "cp_params"), amap, P, 2 * d.L, s);
+        if (!h->cp_enc) {           // (an encoder stack that ran compact has left all three in place)
+            launch_gather_agents(W(h, "HxHy"), W(h, "cp_HxHy"), amap, P, 2 * H, s);
+            launch_gather_agents(W(h, "p_last"), W(h, "cp_plast"), amap, P, 2, s);
+            if (d.posterior) launch_gather_agents(W(h, "params"), W(h, "cp_params"), amap, P, 2 * d.L, s);
+        }
         HxS = W(h, "cp_HxHy"); plS = W(h, "cp_plast"); Yout = W(h, "cp_Y0");
     }
     if (compact) { Timer t(h, s, "reparam"); launch_reparam_c(W(h, "cp_params"), dev_eps, W(h, "z"), static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.L, d.posterior, s); }

@@ -70,6 +70,7 @@ struct desire_ctx {
     // into, the event behind it, the count of the last desire_sample (-1: none yet)
     int32_t* cp_host = nullptr; hipEvent_t cp_ev = nullptr; bool cp_pending = false; int cp_P = -1;
     int ci_n = 0, ci_cls[4] = {0, 0, 0, 0}, ci_cnt[4] = {0, 0, 0, 0}; bool ci_last = false; int ci_min_rows = 8192;     // DESIRE_FLAG_COMPACT_IOC: the classes the last IOC stage ran (class index, windows)
+    bool cp_enc = false;                                     // the last desire_encode ran its stack on the present agents only (saves in compact agent order)
     bool cp_last = false;                                    // the last desire_sample ran compacted (desire_backward follows it, not the flag)
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;

@@ -295,3 +295,8 @@ void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, cons
                               float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s);
 void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s);
 void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* cmap, int NA, int n, hipStream_t s);
+// encoder-stage compaction
+void launch_valid_from_frames(const float* past, int n_scenes, int T, int mno, uint8_t* valid, hipStream_t s);
+void launch_gather_frames(const float* frames, float* out, const int32_t* amap, int P, int T, int mno, hipStream_t s);
+void launch_scatter_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s);
+void launch_gather_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* amap, int P, int n, hipStream_t s);

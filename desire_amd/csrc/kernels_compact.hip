@@ -260,3 +260,59 @@ void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo
     if (t <= 0) return;
     hipLaunchKernelGGL(k_cls_scatter_add_agents, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, cmap, NA, n);
 }
+
+// =====================================================================================================================================
+// Encoder-stage compaction (DESIRE_FLAG_COMPACT_ROWS, round 5b): the GRU encoders and the CVAE encoder are per-agent too.  `valid` is read off
+// the last observed frame BEFORE the encoders, the windows of the present agents are gathered into one pseudo-scene [1, T, P, 3], and the encoder
+// stack runs on P agents; HxHy / p_last / params are scattered back for the stages that keep the caller's layout (IOC, losses).
+// =====================================================================================================================================
+__global__ void k_valid_from_frames(const float* __restrict__ past, int n_scenes, int T, int mno, uint8_t* __restrict__ valid) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_scenes * mno) return;
+    const int sc = a / mno, slot = a - sc * mno;
+    valid[a] = past[(((size_t)sc * T + (T - 1)) * mno + slot) * 3] != 0.f ? 1 : 0;          // id != 0 at the last observed frame (k_encoder's rule)
+}
+void launch_valid_from_frames(const float* past, int n_scenes, int T, int mno, uint8_t* valid, hipStream_t s) {
+    const int A = n_scenes * mno;
+    hipLaunchKernelGGL(k_valid_from_frames, dim3((A + 255) / 256), dim3(256), 0, s, past, n_scenes, T, mno, valid);
+}
+// frames_c[0, t, a', :] = frames[scene, t, slot, :]
+__global__ void k_gather_frames(const float* __restrict__ frames, float* __restrict__ out, const int32_t* __restrict__ amap, int P, int T, int mno) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * P) return;
+    const int t = (int)(i / P), ap = (int)(i - (long)t * P);
+    const int a = amap[ap];
+    const int sc = a / mno, slot = a - sc * mno;
+    const float* src = frames + (((size_t)sc * T + t) * mno + slot) * 3;
+    float* dst = out + (size_t)i * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+void launch_gather_frames(const float* frames, float* out, const int32_t* amap, int P, int T, int mno, hipStream_t s) {
+    const long n = (long)T * P;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frames, out, amap, P, T, mno);
+}
+// out[amap[a'], c] = in[a', c]   (rows of absent agents untouched: the caller zero-fills)
+__global__ void k_scatter_agents(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ amap, int P, int ld) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * ld) return;
+    const int ap = (int)(i / ld), c = (int)(i - (long)ap * ld);
+    out[(size_t)amap[ap] * ld + c] = in[i];
+}
+void launch_scatter_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s) {
+    const long n = (long)P * ld;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_scatter_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, amap, P, ld);
+}
+// out[a', c] += in[amap[a'], c]   (n columns; agent-level gradient from the caller's layout into the compact one)
+__global__ void k_gather_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ amap, int P, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * n) return;
+    const int ap = (int)(i / n), c = (int)(i - (long)ap * n);
+    out[(size_t)ap * ldo + c] += in[(size_t)amap[ap] * ldi + c];
+}
+void launch_gather_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* amap, int P, int n, hipStream_t s) {
+    const long t = (long)P * n;
+    if (t <= 0) return;
+    hipLaunchKernelGGL(k_gather_add_agents, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, amap, P, n);
+}

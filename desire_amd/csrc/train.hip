@@ -486,6 +486,13 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
                     ensure(h, "cp_dHx", (size_t)h->A * H * sizeof(float))))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the compact-row gradient buffers");
     const int32_t* amap = compact ? static_cast<const int32_t*>(h->ws["cp_amap"].p) : nullptr;
+    const bool enc_c = compact && h->cp_enc;                // the encoder stack ran on the present agents as well (desire_encode)
+    const int Ae = enc_c ? P : h->A;
+    if (enc_c && (ensure(h, "cp_dparams", (size_t)h->A * 2 * d.L * sizeof(float)) || ensure(h, "cp_dHxHy", (size_t)h->A * 2 * H * sizeof(float)) ||
+                  ensure(h, "dHxHy_ioc", (size_t)h->A * H * sizeof(float))))
+        return fail(DESIRE_ERR_HIP, "hipMalloc failed for the compact encoder gradient buffers");
+    const float* HxE = enc_c ? W(h, "cp_HxHy") : W(h, "HxHy");
+    float* dHE = enc_c ? W(h, "cp_dHxHy") : W(h, "dHxHy");
     const float* HxS = compact ? W(h, "cp_HxHy") : W(h, "HxHy");
     float* dHxS = compact ? W(h, "cp_dHx_rows") : W(h, "dHx_rows");
     launch_fill_f32(W(h, "Gflat"), h->n_params, 0.f, s);
@@ -727,10 +734,16 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         Timer t(h, s, "bwd_cvae_enc");
         launch_reparam_bwd(W(h, "dz"), dev_eps, W(h, "params"), valid, W(h, "nvalid"), W(h, "dparams"), d.n_scenes, d.mno, d.K, L, s,
                            compact ? static_cast<const int32_t*>(h->ws["cp_inv"].p) : nullptr, P);
-        tn(h, W(h, "c3"), 2048, W(h, "dparams"), 2 * L, A, 2048, 2 * L, G(h, "vae_enc/fc/w"), 2 * L, 0, s);
-        colsum(h, W(h, "dparams"), 2 * L, A, 2 * L, G(h, "vae_enc/fc/b"), 0, s);
+        // the encoder stack ran on the P present agents (desire_encode, DESIRE_FLAG_COMPACT_ROWS): its saves are in compact agent order and its
+        // backward runs on the same agents -- dparams gathered in, d loss / d (Hx | Hy) assembled in the compact order (dHE)
+        if (enc_c) launch_gather_agents(W(h, "dparams"), W(h, "cp_dparams"), amap, P, 2 * L, s);
+        const float* dparE = enc_c ? W(h, "cp_dparams") : W(h, "dparams");
+        if (Ae > 0) {
+        const int A = Ae;                                  // (shadows the handle's agent count inside this block)
+        tn(h, W(h, "c3"), 2048, dparE, 2 * L, A, 2048, 2 * L, G(h, "vae_enc/fc/w"), 2 * L, 0, s);
+        colsum(h, dparE, 2 * L, A, 2 * L, G(h, "vae_enc/fc/b"), 0, s);
         GemmArgs g{};
-        g.A = W(h, "dparams"); g.lda = 2 * L; g.M = A; g.K = 2 * L; g.Bp = D4(h, "vae_enc/fc/WT"); g.G = 2 * L / 8; g.NT = 64;
+        g.A = dparE; g.lda = 2 * L; g.M = A; g.K = 2 * L; g.Bp = D4(h, "vae_enc/fc/WT"); g.G = 2 * L / 8; g.NT = 64;
         g.out = W(h, "dconvE3"); g.ldo = 2048; g.N = 2048; g.p0 = D(h, "vae_enc/conv3/scale"); g.chmod = 128; g.aux = W(h, "c3");
         if (bn1) {
             launch_gemm_rows(g, EPI_NONE, s);
@@ -761,29 +774,45 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         if (!bn1) colsum(h, W(h, "dconvE1"), 32, (long)A * 256, 32, G(h, "vae_enc/conv1/b"), 0, s);
         c.in = W(h, "dconvE1"); c.out = W(h, "dq_c"); c.w_raw = D(h, "vae_enc/conv1/raw"); c.mode = 2; c.yprev = W(h, "vae_in");
         launch_deconv4(c, s);
-        tn(h, W(h, "HxHy"), 2 * H, W(h, "dq_c"), V, A, 2 * H, V, G(h, "fc_c/w"), V, 0, s);
+        tn(h, HxE, 2 * H, W(h, "dq_c"), V, A, 2 * H, V, G(h, "fc_c/w"), V, 0, s);
         colsum(h, W(h, "dq_c"), V, A, V, G(h, "fc_c/b"), 0, s);
         g = GemmArgs{};
         g.A = W(h, "dq_c"); g.lda = V; g.M = A; g.K = V; g.Bp = D4(h, "fc_c/WT"); g.G = V / 8; g.NT = 2 * H / 32;
-        g.out = W(h, "dHxHy"); g.ldo = 2 * H; g.N = 2 * H;
+        g.out = dHE; g.ldo = 2 * H; g.N = 2 * H;
         launch_gemm_rows(g, EPI_NONE, s);
-        launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
-        if (h->ci_last) launch_rows_to_agents(W(h, "dHxHy_ioc"), W(h, "dHxHy"), 2 * H, h->A, 1, 1, H, s);       // + the slot classes' share (one "row" per agent)
-        if (compact && P > 0) {         // the compact stages' share of d loss / d Hx: rows -> compact agents -> agents
-            launch_fill_f32(W(h, "cp_dHx"), (size_t)P * H, 0.f, s);
-            launch_rows_to_agents(dHxS, W(h, "cp_dHx"), H, 1, P, d.K, H, s);
-            launch_scatter_add_agents(W(h, "cp_dHx"), H, W(h, "dHxHy"), 2 * H, amap, P, H, s);
+        }       // Ae > 0
+        if (enc_c) {
+            if (P > 0) {
+                launch_rows_to_agents(dHxS, dHE, 2 * H, 1, P, d.K, H, s);                      // decoder + mask share: compact rows -> compact agents
+                if (!h->ci_last) {                                                                // IOC share: the caller's rows -> agents -> compact agents
+                    launch_fill_f32(W(h, "dHxHy_ioc"), (size_t)h->A * H, 0.f, s);
+                    launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy_ioc"), H, d.n_scenes, d.mno, d.K, H, s);
+                }
+                launch_gather_add_agents(W(h, "dHxHy_ioc"), H, dHE, 2 * H, amap, P, H, s);
+            }
+        } else {
+            launch_rows_to_agents(W(h, "dHx_rows"), W(h, "dHxHy"), 2 * H, d.n_scenes, d.mno, d.K, H, s);
+            if (h->ci_last) launch_rows_to_agents(W(h, "dHxHy_ioc"), W(h, "dHxHy"), 2 * H, h->A, 1, 1, H, s);       // + the slot classes' share (one "row" per agent)
+            if (compact && P > 0) {         // the compact stages' share of d loss / d Hx: rows -> compact agents -> agents
+                launch_fill_f32(W(h, "cp_dHx"), (size_t)P * H, 0.f, s);
+                launch_rows_to_agents(dHxS, W(h, "cp_dHx"), H, 1, P, d.K, H, s);
+                launch_scatter_add_agents(W(h, "cp_dHx"), H, W(h, "dHxHy"), 2 * H, amap, P, H, s);
+            }
         }
     }
     // ---- encoders: BPTT from the final state (Hx / Hy), zero initial state ----
     const bool head_loss = h->head_loss_w > 0.f;
+    if (Ae > 0) {
+    const int A = Ae;                                      // encoders: the agents the stack ran on
+    const float* pastE = enc_c ? W(h, "cp_past") : dev_past; const float* futE = enc_c ? W(h, "cp_fut") : dev_fut;
+    const int mnoE = enc_c ? Ae : d.mno;
     if (head_loss) {
         // Gaussian-head term (desire_set_head_loss): nll and d nll / d o per (agent, observed frame), the mean, its gradient; then the
         // head's own weight gradients.  The gradient w.r.t. the encoder states enters the X-encoder BPTT below, step by step.
         const int n = A * d.T_obs;
         Timer t(h, s, "bwd_head_nll");
-        hipLaunchKernelGGL(k_head_nll, dim3((n * 64 + 255) / 256), dim3(256), 0, s, W(h, "ex_sv_h"), W(h, "ex_sv_x"), dev_past, dev_fut,
-                           D(h, "gauss_head/w"), D(h, "gauss_head/b"), A, d.T_obs, d.T_pred, H, d.mno, d.sx, d.sy, W(h, "head_nll"), W(h, "head_cnt"),
+        hipLaunchKernelGGL(k_head_nll, dim3((n * 64 + 255) / 256), dim3(256), 0, s, W(h, "ex_sv_h"), W(h, "ex_sv_x"), pastE, futE,
+                           D(h, "gauss_head/w"), D(h, "gauss_head/b"), A, d.T_obs, d.T_pred, H, mnoE, d.sx, d.sy, W(h, "head_nll"), W(h, "head_cnt"),
                            W(h, "head_dO"));
         hipLaunchKernelGGL(k_head_sum, dim3(1), dim3(256), 0, s, W(h, "head_nll"), W(h, "head_cnt"), n, h->head_loss_w, W(h, "loss_out"));
         hipLaunchKernelGGL(k_head_scale, dim3((n * 5 + 255) / 256), dim3(256), 0, s, W(h, "head_dO"), n * 5, h->head_loss_w, W(h, "loss_out"));
@@ -797,9 +826,9 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         e.w_head = D(h, "head/w");
         if (head_loss && p == "enc_x") { e.dY0 = W(h, "head_dO"); e.w_head = D(h, "gauss_head/w"); e.nw = 5; }     // d L_head / d h_t = dO_t W5^T, every step
         e.WcT_h = D4(h, (p + "/WcT_h").c_str()); e.WgT_h = D4(h, (p + "/WgT_h").c_str());
-        e.R = A; e.K = 1; e.mno = d.mno; e.T = Te; e.H = H;
+        e.R = A; e.K = 1; e.mno = mnoE; e.T = Te; e.H = H;
         e.dag = W(h, "enc_dag"); e.dac = W(h, "enc_dac"); e.rh = W(h, "enc_rh"); e.hprev = W(h, "enc_hprev");
-        e.dh_init = W(h, "dHxHy") + col0; e.ld_init = 2 * H;
+        e.dh_init = dHE + col0; e.ld_init = 2 * H;
         launch_decoder_bwd(e, s);
         const float* xs = W(h, (std::string(sv) + "_sv_x").c_str());
         float* gk = G(h, p + "/gates/kernel");           // [(2+H), 2H]
@@ -813,6 +842,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
     };
     { Timer t(h, s, "bwd_encoder_y"); enc_bwd("enc_y", "ey", d.T_pred, H); }
     { Timer t(h, s, "bwd_encoder_x"); enc_bwd("enc_x", "ex", d.T_obs, 0); }
+    }       // Ae > 0
     HIPCHK(hipGetLastError());
     if (ioc_uses_cluster(d.mno, d.H, d.grid_size * d.grid_size, 0)) {
         int e = 0;

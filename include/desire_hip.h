@@ -113,11 +113,14 @@ typedef struct desire_dims {
                                       masks id-0 objects in the cost only (model/model.py:351-366); with this bit the per-row sample-generation stages
                                       (reparameterisation, deconv1..4, mask fc, GRU decoder -- and in training their saves and their whole backward) run on
                                       the K rows of the agents PRESENT at the last observed frame only.  Rows of present agents are bit-identical to the
-                                      uncompacted path (every stage is row-independent); rows of absent agents come back as zeros in dev_Yhat / "Y0" instead
+                                      uncompacted path (every stage is row-independent); the GRU encoders and the CVAE encoder run on the present agents too (their
+                                      windows gathered into one pseudo-scene; "Hx" / "Hy" / "z_mean" of absent agents read back as zeros; not while
+                                      desire_set_head_loss is on, whose term also counts objects that left before the last observed frame); rows of absent
+                                      agents come back as zeros in dev_Yhat / "Y0" instead
                                       of the decode of an all-zero track.  The IOC stage keeps its scene-shaped tiles.  Costs one host wait per desire_sample
                                       (the present count is read back through a mapped word, overlapped with the CVAE encoder), so a compacted
                                       desire_sample / desire_forward cannot be captured in a hipGraph.  Not with bn_mode = 2 (whole-batch statistics would
-                                      change) or ref_compat.  The intermediates "z", "d1".."d3", "xhat", "xz" of desire_read_buffer are then in the COMPACT
+                                      change) or ref_compat.  The intermediates "vae_in", "z", "d1".."d3", "xhat", "xz" of desire_read_buffer are then in the COMPACT
                                       row order r' = k*P + a' (P = present agents, a' = rank of the agent among them). */
 
 #define DESIRE_FLAG_COMPACT_IOC 8   /* IOC SLOT CLASSES.  The IOC kernels tile rows by whole (scene, k) groups of mno slots, so a window with 9 of 32 slots present

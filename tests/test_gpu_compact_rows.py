@@ -37,6 +37,14 @@ def ragged_case(d, seed, keep=0.35):
     fut[~keep_m[:, None, :].repeat(d.T_pred, 1)] = 0
     gone = rng.uniform(size=fut.shape[:3]) < 0.1                 # objects leaving the scene mid-target
     fut[gone] = 0
+    # objects that were observed but have LEFT by the last observed frame: not `valid`, i.e. padding for every stage (and outside the compact maps)
+    left = keep_m & (rng.uniform(size=keep_m.shape) < 0.15)
+    if d.n_scenes >= 3:
+        left[2] = False
+    for sc, sl in zip(*np.nonzero(left)):
+        past[sc, -2:, sl, :] = 0
+        fut[sc, :, sl, :] = 0
+    keep_m = keep_m & ~left
     return past, fut, eps, grids, gos, keep_m
 
 
@@ -375,3 +383,30 @@ def test_model_api_with_skip_padding(torch_cuda):
     assert abs(float(m0.cost) - float(m1.cost)) < 1e-6 * max(1.0, abs(float(m0.cost)))
     l0 = m0.train_step(x, y, seed=2); l1 = m1.train_step(x, y, seed=2)
     assert abs(float(l0["loss"]) - float(l1["loss"])) < 1e-5 * max(1.0, abs(float(l0["loss"])))
+
+
+def test_training_with_the_gaussian_head_loss_keeps_every_observed_object(torch_cuda):
+    """The Gaussian-head term counts (object, observed frame) pairs of objects that may have left by the last observed frame -- they are outside the
+    present-agent map -- so with desire_set_head_loss on the encoder stack stays on all agents (the per-row stages still compact): loss terms and
+    gradients, gauss_head included, equal the padded step's."""
+    from desire_amd import _lib
+    from desire_amd.spec import FLAG_COMPACT_IOC
+    torch = torch_cuda
+    d = small_dims(n_scenes=4, K=3, T_obs=6, T_pred=7, n_grids=1)
+    w = _spread(init_weights(d, 41))
+    past, fut, eps, grids, gos, keep = ragged_case(d, seed=46)
+    res = []
+    for flags in (0, FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC):
+        h = _lib.Handle(d.replace(flags=flags)); h.set_weights(w); h.set_option("compact_min_rows", 0); h.set_training(True); h.set_head_loss(0.5)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+        p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+        h.set_scene_grids(g_t.data_ptr(), gos)
+        Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+        h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr())
+        h.backward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr())
+        torch.cuda.synchronize()
+        res.append({k: h.get_grad(k, w[k].shape) for k in ("gauss_head/w", "gauss_head/b", "enc_x/gates/kernel", "enc_y/candidate/kernel", "fc_c/w", "vae_enc/conv2/w")})
+        h.close()
+    for k in res[0]:
+        ref = np.abs(res[0][k]).max()
+        assert ref > 0 and np.abs(res[0][k] - res[1][k]).max() / ref < 3e-5, k
