@@ -1175,8 +1175,19 @@ void launch_ioc_cluster(const IocArgs& a, hipStream_t s) {
 // groups of 96 .. 256 agents, H = 256): the same step with every contraction as three / six bf16 MFMAs per fp32 product -- A fragments
 // split on the fly out of the fp32 LDS tiles (split.h: mma6_groups), weights = the [hi | lo (| lo2)] packs in plain k order
 // ("ioc/Wg16", "ioc/Wc16", "ioc/Wsoc16l"); accumulators, state, gate math and layouts are the fp32 kernel's.
+#ifndef STEP_RING
+#define STEP_RING 8               // k-groups of weight fragments in flight in the split forms (0: the one-ahead mma6_groups of round 4)
+#endif
+// (split forms: ONE workgroup per CU is all the LDS tile allows at H = 256 anyway -- asking for two capped the kernel at 128 registers, which is what
+//  kept its fragment prefetch one group deep)
 template <int H, int EV, int C, int NP = 0>
-__global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_step(IocStepArgs a) {
+__global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) void k_ioc_step(IocStepArgs a) {
+#ifdef STEP_TIMING
+    long long tk[10]; int nk = 0; tk[nk++] = clock64();
+#define STK() { tk[nk++] = clock64(); }
+#else
+#define STK()
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 32;
     const int MW = (a.m_loc * a.nranks + 63) >> 6;      // 64-bit mask words per (row, bin): 1 .. 4 (up to 256 agents per scene) -- sized by the scene, so
@@ -1227,6 +1238,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         return *reinterpret_cast<const float2*>(a.Yall + ((((size_t)rk * n_groups + grp) * a.m_loc + s) * a.T + t) * 2);
     };
     __syncthreads();
+    STK()          // 1: prologue (weights, masks clear, h tile)
     f32x16 h;
 #pragma unroll
     for (int i = 0; i < 16; ++i) h[i] = my_x[((i & 3) + 8 * (i >> 2)) * LDX + E];
@@ -1261,6 +1273,11 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         }
     }
     __syncthreads();
+    STK()          // 2: P1 (positions, e_v, e_s, neighbour search)
+    // pooled operand of bin b for my row: sum of the neighbours' h_{t-1} in ascending global-slot order.  The rows come from L2 / a peer's HBM, one
+    // dependent round trip per neighbour if taken one at a time (63 of them at 64 agents per scene: that chain, not the MFMAs, was the step's length);
+    // NBAT neighbours' loads are issued together and added in slot order afterwards -- the same sums, bit for bit.
+    constexpr int NBAT = (NP != 0 || NT <= 4) ? 4 : 2;
     auto build = [&](int b, int buf) {
         float* ab = AB + buf * TM * LDB + r8 * LDB;
         float4 s[NCH];
@@ -1269,16 +1286,32 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         for (int wd = 0; wd < MW; ++wd) {
             unsigned long long m2 = masks[(r8 * B + b) * MW + wd];
             while (m2) {
-                const int j = wd * 64 + __ffsll((long long)m2) - 1;
-                m2 &= m2 - 1;
-                const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
-                const float* hb = a.peer ? a.Hp[rk] : a.Hall + (size_t)rk * n_groups * a.m_loc * H;
-                const float* src = hb + ((size_t)grp * a.m_loc + sj) * H;
+                const float* src[NBAT];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float4 v = a.peer ? ld_sys_f4(src + q8 * 4 + c * 4 * TPR) : *reinterpret_cast<const float4*>(src + q8 * 4 + c * 4 * TPR);
-                    s[c].x += v.x; s[c].y += v.y; s[c].z += v.z; s[c].w += v.w;
+                for (int q = 0; q < NBAT; ++q) {
+                    src[q] = nullptr;
+                    if (m2) {
+                        const int j = wd * 64 + __ffsll((long long)m2) - 1;
+                        m2 &= m2 - 1;
+                        const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
+                        const float* hb = a.peer ? a.Hp[rk] : a.Hall + (size_t)rk * n_groups * a.m_loc * H;
+                        src[q] = hb + ((size_t)grp * a.m_loc + sj) * H + q8 * 4;
+                    }
                 }
+                float4 v[NBAT][NCH];
+#pragma unroll
+                for (int q = 0; q < NBAT; ++q)
+                    if (src[q]) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+                            v[q][c] = a.peer ? ld_sys_f4(src[q] + c * 4 * TPR) : *reinterpret_cast<const float4*>(src[q] + c * 4 * TPR);
+                    }
+#pragma unroll
+                for (int q = 0; q < NBAT; ++q)
+                    if (src[q]) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) { s[c].x += v[q][c].x; s[c].y += v[q][c].y; s[c].z += v[q][c].z; s[c].w += v[q][c].w; }
+                    }
             }
         }
 #pragma unroll
@@ -1290,6 +1323,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     int buf = 0;
     if (om) build(ffs_(om) - 1, 0);
     __syncthreads();
+    STK()          // 3: first build
     while (om) {                                                          // occupied bins only (see k_ioc)
         const int b = ffs_(om) - 1;
         om &= om - 1;
@@ -1297,13 +1331,19 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         if constexpr (NP == 0) mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
         else {
             f32x16 t1[1] = {soc};
-            const uint4* bl[1] = {reinterpret_cast<const uint4*>(a.Wsoc) + ((size_t)(b * NT + cb) * (H / 16)) * 64 + lane};
-            mma6_groups<1, NP>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), bl, a.plo_soc, H / 16);
+            if constexpr (STEP_RING > 0) {
+                const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
+                mma6_ring<1, NP, STEP_RING>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), reinterpret_cast<const uint4*>(a.Wsoc), t0, a.plo_soc, H / 16);
+            } else {
+                const uint4* bl[1] = {reinterpret_cast<const uint4*>(a.Wsoc) + ((size_t)(b * NT + cb) * (H / 16)) * 64 + lane};
+                mma6_groups<1, NP>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), bl, a.plo_soc, H / 16);
+            }
             soc = t1[0];
         }
         __syncthreads();
         buf ^= 1;
     }
+    STK()          // 4: bins loop
 #pragma unroll
     for (int i = 0; i < 16; ++i) my_x[((i & 3) + 8 * (i >> 2)) * LDX + EV + C] = fmaxf(soc[i] + bso, 0.f);
     __syncthreads();
@@ -1314,8 +1354,13 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     } else {
         f32x16 t2[2] = {rh, u};
         const uint4* wg = reinterpret_cast<const uint4*>(a.Wg);
-        const uint4* bl[2] = {wg + ((size_t)cb * (KX / 16)) * 64 + lane, wg + ((size_t)(cb + NT) * (KX / 16)) * 64 + lane};
-        mma6_groups<2, NP>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), bl, a.plo_g, KX / 16);
+        if constexpr (STEP_RING > 0) {
+            const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
+            mma6_ring<2, NP, (STEP_RING > 4 ? 4 : STEP_RING)>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), wg, t0, a.plo_g, KX / 16);
+        } else {
+            const uint4* bl[2] = {wg + ((size_t)cb * (KX / 16)) * 64 + lane, wg + ((size_t)(cb + NT) * (KX / 16)) * 64 + lane};
+            mma6_groups<2, NP>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), bl, a.plo_g, KX / 16);
+        }
         rh = t2[0]; u = t2[1];
     }
 #pragma unroll
@@ -1325,6 +1370,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
 #pragma unroll
     for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
     __syncthreads();
+    STK()          // 5: gates
     f32x16 ac = zero16();
     if constexpr (NP == 0) {
         mma1(ac, x_lane, a.Wc + ((size_t)cb * G8) * 64 + lane, GX);
@@ -1332,10 +1378,16 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
     } else {
         f32x16 t1[1] = {ac};
         const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
-        const uint4* bx[1] = {wc + ((size_t)cb * (KX / 16)) * 64 + lane};
-        mma6_groups<1, NP>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), bx, a.plo_c, E / 16);
-        const uint4* bh[1] = {wc + ((size_t)cb * (KX / 16) + E / 16) * 64 + lane};
-        mma6_groups<1, NP>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), bh, a.plo_c, H / 16);
+        if constexpr (STEP_RING > 0) {
+            const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
+            mma6_ring<1, NP, STEP_RING>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), wc, tx, a.plo_c, E / 16);
+            mma6_ring<1, NP, STEP_RING>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), wc, th, a.plo_c, H / 16);
+        } else {
+            const uint4* bx[1] = {wc + ((size_t)cb * (KX / 16)) * 64 + lane};
+            mma6_groups<1, NP>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), bx, a.plo_c, E / 16);
+            const uint4* bh[1] = {wc + ((size_t)cb * (KX / 16) + E / 16) * 64 + lane};
+            mma6_groups<1, NP>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), bh, a.plo_c, H / 16);
+        }
         ac = t1[0];
     }
 #pragma unroll
@@ -1351,12 +1403,259 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_st
         if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
     }
     __syncthreads();
+    STK()          // 6: candidate + epilogue
+#ifdef STEP_TIMING
+    if (blockIdx.x == 7 && tid == 0 && a.t == 20)
+        printf("k_ioc_step<%d,NP=%d> t=20 block 7: prologue %lld  P1 %lld  build0 %lld  bins %lld  gates %lld  cand+epi %lld  total %lld cycles\n", H, NP,
+               tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[6] - tk[0]);
+#endif
     if (tid < TM && row0 + tid < a.R) {
         float sc = 0.f;
 #pragma unroll
         for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
         a.st_score[row0 + tid] = (a.t == 0 ? 0.f : a.st_score[row0 + tid]) + sc;
     }
+}
+// ------------------------------------------------------------------------------------------------
+// k_ioc_step with two-piece operands (dims.bf16 = 2), round 5: the same step with the operand tiles in LDS as bf16 PIECE IMAGES (hi | lo), written
+// once by whoever produces the values, instead of fp32 tiles that each of the NT waves splits again for every k-group (44 VALU instructions per
+// fragment next to the three MFMAs it feeds), and with STEP_RING k-groups of weight fragments in flight.  Phase counters of the fp32-tile form at
+// configs[3]'s shape (-DSTEP_TIMING): 245 k cycles per step, 168 k of them in the bin loop = 10.5 k per bin for 3 k matrix cycles.
+// Same pieces (splitp) and the same products per accumulator as k_ioc_step<H, EV, C, 2>; measured against it (scratch/ab_x2b.sh, three shapes): positions
+// within 1.5e-6, scores within 5e-6 -- the fp32 rounding class, not bit-identical.  configs[3]'s per-GPU shape: IOC 8.6 -> 8.0 ms, step 12.75 -> 12.16 ms.
+// ------------------------------------------------------------------------------------------------
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a) {
+#ifdef STEP_TIMING
+    long long tk[10]; int nk = 0; tk[nk++] = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int TM = 32, NP = 2, RD = STEP_RING > 0 ? STEP_RING : 1;
+    const int MW = (a.m_loc * a.nranks + 63) >> 6;
+    constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDXB = KX + 8, LDBB = H + 8;      // bf16 elements; (ld / 2) = 4 mod 8 dwords: conflict-free b128 reads
+    constexpr int XLO = TM * LDXB, BLO = TM * LDBB;                                            // elements between the two piece images of a tile
+    constexpr int NTHR = NT * 64, TPR = NTHR / TM;
+    constexpr int NCH = H / (4 * TPR);
+    const int B = a.G * a.G;
+    u16* Xb = reinterpret_cast<u16*>(smem_raw);                         // [NP][TM][LDXB]   e_v | e_s | e_r | h
+    u16* ABb = Xb + NP * XLO;                                           // [2][NP][TM][LDBB] pooled operand (double-buffered), then r * h in buffer 0
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(ABb + 2 * NP * BLO);   // [TM][B][MW]
+    float* wv = reinterpret_cast<float*>(masks + TM * B * MW);          // [3][EV]
+    float* red = wv + 3 * EV;                                           // [NT][TM]
+    unsigned* occ = reinterpret_cast<unsigned*>(red + NT * TM);
+    const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int row0 = blockIdx.x * TM;
+    const int mall = a.m_loc * a.nranks;
+    const int n_groups = a.R / a.m_loc;
+    auto st1 = [](u16* img, int plo, float v) {                         // one value -> its two pieces
+        const u16 hi = bf16_of(v);
+        img[0] = hi; img[plo] = bf16_of(v - __uint_as_float((unsigned)hi << 16));
+    };
+    auto st2 = [](u16* img, int plo, float v0, float v1) {              // two adjacent values (4-byte aligned)
+        unsigned pp[2];
+        splitp<2>(v0, v1, pp);
+        *reinterpret_cast<unsigned*>(img) = pp[0]; *reinterpret_cast<unsigned*>(img + plo) = pp[1];
+    };
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    for (int i = tid; i < TM * B * MW; i += NTHR) masks[i] = 0ull;
+    if (tid < 2) occ[tid] = 0;
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+        const int r = i / (H >> 2), c4 = i - r * (H >> 2);
+        const float* sp = a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4;
+        const float4 v = a.peer ? ld_sys_f4(sp) : *reinterpret_cast<const float4*>(sp);
+        st2(Xb + r * LDXB + E + c4 * 4, XLO, v.x, v.y); st2(Xb + r * LDXB + E + c4 * 4 + 2, XLO, v.z, v.w);
+    }
+    const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
+    const u16* x_lane = Xb + (lane & 31) * LDXB + 8 * (lane >> 5);
+    const int my_row = min(row0 + r8, a.R - 1);
+    const int grp = my_row / a.m_loc, sl = my_row - grp * a.m_loc;
+    const int scene = grp / a.K;
+    const int my_gslot = a.rank * a.m_loc + sl;
+    auto pos_of = [&](int j, int t) {
+        const int rk = j / a.m_loc, s = j - rk * a.m_loc;
+        if (t < 0) {
+            if (a.peer) return ld_sys_f2(a.plp[rk] + ((size_t)scene * a.m_loc + s) * 2);
+            return *reinterpret_cast<const float2*>(a.plast_all + ((size_t)(rk * a.n_scenes + scene) * a.m_loc + s) * 2);
+        }
+        if (a.peer) return ld_sys_f2(a.Yp[rk] + (((size_t)grp * a.m_loc + s) * a.T + t) * 2);
+        return *reinterpret_cast<const float2*>(a.Yall + ((((size_t)rk * n_groups + grp) * a.m_loc + s) * a.T + t) * 2);
+    };
+    // h_{t-1} of my accumulator elements straight from the state (the LDS tile holds pieces only)
+    f32x16 h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float* sp = a.st_h + (size_t)min(row0 + acc_row(i), a.R - 1) * H + col;
+        h[i] = a.peer ? __uint_as_float(ld_sys_u32(sp)) : *sp;
+    }
+    {
+        const float2 pcur = pos_of(my_gslot, a.t), pprev = pos_of(my_gslot, a.t - 1);
+        const float px = pcur.x, py = pcur.y;
+        const float vx = px - pprev.x, vy = py - pprev.y;
+        constexpr int per = EV / TPR;
+#pragma unroll
+        for (int j = q8 * per; j < (q8 + 1) * per; ++j)
+            st1(Xb + r8 * LDXB + j, XLO, fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f));
+        int cy, cx;
+        scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+        const float* gsrc = a.grids + (size_t)a.grid_of_scene[scene] * a.Gh * a.Gw * C + ((size_t)cy * a.Gw + cx) * C;
+        constexpr int cper = C / TPR;
+        if (cper >= 4) {
+#pragma unroll
+            for (int j = q8 * cper; j < (q8 + 1) * cper; j += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
+                st2(Xb + r8 * LDXB + EV + j, XLO, g4.x, g4.y); st2(Xb + r8 * LDXB + EV + j + 2, XLO, g4.z, g4.w);
+            }
+        } else {
+            const float2 g2 = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
+            st2(Xb + r8 * LDXB + EV + q8 * 2, XLO, g2.x, g2.y);
+        }
+        for (int j = q8; j < mall; j += TPR) {
+            const int rk = j / a.m_loc, s = j - rk * a.m_loc;
+            bool there;
+            if (a.peer) { const size_t ix = (size_t)scene * a.m_loc + s; there = (ld_sys_u32(a.vp[rk] + (ix & ~(size_t)3)) >> (8 * (ix & 3))) & 0xffu; }
+            else there = a.valid_all[(size_t)(rk * a.n_scenes + scene) * a.m_loc + s];
+            if (j == my_gslot || !there) continue;
+            const float2 pj = pos_of(j, a.t);
+            const int b = neighbor_bin_dev(px, py, pj.x, pj.y, a.nb_w, a.nb_h, a.G, a.bin_tab);
+            if (b >= 0) { atomicOr(&masks[(r8 * B + b) * MW + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
+        }
+    }
+    __syncthreads();
+#ifdef STEP_TIMING
+    tk[nk++] = clock64();
+#endif
+    // (the gather was also tried in two halves around the bin's MFMAs -- rows requested before the contraction, added after it -- and LOST, 9.4 vs 8.0 ms:
+    //  vmcnt retires loads in issue order, so the first wait for a weight fragment also waits for the gather issued before it)
+    constexpr int NBAT = 4;
+    auto build = [&](int b, int buf) {
+        u16* ab = ABb + buf * NP * BLO + r8 * LDBB;
+        float4 s[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int wd = 0; wd < MW; ++wd) {
+            unsigned long long m2 = masks[(r8 * B + b) * MW + wd];
+            while (m2) {
+                const float* src[NBAT];
+#pragma unroll
+                for (int q = 0; q < NBAT; ++q) {
+                    src[q] = nullptr;
+                    if (m2) {
+                        const int j = wd * 64 + __ffsll((long long)m2) - 1;
+                        m2 &= m2 - 1;
+                        const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
+                        const float* hb = a.peer ? a.Hp[rk] : a.Hall + (size_t)rk * n_groups * a.m_loc * H;
+                        src[q] = hb + ((size_t)grp * a.m_loc + sj) * H + q8 * 4;
+                    }
+                }
+                float4 v[NBAT][NCH];
+#pragma unroll
+                for (int q = 0; q < NBAT; ++q)
+                    if (src[q]) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+                            v[q][c] = a.peer ? ld_sys_f4(src[q] + c * 4 * TPR) : *reinterpret_cast<const float4*>(src[q] + c * 4 * TPR);
+                    }
+#pragma unroll
+                for (int q = 0; q < NBAT; ++q)
+                    if (src[q]) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) { s[c].x += v[q][c].x; s[c].y += v[q][c].y; s[c].z += v[q][c].z; s[c].w += v[q][c].w; }
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            u16* dst = ab + q8 * 4 + c * 4 * TPR;
+            st2(dst, BLO, s[c].x, s[c].y); st2(dst + 2, BLO, s[c].z, s[c].w);
+        }
+    };
+    f32x16 soc = zero16();
+    unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
+    om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
+    int buf = 0;
+    if (om) build(ffs_(om) - 1, 0);
+    __syncthreads();
+#ifdef STEP_TIMING
+    tk[nk++] = clock64();
+#endif
+    const uint4* Wsoc = reinterpret_cast<const uint4*>(a.Wsoc);
+    while (om) {
+        const int b = ffs_(om) - 1;
+        om &= om - 1;
+        if (om) build(ffs_(om) - 1, buf ^ 1);
+        {
+            f32x16 t1[1] = {soc};
+            const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
+            mmaxp_ring<1, NP, RD>(t1, ABb + buf * NP * BLO + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, Wsoc, t0, a.plo_soc, H / 16);
+            soc = t1[0];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#ifdef STEP_TIMING
+    tk[nk++] = clock64();
+#endif
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st1(Xb + acc_row(i) * LDXB + EV + C + col, XLO, fmaxf(soc[i] + bso, 0.f));
+    __syncthreads();
+    f32x16 rh = zero16(), u = zero16();
+    {
+        f32x16 t2[2] = {rh, u};
+        const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
+        mmaxp_ring<2, NP, (RD > 4 ? 4 : RD)>(t2, x_lane, XLO, reinterpret_cast<const uint4*>(a.Wg), t0, a.plo_g, KX / 16);
+        rh = t2[0]; u = t2[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st1(ABb + acc_row(i) * LDBB + col, BLO, rh[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
+    __syncthreads();
+#ifdef STEP_TIMING
+    tk[nk++] = clock64();
+#endif
+    f32x16 ac = zero16();
+    {
+        f32x16 t1[1] = {ac};
+        const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
+        const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
+        mmaxp_ring<1, NP, RD>(t1, x_lane, XLO, wc, tx, a.plo_c, E / 16);
+        mmaxp_ring<1, NP, RD>(t1, ABb + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, wc, th, a.plo_c, H / 16);
+        ac = t1[0];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
+        const int row = row0 + acc_row(i);
+        if (row < a.R) {
+            if (a.peer) st_sys_f32(a.st_h_out + (size_t)row * H + col, h[i]); else a.st_h_out[(size_t)row * H + col] = h[i];
+            if (a.st_h_copy) a.st_h_copy[(size_t)row * H + col] = h[i];
+        }
+        float v = h[i] * wsc;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+        if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
+    }
+    __syncthreads();
+#ifdef STEP_TIMING
+    tk[nk++] = clock64();
+    if (blockIdx.x == 7 && tid == 0 && a.t == 20)
+        printf("k_ioc_step_x2<%d> t=20 block 7: prologue+P1 %lld  build0 %lld  bins %lld  gates %lld  cand+epi %lld  total %lld cycles\n", H,
+               tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[5] - tk[0]);
+#endif
+    if (tid < TM && row0 + tid < a.R) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
+        a.st_score[row0 + tid] = (a.t == 0 ? 0.f : a.st_score[row0 + tid]) + sc;
+    }
+}
+static size_t ioc_step_x2_lds(const IocStepArgs& a) {
+    const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, KX = E + H, B = a.G * a.G, TM = 32;
+    const int MW = (a.m_loc * a.nranks + 63) >> 6;
+    return (size_t)2 * TM * (KX + 8) * 2 + (size_t)2 * 2 * TM * (H + 8) * 2 + (size_t)TM * B * MW * 8 + (3 * EV + NT * TM) * sizeof(float) + 64;
 }
 static size_t ioc_step_lds(const IocStepArgs& a) {
     const int EV = 16, H = a.H, NT = H / 32, E = EV + 32 + H, LDX = E + H + 4, LDB = H + 4, B = a.G * a.G, TM = 32;
@@ -1367,7 +1666,18 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 31) / 32), block((a.H / 32) * 64);
     const size_t lds = ioc_step_lds(a);
 #define STEP_LAUNCH(HH, NPP) { allow_big_lds(k_ioc_step<HH, 16, 32, NPP>); hipLaunchKernelGGL((k_ioc_step<HH, 16, 32, NPP>), grid, block, lds, s, a); }
-    if (a.np == 2) { if (a.H == 256) STEP_LAUNCH(256, 2) else if (a.H == 128) STEP_LAUNCH(128, 2) else STEP_LAUNCH(64, 2) return; }
+    if (a.np == 2) {                 // two-piece operands: the piece-image form (STEP_X2_IMAGES = 0: the fp32-tile form of round 4, for the A/B)
+#ifndef STEP_X2_IMAGES
+#define STEP_X2_IMAGES 1
+#endif
+        if (STEP_X2_IMAGES) {
+            const size_t l2 = ioc_step_x2_lds(a);
+#define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32>), grid, block, l2, s, a); }
+            if (a.H == 256) STEP2_LAUNCH(256) else if (a.H == 128) STEP2_LAUNCH(128) else STEP2_LAUNCH(64)
+#undef STEP2_LAUNCH
+            return;
+        }
+        if (a.H == 256) STEP_LAUNCH(256, 2) else if (a.H == 128) STEP_LAUNCH(128, 2) else STEP_LAUNCH(64, 2) return; }
     if (a.np == 3) { if (a.H == 256) STEP_LAUNCH(256, 3) else if (a.H == 128) STEP_LAUNCH(128, 3) else STEP_LAUNCH(64, 3) return; }
     if (a.H == 256) STEP_LAUNCH(256, 0) else if (a.H == 128) STEP_LAUNCH(128, 0) else STEP_LAUNCH(64, 0)
 #undef STEP_LAUNCH
