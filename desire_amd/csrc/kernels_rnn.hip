@@ -1424,18 +1424,24 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
 // Same pieces (splitp) and the same products per accumulator as k_ioc_step<H, EV, C, 2>; measured against it (scratch/ab_x2b.sh, three shapes): positions
 // within 1.5e-6, scores within 5e-6 -- the fp32 rounding class, not bit-identical.  configs[3]'s per-GPU shape: IOC 8.6 -> 8.0 ms, step 12.75 -> 12.16 ms.
 // ------------------------------------------------------------------------------------------------
-template <int H, int EV, int C>
-__global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a) {
+// PW > 0: PW extra PRODUCER waves per workgroup build the pooled operand of bin b + 1 (the neighbour gather: an L2 / Infinity-Cache round trip per batch
+// of rows) while the NT consumer waves contract bin b -- two instruction streams, so the gather's loads no longer sit in front of the weight-fragment
+// loads in the consumers' in-order vmcnt queue (the single-stream attempt to overlap them lost for exactly that reason).
+template <int H, int EV, int C, int PW>
+__global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepArgs a) {
 #ifdef STEP_TIMING
     long long tk[10]; int nk = 0; tk[nk++] = clock64();
+    long long tbl = 0, tmm = 0, tbar = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int TM = 32, NP = 2, RD = STEP_RING > 0 ? STEP_RING : 1;
+    constexpr int TM = 32, NP = 2, RD = STEP_RING > 0 ? ((PW && (H / 32) > 4 && STEP_RING > 4) ? 4 : STEP_RING) : 1;      // (twelve waves at H = 256: 168 registers each)
     const int MW = (a.m_loc * a.nranks + 63) >> 6;
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDXB = KX + 8, LDBB = H + 8;      // bf16 elements; (ld / 2) = 4 mod 8 dwords: conflict-free b128 reads
     constexpr int XLO = TM * LDXB, BLO = TM * LDBB;                                            // elements between the two piece images of a tile
     constexpr int NTHR = NT * 64, TPR = NTHR / TM;
-    constexpr int NCH = H / (4 * TPR);
+    constexpr int NALL = (NT + PW) * 64;                                  // all threads (consumers + producers)
+    constexpr int NBT = PW ? PW * 64 : NTHR, TPB = NBT / TM;               // threads that build the pooled operand, per row
+    constexpr int NCH = H / (4 * TPB);
     const int B = a.G * a.G;
     u16* Xb = reinterpret_cast<u16*>(smem_raw);                         // [NP][TM][LDXB]   e_v | e_s | e_r | h
     u16* ABb = Xb + NP * XLO;                                           // [2][NP][TM][LDBB] pooled operand (double-buffered), then r * h in buffer 0
@@ -1444,8 +1450,12 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
     float* red = wv + 3 * EV;                                           // [NT][TM]
     unsigned* occ = reinterpret_cast<unsigned*>(red + NT * TM);
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
-    const int col = cb * 32 + (lane & 31);
-    const int r8 = tid / TPR, q8 = tid % TPR;
+    const bool consumer = tid < NTHR;                                      // (wave-uniform)
+    const int col = (consumer ? cb : 0) * 32 + (lane & 31);
+    const int r8 = consumer ? tid / TPR : 0, q8 = tid % TPR;
+    const int tb = PW ? tid - NTHR : tid;                                  // builder index
+    const bool builder = PW ? !consumer : true;
+    const int rb = builder ? tb / TPB : 0, qb = builder ? tb % TPB : 0;
     const int row0 = blockIdx.x * TM;
     const int mall = a.m_loc * a.nranks;
     const int n_groups = a.R / a.m_loc;
@@ -1458,10 +1468,10 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
         splitp<2>(v0, v1, pp);
         *reinterpret_cast<unsigned*>(img) = pp[0]; *reinterpret_cast<unsigned*>(img + plo) = pp[1];
     };
-    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
-    for (int i = tid; i < TM * B * MW; i += NTHR) masks[i] = 0ull;
+    for (int i = tid; i < 3 * EV; i += NALL) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    for (int i = tid; i < TM * B * MW; i += NALL) masks[i] = 0ull;
     if (tid < 2) occ[tid] = 0;
-    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+    for (int i = tid; i < TM * (H >> 2); i += NALL) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
         const float* sp = a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4;
         const float4 v = a.peer ? ld_sys_f4(sp) : *reinterpret_cast<const float4*>(sp);
@@ -1473,6 +1483,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
     const int grp = my_row / a.m_loc, sl = my_row - grp * a.m_loc;
     const int scene = grp / a.K;
     const int my_gslot = a.rank * a.m_loc + sl;
+    const int grp_b = min(row0 + rb, a.R - 1) / a.m_loc;                   // the builder's row may differ from the thread's P1 row
     auto pos_of = [&](int j, int t) {
         const int rk = j / a.m_loc, s = j - rk * a.m_loc;
         if (t < 0) {
@@ -1483,13 +1494,15 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
         return *reinterpret_cast<const float2*>(a.Yall + ((((size_t)rk * n_groups + grp) * a.m_loc + s) * a.T + t) * 2);
     };
     // h_{t-1} of my accumulator elements straight from the state (the LDS tile holds pieces only)
-    f32x16 h;
+    f32x16 h = zero16();
+    if (consumer) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float* sp = a.st_h + (size_t)min(row0 + acc_row(i), a.R - 1) * H + col;
-        h[i] = a.peer ? __uint_as_float(ld_sys_u32(sp)) : *sp;
+        for (int i = 0; i < 16; ++i) {
+            const float* sp = a.st_h + (size_t)min(row0 + acc_row(i), a.R - 1) * H + col;
+            h[i] = a.peer ? __uint_as_float(ld_sys_u32(sp)) : *sp;
+        }
     }
-    {
+    if (consumer) {
         const float2 pcur = pos_of(my_gslot, a.t), pprev = pos_of(my_gslot, a.t - 1);
         const float px = pcur.x, py = pcur.y;
         const float vx = px - pprev.x, vy = py - pprev.y;
@@ -1530,12 +1543,12 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
     //  vmcnt retires loads in issue order, so the first wait for a weight fragment also waits for the gather issued before it)
     constexpr int NBAT = 4;
     auto build = [&](int b, int buf) {
-        u16* ab = ABb + buf * NP * BLO + r8 * LDBB;
+        u16* ab = ABb + buf * NP * BLO + rb * LDBB;
         float4 s[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int wd = 0; wd < MW; ++wd) {
-            unsigned long long m2 = masks[(r8 * B + b) * MW + wd];
+            unsigned long long m2 = masks[(rb * B + b) * MW + wd];
             while (m2) {
                 const float* src[NBAT];
 #pragma unroll
@@ -1546,7 +1559,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
                         m2 &= m2 - 1;
                         const int rk = j / a.m_loc, sj = j - rk * a.m_loc;
                         const float* hb = a.peer ? a.Hp[rk] : a.Hall + (size_t)rk * n_groups * a.m_loc * H;
-                        src[q] = hb + ((size_t)grp * a.m_loc + sj) * H + q8 * 4;
+                        src[q] = hb + ((size_t)grp_b * a.m_loc + sj) * H + qb * 4;
                     }
                 }
                 float4 v[NBAT][NCH];
@@ -1555,7 +1568,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
                     if (src[q]) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c)
-                            v[q][c] = a.peer ? ld_sys_f4(src[q] + c * 4 * TPR) : *reinterpret_cast<const float4*>(src[q] + c * 4 * TPR);
+                            v[q][c] = a.peer ? ld_sys_f4(src[q] + c * 4 * TPB) : *reinterpret_cast<const float4*>(src[q] + c * 4 * TPB);
                     }
 #pragma unroll
                 for (int q = 0; q < NBAT; ++q)
@@ -1567,7 +1580,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            u16* dst = ab + q8 * 4 + c * 4 * TPR;
+            u16* dst = ab + qb * 4 + c * 4 * TPB;
             st2(dst, BLO, s[c].x, s[c].y); st2(dst + 2, BLO, s[c].z, s[c].w);
         }
     };
@@ -1575,7 +1588,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
     unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
     om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
     int buf = 0;
-    if (om) build(ffs_(om) - 1, 0);
+    if (om && builder) build(ffs_(om) - 1, 0);
     __syncthreads();
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
@@ -1584,41 +1597,57 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
     while (om) {
         const int b = ffs_(om) - 1;
         om &= om - 1;
-        if (om) build(ffs_(om) - 1, buf ^ 1);
-        {
+#ifdef STEP_TIMING
+        const long long c0 = clock64();
+#endif
+        if (om && builder) build(ffs_(om) - 1, buf ^ 1);
+#ifdef STEP_TIMING
+        const long long c1 = clock64();
+#endif
+        if (consumer) {
             f32x16 t1[1] = {soc};
             const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
             mmaxp_ring<1, NP, RD>(t1, ABb + buf * NP * BLO + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, Wsoc, t0, a.plo_soc, H / 16);
             soc = t1[0];
         }
+#ifdef STEP_TIMING
+        const long long c2 = clock64();
+#endif
         __syncthreads();
+#ifdef STEP_TIMING
+        tbl += c1 - c0; tmm += c2 - c1; tbar += clock64() - c2;
+#endif
         buf ^= 1;
     }
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
 #endif
+    if (consumer) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st1(Xb + acc_row(i) * LDXB + EV + C + col, XLO, fmaxf(soc[i] + bso, 0.f));
+        for (int i = 0; i < 16; ++i) st1(Xb + acc_row(i) * LDXB + EV + C + col, XLO, fmaxf(soc[i] + bso, 0.f));
+    }
     __syncthreads();
     f32x16 rh = zero16(), u = zero16();
-    {
+    if (consumer) {
         f32x16 t2[2] = {rh, u};
         const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
         mmaxp_ring<2, NP, (RD > 4 ? 4 : RD)>(t2, x_lane, XLO, reinterpret_cast<const uint4*>(a.Wg), t0, a.plo_g, KX / 16);
         rh = t2[0]; u = t2[1];
     }
+    if (consumer) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
+        for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st1(ABb + acc_row(i) * LDBB + col, BLO, rh[i]);
+        for (int i = 0; i < 16; ++i) st1(ABb + acc_row(i) * LDBB + col, BLO, rh[i]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
+        for (int i = 0; i < 16; ++i) u[i] = sigmoidf_(u[i] + bgu);
+    }
     __syncthreads();
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
 #endif
     f32x16 ac = zero16();
-    {
+    if (consumer) {
         f32x16 t1[1] = {ac};
         const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
         const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
@@ -1626,6 +1655,7 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
         mmaxp_ring<1, NP, RD>(t1, ABb + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, wc, th, a.plo_c, H / 16);
         ac = t1[0];
     }
+    if (consumer) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
@@ -1638,12 +1668,13 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a)
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
         if ((lane & 31) == 0) red[cb * TM + acc_row(i)] = v;
     }
+    }
     __syncthreads();
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
     if (blockIdx.x == 7 && tid == 0 && a.t == 20)
-        printf("k_ioc_step_x2<%d> t=20 block 7: prologue+P1 %lld  build0 %lld  bins %lld  gates %lld  cand+epi %lld  total %lld cycles\n", H,
-               tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[5] - tk[0]);
+        printf("k_ioc_step_x2<%d> t=20 block 7: prologue+P1 %lld  build0 %lld  bins %lld (wave 0: gather+split %lld, mfma %lld, barrier %lld)  gates %lld  cand+epi %lld  total %lld cycles\n", H,
+               tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tbl, tmm, tbar, tk[4] - tk[3], tk[5] - tk[4], tk[5] - tk[0]);
 #endif
     if (tid < TM && row0 + tid < a.R) {
         float sc = 0.f;
@@ -1672,7 +1703,12 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
 #endif
         if (STEP_X2_IMAGES) {
             const size_t l2 = ioc_step_x2_lds(a);
-#define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32>), grid, block, l2, s, a); }
+#ifndef STEP_PW
+#define STEP_PW 0                 // producer waves per workgroup building the pooled operand of the next bin (0: the consumers build it themselves).
+                                  // Measured at configs[3]'s shape (scratch/ab_pw.sh, results bit-identical): 0 -> IOC 8.0 ms, 4 -> 10.5 ms (twelve waves at H = 256
+                                  // leave 168 registers each: 292 B of scratch per lane), 2 -> 26 ms
+#endif
+#define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32, STEP_PW>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32, STEP_PW>), grid, dim3(block.x + STEP_PW * 64), l2, s, a); }
             if (a.H == 256) STEP2_LAUNCH(256) else if (a.H == 128) STEP2_LAUNCH(128) else STEP2_LAUNCH(64)
 #undef STEP2_LAUNCH
             return;
