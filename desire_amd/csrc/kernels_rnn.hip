@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
 // once by whoever produces the values, instead of fp32 tiles that each of the NT waves splits again for every k-group (44 VALU instructions per
 // fragment next to the three MFMAs it feeds), and with STEP_RING k-groups of weight fragments in flight.  Phase counters of the fp32-tile form at
 // configs[3]'s shape (-DSTEP_TIMING): 245 k cycles per step, 168 k of them in the bin loop = 10.5 k per bin for 3 k matrix cycles.
-// Same pieces (splitp) and the same products per accumulator as k_ioc_step<H, EV, C, 2>; measured against it (scratch/ab_x2b.sh, three shapes): positions
+// Same pieces (splitp) and the same products per accumulator as k_ioc_step<H, EV, C, 2>; measured against it (profiles/ab/ab_x2b.sh, three shapes): positions
 // within 1.5e-6, scores within 5e-6 -- the fp32 rounding class, not bit-identical.  configs[3]'s per-GPU shape: IOC 8.6 -> 8.0 ms, step 12.75 -> 12.16 ms.
 // ------------------------------------------------------------------------------------------------
 // PW > 0: PW extra PRODUCER waves per workgroup build the pooled operand of bin b + 1 (the neighbour gather: an L2 / Infinity-Cache round trip per batch
@@ -1705,7 +1705,7 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
             const size_t l2 = ioc_step_x2_lds(a);
 #ifndef STEP_PW
 #define STEP_PW 0                 // producer waves per workgroup building the pooled operand of the next bin (0: the consumers build it themselves).
-                                  // Measured at configs[3]'s shape (scratch/ab_pw.sh, results bit-identical): 0 -> IOC 8.0 ms, 4 -> 10.5 ms (twelve waves at H = 256
+                                  // Measured at configs[3]'s shape (profiles/ab/ab_pw.sh, results bit-identical): 0 -> IOC 8.0 ms, 4 -> 10.5 ms (twelve waves at H = 256
                                   // leave 168 registers each: 292 B of scratch per lane), 2 -> 26 ms
 #endif
 #define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32, STEP_PW>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32, STEP_PW>), grid, dim3(block.x + STEP_PW * 64), l2, s, a); }
