@@ -264,6 +264,26 @@ def with_loader_leg(d_full, w, seed, dev, steps):
                                  "note": "loader thread -> pinned float32 staging -> copy stream -> device, 2 batches in flight"}
     out["fed_by_device_builder"] = {"value": d.R / t_devf, "unit": "samples/s", "ms_per_step": t_devf * 1e3, "fraction_of_resident": t_res / t_devf,
                                     "note": "pointer walk on the host thread, windows cut and slot-assigned on the copy stream from the resident video"}
+    # the same three with padding skipped (dims.flags = DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC): the step is 2.8x shorter, so the loader has
+    # 2.8x less time per batch -- does it still keep up?
+    h.set_option("flags", 12)
+    for _ in range(2):
+        fwd(past_t, fut_t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        fwd(past_t, fut_t)
+    torch.cuda.synchronize()
+    c_res = (time.perf_counter() - t0) / n_steps
+    random.seed(seed); dl.reset_batch_pointer()
+    c_host = fed(WindowFeeder(dl, d.T_obs, d.T_pred, device=dev, depth=2, num_epochs=1, mno=mno))
+    random.seed(seed); dl.reset_batch_pointer()
+    c_devf = fed(DeviceWindowFeeder(dl, h, dev, depth=2, num_epochs=1))
+    assert bool(torch.isfinite(Y).all())
+    out["skip_padding"] = {"resident_ms_per_step": c_res * 1e3, "fed_by_host_loader_ms_per_step": c_host * 1e3, "fed_by_device_builder_ms_per_step": c_devf * 1e3,
+                           "host_loader_fraction_of_resident": c_res / c_host, "device_builder_fraction_of_resident": c_res / c_devf,
+                           "note": "dims.flags = 12 on the same handle: with the step this short one Python loader thread (next_batch_into) is the limit when the "
+                                   "fraction drops below 1; the device builder ships window starts only"}
     h.close()
     return out
 
@@ -651,4 +671,20 @@ def sdd_leg(a, d, w, grids_t, gos, eps_t, Y, score, stream, dev):
                                                 "kernel_ms_per_step": {k: round(float(np.sum(v)) / n2, 4) for k, v in k5.items()},
                                                 "note": "dims.bf16 = 2 (six-product sample generation, three-product IOC: fp32-class results) with both compaction bits"}
     h5.close()
+    # ... and BASELINE configs[2]'s arithmetic (bf16 operands, fp32 state / accumulation) on the same windows, padded and compacted
+    for tag, fl in (("bf16", 0), ("bf16_compact_rows_and_ioc", 12)):
+        h6 = _lib.Handle(d2.replace(flags=fl, bf16=1))
+        h6.set_weights(w)
+        h6.set_scene_grids(grids_t.data_ptr(), gos)
+        for _ in range(2):
+            h6.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Ys.data_ptr(), sci.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n2):
+            h6.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Ys.data_ptr(), sci.data_ptr(), stream)
+        torch.cuda.synchronize()
+        b_dt = (time.perf_counter() - ts) / n2
+        assert bool(torch.isfinite(Ys).all())
+        sdd[tag] = {"ms_per_step": b_dt * 1e3, "value_present_agents_only": present * d.K * d.n_scenes / b_dt}
+        h6.close()
     return sdd

@@ -230,6 +230,9 @@ extern "C" int desire_set_option(desire_handle* h, const char* name, int32_t val
     }
     else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags, compact_min_rows)");
     if (int rc = check_options(d)) return rc;
+    if ((d.flags ^ h->d.flags) & (DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC)) {
+        h->cp_pending = false; h->cp_enc = false;       // the maps of the last desire_encode were built for the other setting: a new desire_encode comes first
+    }
     h->d = d;
     return DESIRE_OK;
 }

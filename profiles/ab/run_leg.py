@@ -15,6 +15,8 @@ elif a.leg == "config3_shape":
     out = bench.config3_shape_leg(a.seed, dev, a.steps)
 elif a.leg == "few_windows":
     out = bench.few_windows_leg(d, a.seed, dev)
+elif a.leg == "with_loader":
+    out = bench.with_loader_leg(d, init_weights(d, a.seed), a.seed, dev, a.steps)
 elif a.leg == "bf16_config2":
     out = bench.bf16_config2_leg(d, init_weights(d, a.seed), a.seed, dev, a.steps, with_accuracy=False)
 else:
