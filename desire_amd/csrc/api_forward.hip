@@ -19,9 +19,17 @@ bool compact_ioc(const desire_ctx* h) {
     const bool split_served = ioc_x3_supported(d.mno, d.H, B_) || (d.mno == 64 && ioc_x6r2_supported(d.mno, d.H, B_));
     return !(split_mode && !split_served && d.H == 256 && d.ioc_form == DESIRE_IOC_AUTO);
 }
-int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: the three largest of 8, 16, 32, 64, 96 below the handle's own mno, then mno itself
-    int cand[5], nc = 0;
-    for (int m : {8, 16, 32, 64, 96}) if (m < h->d.mno) cand[nc++] = m;
+// slot classes that do not divide 32 (padded tiles: k_ioc<TM = 32> and k_ioc_x3 have that form, inference, groups of <= 32 slots, H <= 128)
+bool compact_padded_ok(const desire_ctx* h) {
+    const desire_dims& d = h->d;
+    return !h->training && (d.bf16 == 0 || d.bf16 == 2) && d.H <= 128 && d.ioc_form == DESIRE_IOC_AUTO;
+}
+int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: the three largest candidates below the handle's own mno, then mno itself
+    // candidates: 8, 16, 32, 64, 96; where the padded-tile kernels serve the handle also 10 (three groups of <= 10 slots per 32-row tile: a window with
+    // 9 present agents -- the typical SDD bookstore window -- runs in 10 rows per sample instead of 16)
+    int cand[6], nc = 0;
+    const bool pad = compact_padded_ok(h);
+    for (int m : {8, 10, 16, 32, 64, 96}) if (m < h->d.mno && (m != 10 || pad)) cand[nc++] = m;
     int n = 0;
     for (int i = nc > 3 ? nc - 3 : 0; i < nc; ++i) m4[n++] = cand[i];
     m4[n++] = h->d.mno;
@@ -36,7 +44,7 @@ int compact_setup(desire_ctx* h) {
                        {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f},
                        {"cp_past", A * (size_t)d.T_obs * 3 * f}, {"cp_fut", A * (size_t)d.T_pred * 3 * f}, {"cp_valid2", A}};
     const WS list_ioc[] = {{"ci_win", 4 * (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_map", 4 * A * sizeof(int32_t)}, {"ci_Hx", A * 2 * d.H * f}, {"ci_pl", A * 2 * f},
-                           {"ci_valid", A}, {"ci_gos", (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_Y", R * (size_t)d.T_pred * 2 * f}, {"ci_score", R * f}};
+                           {"ci_valid", A}, {"ci_gos", (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_Y", (R + 128) * (size_t)d.T_pred * 2 * f}, {"ci_score", (R + 128) * f}};      // (+ a partial padded tile per class)
     for (const WS& w : list)
         if (!h->ws[w.n].p && h->ws[w.n].alloc(w.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n);
     if (h->d.flags & DESIRE_FLAG_COMPACT_IOC)
@@ -309,6 +317,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
 // n_scenes windows of mno slots each with their own agent-level inputs; training-mode saves go to the view's row offset in the shared buffers.
 struct IocView {
     int R, mno, n_scenes; float* Y; float* score; const float* Hx; int ldhx; const float* p_last; const uint8_t* valid; const int32_t* gos; size_t row_off;
+    int gpt = 0, ngrp = 0;       // padded tiles (slot classes that do not divide 32; kernels.h: IocArgs.gpt): groups per 32-row tile, real groups; R = tiles * 32
 };
 static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
     const desire_dims& d = h->d;
@@ -325,11 +334,12 @@ static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
     a.w_score = D(h, "ioc/score_w"); a.b_score = D(h, "ioc/score_b");
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     a.variant = d.ioc_form;
+    a.gpt = v.gpt; a.ngrp = v.ngrp;
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
     // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
     // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
     const bool wide64 = v.mno == 64 && !h->training && ioc_x6r2_supported(v.mno, d.H, d.grid_size * d.grid_size);
-    const bool x3 = d.bf16 == 2 && (ioc_x3_supported(v.mno, d.H, d.grid_size * d.grid_size) || wide64);
+    const bool x3 = d.bf16 == 2 && (ioc_x3_supported(v.mno, d.H, d.grid_size * d.grid_size) || wide64 || (v.gpt > 0 && ioc_x3_supported(32, d.H, d.grid_size * d.grid_size)));
     const bool x6 = d.bf16 == 3 && (ioc_x3_supported(v.mno, d.H, d.grid_size * d.grid_size) || wide64);     // six-product form: inference only
     const bool cluster = d.bf16 == 1 ? (v.mno > 64 || (v.mno == 64 && (a.variant == 4 || a.variant == 6)))
                                 : (!(x3 || x6) || h->training) && ioc_uses_cluster(v.mno, d.H, d.grid_size * d.grid_size, a.variant);
@@ -347,7 +357,7 @@ static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
     // a handful of windows, fp32 inference: the bins of every tile split over several workgroups (k_ioc NSPL; dims.ioc_split = 1: off).
     // The members of a tile wait for each other, so the split is taken only when the whole launch is co-resident on THIS device
     // (occupancy x compute units, not a constant: a partition with fewer CUs falls back to the plain form).
-    if (!cluster && d.bf16 == 0 && !h->training && d.ioc_split != 1 && a.variant == 0) {
+    if (!cluster && d.bf16 == 0 && !h->training && d.ioc_split != 1 && a.variant == 0 && v.gpt == 0) {
         int nspl = ioc_bin_split(v.R, v.mno, d.H, d.grid_size * d.grid_size, d.iters);
         if (nspl > 1 && d.ioc_split > 1) nspl = std::min(nspl, d.ioc_split);
         const size_t tiles = ((size_t)v.R + 31) / 32, tiles_max = ((size_t)h->R + 31) / 32;
@@ -510,20 +520,22 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
             if (n_c == 0) continue;
             const int32_t* cmap = static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A;
             const int32_t* win = static_cast<const int32_t*>(h->ws["ci_win"].p) + (size_t)c * d.n_scenes;
-            const int R_c = n_c * d.K * m_c;
+            const int gpt = (m_c <= 32 && 32 % m_c) ? 32 / m_c : 0, ngrp = n_c * d.K;              // padded tiles for a class that does not divide 32
+            const int R_c = gpt ? ((ngrp + gpt - 1) / gpt) * 32 : n_c * d.K * m_c;
             IocView v{R_c, m_c, n_c, W(h, "ci_Y") + roff * T2, W(h, "ci_score") + roff, W(h, "ci_Hx") + aoff * 2 * d.H, 2 * d.H, W(h, "ci_pl") + aoff * 2,
                       static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, static_cast<const int32_t*>(h->ws["ci_gos"].p) + woff, roff};
+            v.gpt = gpt; v.ngrp = ngrp;
             {
                 Timer t(h, s, "ioc_repack");
                 launch_cls_gather_agents(W(h, "HxHy"), 2 * d.H, W(h, "p_last"), static_cast<const int32_t*>(h->ws["grid_of_scene"].p), cmap, win, n_c, m_c,
                                          const_cast<float*>(v.Hx), const_cast<float*>(v.p_last), const_cast<uint8_t*>(v.valid), const_cast<int32_t*>(v.gos), s);
-                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 0, s);
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 0, s, gpt);
             }
             if (int rc = ioc_core(h, v, s)) return rc;
             {
                 Timer t(h, s, "ioc_repack");
-                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 1, s);
-                launch_cls_rows(dev_score, v.score, cmap, n_c, m_c, d.K, d.mno, 1, 1, s);
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 1, s, gpt);
+                launch_cls_rows(dev_score, v.score, cmap, n_c, m_c, d.K, d.mno, 1, 1, s, gpt);
             }
             h->ci_cls[h->ci_n] = c; h->ci_cnt[h->ci_n] = n_c; ++h->ci_n;
             aoff += (size_t)n_c * m_c; roff += (size_t)R_c; woff += (size_t)n_c;

@@ -220,9 +220,18 @@ __device__ __forceinline__ int neighbor_bin_dev(float xi, float yi, float xj, fl
     return (int)cx + (int)cy * G;
 }
 
+// the same for the IOC kernels' padded tiles (IocArgs.gpt > 0): -1 = a dead row
+__device__ __forceinline__ int ioc_agent_of_row(int r, int K, int mno, int gpt, int ngrp);
 // row r = (scene*K + k)*mno + slot  ->  agent = scene*mno + slot
 __device__ __forceinline__ int agent_of_row(int r, int K, int mno) {
     const int per_scene = K * mno;
     const int scene = r / per_scene;
     return scene * mno + (r % mno);
+}
+__device__ __forceinline__ int ioc_agent_of_row(int r, int K, int mno, int gpt, int ngrp) {
+    if (gpt == 0) return agent_of_row(r, K, mno);
+    const int tile = r >> 5, i = r & 31, gi = i / mno;
+    const int G = tile * gpt + gi;
+    if (gi >= gpt || G >= ngrp) return -1;
+    return (G / K) * mno + (i - gi * mno);
 }

@@ -128,6 +128,7 @@ int desire_upload(desire_ctx* h, const std::string& name, const std::vector<floa
 int desire_ready(desire_handle* h);
 bool compact_rows(const desire_ctx* h);                        // DESIRE_FLAG_COMPACT_ROWS set
 bool compact_ioc(const desire_ctx* h);                         // DESIRE_FLAG_COMPACT_IOC set and the shape is served
+bool compact_padded_ok(const desire_ctx* h);                   // the padded-tile IOC kernels serve this handle (slot class 10)
 int compact_classes(const desire_ctx* h, int* m4);             // its slot classes (ascending, the handle's mno last): returns how many
 int compact_setup(desire_ctx* h);                              // its buffers, event and mapped count word (idempotent)
 int desire_pack_all(desire_ctx* h);                            // (re)builds every packed / folded device tensor from host_w

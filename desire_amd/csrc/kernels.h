@@ -108,6 +108,10 @@ struct IocArgs {
     int nspl;                                              // > 1: bin-split form of k_ioc (hex = [tiles][2][nspl][32 H], grp_cnt per tile)
     float* sv_x; float* sv_r; float* sv_u; float* sv_c; float* sv_h;   // training saves: [R,T,E], [R,T,H] x4 (32-row form only)
     const float* bin_tab;                                  // log-polar bin table (common.h:neighbor_bin_dev) or nullptr = rectangular grid
+    // PADDED TILES (slot classes that do not divide 32, DESIRE_FLAG_COMPACT_IOC; k_ioc<.., TM = 32> and k_ioc_x3, inference): gpt > 0 = a 32-row tile holds
+    // gpt whole groups of mno slots (gpt * mno <= 32) followed by dead rows; group G = tile * gpt + (row & 31) / mno, ngrp real groups; R = tiles * 32.
+    // gpt = 0: rows are packed, r = (scene * K + k) * mno + slot (mno divides 32).
+    int gpt; int ngrp;
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 // Which IOC form serves (mno, H, bins): the cluster form (32-row tiles exchanging hidden states through global memory) takes every
@@ -293,7 +297,7 @@ void launch_class_scan(const uint8_t* valid, int n_scenes, int mno, int n_cls, c
                        int32_t* cnt_dev, int32_t* cnt_host, hipStream_t s);
 void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
                               float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s);
-void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s);
+void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s, int gpt = 0);
 void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* cmap, int NA, int n, hipStream_t s);
 // encoder-stage compaction
 void launch_valid_from_frames(const float* past, int n_scenes, int T, int mno, uint8_t* valid, hipStream_t s);

@@ -230,22 +230,32 @@ void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, cons
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cls_gather_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Hx, ld, p_last, gos, cmap, win, n_c, m_c, Hx_c, p_c, valid_c, gos_c);
 }
-// rows: dir = 0 gather  comp[(w'*K + k)*m_c + j, :] = full[row(cmap, k), :] (zeros for padding);  dir = 1 scatter back (padding rows dropped)
-__global__ void k_cls_rows(float* __restrict__ full, float* __restrict__ comp, const int32_t* __restrict__ cmap, int n_c, int m_c, int K, int mno, int n, int dir) {
+// rows: dir = 0 gather  comp[class row of (w', k, j), :] = full[row(cmap, k), :] (zeros for padding);  dir = 1 scatter back (padding rows dropped).
+// Class row of (w', k, j): packed (gpt = 0) (w'*K + k)*m_c + j; padded tiles (gpt > 0) tile*32 + (G % gpt)*m_c + j with G = w'*K + k, tile = G / gpt.
+__global__ void k_cls_rows(float* __restrict__ full, float* __restrict__ comp, const int32_t* __restrict__ cmap, int n_c, int m_c, int K, int mno, int n, int dir,
+                           int gpt, long rows) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)n_c * K * m_c * n) return;
+    if (i >= rows * n) return;
     const long rc = i / n; const int c = (int)(i - rc * n);
-    const int j = (int)(rc % m_c); const long g = rc / m_c; const int k = (int)(g % K); const int wp = (int)(g / K);
+    int j; long g;
+    if (gpt) {
+        const int il = (int)(rc & 31), gi = il / m_c;
+        j = il - gi * m_c; g = (rc >> 5) * gpt + gi;
+        if (gi >= gpt || g >= (long)n_c * K) { if (!dir) comp[i] = 0.f; return; }
+    } else { j = (int)(rc % m_c); g = rc / m_c; }
+    const int k = (int)(g % K); const int wp = (int)(g / K);
     const int a = cmap[(size_t)wp * m_c + j];
     if (a < 0) { if (!dir) comp[i] = 0.f; return; }
     const int sc = a / mno, slot = a - sc * mno;
     const size_t r = ((size_t)sc * K + k) * mno + slot;
     if (dir) full[r * n + c] = comp[i]; else comp[i] = full[r * n + c];
 }
-void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s) {
-    const long t = (long)n_c * K * m_c * n;
+void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s, int gpt) {
+    const long ngrp = (long)n_c * K;
+    const long rows = gpt ? ((ngrp + gpt - 1) / gpt) * 32 : ngrp * m_c;
+    const long t = rows * n;
     if (t <= 0) return;
-    hipLaunchKernelGGL(k_cls_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir);
+    hipLaunchKernelGGL(k_cls_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir, gpt, rows);
 }
 // out[cmap[i], c] += in[i, c] for the seated agents of a class (cmap[i] >= 0; one writer per element: an agent sits in exactly one class slot)
 __global__ void k_cls_scatter_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ cmap, int NA, int n) {

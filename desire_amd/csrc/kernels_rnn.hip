@@ -379,7 +379,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (mod NSPL) only, the members add their partial e_r pre-activations through global memory once per step (cluster.h write-through
 // hand-off, fixed member order: every member holds bit-identical state afterwards) and everything else runs redundantly in each of
 // them; member 0 writes the results.  One pass only (a second pass would need member 0's refined Y in every member).
-template <int H, int EV, int C, int TM, bool TRAIN, bool CP = false, int NSPL = 1>
+// PAD: padded tiles (IocArgs.gpt; slot classes that do not divide 32).  A template parameter, so that the packed-row instantiations -- the headline's
+// among them -- compile to exactly the code they had before.
+template <int H, int EV, int C, int TM, bool TRAIN, bool CP = false, int NSPL = 1, bool PAD = false>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 2) ? 1 : 2) void k_ioc(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -415,13 +417,17 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid / TPR, q8 = tid % TPR;           // TPR threads per row for the VALU phases
     const int my_row = min(row0 + r8, a.R - 1);
-    const int my_scene = my_row / (a.K * a.mno);
+    // (padded tiles, a.gpt > 0: the tile holds gpt whole groups and dead rows behind them -- kernels.h: IocArgs)
+    const int gpt = PAD ? a.gpt : 0;
+    const bool dead_row = gpt && (r8 / a.mno >= gpt || tile * gpt + r8 / a.mno >= a.ngrp);
+    const int my_scene = gpt ? min(tile * gpt + min(r8 / a.mno, gpt - 1), a.ngrp - 1) / a.K : my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;          // first local row of my (scene,k) group
     const int my_slot = r8 - grp_base;
+    const int n_nb = dead_row ? 0 : a.mno;              // slots my row looks for neighbours in
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     for (int i = tid; i < LDX; i += NTHR) XH[TM * LDX + i] = 0.f;
-    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    if (tid < TM) { const int ag = ioc_agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno, gpt, a.ngrp); vld[tid] = ag >= 0 ? a.valid[ag] : 0; }
 
     float bgr = 0, bgu = 0, bcc = 0, bso = 0, wsc = 0;
     if (active) { bgr = a.b_g[col]; bgu = a.b_g[H + col]; bcc = a.b_c[col]; bso = a.b_soc[col]; wsc = a.w_score[col]; }
@@ -476,14 +482,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         // h_0 = Hx[agent]
         for (int i = tid; i < TM * (H >> 2); i += NTHR) {
             const int r = i / (H >> 2), c4 = i - r * (H >> 2);
-            const int ag = agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno);
+            const int ag = ioc_agent_of_row(min(row0 + r, a.R - 1), a.K, a.mno, gpt, a.ngrp);
             *reinterpret_cast<float4*>(XH + r * LDX + E + c4 * 4) =
-                *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4);
+                ag >= 0 ? *reinterpret_cast<const float4*>(a.Hx + (size_t)ag * a.ldhx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < TM) {
-            const int ag = agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno);
-            pp[tid * 2] = a.p_last[(size_t)ag * 2];
-            pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            const int ag = ioc_agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno, gpt, a.ngrp);
+            pp[tid * 2] = ag >= 0 ? a.p_last[(size_t)ag * 2] : 0.f;
+            pp[tid * 2 + 1] = ag >= 0 ? a.p_last[(size_t)ag * 2 + 1] : 0.f;
         }
         __syncthreads();
         f32x16 h = zero16(), sp = zero16();
@@ -530,7 +536,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 } else {
                     *reinterpret_cast<float2*>(XH + r8 * LDX + EV + q8 * 2) = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
                 }
-                for (int j = q8; j < a.mno; j += TPR) {
+                for (int j = q8; j < n_nb; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
                                                    a.nb_w, a.nb_h, a.G, a.bin_tab);
@@ -842,6 +848,13 @@ static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
                 case 4: allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 4>); hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 4>), gs, block, ioc_lds_bytes(a, TM), s, a); return;
                 default: allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 2>); hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 2>), gs, block, ioc_lds_bytes(a, TM), s, a); return;
             }
+        }
+    }
+    if constexpr (TM == 32 && H <= 128) {
+        if (a.gpt > 0) {                                       // padded tiles (slot classes that do not divide 32)
+            allow_big_lds(k_ioc<H, 16, 32, 32, false, false, 1, true>);
+            hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, false, false, 1, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+            return;
         }
     }
     allow_big_lds(k_ioc<H, 16, 32, TM, false>);
@@ -1331,7 +1344,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
         if constexpr (NP == 0) mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
         else {
             f32x16 t1[1] = {soc};
-            if constexpr (STEP_RING > 0) {
+            if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
                 const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
                 mma6_ring<1, NP, STEP_RING>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), reinterpret_cast<const uint4*>(a.Wsoc), t0, a.plo_soc, H / 16);
             } else {
@@ -1354,7 +1367,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
     } else {
         f32x16 t2[2] = {rh, u};
         const uint4* wg = reinterpret_cast<const uint4*>(a.Wg);
-        if constexpr (STEP_RING > 0) {
+        if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
             const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
             mma6_ring<2, NP, (STEP_RING > 4 ? 4 : STEP_RING)>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), wg, t0, a.plo_g, KX / 16);
         } else {
@@ -1378,7 +1391,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
     } else {
         f32x16 t1[1] = {ac};
         const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
-        if constexpr (STEP_RING > 0) {
+        if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
             const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
             mma6_ring<1, NP, STEP_RING>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), wc, tx, a.plo_c, E / 16);
             mma6_ring<1, NP, STEP_RING>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), wc, th, a.plo_c, H / 16);

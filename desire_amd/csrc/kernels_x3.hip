@@ -28,7 +28,8 @@
 #endif
 // NP = bf16 pieces per fp32 operand: 2 (dims.bf16 = 2, three products per fp32 product, two workgroups per CU) or 3 (dims.bf16 = 3,
 // six products, fp32-class accuracy; three operand images = 120 KB of LDS, one workgroup per CU with the whole register file).
-template <int H, int EV, int C, bool TRAIN, int NP = 2>      // TRAIN: keep x_t = [e_v | e_s | e_r], r, u, c, h_t of every step (fp32) for the backward pass
+// PAD: padded tiles (IocArgs.gpt: slot classes that do not divide 32), a template parameter so that the packed-row instantiations stay as they were
+template <int H, int EV, int C, bool TRAIN, int NP = 2, bool PAD = false>      // TRAIN: keep x_t = [e_v | e_s | e_r], r, u, c, h_t of every step (fp32) for the backward pass
 __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -63,9 +64,13 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
     const int col = cb * 32 + c31;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
-    const int my_scene = my_row / (a.K * a.mno);
+    const int tile = blockIdx.x;
+    const int gpt = PAD ? a.gpt : 0;
+    const bool dead_row = gpt && (r8 / a.mno >= gpt || tile * gpt + r8 / a.mno >= a.ngrp);            // padded tiles (kernels.h: IocArgs.gpt)
+    const int my_scene = gpt ? min(tile * gpt + min(r8 / a.mno, gpt - 1), a.ngrp - 1) / a.K : my_row / (a.K * a.mno);
     const int grp_base = (r8 / a.mno) * a.mno;
     const int my_slot = r8 - grp_base;
+    const int n_nb = dead_row ? 0 : a.mno;
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
     if (tid < 16) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
         const unsigned hi2 = ((tid & 4) ? 0x3F80u : 0u) | ((tid & 8) ? 0x3F800000u : 0u);
         lut[tid] = make_uint2(lo, hi2);
     }
-    if (tid < TM) vld[tid] = a.valid[agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno)];
+    if (tid < TM) { const int ag = ioc_agent_of_row(min(row0 + tid, a.R - 1), a.K, a.mno, gpt, a.ngrp); vld[tid] = ag >= 0 ? a.valid[ag] : 0; }
     const float bgr = a.b_g[col], bgu = a.b_g[H + col], bcc = a.b_c[col], bso = a.b_soc[col], wsc = a.w_score[col];
     const float* grid = a.grids + (size_t)a.grid_of_scene[my_scene] * a.Gh * a.Gw * C;
     const uint4* Wg = reinterpret_cast<const uint4*>(a.Wg);
@@ -120,15 +125,16 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = min(row0p + arow + (i & 3) + 8 * (i >> 2), a.R - 1);
-            h[i] = a.Hx[(size_t)agent_of_row(row, a.K, a.mno) * a.ldhx + col];
+            const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp);
+            h[i] = ag >= 0 ? a.Hx[(size_t)ag * a.ldhx + col] : 0.f;
         }
         __syncthreads();                                  // previous pass's readers of Xb / Ht are done
         publish_h(h);
         float2 ynext = make_float2(0.f, 0.f);
         if (tid < TM) {
             const int row = min(row0 + tid, a.R - 1);
-            const int ag = agent_of_row(row, a.K, a.mno);
-            pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
+            const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp);
+            pp[tid * 2] = ag >= 0 ? a.p_last[(size_t)ag * 2] : 0.f; pp[tid * 2 + 1] = ag >= 0 ? a.p_last[(size_t)ag * 2 + 1] : 0.f;
             const float2 y0 = *reinterpret_cast<const float2*>(a.Y + ((size_t)row * a.T) * 2);
             pc[tid * 2] = y0.x; pc[tid * 2 + 1] = y0.y;
         }
@@ -164,7 +170,7 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(Xb + i * XLO + r8 * LDXB + EV + j) = make_uint2(ga[i], gb[i]);
                     if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + EV + j)) = g4;
                 }
-                for (int j = q8; j < a.mno; j += TPR) {
+                for (int j = q8; j < n_nb; j += TPR) {
                     if (j == my_slot || !vld[grp_base + j]) continue;
                     const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                     if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1u << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
@@ -493,6 +499,11 @@ static void launch_x3(const IocArgs& a, hipStream_t s) {
         allow_big_lds(k_ioc_x3<H, 16, 32, true>);
         hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, true>), grid, block, iocx3_lds(a), s, a);
     } else {
+        if (a.gpt > 0) {                                      // padded tiles
+            allow_big_lds(k_ioc_x3<H, 16, 32, false, 2, true>);
+            hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, false, 2, true>), grid, block, iocx3_lds(a), s, a);
+            return;
+        }
         allow_big_lds(k_ioc_x3<H, 16, 32, false>);
         hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, false>), grid, block, iocx3_lds(a), s, a);
     }
