@@ -124,7 +124,7 @@ typedef struct desire_dims {
                                       row order r' = k*P + a' (P = present agents, a' = rank of the agent among them). */
 
 #define DESIRE_FLAG_COMPACT_IOC 8   /* IOC SLOT CLASSES.  The IOC kernels tile rows by whole (scene, k) groups of mno slots, so a window with 9 of 32 slots present
-                                      still costs 32 rows per sample.  With this bit every window is re-seated in the smallest slot class m in {8, 16, 32, 64, 96 (the three largest below mno), mno}
+                                      still costs 32 rows per sample.  With this bit every window is re-seated in the smallest slot class m in {8, 10, 16, 32, 64, 96 (the three largest below mno; 10 = three groups per padded 32-row tile, where the padded-tile kernels serve the handle: inference, fp32 or split operands, H <= 128), mno}
                                       that holds its present agents (compacted to the front, order kept), the windows of a class run as one pseudo-batch on the
                                       same kernels, and windows without a present agent are not run (their dev_Yhat rows are left as they came, score 0); rows of
                                       absent agents inside a window likewise keep their incoming dev_Yhat and get score 0.  A class too small to fill the device
