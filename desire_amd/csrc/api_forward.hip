@@ -22,7 +22,8 @@ bool compact_ioc(const desire_ctx* h) {
 // slot classes that do not divide 32 (padded tiles: k_ioc<TM = 32> and k_ioc_x3 have that form, inference, groups of <= 32 slots, H <= 128)
 bool compact_padded_ok(const desire_ctx* h) {
     const desire_dims& d = h->d;
-    return !h->training && (d.bf16 == 0 || d.bf16 == 2) && d.H <= 128 && d.ioc_form == DESIRE_IOC_AUTO;
+    if (h->training && !((d.bf16 == 0 || (d.bf16 == 2 && (train_x3_mask(h) & 4))) && d.ioc_form == DESIRE_IOC_AUTO)) return false;      // (BPTT: k_ioc_bwd / k_ioc_bwd_x3)
+    return (d.bf16 == 0 || d.bf16 == 2) && d.H <= 128 && (d.ioc_form == DESIRE_IOC_AUTO);
 }
 int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: the three largest candidates below the handle's own mno, then mno itself
     // candidates: 8, 16, 32, 64, 96; where the padded-tile kernels serve the handle also 10 (three groups of <= 10 slots per 32-row tile: a window with
@@ -396,7 +397,7 @@ static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
         // training-mode forward: one launch per refinement pass, each keeping its own activations and the positions it ran on
         // (the pass's input is DETACHED where it enters the features -- cells, bins, velocity embedding -- and Y_p = Y_{p-1} + dY_p
         // carries the gradient: DESIGN.md section 8)
-        const size_t RT = (size_t)v.R * d.T_pred, RTf = (size_t)h->R * d.T_pred, ro = v.row_off * d.T_pred;     // a view's saves sit at its row offset
+        const size_t RT = (size_t)v.R * d.T_pred, RTf = (size_t)(h->R + 128) * d.T_pred, ro = v.row_off * d.T_pred;     // a view's saves sit at its row offset
         a.iters = 1;
         for (int p = 0; p < d.iters; ++p) {
             const size_t po = (size_t)p * RTf + ro;

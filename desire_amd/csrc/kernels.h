@@ -260,7 +260,7 @@ void launch_conv_wgrad(const ConvWgradArgs& a, int nslices, float* out, hipStrea
 void launch_w1ch_grad(const float* Lg, const float* S, int n, int nslices, float* partial, float* out, hipStream_t s);
 void launch_reparam_bwd(const float* dz, const float* eps, const float* params, const uint8_t* valid, const float* nvalid,
                         float* dparams, int n_scenes, int mno, int K, int L, hipStream_t s, const int32_t* inv = nullptr, int P = 0);
-void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s);
+void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s, int gpt = 0);
 void launch_score_grad(const float* Y0, const float* fut, const float* score, const uint8_t* valid, const float* nvalid,
                        float* dscore, float* dscoreT, int n_scenes, int mno, int K, int T, float sx, float sy, hipStream_t s);
 struct IocBwdArgs {
@@ -278,6 +278,7 @@ struct IocBwdArgs {
     const float* bin_tab;
     float* bias_part;                                      // optional [32-row blocks][4H]: column sums of da_r | da_u | da_c | dpre_r (32-row forms only)
     long long* dbg;                                        // per-phase cycle counters (DESIRE_IOC_TIMING builds)
+    int gpt; int ngrp;                                     // padded tiles (see IocArgs.gpt): 32-row forms of k_ioc_bwd / k_ioc_bwd_x3
 };
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s);
 bool ioc_bwd_x3_supported(int mno, int H);                       // kernels_bwd_x3.hip: groups of up to 32 agents, H = 64 / 128

@@ -1043,18 +1043,22 @@ void launch_reparam_bwd(const float* dz, const float* eps, const float* params, 
 }
 
 // ---- dHx[a] (+)= sum_k dHx_rows[(scene,k,slot)] --------------------------------------------------------------------------
-__global__ void k_rows_to_agents(const float* __restrict__ rows, float* __restrict__ out, int ldo, int n_scenes, int mno, int K, int H) {
+__global__ void k_rows_to_agents(const float* __restrict__ rows, float* __restrict__ out, int ldo, int n_scenes, int mno, int K, int H, int gpt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_scenes * mno * H) return;
     const int a = i / H, c = i - a * H;
     const int sc = a / mno, slot = a - sc * mno;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += rows[(((size_t)sc * K + k) * mno + slot) * H + c];
+    for (int k = 0; k < K; ++k) {
+        size_t r = ((size_t)sc * K + k) * mno + slot;
+        if (gpt) { const int G = sc * K + k; r = (size_t)(G / gpt) * 32 + (size_t)(G % gpt) * mno + slot; }      // padded tiles (kernels.h: IocArgs.gpt)
+        s += rows[r * H + c];
+    }
     out[(size_t)a * ldo + c] += s;
 }
-void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s) {
+void launch_rows_to_agents(const float* rows, float* out, int ldo, int n_scenes, int mno, int K, int H, hipStream_t s, int gpt) {
     const int n = n_scenes * mno * H;
-    hipLaunchKernelGGL(k_rows_to_agents, dim3((n + 255) / 256), dim3(256), 0, s, rows, out, ldo, n_scenes, mno, K, H);
+    hipLaunchKernelGGL(k_rows_to_agents, dim3((n + 255) / 256), dim3(256), 0, s, rows, out, ldo, n_scenes, mno, K, H, gpt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1165,7 +1169,7 @@ __device__ __forceinline__ int ffsm(unsigned long long m) { return __ffsll((long
 // hidden columns -- 16-byte stream and LDS accesses and a quarter of the stream offsets (the row-major kernel of rounds 1-3 spilled 94
 // dwords at H = 128 and took 7.4 ms longer per 81 920-row step); bias column sums by a butterfly over the rows (colsum16).  The packed
 // 16 x 16 dpool contraction (CPB) writes its own LDS rows and is unaffected.
-template <int H, int EV, int C, int TM>
+template <int H, int EV, int C, int TM, bool PAD = false>      // PAD: padded tiles (IocBwdArgs.gpt), 32-row form; a template parameter so that the packed form is unchanged
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <= 4) ? IOC_BWD_OCC : ((H / 32) * (TM / 32) <= 8 ? 2 : 1)) void k_ioc_bwd(IocBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = H / 32, NTHR = NT * (TM / 32) * 64, TPR = NTHR / TM, NCH = H / (4 * TPR);
@@ -1201,6 +1205,9 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
     const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
+    const int gpt = PAD ? a.gpt : 0;                       // padded tiles (kernels.h: IocArgs.gpt): dead rows behind the tile's gpt groups
+    const bool dead_row = gpt && (r8 / a.mno >= gpt || (int)blockIdx.x * gpt + r8 / a.mno >= a.ngrp);
+    const int n_nb = dead_row ? 0 : a.mno;
     const float* a1_lane = A1 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
     const float* a2_lane = A2 + (mt * 32 + (lane & 31)) * LD2 + 4 * (lane >> 5);
     const float* a3_lane = A3 + (mt * 32 + (lane & 31)) * LD1 + 4 * (lane >> 5);
@@ -1246,7 +1253,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
     if (tid < TM) {
         const int row = min(row0 + tid, a.R - 1);
-        vld[tid] = a.valid[agent_of_row(row, a.K, a.mno)];
+        { const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp); vld[tid] = ag >= 0 ? a.valid[ag] : 0; }
         dsc[tid] = (row0 + tid < a.R) ? a.dscore[row] : 0.f;
     }
     for (int i = tid; i < TM * KR; i += NTHR) {
@@ -1276,7 +1283,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
             float2 pv;
             if (t > 0) pv = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t - 1) * 2);
-            else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
+            else { const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp); pv = ag >= 0 ? make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]) : make_float2(0.f, 0.f); }
             if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
         }
         for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
@@ -1286,9 +1293,10 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {
                 const int r = i / (H >> 2), c4 = i - r * (H >> 2);
                 const int row = min(row0 + r, a.R - 1);
+                const int ag0 = (t > 0) ? 0 : ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp);
                 const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
-                                           : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
-                const float4 hv = *reinterpret_cast<const float4*>(src + c4 * 4);
+                                           : a.Hx + (size_t)max(ag0, 0) * a.ldhx;
+                const float4 hv = ag0 >= 0 ? *reinterpret_cast<const float4*>(src + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = hv;
                 if (keep && r < nloc) *reinterpret_cast<float4*>(o_hp + (size_t)(r * a.T + t) * H + c4 * 4) = hv;
             }
@@ -1298,7 +1306,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         // ---- P1: neighbour / observer masks ----
         {
             const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
-            for (int j = q8; j < a.mno; j += TPR) {
+            for (int j = q8; j < n_nb; j += TPR) {
                 if (j == my_slot || !vld[grp_base + j]) continue;
                 const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                 if (b >= 0) {
@@ -1541,6 +1549,11 @@ static void launch_ioc_bwd_t(const IocBwdArgs& a, hipStream_t s) {
 void launch_ioc_bwd(const IocBwdArgs& a, hipStream_t s) {
     if (a.mno > 32) {
         if (a.H == 128) launch_ioc_bwd_t<128, 64>(a, s); else launch_ioc_bwd_t<64, 64>(a, s);
+        return;
+    }
+    if (a.gpt > 0 && a.H <= 128) {                          // padded tiles (slot classes that do not divide 32)
+        if (a.H == 128) { allow_big_lds(k_ioc_bwd<128, 16, 32, 32, true>); hipLaunchKernelGGL((k_ioc_bwd<128, 16, 32, 32, true>), dim3((a.R + 31) / 32), dim3(256), ioc_bwd_lds(a, 32), s, a); }
+        else { allow_big_lds(k_ioc_bwd<64, 16, 32, 32, true>); hipLaunchKernelGGL((k_ioc_bwd<64, 16, 32, 32, true>), dim3((a.R + 31) / 32), dim3(128), ioc_bwd_lds(a, 32), s, a); }
         return;
     }
     if (a.H == 256) launch_ioc_bwd_t<256, 32>(a, s);

@@ -452,7 +452,7 @@ __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v
 #else
 #define TICKB(k)
 #endif
-template <int H, int EV, int C>
+template <int H, int EV, int C, bool PAD = false>      // PAD: padded tiles (IocBwdArgs.gpt); a template parameter so that the packed form is unchanged
 __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
 #ifdef DESIRE_IOC_TIMING
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -490,6 +490,9 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
     const int grp_base = (r8 / a.mno) * a.mno, my_slot = r8 - grp_base;
+    const int gpt = PAD ? a.gpt : 0;                       // padded tiles (kernels.h: IocArgs.gpt): dead rows behind the tile's gpt groups
+    const bool dead_row = gpt && (r8 / a.mno >= gpt || (int)blockIdx.x * gpt + r8 / a.mno >= a.ngrp);
+    const int n_nb = dead_row ? 0 : a.mno;
     const u16* a2_lane = I2 + (lane & 31) * LDB2 + 8 * (lane >> 5);
     const u16* a3_lane = I3 + (lane & 31) * LDB1 + 8 * (lane >> 5);
     // four consecutive columns c..c+3 of this lane's row -> both piece images of a row-major bf16 tile: one 8-byte LDS write per piece
@@ -573,7 +576,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
     for (int i = tid; i < H; i += NTHR) wsc[i] = a.w_score[i];
     if (tid < TM) {
         const int row = min(row0 + tid, a.R - 1);
-        vld[tid] = a.valid[agent_of_row(row, a.K, a.mno)];
+        { const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp); vld[tid] = ag >= 0 ? a.valid[ag] : 0; }
         dsc[tid] = (row0 + tid < a.R) ? a.dscore[row] : 0.f;
     }
     for (int i = tid; i < TM * KR; i += NTHR) {
@@ -617,7 +620,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             pc[tid * 2] = y.x; pc[tid * 2 + 1] = y.y;
             float2 pv;
             if (t > 0) pv = *reinterpret_cast<const float2*>(a.Y0 + ((size_t)row * a.T + t - 1) * 2);
-            else { const int ag = agent_of_row(row, a.K, a.mno); pv = make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]); }
+            else { const int ag = ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp); pv = ag >= 0 ? make_float2(a.p_last[(size_t)ag * 2], a.p_last[(size_t)ag * 2 + 1]) : make_float2(0.f, 0.f); }
             if (row0 + tid < a.R) { a.vel[((size_t)row * a.T + t) * 2] = y.x - pv.x; a.vel[((size_t)row * a.T + t) * 2 + 1] = y.y - pv.y; }
         }
         for (int i = tid; i < 2 * TM * B; i += NTHR) masks[i] = 0;             // masks and obs are contiguous
@@ -626,9 +629,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             for (int i = tid; i < TM * (H >> 2); i += NTHR) {
                 const int r = i / (H >> 2), c4 = i - r * (H >> 2);
                 const int row = min(row0 + r, a.R - 1);
+                const int ag0 = (t > 0) ? 0 : ioc_agent_of_row(row, a.K, a.mno, gpt, a.ngrp);
                 const float* src = (t > 0) ? a.sv_h + ((size_t)row * a.T + t - 1) * H
-                                           : a.Hx + (size_t)agent_of_row(row, a.K, a.mno) * a.ldhx;
-                const float4 hv = *reinterpret_cast<const float4*>(src + c4 * 4);
+                                           : a.Hx + (size_t)max(ag0, 0) * a.ldhx;
+                const float4 hv = ag0 >= 0 ? *reinterpret_cast<const float4*>(src + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(HP + r * LD1 + c4 * 4) = hv;
                 if (r < nloc) *reinterpret_cast<float4*>(o_hp + (size_t)(r * a.T + t) * H + c4 * 4) = hv;      // the weight gradient's h_{t-1} operand, whole rows
             }
@@ -640,7 +644,7 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
         // ---- P1: neighbour / observer masks ----
         {
             const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
-            for (int j = q8; j < a.mno; j += TPR) {
+            for (int j = q8; j < n_nb; j += TPR) {
                 if (j == my_slot || !vld[grp_base + j]) continue;
                 const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
                 if (b >= 0) {
@@ -854,6 +858,11 @@ void launch_ioc_bwd_x3_t(const IocBwdArgs& a, hipStream_t s) {
     const int B = a.G * a.G;
     const size_t lds = (size_t)(32 * (H + 4) * 3) * sizeof(float) + (size_t)2 * 32 * (H + 8) * sizeof(u16) + (size_t)2 * 32 * B * sizeof(unsigned)
                        + (size_t)(32 * 2 + 32 + H) * sizeof(float) + 32 + 64 + 16 * sizeof(uint2);
+    if (a.gpt > 0) {                                        // padded tiles
+        allow_big_lds(k_ioc_bwd_x3<H, 16, 32, true>);
+        hipLaunchKernelGGL((k_ioc_bwd_x3<H, 16, 32, true>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
+        return;
+    }
     allow_big_lds(k_ioc_bwd_x3<H, 16, 32>);
     hipLaunchKernelGGL((k_ioc_bwd_x3<H, 16, 32>), dim3((a.R + 31) / 32), dim3((H / 32) * 64), lds, s, a);
 }

@@ -820,6 +820,13 @@ template <int H, int TM>
 static void launch_ioc_t(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + TM - 1) / TM), block((H / 32) * (TM / 32) * 64);
     if (a.sv_h) {                                              // training-mode forward: keeps x_t, r, u, c, h per step
+        if constexpr (TM == 32 && H <= 128) {
+            if (a.gpt > 0) {                                   // padded tiles (slot classes that do not divide 32): the row-compacted pooling form
+                allow_big_lds(k_ioc<H, 16, 32, 32, true, true, 1, true>);
+                hipLaunchKernelGGL((k_ioc<H, 16, 32, 32, true, true, 1, true>), grid, block, ioc_lds_bytes(a, TM), s, a);
+                return;
+            }
+        }
         if constexpr (TM == 32 && H <= 128) {                  // 32-row tiles: the row-compacted pooling (k_ioc CP) also while training
             if (a.variant != 9) {                              // (DESIRE_IOC_TRAIN_DENSE: dense pooling, A/B)
                 allow_big_lds(k_ioc<H, 16, 32, 32, true, true>);

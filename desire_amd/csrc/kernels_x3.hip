@@ -496,6 +496,11 @@ template <int H>
 static void launch_x3(const IocArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 31) / 32), block((H / 32) * 64);
     if (a.sv_h) {                                              // training-mode forward
+        if (a.gpt > 0) {                                       // padded tiles
+            allow_big_lds(k_ioc_x3<H, 16, 32, true, 2, true>);
+            hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, true, 2, true>), grid, block, iocx3_lds(a), s, a);
+            return;
+        }
         allow_big_lds(k_ioc_x3<H, 16, 32, true>);
         hipLaunchKernelGGL((k_ioc_x3<H, 16, 32, true>), grid, block, iocx3_lds(a), s, a);
     } else {

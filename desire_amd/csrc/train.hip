@@ -417,6 +417,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         h->n_params = off;
     }
     const size_t R = h->R, T = d.T_pred, H = d.H, f = sizeof(float);
+    const size_t RS = R + 128;                                  // IOC buffers: rows + slack for the partial padded tiles of the slot classes (DESIRE_FLAG_COMPACT_IOC)
     const size_t Tm = d.T_pred > d.T_obs ? d.T_pred : d.T_obs;
     const size_t NP = d.iters;                                  // IOC passes: each keeps its own saves
     struct B { const char* n; size_t bytes; };
@@ -430,14 +431,14 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         {"dz", R * d.L * f}, {"dparams", (size_t)h->A * 2 * d.L * f}, {"dconvE3", (size_t)h->A * 2048 * f},
         {"dconvE2", (size_t)h->A * 4096 * f}, {"dconvE1", (size_t)h->A * 8192 * f}, {"dq_c", (size_t)h->A * h->V * f},
         {"dHxHy", (size_t)h->A * 2 * H * f},
-        {"ioc_sv_x", NP * R * T * (size_t)h->E * f}, {"ioc_sv_r", NP * R * T * H * f}, {"ioc_sv_u", NP * R * T * H * f}, {"ioc_sv_c", NP * R * T * H * f},
-        {"ioc_sv_h", NP * R * T * H * f}, {"ioc_Yin", NP * R * T * 2 * f}, {"dscore0", R * f},
+        {"ioc_sv_x", NP * RS * T * (size_t)h->E * f}, {"ioc_sv_r", NP * RS * T * H * f}, {"ioc_sv_u", NP * RS * T * H * f}, {"ioc_sv_c", NP * RS * T * H * f},
+        {"ioc_sv_h", NP * RS * T * H * f}, {"ioc_Yin", NP * RS * T * 2 * f}, {"dscore0", RS * f},
         {"Y_ref", R * T * 2 * f}, {"score_sv", R * f}, {"dYr", R * T * 2 * f}, {"dscore", R * f},
-        {"dscoreT", R * T * f}, {"ioc_dag", R * T * 2 * H * f}, {"ioc_dac", R * T * H * f}, {"ioc_rh", R * T * H * f},
-        {"ioc_hprev", R * T * H * f}, {"ioc_dpre_r", R * T * H * f}, {"ioc_dpre_v", R * T * d.E_v * f}, {"ioc_vel", R * T * 2 * f},
-        {"ioc_pooled", R * T * (size_t)h->B * H * f}, {"ioc_pool_flags", R * T * sizeof(unsigned long long)},
-        {"bin_counts", ((R * T + 2047) / 2048) * (size_t)h->B * sizeof(int)}, {"bin_base", ((size_t)h->B + 1) * sizeof(int)},
-        {"bin_total", (size_t)h->B * sizeof(int)}, {"bin_list", H == 128 ? R * T * (size_t)h->B * sizeof(int) : 4},
+        {"dscoreT", R * T * f}, {"ioc_dag", RS * T * 2 * H * f}, {"ioc_dac", RS * T * H * f}, {"ioc_rh", RS * T * H * f},
+        {"ioc_hprev", RS * T * H * f}, {"ioc_dpre_r", RS * T * H * f}, {"ioc_dpre_v", RS * T * d.E_v * f}, {"ioc_vel", RS * T * 2 * f},
+        {"ioc_pooled", RS * T * (size_t)h->B * H * f}, {"ioc_pool_flags", RS * T * sizeof(unsigned long long)},
+        {"bin_counts", ((RS * T + 2047) / 2048) * (size_t)h->B * sizeof(int)}, {"bin_base", ((size_t)h->B + 1) * sizeof(int)},
+        {"bin_total", (size_t)h->B * sizeof(int)}, {"bin_list", H == 128 ? RS * T * (size_t)h->B * sizeof(int) : 4},
         {"enc_dag", (size_t)h->A * Tm * 2 * H * f}, {"enc_dac", (size_t)h->A * Tm * H * f}, {"enc_rh", (size_t)h->A * Tm * H * f},
         {"enc_hprev", (size_t)h->A * Tm * H * f},
         {"ex_sv_r", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_u", (size_t)h->A * d.T_obs * H * f}, {"ex_sv_c", (size_t)h->A * d.T_obs * H * f},
@@ -457,7 +458,7 @@ extern "C" int desire_set_training(desire_handle* h, int enable) {
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the batch-norm backward scratch");
     if (ensure(h, "head_nll", (size_t)h->A * d.T_obs * f) || ensure(h, "head_cnt", (size_t)h->A * d.T_obs * f) || ensure(h, "head_dO", (size_t)h->A * d.T_obs * 5 * f))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the Gaussian-head loss buffers");
-    if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f) || ensure(h, "bias_part", ((R + 31) / 32 + 1) * 4 * H * f))
+    if (ensure(h, "loss_pa", (size_t)h->A * 4 * f) || ensure(h, "loss_out", 8 * f) || ensure(h, "bias_part", ((RS + 31) / 32 + 1) * 4 * H * f))
         return fail(DESIRE_ERR_HIP, "hipMalloc failed for the loss / bias-gradient buffers");
     HIPCHK(hipMemset(h->ws["loss_out"].p, 0, 8 * f));
     if (int rc = build_repack_maps(h)) return rc;
@@ -555,11 +556,11 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         // DESIRE_FLAG_COMPACT_IOC: the forward ran one launch sequence per slot class (api.hip: IocView) and left each class's saves at its row
         // offset; the BPTT and every weight-gradient reduction below run per class on the same views, accumulating.  Otherwise: one view, the
         // handle's own shape.
-        struct BView { long R; int mno, n_scenes; const float* Hx; const float* p_last; const uint8_t* valid; size_t row_off; const int32_t* cmap; };
+        struct BView { long R; int mno, n_scenes; const float* Hx; const float* p_last; const uint8_t* valid; size_t row_off; const int32_t* cmap; int gpt, ngrp; };
         std::vector<BView> views;
         if (h->ci_last) {
-            if (ensure(h, "ci_dYr", (size_t)R * T * 2 * sizeof(float)) || ensure(h, "ci_dscore", (size_t)R * sizeof(float)) || ensure(h, "ci_dscoreT", (size_t)R * T * sizeof(float)) ||
-                ensure(h, "ci_dHx_rows", (size_t)R * H * sizeof(float)) || ensure(h, "ci_dHx", (size_t)h->A * H * sizeof(float)) || ensure(h, "dHxHy_ioc", (size_t)h->A * H * sizeof(float)))
+            if (ensure(h, "ci_dYr", (size_t)(R + 128) * T * 2 * sizeof(float)) || ensure(h, "ci_dscore", (size_t)(R + 128) * sizeof(float)) || ensure(h, "ci_dscoreT", (size_t)(R + 128) * T * sizeof(float)) ||
+                ensure(h, "ci_dHx_rows", (size_t)(R + 128) * H * sizeof(float)) || ensure(h, "ci_dHx", (size_t)h->A * H * sizeof(float)) || ensure(h, "dHxHy_ioc", (size_t)h->A * H * sizeof(float)))
                 return fail(DESIRE_ERR_HIP, "hipMalloc failed for the slot-class gradient buffers");
             launch_fill_f32(W(h, "dHxHy_ioc"), (size_t)h->A * H, 0.f, s);
             int m4[4];
@@ -567,13 +568,15 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             size_t aoff = 0, roff = 0;
             for (int i = 0; i < h->ci_n; ++i) {
                 const int c = h->ci_cls[i], n_c = h->ci_cnt[i], m_c = m4[c];
-                views.push_back(BView{(long)n_c * d.K * m_c, m_c, n_c, W(h, "ci_Hx") + aoff * 2 * H, W(h, "ci_pl") + aoff * 2,
-                                      static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, roff, static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A});
-                aoff += (size_t)n_c * m_c; roff += (size_t)n_c * d.K * m_c;
+                const int gpt = (m_c <= 32 && 32 % m_c) ? 32 / m_c : 0, ngrp = n_c * d.K;          // padded tiles: as desire_ioc_refine seated the class
+                const long R_c = gpt ? (long)((ngrp + gpt - 1) / gpt) * 32 : (long)n_c * d.K * m_c;
+                views.push_back(BView{R_c, m_c, n_c, W(h, "ci_Hx") + aoff * 2 * H, W(h, "ci_pl") + aoff * 2,
+                                      static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, roff, static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A, gpt, ngrp});
+                aoff += (size_t)n_c * m_c; roff += (size_t)R_c;
             }
         } else
-            views.push_back(BView{R, d.mno, d.n_scenes, W(h, "HxHy"), W(h, "p_last"), static_cast<const uint8_t*>(h->ws["valid"].p), 0, nullptr});
-        const long RTf = R * T;
+            views.push_back(BView{R, d.mno, d.n_scenes, W(h, "HxHy"), W(h, "p_last"), static_cast<const uint8_t*>(h->ws["valid"].p), 0, nullptr, 0, 0});
+        const long RTf = (R + 128) * T;                    // stride of a refinement pass's saves (desire_set_training: rows + slack)
         launch_fill_f32(W(h, "dscore0"), (size_t)R, 0.f, s);
         bool first = true;                          // the first launch sequence writes the weight gradients, the others accumulate
         for (size_t vi = 0; vi < views.size(); ++vi) {
@@ -583,9 +586,9 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         float* dYr_v = W(h, "dYr"); float* dscore_v = W(h, "dscore"); float* dscoreT_v = W(h, "dscoreT"); float* dHx_v = W(h, "dHx_rows");
         if (v.cmap) {          // the class's rows of the loss gradients; its own d loss / d Hx rows
             dYr_v = W(h, "ci_dYr"); dscore_v = W(h, "ci_dscore"); dscoreT_v = W(h, "ci_dscoreT"); dHx_v = W(h, "ci_dHx_rows");
-            launch_cls_rows(W(h, "dYr"), dYr_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 2 * T, 0, s);
-            launch_cls_rows(W(h, "dscore"), dscore_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 1, 0, s);
-            launch_cls_rows(W(h, "dscoreT"), dscoreT_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, T, 0, s);
+            launch_cls_rows(W(h, "dYr"), dYr_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 2 * T, 0, s, v.gpt);
+            launch_cls_rows(W(h, "dscore"), dscore_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, 1, 0, s, v.gpt);
+            launch_cls_rows(W(h, "dscoreT"), dscoreT_v, v.cmap, v.n_scenes, v.mno, d.K, d.mno, T, 0, s, v.gpt);
             launch_fill_f32(dHx_v, (size_t)Rv * H, 0.f, s);
         }
         for (int p = d.iters - 1; p >= 0; --p) {
@@ -602,6 +605,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
             q.sv_x = sv_x; q.sv_r = W(h, "ioc_sv_r") + po * H; q.sv_u = W(h, "ioc_sv_u") + po * H; q.sv_c = W(h, "ioc_sv_c") + po * H; q.sv_h = sv_h;
             q.w_score = D(h, "ioc/score_w");
             q.R = (int)Rv; q.K = d.K; q.mno = v.mno; q.T = T; q.H = H; q.G = d.grid_size; q.nb_w = d.nb_w; q.nb_h = d.nb_h;
+            q.gpt = v.gpt; q.ngrp = v.ngrp;
             q.WrT = D4(h, "ioc/WrT"); q.WcT_h = D4(h, "ioc/WcT_h"); q.WcT_er = D4(h, "ioc/WcT_er"); q.WcT_ev = D4(h, "ioc/WcT_ev");
             q.WgT_h = D4(h, "ioc/WgT_h"); q.WgT_er = D4(h, "ioc/WgT_er"); q.WgT_ev = D4(h, "ioc/WgT_ev"); q.WsT = D4(h, "ioc/WsT"); q.WsT_c = D4(h, "ioc/WsT_c");
             q.dag = W(h, "ioc_dag"); q.dac = W(h, "ioc_dac"); q.rh = W(h, "ioc_rh"); q.hprev = W(h, "ioc_hprev");
@@ -672,7 +676,7 @@ extern "C" int desire_backward(desire_handle* h, const float* dev_past, const fl
         }
         if (v.cmap) {          // the class's share of d loss / d Hx: rows -> class agents -> agents (padding slots dropped)
             launch_fill_f32(W(h, "ci_dHx"), (size_t)v.n_scenes * v.mno * H, 0.f, s);
-            launch_rows_to_agents(dHx_v, W(h, "ci_dHx"), H, v.n_scenes, v.mno, d.K, H, s);
+            launch_rows_to_agents(dHx_v, W(h, "ci_dHx"), H, v.n_scenes, v.mno, d.K, H, s, v.gpt);
             launch_cls_scatter_add_agents(W(h, "ci_dHx"), H, W(h, "dHxHy_ioc"), H, v.cmap, v.n_scenes * v.mno, H, s);
         }
         }       // views
