@@ -58,7 +58,19 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
         bin_mode=int(getattr(args, "social_layout", "rect") == "logpolar"),
         bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")],
         bf16=_operand_mode(getattr(args, "bf16", False)),
-        flags=int(getattr(args, "dims_flags", 0)))             # DESIRE_FLAG_* bits (train.py --two_piece_forward)
+        flags=_flags_from_args(args))                          # DESIRE_FLAG_* bits (train.py --two_piece_forward / --skip_padding, or args.dims_flags)
+
+
+def _flags_from_args(args) -> int:
+    """desire_dims.flags from the argparse Namespace: args.dims_flags as given, plus the bits of train.py's switches (so that train(args) called as a
+    function behaves like the command line)."""
+    from .spec import FLAG_COMPACT_IOC, FLAG_COMPACT_ROWS, FLAG_TRAIN_FWD_3P
+    f = int(getattr(args, "dims_flags", 0) or 0)
+    if getattr(args, "two_piece_forward", False):
+        f |= FLAG_TRAIN_FWD_3P
+    if getattr(args, "skip_padding", False):
+        f |= FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC
+    return f
 
 
 def _operand_mode(v) -> int:

@@ -47,7 +47,7 @@ def _synthetic_video(n_frames, mno, n_ids, rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("operands", ["", "x3"])          # fp32, and split-bf16 operands in the training step (dims.bf16 = 2)
+@pytest.mark.parametrize("operands", ["", "x3", "skip", "x3+skip"])      # fp32; split-bf16 operands (dims.bf16 = 2); --skip_padding (DESIRE_FLAG_COMPACT_*)
 def test_training_loop_runs_saves_and_learns(tmp_path, operands):
     from desire_amd.data_loader import DataLoader
     from desire_amd.model import DESIREModel
@@ -56,7 +56,8 @@ def test_training_loop_runs_saves_and_learns(tmp_path, operands):
     a = T.build_parser().parse_args(["--batch_size", "4", "--seq_length", "4", "--pred_length", "6", "--max_num_obj", "8",
                                      "--d_dim", "64", "--latent_size", "64", "--num_samples", "3", "--num_epochs", "3",
                                      "--save_every", "5", "--learning_rate", "0.0005", "--neighborhood_size", "256",
-                                     "--save_dir", str(tmp_path / "save")] + (["--bf16", operands] if operands else []))
+                                     "--save_dir", str(tmp_path / "save")] + (["--bf16", "x3"] if "x3" in operands else []) +
+                                    (["--skip_padding"] if "skip" in operands else []))
     dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
     assert dl.num_batches > 0
     import random
