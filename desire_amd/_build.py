@@ -14,6 +14,16 @@ LIB = os.path.join(HERE, "libdesire_hip.so")
 SOURCES = ["api.hip", "api_pack.hip", "api_forward.hip", "api_peer.hip", "api_ops.hip", "kernels_gemm.hip", "kernels_conv.hip", "kernels_rnn.hip", "kernels_aux.hip", "kernels_compact.hip", "kernels_bwd.hip", "kernels_bwd_x3.hip", "kernels_bwd_cl.hip", "kernels_bf16.hip", "kernels_bf16_cl.hip", "kernels_x3.hip", "kernels_x6.hip", "kernels_x6r2.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 FLAGS += os.environ.get("DESIRE_HIPCC_FLAGS", "").split()      # e.g. -DDESIRE_IOC_TIMING for the per-phase cycle counters (build_lib(force=True))
+# Per-file code-generation flags (part of source_hash).  -sink-insts-to-avoid-spills: MachineLICM sinks hoisted loop invariants (the
+# fragment base addresses and bias splats of the time loops) back into the loop instead of spilling them -- k_ioc_bf16_cl<128,..,4>
+# 190 -> 63 spilled registers, 540 -> 256 bytes of scratch per lane (round 5, DESIGN_DETAIL section 13 item 2).
+FILE_FLAGS = {
+    "kernels_bf16_cl.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
+}
+_extra = os.environ.get("DESIRE_FILE_FLAGS", "")                 # A/B: "file.hip=-mllvm,-x;other.hip=..." replaces the table's entry
+for _item in filter(None, _extra.split(";")):
+    _f, _, _v = _item.partition("=")
+    FILE_FLAGS[_f] = [x for x in _v.split(",") if x]
 
 
 def _sha(paths, extra: str = "") -> str:
@@ -34,7 +44,7 @@ def source_hash() -> str:
     16 hex digits into the library (desire_build_hash()), so `the tested .so == the tree` is checkable (tests/test_abi.py) instead of trusted to
     file times -- built objects travel to the GPU box with the snapshot, git-ignored but not gpurun-ignored."""
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    return _sha(srcs + _headers(), " ".join(FLAGS))[:16]
+    return _sha(srcs + _headers(), " ".join(FLAGS) + repr(sorted(FILE_FLAGS.items())))[:16]
 
 
 def _read(path: str) -> str:
@@ -61,7 +71,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     def cc(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        flags = list(FLAGS)
+        flags = list(FLAGS) + FILE_FLAGS.get(src, [])
         if src == "api.hip":                      # the library reports the tree it was built from
             flags.append('-DDESIRE_SRC_HASH="%s"' % want)
         key = _sha([os.path.join(CSRC, src)] + hdrs, " ".join(flags))

@@ -43,6 +43,22 @@ __device__ __forceinline__ uint2 ld_agent_u64(const void* p) {
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint2((unsigned)v, (unsigned)(v >> 32));
 }
+// 16-byte forms of the same (a relaxed agent-scope __hip_atomic_* lowers to sc1 only up to 8 bytes): buffer accesses with aux = sc1
+// through a descriptor over the exchange buffer (wave-uniform), byte offsets in a VGPR.  16-byte write-through stores run at the
+// plain-store rate where 8-byte ones cost 2.7x per byte, and 16-byte sc1 loads at 1.4 - 1.9x the 8-byte rate (MI355X_MICROARCH.md)
+typedef unsigned v4u32_ __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t agent_buf;
+__device__ __forceinline__ agent_buf agent_buffer(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void st_agent_u128(agent_buf r, unsigned byte_off, uint4 v) {
+    const v4u32_ x = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ uint4 ld_agent_u128(agent_buf r, unsigned byte_off) {
+    const v4u32_ x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+    return make_uint4(x[0], x[1], x[2], x[3]);
+}
 __device__ __forceinline__ void group_publish_wt(int* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -220,6 +220,61 @@ __device__ __forceinline__ int neighbor_bin_dev(float xi, float yi, float xj, fl
     return (int)cx + (int)cy * G;
 }
 
+// The rectangular layout with the loop invariants of a centre taken out of the pair loop and the two IEEE divisions by nb_w / nb_h
+// replaced by their correctly rounded equivalent for a FIXED divisor: y = RN(1 / b) (one real division per kernel), q0 = RN(a y),
+// r = a - q0 b (exact in one fma), q = RN(q0 + r y) = RN(a / b) -- Markstein's theorem; its one exception is a divisor whose significand
+// is all ones (y then rounds to a power of two), which keeps the real division (`fast` is wave-uniform).  Checked against IEEE division
+// over every significand of a in thirteen binades for twelve divisors (scratch/div_check.py of round 5: 0 differences outside the
+// excepted divisors).  3 VALU instead of the ~12 (two of them quarter-rate) of v_div_scale / v_rcp / v_div_fmas / v_div_fixup.
+struct DivBy { float b, y; bool fast; };
+__device__ __forceinline__ DivBy div_by(float b) {
+    DivBy d;
+    d.b = b; d.y = __fdiv_rn(1.0f, b);
+    const unsigned u = __float_as_uint(b), e = (u >> 23) & 0xffu;
+    // |b| in 2^-62 .. 2^62: no over / underflow anywhere near the window.  (b is wave-uniform at every call site: the flag is made scalar)
+    d.fast = __builtin_amdgcn_readfirstlane((int)((u & 0x7fffffu) != 0x7fffffu && e > 64u && e < 190u)) != 0;
+    return d;
+}
+__device__ __forceinline__ float div_rn(float a, const DivBy& d) {
+    if (!d.fast) return __fdiv_rn(a, d.b);
+    const float q0 = __fmul_rn(a, d.y);
+    const float r = fmaf(-q0, d.b, a);
+    return fmaf(r, d.y, q0);
+}
+struct NbRect { float lx, hx, ly, hy; };
+__device__ __forceinline__ NbRect nb_rect(float xi, float yi, float nb_w, float nb_h) {
+    const float hw = __fdiv_rn(nb_w, 2.0f), hh = __fdiv_rn(nb_h, 2.0f);
+    NbRect w;
+    w.lx = __fsub_rn(xi, hw); w.hx = __fadd_rn(xi, hw); w.ly = __fsub_rn(yi, hh); w.hy = __fadd_rn(yi, hh);
+    return w;
+}
+// == neighbor_bin_dev(xi, yi, xj, yj, nb_w, nb_h, G) bit for bit, w = nb_rect(xi, yi, ..), dw / dh = div_by(nb_w / nb_h)
+__device__ __forceinline__ int neighbor_bin_rect(const NbRect& w, float xj, float yj, const DivBy& dw, const DivBy& dh, int G) {
+    if (!(xj < w.hx) || !(xj >= w.lx) || !(yj < w.hy) || !(yj >= w.ly)) return -1;
+    float cx = floorf(__fmul_rn(div_rn(__fsub_rn(xj, w.lx), dw), (float)G));
+    float cy = floorf(__fmul_rn(div_rn(__fsub_rn(yj, w.ly), dh), (float)G));
+    cx = fminf(fmaxf(cx, 0.f), (float)(G - 1));
+    cy = fminf(fmaxf(cy, 0.f), (float)(G - 1));
+    return (int)cx + (int)cy * G;
+}
+
+// branch-free form for batched pair loops (same value; ONLY when dw.fast && dh.fast -- the caller branches once, on wave-uniform flags,
+// and keeps the loop over neighbor_bin_dev for the excepted divisors): the cell is computed whatever the window test says and selected
+// at the end; a NaN position (how the batched loops mark absent agents) fails the window test
+__device__ __forceinline__ float div_rn_fast(float a, const DivBy& d) {
+    const float q0 = __fmul_rn(a, d.y);
+    return fmaf(fmaf(-q0, d.b, a), d.y, q0);
+}
+__device__ __forceinline__ int neighbor_bin_rect_nb(const NbRect& w, float xj, float yj, const DivBy& dw, const DivBy& dh, int G) {
+    const bool in = (xj < w.hx) & (xj >= w.lx) & (yj < w.hy) & (yj >= w.ly);
+    float cx = floorf(__fmul_rn(div_rn_fast(__fsub_rn(xj, w.lx), dw), (float)G));
+    float cy = floorf(__fmul_rn(div_rn_fast(__fsub_rn(yj, w.ly), dh), (float)G));
+    cx = fminf(fmaxf(cx, 0.f), (float)(G - 1));
+    cy = fminf(fmaxf(cy, 0.f), (float)(G - 1));
+    const int b = (int)cx + (int)cy * G;
+    return in ? b : -1;
+}
+
 // the same for the IOC kernels' padded tiles (IocArgs.gpt > 0): -1 = a dead row
 __device__ __forceinline__ int ioc_agent_of_row(int r, int K, int mno, int gpt, int ngrp);
 // row r = (scene*K + k)*mno + slot  ->  agent = scene*mno + slot

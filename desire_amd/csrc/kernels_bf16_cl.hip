@@ -55,6 +55,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
     float* red = wv + 3 * EV;                                          // [NT][TM]
     unsigned char* vld = reinterpret_cast<unsigned char*>(red + NT * TM);   // [CLMAXM]
     unsigned* occ = reinterpret_cast<unsigned*>(vld + CLMAXM);              // [2] bins that hold a neighbour anywhere in the tile
+    float2* pgv = reinterpret_cast<float2*>(occ + 2);                        // [CLMAXM] the same positions with NaN for absent agents (pair loop)
     // partial-tile exchange of the bin-split pooling: two sets of NT 4 KB slots INSIDE the Ht tile.  Ht is dead between the end of the
     // pooling chains and the end of the step (my columns are rewritten by publish_h, the other members' by the next step's copy), so
     // the exchange costs no LDS of its own and two workgroups still share a CU
@@ -66,6 +67,8 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int tile_pos = blockIdx.x % tpg;                             // my tile inside its group
     const int n_tiles = a.R / TM;
+    static_assert(NTHR >= CLMAXM, "one thread per group slot for the position loads");
+    const agent_buf hexr = agent_buffer(hex16, 2u * (unsigned)n_tiles * (H * TM * 2));
     const int my_slot = tile_pos * TM + r8;                            // group-local slot of my VALU row
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
@@ -93,14 +96,21 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
         __syncthreads();
         for (int i = tid; i < a.mno; i += NTHR) vld[i] = a.valid[agent_of_row(grow0 + i, a.K, a.mno)];
         // h (fp32, accumulator layout) -> the bf16 images: my rows of Xb, my columns of Ht and (steps only) the exchange buffer
-        auto publish_h = [&](const f32x16& h, u16* gdst) {
+        // exchange order of a tile's column: position (i >> 3) * 16 + hi * 8 + (i & 7) for accumulator element i of lane half hi, so that
+        // a lane's sixteen values are two 16-byte write-through stores and the two halves of a store instruction fill 32 contiguous bytes
+        auto publish_h = [&](const f32x16& h, bool pub, unsigned gbyte) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) Xb[(arow + (i & 3) + 8 * (i >> 2)) * LDXB + E + col] = bf16_of(h[i]);
+            unsigned pk[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint2 v = make_uint2(pk_bf16(h[4 * q], h[4 * q + 1]), pk_bf16(h[4 * q + 2], h[4 * q + 3]));
-                *reinterpret_cast<uint2*>(Ht + col * LDT + tile_pos * TM + arow + 8 * q) = v;
-                if (gdst) st_agent_u64(gdst + (size_t)col * TM + arow + 8 * q, v);       // write-through (cluster.h)
+                pk[2 * q] = pk_bf16(h[4 * q], h[4 * q + 1]); pk[2 * q + 1] = pk_bf16(h[4 * q + 2], h[4 * q + 3]);
+                *reinterpret_cast<uint2*>(Ht + col * LDT + tile_pos * TM + arow + 8 * q) = make_uint2(pk[2 * q], pk[2 * q + 1]);
+            }
+            if (pub) {
+                const unsigned off = gbyte + (unsigned)col * (TM * 2) + 16u * hi;
+                st_agent_u128(hexr, off, make_uint4(pk[0], pk[1], pk[2], pk[3]));            // write-through (cluster.h)
+                st_agent_u128(hexr, off + 32u, make_uint4(pk[4], pk[5], pk[6], pk[7]));
             }
         };
 
@@ -111,7 +121,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
             for (int i = 0; i < 16; ++i)
                 h[i] = a.Hx[(size_t)agent_of_row(row0 + arow + (i & 3) + 8 * (i >> 2), a.K, a.mno) * a.ldhx + col];
             __syncthreads();                                  // previous pass's readers of Xb / Ht are done
-            publish_h(h, nullptr);
+            publish_h(h, false, 0u);
             // h_{-1} = Hx of the OTHER tiles' agents: every member computes it itself (no hand-off before step 0)
             for (int i = tid; i < a.mno * (H >> 2); i += NTHR) {
                 const int j = i / (H >> 2), c4 = i - j * (H >> 2);
@@ -125,10 +135,13 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
             }
 
+            float2 ynx = make_float2(0.f, 0.f);                                  // my agent's position at the NEXT step, requested a phase ahead
+            if (tid < a.mno) ynx = *reinterpret_cast<const float2*>(a.Y + (size_t)(grow0 + tid) * a.T * 2);
             for (int t = 0; t < a.T; ++t) {
-                for (int i = tid; i < a.mno; i += NTHR) {
-                    const float2 y = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + i) * a.T + t) * 2);
-                    pg[i * 2] = y.x; pg[i * 2 + 1] = y.y;
+                if (tid < a.mno) {
+                    pg[tid * 2] = ynx.x; pg[tid * 2 + 1] = ynx.y;
+                    const float qn = __int_as_float(0x7fc00000);
+                    pgv[tid] = vld[tid] ? ynx : make_float2(qn, qn);          // (vld[tid] was written by this thread)
                 }
                 for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
                 if (tid < 2) occ[tid] = 0;
@@ -138,37 +151,102 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 {
                     const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
                     const float vx = px - pp[r8 * 2], vy = py - pp[r8 * 2 + 1];
+                    // the scene-feature line is requested first and lands under the pair loop
+                    int cy, cx;
+                    scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
+                    const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
+                    constexpr int NGQ = (C + 4 * TPR - 1) / (4 * TPR);
+                    float4 g4[NGQ];
+#pragma unroll
+                    for (int k = 0; k < NGQ; ++k)
+                        if (4 * (q8 + k * TPR) < C) g4[k] = *reinterpret_cast<const float4*>(gsrc + 4 * (q8 + k * TPR));
                     for (int j = 2 * q8; j < EV; j += 2 * TPR) {
                         const float e0 = fmaxf(fmaf(vy, wv[EV + j], vx * wv[j]) + wv[2 * EV + j], 0.f);
                         const float e1 = fmaxf(fmaf(vy, wv[EV + j + 1], vx * wv[j + 1]) + wv[2 * EV + j + 1], 0.f);
                         *reinterpret_cast<unsigned*>(Xb + r8 * LDXB + j) = pk_bf16(e0, e1);
                     }
-                    int cy, cx;
-                    scene_cell_dev(px, py, a.Gh, a.Gw, cy, cx);
-                    const float* gsrc = grid + ((size_t)cy * a.Gw + cx) * C;
-                    for (int j = 4 * q8; j < C; j += 4 * TPR) {
-                        const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
-                        *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(pk_bf16(g4.x, g4.y), pk_bf16(g4.z, g4.w));
+                    // bins that hold a neighbour: collected per lane, ONE LDS atomic per lane and word at the end (a same-address atomic per
+                    // pair serialises the wave)
+                    unsigned oc0 = 0u, oc1 = 0u;
+                    // (the divisors' reciprocals are formed per step from opaque copies: as invariants of the time loop they are spilled and
+                    //  reloaded from scratch inside the pair loop, a memory round trip per pair)
+                    float nbw, nbh;
+                    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(nbw), "=v"(nbh) : "s"(a.nb_w), "s"(a.nb_h));
+                    const DivBy dvw = div_by(nbw), dvh = div_by(nbh);
+                    if (a.bin_tab || !dvw.fast || !dvh.fast) {
+                        for (int j = q8; j < a.mno; j += TPR) {
+                            if (j == my_slot || !vld[j]) continue;
+                            const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
+                            if (b >= 0) { atomicOr(&masks[(r8 * LDM + b) * 2 + (j >> 6)], 1ull << (j & 63)); if (b < 32) oc0 |= 1u << b; else oc1 |= 1u << (b - 32); }
+                        }
+                    } else {
+                        const NbRect win = nb_rect(px, py, nbw, nbh);
+                        // eight pairs at a time: positions read in one batch, cells branch-free, only the atomics predicated
+                        const int mno_ = TPGT ? 32 * TPGT : a.mno;
+                        unsigned long long oc = 0ull;
+                        for (int j0 = q8; j0 < mno_; j0 += 8 * TPR) {
+                            float2 pj[8];
+#pragma unroll
+                            for (int m = 0; m < 8; ++m) pj[m] = pgv[min(j0 + m * TPR, CLMAXM - 1)];
+#pragma unroll
+                            for (int m = 0; m < 8; ++m) {
+                                const int j = j0 + m * TPR;
+                                const int b = neighbor_bin_rect_nb(win, pj[m].x, pj[m].y, dvw, dvh, a.G);
+                                if (b >= 0 && j != my_slot && j < mno_) {
+                                    atomicOr(&masks[(r8 * LDM + b) * 2 + (j >> 6)], 1ull << (j & 63));
+                                    oc |= 1ull << b;
+                                }
+                            }
+                        }
+                        oc0 = (unsigned)oc; oc1 = (unsigned)(oc >> 32);
                     }
-                    for (int j = q8; j < a.mno; j += TPR) {
-                        if (j == my_slot || !vld[j]) continue;
-                        const int b = neighbor_bin_dev(px, py, pg[j * 2], pg[j * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                        if (b >= 0) { atomicOr(&masks[(r8 * LDM + b) * 2 + (j >> 6)], 1ull << (j & 63)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
-                    }
+                    if (oc0) atomicOr(&occ[0], oc0);
+                    if (oc1) atomicOr(&occ[1], oc1);
+#pragma unroll
+                    for (int k = 0; k < NGQ; ++k)
+                        if (4 * (q8 + k * TPR) < C)
+                            *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + 4 * (q8 + k * TPR)) = make_uint2(pk_bf16(g4[k].x, g4[k].y), pk_bf16(g4[k].z, g4[k].w));
                 }
                 TICKC(1)
                 // ---- neighbours' h_{t-1}: published by their tiles at the end of step t-1 (parity (t-1)&1) ----
                 if (t > 0) {
                     group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
                     TICKC(2)
-                    const u16* src0 = hex16 + (size_t)((t + 1) & 1) * n_tiles * H * TM;
-                    // (one load -> wait -> LDS store at a time ON PURPOSE: with all twelve loads of a thread in flight first -- 24 more live
-                    //  registers in a kernel that already sits at 256 -- the pass measured 7.33 instead of 6.62 ms, same box)
-                    for (int tp = 0; tp < tpg; ++tp) {
-                        if (tp == tile_pos) continue;
-                        const u16* src = src0 + (size_t)(tile - tile_pos + tp) * H * TM;
-                        for (int i = tid; i < H * 8; i += NTHR)                   // 8-byte words: [H][32] bf16 = H * 8 of them
-                            *reinterpret_cast<uint2*>(Ht + (i >> 3) * LDT + tp * TM + 4 * (i & 7)) = ld_agent_u64(src + (size_t)i * 4);
+                    // 16-byte write-through-side loads (sc1), all of a thread's chunks in flight: chunk i of a tile = column i >> 2, exchange
+                    // positions 8 (i & 3) .. + 7 = lane half (i & 1), accumulator elements 8 (i >> 1 & 1) .. + 7 (publish_h)
+                    const unsigned pbyte = (unsigned)((t + 1) & 1) * (unsigned)n_tiles * (H * TM * 2);
+                    constexpr int CPT = (H * 4 + NTHR - 1) / NTHR;                 // chunks per thread and peer tile
+                    if constexpr (TPGT > 0) {
+                        uint4 v[(TPGT - 1) * CPT];
+#pragma unroll
+                        for (int pi = 0; pi < TPGT - 1; ++pi) {
+                            const int tp = pi + (pi >= tile_pos ? 1 : 0);
+                            const unsigned base = pbyte + (unsigned)(tile - tile_pos + tp) * (H * TM * 2);
+#pragma unroll
+                            for (int k = 0; k < CPT; ++k) v[pi * CPT + k] = ld_agent_u128(hexr, base + (unsigned)(tid + k * NTHR) * 16u);
+                        }
+#pragma unroll
+                        for (int pi = 0; pi < TPGT - 1; ++pi) {
+                            const int tp = pi + (pi >= tile_pos ? 1 : 0);
+#pragma unroll
+                            for (int k = 0; k < CPT; ++k) {
+                                const int i = tid + k * NTHR;
+                                u16* dst = Ht + (i >> 2) * LDT + tp * TM + 4 * (i & 1) + 16 * ((i >> 1) & 1);
+                                *reinterpret_cast<uint2*>(dst) = make_uint2(v[pi * CPT + k].x, v[pi * CPT + k].y);
+                                *reinterpret_cast<uint2*>(dst + 8) = make_uint2(v[pi * CPT + k].z, v[pi * CPT + k].w);
+                            }
+                        }
+                    } else {
+                        for (int tp = 0; tp < tpg; ++tp) {
+                            if (tp == tile_pos) continue;
+                            const unsigned base = pbyte + (unsigned)(tile - tile_pos + tp) * (H * TM * 2);
+                            for (int i = tid; i < H * 4; i += NTHR) {
+                                const uint4 v = ld_agent_u128(hexr, base + (unsigned)i * 16u);
+                                u16* dst = Ht + (i >> 2) * LDT + tp * TM + 4 * (i & 1) + 16 * ((i >> 1) & 1);
+                                *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+                                *reinterpret_cast<uint2*>(dst + 8) = make_uint2(v.z, v.w);
+                            }
+                        }
                     }
                 }
                 __syncthreads();
@@ -358,7 +436,8 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         h[i] = gru_blend(u[i], h[i], c);
                         sp[i] = fmaf(h[i], wsc, sp[i]);
                     }
-                    publish_h(h, hex16 + ((size_t)(t & 1) * n_tiles + tile) * H * TM);       // LDS images + exchange buffer, parity t & 1
+                    if (t + 1 < a.T && tid < a.mno) ynx = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + tid) * a.T + t + 1) * 2);
+                    publish_h(h, true, (unsigned)((t & 1) * n_tiles + tile) * (H * TM * 2));       // LDS images + exchange buffer, parity t & 1
                 }
                 if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
                 TICKC(8)
@@ -410,7 +489,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
 static size_t ioc16_cl_lds(const IocArgs& a, bool split) {
     const int H = a.H, TM = 32, E = 16 + 32 + H, KX = E + H, B = a.G * a.G, NT = H / 32;
     size_t b = (size_t)TM * (KX + 8) * 2 + (size_t)TM * (H + 8) * 2 + (size_t)H * (CLMAXM + 8) * 2;
-    b += (size_t)TM * (B + 1) * 16 + 16 * 8 + (size_t)CLMAXM * 2 * 4 + TM * 2 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + CLMAXM + 8 + 64;
+    b += (size_t)TM * (B + 1) * 16 + 16 * 8 + (size_t)CLMAXM * 2 * 4 + TM * 2 * 4 + 3 * 16 * 4 + (size_t)NT * TM * 4 + CLMAXM + 8 + CLMAXM * 8 + 64;
     (void)split;                                           // the bin-split exchange lives inside the Ht tile
     return b;
 }
