@@ -15,11 +15,12 @@ SOURCES = ["api.hip", "api_pack.hip", "api_forward.hip", "api_peer.hip", "api_op
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 FLAGS += os.environ.get("DESIRE_HIPCC_FLAGS", "").split()      # e.g. -DDESIRE_IOC_TIMING for the per-phase cycle counters (build_lib(force=True))
 # Per-file code-generation flags (part of source_hash).  -sink-insts-to-avoid-spills: MachineLICM sinks hoisted loop invariants (the
-# fragment base addresses and bias splats of the time loops) back into the loop instead of spilling them -- k_ioc_bf16_cl<128,..,4>
-# 190 -> 63 spilled registers, 540 -> 256 bytes of scratch per lane (round 5, DESIGN_DETAIL section 13 item 2).
-FILE_FLAGS = {
-    "kernels_bf16_cl.hip": ["-mllvm", "-sink-insts-to-avoid-spills"],
-}
+# fragment base addresses and bias splats of the time loops) back into the loop instead of spilling them.  Registers spilled with /
+# without it: k_ioc_bf16_cl<128,..,4> 63 / 190 (256 / 540 B of scratch per lane), k_ioc_x3<128> 2 - 15 / 40 - 52.  Same-box A/B (round 5):
+# configs[2] IOC 5.7 -> 5.1 ms, split IOC 29.4 -> 28.0 ms (training-mode 9.5 -> 8.6 ms).  Measured neutral (spills gone, time not) and
+# therefore left at the default: kernels_rnn (headline k_ioc 6 -> 0 spilled, 79.5 ms both), kernels_bf16, kernels_x6r2, kernels_bwd*.
+_SINK = ["-mllvm", "-sink-insts-to-avoid-spills"]
+FILE_FLAGS = {f: list(_SINK) for f in ("kernels_bf16_cl.hip", "kernels_x3.hip")}
 _extra = os.environ.get("DESIRE_FILE_FLAGS", "")                 # A/B: "file.hip=-mllvm,-x;other.hip=..." replaces the table's entry
 for _item in filter(None, _extra.split(";")):
     _f, _, _v = _item.partition("=")
