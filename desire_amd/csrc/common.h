@@ -275,6 +275,71 @@ __device__ __forceinline__ int neighbor_bin_rect_nb(const NbRect& w, float xj, f
     return in ? b : -1;
 }
 
+// One tile row's neighbour search against the n_nb slots of its group: slots j_first, j_first + j_step, .. (the TPR threads of a row
+// interleave).  hit(j, b) records slot j in bin b (the mask atomics); the return value is this LANE's set of bins that got a neighbour
+// (the caller folds it over the wave with wave_or and issues ONE atomic per wave and word).  Rectangular layout with Markstein-safe
+// divisors: NPB pairs per batch -- positions and presence flags read together, cells computed branch-free, only the atomics
+// predicated; otherwise (log-polar table, excepted divisors) the pair-by-pair loop over neighbor_bin_dev.  nbw / nbh: per-step opaque
+// copies of a.nb_w / a.nb_h (nb_opaque), so that nothing derived from them is an invariant of the time loop (it would be spilled and
+// reloaded inside the pair loop, a memory round trip per pair).
+__device__ __forceinline__ void nb_opaque(float w, float h, float& nbw, float& nbh) {
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(nbw), "=v"(nbh) : "s"(w), "s"(h));
+}
+template <int NPB, class Hit>
+__device__ __forceinline__ unsigned long long nb_search(const float* pc, const unsigned char* vld, int grp_base, int n_nb, int j_first, int j_step,
+                                                         int my_slot, float px, float py, float nbw, float nbh, int G,
+                                                         const float* __restrict__ tab, Hit&& hit) {
+    unsigned long long oc = 0ull;
+    const DivBy dw = div_by(nbw), dh = div_by(nbh);
+    if (tab || !dw.fast || !dh.fast) {
+        for (int j = j_first; j < n_nb; j += j_step) {
+            if (j == my_slot || !vld[grp_base + j]) continue;
+            const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], nbw, nbh, G, tab);
+            if (b >= 0) { hit(j, b); oc |= 1ull << b; }
+        }
+        return oc;
+    }
+    const NbRect win = nb_rect(px, py, nbw, nbh);
+    for (int j0 = j_first; j0 < n_nb; j0 += NPB * j_step) {
+        float2 pj[NPB];
+        unsigned char vj[NPB];
+#pragma unroll
+        for (int m = 0; m < NPB; ++m) {
+            const int j = grp_base + min(j0 + m * j_step, n_nb - 1);
+            pj[m] = *reinterpret_cast<const float2*>(pc + j * 2);
+            vj[m] = vld[j];
+        }
+#pragma unroll
+        for (int m = 0; m < NPB; ++m) {
+            const int j = j0 + m * j_step;
+            const int b = neighbor_bin_rect_nb(win, pj[m].x, pj[m].y, dw, dh, G);
+            if (b >= 0 && vj[m] && j != my_slot && j < n_nb) { hit(j, b); oc |= 1ull << b; }
+        }
+    }
+    return oc;
+}
+// the lanes' bin sets of nb_search -> the tile's occ words (B = number of bins; every lane of the wave active)
+__device__ __forceinline__ void nb_publish_occ(unsigned long long oc, unsigned* occ, int B);
+
+// OR of v over the 64 lanes of a wave (every lane active), the same value in every lane: four row shifts, two row broadcasts (DPP), one
+// readlane.  (An LDS atomicOr that every lane aims at ONE word is turned by the compiler into a scalar loop over the active lanes --
+// ~8 instructions per lane, per call.)
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);       // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);       // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);       // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);       // row_shr:8   -> lane 15 of a row holds its row
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1, 3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ void nb_publish_occ(unsigned long long oc, unsigned* occ, int B) {
+    const unsigned o0 = wave_or((unsigned)oc);
+    const unsigned o1 = B > 32 ? wave_or((unsigned)(oc >> 32)) : 0u;
+    if (lane_id() == 0) { if (o0) atomicOr(&occ[0], o0); if (o1) atomicOr(&occ[1], o1); }
+}
+
 // the same for the IOC kernels' padded tiles (IocArgs.gpt > 0): -1 = a dead row
 __device__ __forceinline__ int ioc_agent_of_row(int r, int K, int mno, int gpt, int ngrp);
 // row r = (scene*K + k)*mno + slot  ->  agent = scene*mno + slot

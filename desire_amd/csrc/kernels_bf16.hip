@@ -144,11 +144,11 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
                     const float4 g4 = *reinterpret_cast<const float4*>(gsrc + j);
                     *reinterpret_cast<uint2*>(Xb + r8 * LDXB + EV + j) = make_uint2(pk_bf16(g4.x, g4.y), pk_bf16(g4.z, g4.w));
                 }
-                for (int j = q8; j < a.mno; j += TPR) {
-                    if (j == my_slot || !vld[grp_base + j]) continue;
-                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
-                }
+                float nbw, nbh;
+                nb_opaque(a.nb_w, a.nb_h, nbw, nbh);
+                const unsigned long long oc = nb_search<4>(pc, vld, grp_base, a.mno, q8, TPR, my_slot, px, py, nbw, nbh, a.G, a.bin_tab,
+                                                          [&](int j, int b) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); });
+                nb_publish_occ(oc, occ, B);
             }
             TICK16(1)
             __syncthreads();

@@ -1306,16 +1306,15 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
         // ---- P1: neighbour / observer masks ----
         {
             const float px = pc[r8 * 2], py = pc[r8 * 2 + 1];
-            for (int j = q8; j < n_nb; j += TPR) {
-                if (j == my_slot || !vld[grp_base + j]) continue;
-                const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                if (b >= 0) {
-                    atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
-                    atomicOr(&obs[(grp_base + j) * B + b], (mask_t)1 << my_slot);
-                    atomicOr(&occ[b >> 5], 1u << (b & 31));
-                    if (CPB) atomicOr(&rowbits[b], 1u << r8);
-                }
-            }
+            float nbw, nbh;
+            nb_opaque(a.nb_w, a.nb_h, nbw, nbh);
+            const unsigned long long oc = nb_search<4>(pc, vld, grp_base, n_nb, q8, TPR, my_slot, px, py, nbw, nbh, a.G, a.bin_tab,
+                                                      [&](int j, int b) {
+                                                          atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
+                                                          atomicOr(&obs[(grp_base + j) * B + b], (mask_t)1 << my_slot);
+                                                          if (CPB) atomicOr(&rowbits[b], 1u << r8);
+                                                      });
+            nb_publish_occ(oc, occ, B);
         }
         // ---- GRU cell backward, part 1 ----
         if (a.pool_flags && q8 == 0 && row0 + r8 < a.R) {      // which bins of this (row, t) hold a neighbour: the weight-gradient

@@ -536,15 +536,14 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 } else {
                     *reinterpret_cast<float2*>(XH + r8 * LDX + EV + q8 * 2) = *reinterpret_cast<const float2*>(gsrc + q8 * 2);
                 }
-                for (int j = q8; j < n_nb; j += TPR) {
-                    if (j == my_slot || !vld[grp_base + j]) continue;
-                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1],
-                                                   a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) {
-                        atomicOr(&masks[r8 * B + b], (mask_t)1 << j); atomicOr(&occ[b >> 5], 1u << (b & 31));
-                        if (CP) atomicOr(&rowbits[b], 1u << r8);
-                    }
-                }
+                float nbw, nbh;
+                nb_opaque(a.nb_w, a.nb_h, nbw, nbh);
+                const unsigned long long oc = nb_search<4>(pc, vld, grp_base, n_nb, q8, TPR, my_slot, px, py, nbw, nbh, a.G, a.bin_tab,
+                                                          [&](int j, int b) {
+                                                              atomicOr(&masks[r8 * B + b], (mask_t)1 << j);
+                                                              if (CP) atomicOr(&rowbits[b], 1u << r8);
+                                                          });
+                nb_publish_occ(oc, occ, B);
                 if (CP) {                                           // e_r columns double as the accumulation tile of the bin loop
 #pragma unroll
                     for (int c = 0; c < NCH; ++c)

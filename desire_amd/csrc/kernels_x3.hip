@@ -170,11 +170,11 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(Xb + i * XLO + r8 * LDXB + EV + j) = make_uint2(ga[i], gb[i]);
                     if (TRAIN && row0 + r8 < a.R) *reinterpret_cast<float4*>(sv_x_t + (unsigned)((r8 * a.T + t) * E + EV + j)) = g4;
                 }
-                for (int j = q8; j < n_nb; j += TPR) {
-                    if (j == my_slot || !vld[grp_base + j]) continue;
-                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1u << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
-                }
+                float nbw, nbh;
+                nb_opaque(a.nb_w, a.nb_h, nbw, nbh);
+                const unsigned long long oc = nb_search<4>(pc, vld, grp_base, n_nb, q8, TPR, my_slot, px, py, nbw, nbh, a.G, a.bin_tab,
+                                                          [&](int j, int b) { atomicOr(&masks[r8 * LDM + b], 1u << (grp_base + j)); });
+                nb_publish_occ(oc, occ, B);
             }
             TICKX(1)
             __syncthreads();

@@ -143,11 +143,11 @@ __global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_x6r2(IocArgs a) {
                 for (int u = 0; u < NG4; ++u)
                     if (4 * q8 + 4 * TPR * u < C)
                         *reinterpret_cast<float4*>(XH + r8 * LDX + EV + 4 * q8 + 4 * TPR * u) = *reinterpret_cast<const float4*>(gsrc + 4 * q8 + 4 * TPR * u);
-                for (int j = q8; j < a.mno; j += TPR) {
-                    if (j == my_slot || !vld[grp_base + j]) continue;
-                    const int b = neighbor_bin_dev(px, py, pc[(grp_base + j) * 2], pc[(grp_base + j) * 2 + 1], a.nb_w, a.nb_h, a.G, a.bin_tab);
-                    if (b >= 0) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); atomicOr(&occ[b >> 5], 1u << (b & 31)); }
-                }
+                float nbw, nbh;
+                nb_opaque(a.nb_w, a.nb_h, nbw, nbh);
+                const unsigned long long oc = nb_search<4>(pc, vld, grp_base, a.mno, q8, TPR, my_slot, px, py, nbw, nbh, a.G, a.bin_tab,
+                                                          [&](int j, int b) { atomicOr(&masks[r8 * LDM + b], 1ull << (grp_base + j)); });
+                nb_publish_occ(oc, occ, B);
             }
             TICK6(1)
             __syncthreads();
