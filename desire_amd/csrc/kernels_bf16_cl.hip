@@ -141,17 +141,21 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
             }
 
-            float2 ynx = make_float2(0.f, 0.f);                                  // my agent's position at the NEXT step, requested a phase ahead
-            if (tid < a.mno) ynx = *reinterpret_cast<const float2*>(a.Y + (size_t)(grow0 + tid) * a.T * 2);
+            // The step has NO barrier of its own at the top: what the position-only phase reads -- the group's positions (pg, pgv), the
+            // previous positions of my rows (pp), cleared masks / occupancy words -- is prepared DURING the previous step, each behind the
+            // barrier after its last reader (positions: after the barrier that closes P1; masks: after the barrier that closes the pooling).
+            float2 ynx = make_float2(0.f, 0.f);                                  // my agent's position at the NEXT step, requested a step ahead
+            auto put_positions = [&]() {
+                pg[tid * 2] = ynx.x; pg[tid * 2 + 1] = ynx.y;
+                const float qn = __int_as_float(0x7fc00000);
+                pgv[tid] = vld[tid] ? ynx : make_float2(qn, qn);              // (vld[tid] was written by this thread)
+            };
+            if (tid < a.mno) { ynx = *reinterpret_cast<const float2*>(a.Y + (size_t)(grow0 + tid) * a.T * 2); put_positions(); }
+            for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
+            if (tid < 2) occ[tid] = 0;
+            __syncthreads();
             for (int t = 0; t < a.T; ++t) {
-                if (tid < a.mno) {
-                    pg[tid * 2] = ynx.x; pg[tid * 2 + 1] = ynx.y;
-                    const float qn = __int_as_float(0x7fc00000);
-                    pgv[tid] = vld[tid] ? ynx : make_float2(qn, qn);          // (vld[tid] was written by this thread)
-                }
-                for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
-                if (tid < 2) occ[tid] = 0;
-                __syncthreads();
+                if (t + 1 < a.T && tid < a.mno) ynx = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + tid) * a.T + t + 1) * 2);
                 TICKC(0)
                 // 16-byte loads (sc1) of the peers' h_{t-1} tiles (published at the end of step t-1, parity (t-1)&1), all of a thread's
                 // chunks in flight: chunk i of a tile = column i >> 2, exchange positions 8 (i & 3) .. + 7 = lane half (i & 1), accumulator
@@ -270,6 +274,11 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 }
                 __syncthreads();
                 TICKC(3)
+                // every reader of this step's positions is past the barrier: the next step's go in, my rows' current ones become "previous"
+                if (t + 1 < a.T && tid < a.mno) {
+                    if ((tid >> 5) == tile_pos) { pp[(tid & 31) * 2] = pg[tid * 2]; pp[(tid & 31) * 2 + 1] = pg[tid * 2 + 1]; }
+                    put_positions();
+                }
                 // ---- P2: social pooling chain -> e_r ----
                 unsigned long long om_all = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
                 om_all |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
@@ -416,6 +425,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 TICKC(5)
                 __syncthreads();
                 TICKC(6)
+                // the pooling chains are done with the neighbour masks and every wave has read the occupancy words: cleared for the next step
+                for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
+                if (tid < 2) occ[tid] = 0;
                 // ---- P4: gates over [x | h], and the candidate's x part (same A fragments: three n-tiles per LDS read) ----
                 // B fragments run through a ring of RD k-groups requested that many groups before their use; their addresses are formed per
                 // step from wave-uniform bases (the opaque zero keeps ~60 of them from being hoisted out of the time loop into spilled
@@ -476,10 +488,8 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         h[i] = gru_blend(u[i], h[i], c);
                         sp[i] = fmaf(h[i], wsc, sp[i]);
                     }
-                    if (t + 1 < a.T && tid < a.mno) ynx = *reinterpret_cast<const float2*>(a.Y + ((size_t)(grow0 + tid) * a.T + t + 1) * 2);
                     publish_h(h, true, (unsigned)((t & 1) * n_tiles + tile) * (H * TM * 2));       // LDS images + exchange buffer, parity t & 1
                 }
-                if (tid < TM) { pp[tid * 2] = pg[(tile_pos * TM + tid) * 2]; pp[tid * 2 + 1] = pg[(tile_pos * TM + tid) * 2 + 1]; }
                 TICKC(8)
                 group_publish_wt(cnt);                       // includes the end-of-step __syncthreads
                 TICKC(9)

@@ -1,0 +1,51 @@
+"""Every IOC kernel's own neighbour search on ADVERSARIAL positions (round 5: the search became a batched, branch-free loop whose two
+divisions by the window size go through a reciprocal -- csrc/common.h nb_search / div_rn; tests/test_div_by.py pins the arithmetic).
+The refinement is started from a trajectory set that lives on the lattice  0.5 + (window / G) * integer: every in-window neighbour
+then sits on (or one ulp off) a cell edge and the window edges themselves are hit, at every step, for every pair.  One neighbour in
+the wrong cell moves a pooled sum by a whole hidden state, far outside the tolerances below (the fp32-class kernels are held to the
+stage-wise 2e-4)."""
+import numpy as np
+import pytest
+
+from desire_amd.spec import init_weights
+from tests.helpers import make_case, small_dims
+from tests.test_gpu_parity import oracle_forward, run_gpu, torch_cuda  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def lattice(d, seed, span=3):
+    rng = np.random.default_rng(seed)
+    cw, ch = np.float32(d.nb_w / d.grid_size), np.float32(d.nb_h / d.grid_size)
+    ij = rng.integers(-span, span + 1, (d.R, d.T_pred, 2)).astype(np.float32)
+    Y = np.empty((d.R, d.T_pred, 2), np.float32)
+    Y[..., 0] = np.float32(0.5) + cw * ij[..., 0]
+    Y[..., 1] = np.float32(0.5) + ch * ij[..., 1]
+    return Y
+
+
+CASES = [
+    (dict(), 0, 2e-4), (dict(), 2, 5e-4), (dict(), 3, 2e-4), (dict(), 1, None),
+    (dict(mno=16, n_scenes=3, K=5), 0, 2e-4), (dict(mno=16, n_scenes=3, K=5), 2, 5e-4),
+    (dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2), 0, 2e-4), (dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2), 1, None),      # 36 bins: both occupancy words
+    (dict(nb_w=0.1, nb_h=0.1, K=2, T_pred=40), 0, 2e-4),                                                               # the bench's window
+    (dict(mno=64, n_scenes=1, K=2, n_grids=1), 0, 2e-4), (dict(mno=64, n_scenes=1, K=2, n_grids=1), 1, None),
+    (dict(mno=128, n_scenes=1, K=2, n_grids=1), 1, None),                                                              # bf16 cluster form (configs[2])
+    (dict(mno=96, n_scenes=1, K=2, n_grids=1, nb_w=0.1, nb_h=0.1), 1, None),
+]
+
+
+@pytest.mark.parametrize("kw,mode,tol", CASES)
+def test_ioc_neighbour_search_on_cell_edges(torch_cuda, kw, mode, tol):
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 5)
+    past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=min(3, d32.mno - 1))
+    Yin = lattice(d32, 11)
+    ref = oracle_forward(d32, w, past, fut, eps, grids, gos, Y_override=Yin, ioc_q=O.bf16_round if mode == 1 else None)
+    _, Y, score = run_gpu(torch_cuda, d32.replace(bf16=mode), w, past, fut, eps, grids, gos, Y_in=Yin)
+    scale = max(1.0, float(np.abs(ref["Y"] - Yin).max()))
+    err = float(np.abs(Y - ref["Y"]).max())
+    print("mode %d: max|Y - oracle| = %.2e (offset scale %.2e)" % (mode, err, scale))
+    assert err < (tol if tol is not None else 7e-3) * scale, err          # bf16 operands: the per-pass budget of test_gpu_bf16.py
+    assert np.abs(score - ref["score"]).max() < (2e-2 if tol is None else 2e-3) * max(1.0, np.abs(ref["score"]).max())
