@@ -447,6 +447,15 @@ __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v
 // the piece images take 8-byte writes, and the per-element stream offsets shrink to four per stream (the row-major kernel of round 3
 // spilled 54 dwords of them and took 4.3 ms longer per 81 920-row step).  Bias column sums by a butterfly over the rows (colsum16).
 // ------------------------------------------------------------------------------------------------------------------
+// gate / candidate contractions of the BPTT step: BWDX3_RD k-groups of pack fragments in flight (0 = mmax_groups: one group ahead)
+#ifndef BWDX3_RD
+#define BWDX3_RD 0
+#endif
+#if BWDX3_RD > 0
+#define BWDX3_MM(NB) mmax_groups_ring<NB, 2, true, BWDX3_RD>
+#else
+#define BWDX3_MM(NB) mmax_groups<NB, 2, true>
+#endif
 #ifdef DESIRE_IOC_TIMING
 #define TICKB(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
 #else
@@ -699,10 +708,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             if (cb == 0) {                                        // (the e_v tile rides on the same fragment stream: one latency chain for this wave, not two)
                 f32x16 t3[3] = {t2[0], t2[1], dev};
                 const uint4* b3[3] = {bc2[0], bc2[1], bcv[0]};
-                mmax_groups<3, 2, true>(t3, a3_lane, ILO1, b3, PLC, G16);
+                BWDX3_MM(3)(t3, a3_lane, ILO1, b3, PLC, G16);
                 t2[0] = t3[0]; t2[1] = t3[1]; dev = t3[2];
             } else
-                mmax_groups<2, 2, true>(t2, a3_lane, ILO1, bc2, PLC, G16);
+                BWDX3_MM(2)(t2, a3_lane, ILO1, bc2, PLC, G16);
             der = t2[1];
             float sc_r[16];
 #pragma unroll
@@ -733,10 +742,10 @@ __global__ __launch_bounds__((H / 32) * 64, 2) void k_ioc_bwd_x3(IocBwdArgs a) {
             if (cb == 0) {
                 f32x16 t3[3] = {t2[0], t2[1], dev};
                 const uint4* b3[3] = {bg2[0], bg2[1], bgv[0]};
-                mmax_groups<3, 2, true>(t3, a2_lane, ILO2, b3, PLG, G32);
+                BWDX3_MM(3)(t3, a2_lane, ILO2, b3, PLG, G32);
                 t2[0] = t3[0]; t2[1] = t3[1]; dev = t3[2];
             } else
-                mmax_groups<2, 2, true>(t2, a2_lane, ILO2, bg2, PLG, G32);
+                BWDX3_MM(2)(t2, a2_lane, ILO2, bg2, PLG, G32);
             float sc_p[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

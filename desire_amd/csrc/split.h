@@ -169,6 +169,37 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
     if (g < G) run(b0, g);
 }
 
+// mmax_groups with D k-groups of pack fragments in flight (ring slot = g % D, the loop over rings stays rolled; per-lane pack pointers as in
+// mmax_groups; the same products in the same order per accumulator: bit-identical results).
+template <int NB, int NP, bool SWAP, int D>
+__device__ __forceinline__ void mmax_groups_ring(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
+    uint4 b[D][NB][NP];
+    auto ld = [&](uint4 (&bb)[NB][NP], int g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) bb[nb][i] = bl[nb][i * blo + (size_t)g * 64];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < G) ld(b[d], d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(disable)
+    for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (g0 + d < G) {                                      // (wave-uniform)
+                uint4 av[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + (g0 + d) * 16);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = SWAP ? mfma_xp<NP>(b[d][nb], av, acc[nb]) : mfma_xp<NP>(av, b[d][nb], acc[nb]);
+                if (g0 + d + D < G) ld(b[d], g0 + d + D);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // mmax_groups with D k-groups of pack fragments in flight and any group count G (guarded tail; ring loop rolled; addresses = uniform base + lane * 16,
 // see mmax_ring below).  Same products in the same order per accumulator as mmax_groups.
 template <int NB, int NP, int D>
