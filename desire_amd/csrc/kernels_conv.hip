@@ -140,6 +140,8 @@ void launch_conv3(const ConvArgs& a, hipStream_t s) {
 // Workgroup = 4 samples; wave = (co-half hf = w&1, sample pair sp = w>>1).
 // M-tile rows = (sample s in {0,1}, input pixel p in 0..15); A (K=128) lives in 64 VGPRs.
 // ------------------------------------------------------------------------------------------------
+// (Measured and dropped, round 5: a one-off half-tap stagger of the second workgroup of every CU -- by dispatch order or by the hardware wave slot --
+// in case the two co-resident workgroups ran their scatters in lock-step: 19.64 -> 19.64 - 20.06 ms, the phases are not aligned to begin with.)
 // (Measured and dropped: two taps interleaved into two accumulators -- the 64-deep dependent chain per tap is ~12 % of the kernel, but
 // with the LDS scatter the paired form was slower)
 template <bool FWD>
