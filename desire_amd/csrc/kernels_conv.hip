@@ -142,6 +142,8 @@ void launch_conv3(const ConvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // (Measured and dropped, round 5: a one-off half-tap stagger of the second workgroup of every CU -- by dispatch order or by the hardware wave slot --
 // in case the two co-resident workgroups ran their scatters in lock-step: 19.64 -> 19.64 - 20.06 ms, the phases are not aligned to begin with.)
+// (Measured and dropped, round 5: the tap's K = 128 as two interleaved chains over its halves, summed at the end -- 19.65 -> 23.3 ms: the chain consumes
+// the B fragments in the order they were requested, the interleaved form needs fragment 8 first; `-amdgpu-sched-strategy=max-ilp` for this file: 20.8 ms.)
 // (Measured and dropped: two taps interleaved into two accumulators -- the 64-deep dependent chain per tap is ~12 % of the kernel, but
 // with the LDS scatter the paired form was slower)
 template <bool FWD>
