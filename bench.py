@@ -95,6 +95,7 @@ def main():
                          "on the rows that have a neighbour in the bin only; NOT the headline (fewer flops are executed than the "
                          "dense formula credits)")
     ap.add_argument("--flags", type=int, default=0, help="dims.flags (DESIRE_FLAG_* of include/desire_hip.h), for A/B runs")
+    ap.add_argument("--ioc_form", type=int, default=0, help="dims.ioc_form (DESIRE_IOC_* of include/desire_hip.h), for A/B runs")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step's launch sequence from a hipGraph (desire_graph_*; 1 GPU): for launch-bound shapes such as "
                          "`--windows 2` (configs[4] puts 2 windows on each of 8 GPUs)")
@@ -149,7 +150,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     d = Dims(n_scenes=a.windows, mno=a.mno, bf16=3 if a.x6 else 2 if a.split else int(a.bf16), bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[a.bn], K=a.K, T_obs=8, T_pred=40, H=a.H, L=128, n_grids=1, grid_size=a.grid,
-             nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1, ioc_form=8 if a.compact else 0, flags=a.flags)
+             nb_w=a.nb, nb_h=a.nb, sx=1.0 / 1400.0, sy=1.0 / 1100.0, iters=1, posterior=1, ioc_form=8 if a.compact else a.ioc_form, flags=a.flags)
     w = init_weights(d, a.seed)
     past, fut, eps, grids, gos = make_case(d, seed=a.seed + 1 + rank, n_absent=0)
     if a.data == "sdd":
