@@ -106,3 +106,16 @@ def test_one_hip_runtime_in_the_process_whatever_the_import_order():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert p.stdout.strip().splitlines()[-1] == "1", p.stdout
+
+
+def test_per_file_flags_are_part_of_the_build_hash(monkeypatch):
+    """A library built with other per-file code-generation flags (desire_amd/_build.py FILE_FLAGS, round 5) is another build: the hash the
+    library reports (desire_build_hash) and the tree's must then differ, so a stale object cannot pass for the tree."""
+    from desire_amd import _build
+    h0 = _build.source_hash()
+    flags = dict(_build.FILE_FLAGS)
+    flags["kernels_rnn.hip"] = ["-mllvm", "-sink-insts-to-avoid-spills"]
+    monkeypatch.setattr(_build, "FILE_FLAGS", flags)
+    assert _build.source_hash() != h0
+    monkeypatch.setattr(_build, "FILE_FLAGS", {})
+    assert _build.source_hash() != h0
