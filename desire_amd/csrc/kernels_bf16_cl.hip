@@ -122,22 +122,26 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
 
         for (int it = 0; it < a.iters; ++it) {
             if (it > 0) group_wait(cnt, tpg * (it * (a.T + 1)), a.err);          // everybody's Y += dY has landed
+            // opaque per-pass copies of the tile's row bases: the prologue / epilogue address math depends on them, so it cannot be hoisted
+            // out of the pass and sit in (spilled) registers across the whole time loop (kernels_bf16.hip does the same)
+            int row0p, grow0p;
+            asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(row0p), "=s"(grow0p) : "s"(row0), "s"(grow0));
             f32x16 h, sp = zero16();
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                h[i] = a.Hx[(size_t)agent_of_row(row0 + arow + (i & 3) + 8 * (i >> 2), a.K, a.mno) * a.ldhx + col];
+                h[i] = a.Hx[(size_t)agent_of_row(row0p + arow + (i & 3) + 8 * (i >> 2), a.K, a.mno) * a.ldhx + col];
             __syncthreads();                                  // previous pass's readers of Xb / Ht are done
             publish_h(h, false, 0u);
             // h_{-1} = Hx of the OTHER tiles' agents: every member computes it itself (no hand-off before step 0)
             for (int i = tid; i < a.mno * (H >> 2); i += NTHR) {
                 const int j = i / (H >> 2), c4 = i - j * (H >> 2);
                 if ((j >> 5) == tile_pos) continue;
-                const float4 v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(grow0 + j, a.K, a.mno) * a.ldhx + c4 * 4);
+                const float4 v = *reinterpret_cast<const float4*>(a.Hx + (size_t)agent_of_row(grow0p + j, a.K, a.mno) * a.ldhx + c4 * 4);
                 Ht[(c4 * 4 + 0) * LDT + j] = bf16_of(v.x); Ht[(c4 * 4 + 1) * LDT + j] = bf16_of(v.y);
                 Ht[(c4 * 4 + 2) * LDT + j] = bf16_of(v.z); Ht[(c4 * 4 + 3) * LDT + j] = bf16_of(v.w);
             }
             if (tid < TM) {
-                const int ag = agent_of_row(row0 + tid, a.K, a.mno);
+                const int ag = agent_of_row(row0p + tid, a.K, a.mno);
                 pp[tid * 2] = a.p_last[(size_t)ag * 2]; pp[tid * 2 + 1] = a.p_last[(size_t)ag * 2 + 1];
             }
 
@@ -150,7 +154,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 const float qn = __int_as_float(0x7fc00000);
                 pgv[tid] = vld[tid] ? ynx : make_float2(qn, qn);              // (vld[tid] was written by this thread)
             };
-            if (tid < a.mno) { ynx = *reinterpret_cast<const float2*>(a.Y + (size_t)(grow0 + tid) * a.T * 2); put_positions(); }
+            if (tid < a.mno) { ynx = *reinterpret_cast<const float2*>(a.Y + (size_t)(grow0p + tid) * a.T * 2); put_positions(); }
             for (int i = tid; i < TM * LDM * 2; i += NTHR) masks[i] = 0ull;
             if (tid < 2) occ[tid] = 0;
             __syncthreads();
@@ -502,11 +506,12 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 if (c31 == 0) red[cb * TM + arow + (i & 3) + 8 * (i >> 2)] = v;
             }
             __syncthreads();
+            asm volatile("s_mov_b32 %0, %1" : "=s"(row0p) : "s"(row0));           // (again opaque: the epilogue's addresses are formed here)
             if (tid < TM && it == a.iters - 1) {
                 float sc = 0.f;
 #pragma unroll
                 for (int c = 0; c < NT; ++c) sc += red[c * TM + tid];
-                a.score[row0 + tid] = sc + (float)a.T * a.b_score[0];
+                a.score[row0p + tid] = sc + (float)a.T * a.b_score[0];
             }
             // ---- regression: Y += h_T W_r + b_r ----
             // (every member has published step T-1, i.e. is past its own load of the group's positions Y[.][T-1]: only now may my rows
@@ -522,7 +527,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                     const float bb = a.b_reg[cc];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float* y = a.Y + (size_t)(row0 + arow + (i & 3) + 8 * (i >> 2)) * 2 * a.T + cc;
+                        float* y = a.Y + (size_t)(row0p + arow + (i & 3) + 8 * (i >> 2)) * 2 * a.T + cc;
                         *y = *y + (acc[0][0][i] + bb);
                     }
                 }
