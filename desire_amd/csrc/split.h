@@ -200,6 +200,42 @@ __device__ __forceinline__ void mmax_groups_ring(f32x16 (&acc)[NB], const u16* a
     }
 }
 
+// TWO row blocks against ONE n-tile of a pack: acc[m] += A_m[32 x 16G] . B[16G x 32], m = 0, 1 (images of block m at ap + m * amo), every pack
+// fragment fetched ONCE and feeding both blocks (2 * Pairs MFMAs per fetched k-group instead of Pairs), D k-groups in flight (ring slot = g % D,
+// ring loop rolled).  Per accumulator the products and their order are those of mmax_groups: bit-identical results.
+template <int NP, int D>
+__device__ __forceinline__ void mmax_rows2_ring(f32x16 (&acc)[2], const u16* ap, int amo, int alo, const uint4* bl, size_t blo, int G) {
+    uint4 b[D][NP];
+    auto ld = [&](uint4 (&bb)[NP], int g) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) bb[i] = bl[i * blo + (size_t)g * 64];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < G) ld(b[d], d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(disable)
+    for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (g0 + d < G) {                                      // (wave-uniform)
+                uint4 a0[NP], a1[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    a0[i] = *reinterpret_cast<const uint4*>(ap + i * alo + (g0 + d) * 16);
+                    a1[i] = *reinterpret_cast<const uint4*>(ap + amo + i * alo + (g0 + d) * 16);
+                }
+#pragma unroll
+                for (int pr = 0; pr < Pairs<NP>::N; ++pr) {        // the two blocks alternate on the pipe (independent accumulators)
+                    acc[0] = mfma16(a0[Pairs<NP>::A[pr]], b[d][Pairs<NP>::B[pr]], acc[0]);
+                    acc[1] = mfma16(a1[Pairs<NP>::A[pr]], b[d][Pairs<NP>::B[pr]], acc[1]);
+                }
+                if (g0 + d + D < G) ld(b[d], g0 + d + D);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // mmax_groups with D k-groups of pack fragments in flight and any group count G (guarded tail; ring loop rolled; addresses = uniform base + lane * 16,
 // see mmax_ring below).  Same products in the same order per accumulator as mmax_groups.
 template <int NB, int NP, int D>
