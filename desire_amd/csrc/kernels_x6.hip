@@ -433,7 +433,8 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv1_x6(GemmArgs a) {          
 #if X6_ROWS2_RD > 0
         // both row blocks per fetched weight fragment, X6_ROWS2_RD k-groups in flight (was: the blocks one after the other, each streaming the
         // n-tile's fragments again).  Same-box A/B, 327 680 rows: deconv1 1.67 (old) / 1.66 (2 in flight) / 1.86 (4, 8) ms -- the kernel waits for its
-        // 2.7 GB of output stores, not for fragments; the mask fc 0.79 / 0.73 / 0.70 ms
+        // 2.7 GB of output stores, not for fragments; the mask fc 0.79 / 0.73 / 0.70 ms.  (Also measured: the ring run ACROSS the wave's n-tiles, so that
+        // no fragment is requested behind a tile's 32 stores per lane -- vmcnt retires in order -- 1.60 -> 1.90 ms.  More loads in flight only hurt here.)
         mmax_rows2_ring<3, X6_ROWS2_RD>(acc2, a8, 32 * LDB6, ILO6, Bp + ((size_t)nt * G16) * 64 + lane, plo, G16);
         f32x16 acc[2][1] = {{acc2[0]}, {acc2[1]}};
 #else
