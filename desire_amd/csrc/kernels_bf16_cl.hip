@@ -13,6 +13,11 @@
 // Pooling is split over BINS between the waves of a tile (H <= 128): a bin's first chain link is run once, by its owner wave, and the
 // partial e_r tiles are summed through exchange slots that live INSIDE the Ht tile (dead between the pooling and the end of the step).
 // Grid: persistent, a multiple of tpg, never more workgroups than are co-resident (occupancy query), members adjacent.
+// Round 5 (docs/DESIGN_DETAIL.md section 13, "Fourth step"): the exchange moves in 16-byte write-through units (a tile's column is stored in the order
+// publish_h documents, so a lane's sixteen values are two stores), all of a thread's peer chunks in flight; the neighbour search is batched and
+// branch-free (common.h: neighbor_bin_rect_nb over NaN-marked positions); the next step's positions / cleared masks are installed behind the
+// barriers of the current step (no barrier at the top of a step); the file is built with -sink-insts-to-avoid-spills and forms its prologue /
+// epilogue addresses from per-pass opaque row bases: 1 spilled register where there were 190.  6.15 -> 4.73 ms at configs[2]'s shape.
 #include "bf16.h"
 #include "cluster.h"
 #include "kernels.h"
