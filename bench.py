@@ -13,7 +13,8 @@ grid 64x64x32; `--windows` windows (DataLoader batch entries, each its own scene
 Multi-GPU: windows are independent scenes (social pooling never crosses a window), so they shard
 across ranks with NO data-path collective; weak scaling (fixed windows per GPU).  Timing: barrier +
 torch.cuda.synchronize() on both sides of exactly K steps, max over ranks, rank 0 prints one JSON
-line.  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
+line LAST on stdout, kept under 4 KB (benchlib/emit.py: the complete record with every extra leg goes to
+bench_full.json and to an earlier stdout line prefixed `#full `).  The line also carries `roofline` (dominant kernel k_ioc vs the fp32 MFMA peak, duration from
 hipEvents on the launch stream over the timed steps) and `cpu_baseline` (the numpy oracle timed on
 this host on a bounded sample: 8 windows = 5120 samples).  Default: 512 windows per step per GPU.
 """
@@ -33,6 +34,7 @@ from benchlib.common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, HBM_P
                              sdd_windows)
 from benchlib.legs_alt import (bf16_config2_leg, config3_shape_leg, few_windows_leg, operand_form_legs, reference_defaults_leg, sdd_leg,  # noqa: E402,F401
                                training_step_leg, with_loader_leg)
+from benchlib.emit import emit  # noqa: E402
 from benchlib.legs_cpu import cpu_baseline  # noqa: E402
 from benchlib.legs_dist import agent_sharded_comm, agent_sharded_setup, multi_rank_legs  # noqa: E402
 
@@ -308,7 +310,7 @@ def main():
         samples = d.R * world * a.steps
         fwd = sum(v for k, v in kern_ms.items() if not k.startswith("bwd_"))
         bwd = sum(v for k, v in kern_ms.items() if k.startswith("bwd_"))
-        print(json.dumps({
+        emit({
             "metric": "TRAINING agent-trajectory-samples/sec (K=20, T_pred=40; fwd+bwd+allreduce+clip+Adam+repack)",
             "value": samples / dt, "unit": "samples/s", "n_gpus": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -317,7 +319,7 @@ def main():
                                    "; dims.bf16 = 2: k_ioc_x3 forward (fp32 saves), k_ioc_bwd_x3, k_gemm_tn2_xp, k_conv_gather_x3, six-product sample generation; the remaining backward kernels fp32" if a.split else ""),
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": "scene-sharded x%d, flat-gradient all-reduce" % world},
             "forward_ms": fwd, "backward_ms": bwd, "kernel_ms": kern_ms,
-            "whole_step_tflops_3x_forward_credit": 3 * whole_tflops}))
+            "whole_step_tflops_3x_forward_credit": 3 * whole_tflops})
     elif rank == 0:
         samples = d.R * world * a.steps
         out = {
@@ -419,9 +421,9 @@ def main():
     # region, into the same line (benchlib/legs_dist.py: multi_rank_legs; one watchdog bounds them all)
     if world > 1 and a.shard == "scenes" and not (a.train or a.graph):
         multi_rank_legs(out if rank == 0 else None, a, d, w, grids_t, rank, world, dev, stream, fence,
-                        lambda: print(json.dumps(out), flush=True))
+                        lambda: emit(out))
     if rank == 0 and not a.train:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         try:
             dist.destroy_process_group()

@@ -55,3 +55,44 @@ def test_profile_summaries_of_this_round_are_per_launch_class():
             assert "workgroups" in c and "workgroup_size" in c and "[wgs=" in name, (p, name)
             if "SQ_WAVES" in c:
                 assert int(round(c["SQ_WAVES"])) == c["waves_expected"], (p, name, c["SQ_WAVES"], c["waves_expected"])
+
+
+def test_the_drivers_line_stays_small():
+    """the 23 KB one-line record of round 5 (committed: profiles/r05_bench_default_full.json) did not parse on the driver's side.
+    benchlib/emit.py reduces it to the contract keys + a few scalars per leg, under 4 KB, and prints it LAST; the whole record goes to a `#full` line
+    and to bench_full.json."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    from benchlib.emit import LINE_BUDGET, compact, emit
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_full.json")) as f:
+        rec = json.load(f)
+    assert len(json.dumps(rec)) > 20000
+    line = compact(rec)
+    assert len(json.dumps(line)) <= LINE_BUDGET
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "step_ms_median", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "accuracy"):
+        assert k in line, k
+    assert line["value"] == rec["value"] and line["ms_per_step"] == rec["ms_per_step"] and line["config"] == rec["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - rec["roofline"]["frac"]) < 1e-4 and r["traffic"] > 0 and r["peak"] == 157.3
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 16 and c["value"] > 0 and "sample" in c
+    assert line["alt_ms"]["few_windows"]["windows_1"] > 0 and line["sdd"]["compact_rows_and_ioc"]["ms_per_step"] > 0
+    # a record bloated with error strings still fits
+    fat = dict(rec, alt={("leg%d" % i): {"error": "x" * 500} for i in range(60)})
+    assert len(json.dumps(compact(fat))) <= LINE_BUDGET
+    with tempfile.TemporaryDirectory() as tmp:
+        os.environ["DESIRE_BENCH_FULL"] = os.path.join(tmp, "full.json")
+        try:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                emit(rec)
+        finally:
+            del os.environ["DESIRE_BENCH_FULL"]
+        lines = buf.getvalue().splitlines()
+        assert len(lines) == 2 and lines[0].startswith("#full {") and lines[1].startswith("{") and len(lines[1]) <= LINE_BUDGET + 100
+        assert json.loads(lines[0][6:])["alt"] == rec["alt"]
+        with open(os.path.join(tmp, "full.json")) as f:
+            assert json.load(f)["sdd"] == rec["sdd"]

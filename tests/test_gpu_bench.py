@@ -13,10 +13,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _line(out):
+    """the driver's line: the LAST stdout line, the only one that starts with `{`, small enough for the driver's parser"""
+    all_lines = [l for l in out.splitlines() if l.strip()]
+    lines = [l for l in all_lines if l.startswith("{")]
+    assert len(lines) == 1 and all_lines[-1] == lines[0], out[-2000:]
+    assert len(lines[0]) < 6000, len(lines[0])
+    o = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in o, k
+    return o
+
+
 def _last_json(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-2000:]
-    return json.loads(lines[0])
+    """the complete record (every leg with its notes and per-kernel tables): the `#full ` line printed before the driver's line; its contract keys
+    must be the ones the driver's line carries"""
+    line = _line(out)
+    full = [l for l in out.splitlines() if l.startswith("#full ")]
+    assert len(full) == 1, out[-2000:]
+    o = json.loads(full[0][len("#full "):])
+    for k in REQUIRED:
+        assert o[k] == line[k], k
+    for k in ("roofline", "cpu_baseline", "accuracy"):
+        assert (k in o) == (k in line), k
+    if "roofline" in o and o["roofline"].get("frac") is not None:
+        assert abs(line["roofline"]["frac"] - o["roofline"]["frac"]) < 1e-4 * abs(o["roofline"]["frac"])
+        assert abs(line["roofline"]["achieved"] - o["roofline"]["achieved"]) < 1e-4 * abs(o["roofline"]["achieved"])
+    return o
 
 
 def test_default_contract_fields():
@@ -26,9 +52,20 @@ def test_default_contract_fields():
     p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--windows", "16"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
+    line = _line(p.stdout)
+    for k in REQUIRED + ("roofline", "cpu_baseline", "accuracy", "step_ms_median"):
+        assert k in line, k
+    lr, lc = line["roofline"], line["cpu_baseline"]
+    assert lr["bound"] == "mfma" and 0 < lr["frac"] < 1 and abs(lr["frac"] - lr["achieved"] / lr["peak"]) < 1e-3 and lr["unit"] == "TFLOP/s" and "traffic" in lr
+    assert lc["kind"] == "port" and lc["value"] > 0 and lc["cores"] >= 1 and lc["sample"] and lc["unit"]
+    assert line["accuracy"]["max_abs_err_Y"] < line["accuracy"]["gate"] == 1e-3
+    assert line["sdd"]["ms_per_step"] > 0 and line["alt_ms"]["few_windows"]["windows_1"] > 0 and line["alt_ms"]["training_step"]["fp32"] > 0
+    assert 0 < line["alt_figures"]["bf16_config2_mno128_ioc_frac_of_bf16_peak"] < 1
+    assert os.path.exists(os.path.join(ROOT, line["full_record"]))
+    with open(os.path.join(ROOT, line["full_record"])) as f:
+        assert json.load(f)["value"] == line["value"]
     o = _last_json(p.stdout)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "accuracy"):
+    for k in ("roofline", "cpu_baseline", "accuracy"):
         assert k in o, k
     assert o["n_gpus"] == 1 and o["steps"] == 2 and o["warmup"] == 1 and o["vs_baseline"] is None and o["scaling"] == "weak"
     r = o["roofline"]
