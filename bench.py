@@ -144,7 +144,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # launched by torch.distributed.run (RANK / MASTER_PORT in the environment): the process group is created at world_size 1 too, so that
+    # `--gpus 1` under the launcher runs its barrier / all-reduces through RCCL like the N > 1 lines do (tests/test_gpu_nccl.py)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
             dist.init_process_group("gloo")
@@ -217,7 +220,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -246,7 +249,7 @@ def main():
         halves[0]["h"].set_profiling(False)
         prof = halves[0]["h"].get_profile()
     ranks_seen = 1
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -333,7 +336,7 @@ def main():
                                    "social grid 4x4, scene grid 64x64x32; %d windows/step/GPU" % a.windows,
                        "windows_per_gpu": a.windows, "rows_per_gpu": d.R, "parallelism": ("scene-sharded x%d" % world) if a.shard == "scenes" else
                                       ("agent-sharded x%d: %d slots/rank of %d-agent scenes, RCCL all-gather of [R_loc, H] per IOC step" % (world, d.mno, d.mno * world)),
-                       "flops_per_sample": flops_per_sample(d)},
+                       "flops_per_sample": flops_per_sample(d), "collective_backend": dist.get_backend() if use_dist else None},
             "roofline": {"bound": "mfma", "kernel": "k_ioc_bf16<128,16,32,1,false>" if a.bf16 else "k_ioc<%d,16,32,32,false,%s>" % (d.H, "true" if a.compact else "false"), "achieved": ioc_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": (ioc_tflops / peak) if ioc_tflops else None,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic else None,
@@ -424,7 +427,7 @@ def main():
                         lambda: emit(out))
     if rank == 0 and not a.train:
         emit(out)
-    if world > 1:
+    if use_dist:
         try:
             dist.destroy_process_group()
         except Exception:                                         # noqa: BLE001 -- a peer that died in an extra leg: the line is already out

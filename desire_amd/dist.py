@@ -42,15 +42,15 @@ def gather_results(local, n_windows: int, group=None):
     return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0)
 
 
-def allreduce_mean_(flat, group=None):
+def allreduce_mean_(flat, group=None, force: bool = False):
     """In-place mean of ONE flat gradient tensor over the data-parallel ranks (no-op when torch.distributed is not
-    initialised or world_size == 1).  Each rank's loss is a mean over ITS present agents, so this is the usual
+    initialised or world_size == 1; `force` issues the collective at world_size 1 too: tests/test_gpu_nccl.py runs RCCL on a one-GPU box).  Each rank's loss is a mean over ITS present agents, so this is the usual
     data-parallel estimate of the global-batch gradient.  RCCL over xGMI on GPU tensors, gloo on CPU tensors."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / world)
@@ -58,12 +58,13 @@ def allreduce_mean_(flat, group=None):
 
 
 # ---- agent-sharded IOC: the north_star's "RCCL all-gather only for the social-pooling neighbour exchange" -------------
-def all_gather_stack(t, group=None):
+def all_gather_stack(t, group=None, force: bool = False):
     """[...] on every rank -> [world, ...] on every rank (rank-major), one all_gather_into_tensor (RCCL on GPU tensors,
-    gloo on CPU tensors); the identity stack when torch.distributed is not initialised."""
+    gloo on CPU tensors); the identity stack when torch.distributed is not initialised or the world is one rank (`force`: the
+    collective is issued at world_size 1 as well -- how a one-GPU box executes the RCCL path, tests/test_gpu_nccl.py)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return t.unsqueeze(0).contiguous()
     world = dist.get_world_size(group)
     t = t.contiguous()

@@ -24,6 +24,49 @@ def lattice(d, seed, span=3):
     return Y
 
 
+def coincident(d, seed):
+    """agents that coincide or sit 1..3 ulps apart, neighbours exactly on / one ulp off the window edges, and -- second half of
+    the steps -- observers at x = window / 2 (so the window's low edge is exactly 0) with neighbours at SUBNORMAL coordinates: x_j - low is then a
+    denormal numerator of the reciprocal division (fp32 denormals are on in every kernel; the quotient may differ from IEEE's there, the cell may not:
+    tests/test_div_by.py::test_subnormal_numerators_land_in_the_same_cell)."""
+    rng = np.random.default_rng(seed)
+    hw, hh = np.float32(d.nb_w) / np.float32(2), np.float32(d.nb_h) / np.float32(2)
+    Y = np.empty((d.R, d.T_pred, 2), np.float32)
+    for ax, half in ((0, hw), (1, hh)):
+        c = np.float32(0.5)
+        pick = rng.integers(0, 5, (d.R, d.T_pred))
+        base = np.choose(pick, [c, c + half, c - half, c, c + half]).astype(np.float32)
+        ulps = rng.integers(-3, 4, (d.R, d.T_pred))
+        v = base.copy()
+        for _ in range(3):
+            v = np.where(ulps > 0, np.nextafter(v, np.float32(2)), np.where(ulps < 0, np.nextafter(v, np.float32(-2)), v)).astype(np.float32)
+            ulps = ulps - np.sign(ulps)
+        tiny = (rng.integers(0, 64, (d.R, d.T_pred)).astype(np.uint32) * np.uint32(1 << 17)).view(np.float32)         # subnormals (and +0)
+        second = np.where(rng.integers(0, 2, (d.R, d.T_pred)) == 0, half, tiny).astype(np.float32)
+        t_half = d.T_pred // 2
+        v[:, t_half:] = second[:, t_half:]
+        Y[..., ax] = v
+    return Y
+
+
+@pytest.mark.parametrize("kw,mode", [(dict(), 0), (dict(), 2), (dict(), 3), (dict(), 1), (dict(mno=16, n_scenes=3, K=5), 0), (dict(mno=64, n_scenes=1, K=2, n_grids=1), 0),
+                                     (dict(mno=128, n_scenes=1, K=2, n_grids=1), 1), (dict(grid_size=6, nb_w=0.5, nb_h=0.5, K=2), 0)])
+def test_ioc_neighbour_search_on_coincident_and_denormal_separations(torch_cuda, kw, mode):
+    from oracle import desire_oracle as O
+    d32 = small_dims(**kw)
+    w = init_weights(d32, 5)
+    past, fut, eps, grids, gos = make_case(d32, seed=6, n_absent=min(3, d32.mno - 1))
+    Yin = coincident(d32, 13)
+    assert (np.abs(Yin[Yin != 0]) < 1.2e-38).any()                       # the denormal coordinates are really there
+    ref = oracle_forward(d32, w, past, fut, eps, grids, gos, Y_override=Yin, ioc_q=O.bf16_round if mode == 1 else None)
+    _, Y, score = run_gpu(torch_cuda, d32.replace(bf16=mode), w, past, fut, eps, grids, gos, Y_in=Yin)
+    scale = max(1.0, float(np.abs(ref["Y"] - Yin).max()))
+    err = float(np.abs(Y - ref["Y"]).max())
+    tol = {0: 2e-4, 2: 5e-4, 3: 2e-4, 1: 7e-3}[mode]
+    assert err < tol * scale, err
+    assert np.abs(score - ref["score"]).max() < (2e-2 if mode == 1 else 2e-3) * max(1.0, np.abs(ref["score"]).max())
+
+
 CASES = [
     (dict(), 0, 2e-4), (dict(), 2, 5e-4), (dict(), 3, 2e-4), (dict(), 1, None),
     (dict(mno=16, n_scenes=3, K=5), 0, 2e-4), (dict(mno=16, n_scenes=3, K=5), 2, 5e-4),

@@ -1,7 +1,9 @@
-"""The RCCL code path itself (backend "nccl" on ROCm), two ranks on two GPUs: scene-sharded forward + result gather, the
-agent-sharded IOC with its per-step neighbour all-gather (plain and pipelined behind compute), and the flat-gradient
-all-reduce.  Skipped when fewer than two devices are visible (the 1-GPU test boxes); on a multi-GPU node it is the test
-that has the collectives run for real."""
+"""The RCCL code path itself (backend "nccl" on ROCm): scene-sharded forward + result gather, the agent-sharded IOC with its
+per-step neighbour all-gather (plain and pipelined behind compute), and the flat-gradient all-reduce.  Two ranks on two GPUs
+when the box has them (skipped on the 1-GPU test boxes); and ONE rank on cuda:0 with the world-size-1 short-circuits of
+desire_amd/dist.py bypassed (`force`), so that the communicator is created and every collective this code base issues --
+all_gather, all_gather_into_tensor, all_reduce, barrier -- has gone through RCCL before the driver's 8-GPU run does it
+(VERDICT r05 next 8).  `bench.py --gpus 1` under torch.distributed.run likewise initialises `nccl`."""
 import os
 import socket
 
@@ -12,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, q):
+    import functools
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -21,7 +24,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         from desire_amd import _lib
-        from desire_amd.dist import PipelinedShardedIoc, ShardedIoc, allreduce_mean_, gather_results, shard_windows
+        from desire_amd.dist import PipelinedShardedIoc, ShardedIoc, all_gather_stack, allreduce_mean_, gather_results, shard_windows
+        force = world == 1                                     # one rank: the collectives are issued all the same
+        gather = functools.partial(all_gather_stack, force=force)
         from desire_amd.spec import init_weights
         from tests.helpers import make_case, small_dims
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
@@ -57,7 +62,7 @@ def _worker(rank, world, port, q):
         hU.ioc_refine(Y0U.data_ptr(), sU.data_ptr())
         ref = Y0U.view(d.n_scenes, d.K, d.mno, d.T_pred, 2)[:, :, sl].reshape(da.R, d.T_pred, 2)
         Ya = t(ha.read_buffer("Y0", (da.R, d.T_pred, 2))); sa = torch.zeros(da.R, device=dev)
-        ShardedIoc(ha, rank, world).run(Ya, sa)
+        ShardedIoc(ha, rank, world, gather=gather).run(Ya, sa)
         torch.cuda.synchronize()
         out["agents"] = float((Ya - ref).abs().max())
         # ---- 3. the same with the gathers hidden behind a second micro-batch ----
@@ -66,7 +71,7 @@ def _worker(rank, world, port, q):
         for half in range(2):
             hs = slice(2 * half, 2 * half + 2)
             hh, tt_, _, _ = run(dh, past[hs][:, :, sl], fut[hs][:, :, sl], eps4[hs][:, :, sl].reshape(-1, d.L), gos[hs])
-            parts.append(ShardedIoc(hh, rank, world)); keep.append(tt_)
+            parts.append(ShardedIoc(hh, rank, world, gather=gather)); keep.append(tt_)
             Ys.append(t(hh.read_buffer("Y0", (dh.R, d.T_pred, 2)))); scs.append(torch.zeros(dh.R, device=dev))
         PipelinedShardedIoc(parts).run(Ys, scs)
         torch.cuda.synchronize()
@@ -82,7 +87,8 @@ def _worker(rank, world, port, q):
         mine = flat.clone()
         both = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(both, mine)
-        allreduce_mean_(flat)
+        allreduce_mean_(flat, force=force)
+        dist.barrier()
         torch.cuda.synchronize()
         out["allreduce"] = float((flat - sum(both) / world).abs().max() / (flat.abs().max() + 1e-30))
         q.put((rank, out))
@@ -90,21 +96,54 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rccl_ranks():
-    import torch
+def _run_ranks(world):
     import torch.multiprocessing as mp
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+def test_one_rccl_rank_runs_every_collective():
+    """backend "nccl" at world_size 1 on cuda:0 (own process): communicator creation + all_gather / all_gather_into_tensor / all_reduce / barrier
+    through RCCL, and the agent-sharded IOC driven through them equals the unsharded refinement."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    (rank, out), = _run_ranks(1)
+    assert out["scene"] == 0.0 and out["agents"] < 2e-6 and out["pipelined"] < 2e-6 and out["allreduce"] < 1e-6, out
+
+
+def test_bench_under_torchrun_with_one_rank_initialises_rccl():
+    import json
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "16", "--headline-only"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    o = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["n_gpus"] == 1 and o["value"] > 0 and o["config"]["collective_backend"] == "nccl"
+
+
+def test_two_rccl_ranks():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    res = _run_ranks(2)
     for rank, out in res:
         assert out["scene"] == 0.0, out                       # same kernels on the same windows: identical
         assert out["agents"] < 2e-6 and out["pipelined"] < 2e-6, out
