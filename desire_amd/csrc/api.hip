@@ -273,13 +273,15 @@ extern "C" int desire_create(const desire_dims* dims, desire_handle** out) {
         {"bn_part", d.bn_mode == 2 ? (size_t)512 * 128 * f : 0}, {"bn_stat", d.bn_mode == 2 ? (size_t)2 * 128 * f : 0},
         {"grid_of_scene", (size_t)d.n_scenes * sizeof(int32_t)},
         // desire_build_windows*: allocated here, not lazily, because a feeder thread may call the builder while the owner thread runs a forward on
-        // the same handle (desire_amd/prefetch.py: DeviceWindowFeeder) -- the builder then touches these two buffers and nothing else of the handle
+        // the same handle (desire_amd/prefetch.py: DeviceWindowFeeder) -- the builder then touches these two buffers (through h->bw_starts / h->bw_err,
+        // never through the map: other calls insert into it) and nothing else of the handle
         {"bw_starts", (size_t)d.n_scenes * sizeof(int32_t)}, {"bw_err", sizeof(int32_t)},
     };
     for (const WS& w : list) {
         if (h->ws[w.n].alloc(w.bytes)) { desire_destroy(h); return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n); }
         (void)hipMemset(h->ws[w.n].p, 0, w.bytes);
     }
+    h->bw_starts = static_cast<int32_t*>(h->ws.at("bw_starts").p); h->bw_err = static_cast<int32_t*>(h->ws.at("bw_err").p);
     if (d.bin_mode == 1) {
         // log-polar social bins: G rings with geometric radii between r_min = nb_h and r_max = nb_w, G equal sectors
         std::vector<float> tab(20, 0.f);

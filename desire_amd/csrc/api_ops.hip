@@ -96,13 +96,13 @@ extern "C" int desire_build_windows_la(desire_handle* h, const float* dev_frames
         if (host_starts[i] < 0 || host_starts[i] + d.T_obs + d.T_pred > n_frames)
             return fail(DESIRE_ERR_ARG, "window start out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // (ws.at, not ws[]: no insertion into the handle's map from this call -- it may run on a feeder thread, see desire_create)
-    HIPCHK(hipMemcpyAsync(h->ws.at("bw_starts").p, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->ws.at("bw_err").p, 0, sizeof(int32_t), s));
-    launch_build_windows(dev_frames, n_frames, mno_in, static_cast<const int32_t*>(h->ws.at("bw_starts").p), n_windows, d.T_obs,
-                         d.T_pred, d.mno, dev_past, dev_fut, static_cast<int32_t*>(h->ws.at("bw_err").p), lookahead, s);
+    // (plain pointers cached by desire_create, not the handle's map: this call may run on a feeder thread while another call inserts into the map)
+    HIPCHK(hipMemcpyAsync(h->bw_starts, host_starts, n_windows * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->bw_err, 0, sizeof(int32_t), s));
+    launch_build_windows(dev_frames, n_frames, mno_in, h->bw_starts, n_windows, d.T_obs,
+                         d.T_pred, d.mno, dev_past, dev_fut, h->bw_err, lookahead, s);
     int32_t err = 0;
-    HIPCHK(hipMemcpyAsync(&err, h->ws.at("bw_err").p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&err, h->bw_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (err & 2) return fail(DESIRE_ERR_ARG, "a window holds more unique ids than max_num_obj slots (utils/data_loader.py:227 IndexError)");
     if (err & 4) return fail(DESIRE_ERR_ARG, "a track id occurs twice in one frame of a window (utils/data_loader.py:224-229 ValueError)");

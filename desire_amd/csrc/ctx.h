@@ -72,6 +72,9 @@ struct desire_ctx {
     int ci_n = 0, ci_cls[4] = {0, 0, 0, 0}, ci_cnt[4] = {0, 0, 0, 0}; bool ci_last = false; int ci_min_rows = 8192;     // DESIRE_FLAG_COMPACT_IOC: the classes the last IOC stage ran (class index, windows)
     bool cp_enc = false;                                     // the last desire_encode ran its stack on the present agents only (saves in compact agent order)
     bool cp_last = false;                                    // the last desire_sample ran compacted (desire_backward follows it, not the flag)
+    // desire_build_windows*: plain pointers, cached at creation -- a feeder thread may run the builder while the owner thread runs a forward or a backward on
+    // the same handle (desire_amd/prefetch.py: DeviceWindowFeeder), and those insert workspace entries lazily: the builder must not walk the map
+    int32_t* bw_starts = nullptr; int32_t* bw_err = nullptr;
     std::vector<Prof> prof;
     std::vector<std::string> prof_name_store;
     // ---- training (train.hip) ----

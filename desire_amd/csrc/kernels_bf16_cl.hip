@@ -564,6 +564,9 @@ static int launch16_cl(const IocArgs& a, u16* hex16, hipStream_t s) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) return -1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     const int tpg = a.mno / 32, n_tiles = a.R / 32;
+    // the 16-byte exchange goes through a raw-buffer descriptor (32-bit size and byte offsets): an exchange buffer of 4 GB or more would wrap, and
+    // out-of-range raw-buffer accesses return 0 / are dropped instead of faulting -- refuse the shape (R * H >= 2^30 rows x columns)
+    if ((unsigned long long)2 * (unsigned long long)n_tiles * (unsigned long long)(H * 32 * 2) >= (1ull << 32)) return -1;
     long cap = (long)per_cu * prop.multiProcessorCount;
     int grid = n_tiles < cap ? n_tiles : (int)cap;           // every workgroup of the grid is resident: members of a group never wait on an unscheduled one
     grid -= grid % tpg;

@@ -58,18 +58,25 @@ def dims_from_args(args, n_scenes: int, posterior: bool = True, ref_compat: bool
         bin_mode=int(getattr(args, "social_layout", "rect") == "logpolar"),
         bn_mode={"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")],
         bf16=_operand_mode(getattr(args, "bf16", False)),
-        flags=_flags_from_args(args))                          # DESIRE_FLAG_* bits (train.py --two_piece_forward / --skip_padding, or args.dims_flags)
+        flags=_flags_from_args(args, {"frozen": 0, "per_object": 1, "batch": 2}[getattr(args, "batch_norm", "frozen")]))                          # DESIRE_FLAG_* bits: padding skipped unless --keep_padding / an explicit args.dims_flags
 
 
-def _flags_from_args(args) -> int:
-    """desire_dims.flags from the argparse Namespace: args.dims_flags as given, plus the bits of train.py's switches (so that train(args) called as a
-    function behaves like the command line)."""
+def _flags_from_args(args, bn_mode: int = 0) -> int:
+    """desire_dims.flags from the argparse Namespace.  PADDING IS SKIPPED BY DEFAULT (round 6): the loader pads every window to max_num_obj slots
+    (utils/data_loader.py:209-229; train.py:74 default 60, SDD frames hold ~8 objects) and the reference masks id-0 objects in the cost only
+    (model/model.py:351-366), so DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC -- present rows bit-identical, absent rows zeros -- is on unless
+      * args.keep_padding is set (train.py --keep_padding), or
+      * args.dims_flags is given (an int: taken literally, plus train.py's --two_piece_forward / --skip_padding bits), or
+      * the batch-norm mode is 'batch' (whole-batch statistics depend on the padding rows: the library refuses the combination)."""
     from .spec import FLAG_COMPACT_IOC, FLAG_COMPACT_ROWS, FLAG_TRAIN_FWD_3P
-    f = int(getattr(args, "dims_flags", 0) or 0)
+    given = getattr(args, "dims_flags", None)
+    f = int(given or 0)
     if getattr(args, "two_piece_forward", False):
         f |= FLAG_TRAIN_FWD_3P
-    if getattr(args, "skip_padding", False):
+    if getattr(args, "skip_padding", False) or (given is None and not getattr(args, "keep_padding", False) and bn_mode != 2):
         f |= FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC
+    if getattr(args, "keep_padding", False):
+        f &= ~(FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC)
     return f
 
 
@@ -407,7 +414,9 @@ class DESIREModel(object):
         blob = load_weights(path)
         opt = {k[4:]: blob.pop(k) for k in list(blob) if k.startswith("opt/")}
         meta = {k[5:]: blob.pop(k) for k in list(blob) if k.startswith("meta/")}
-        head_trained = bool(float(np.asarray(meta["head_trained"]).reshape(-1)[0])) if "head_trained" in meta else False     # (older archives: unknown = not trained)
+        # archives of rounds 2-4 carry no marker: the rule they were written under applies (a head that is in the archive counts as given), so a
+        # checkpoint trained with --head_loss_weight > 0 keeps sample()'s default mode 'rollout' (INTEGRATION.md "Checkpoints")
+        head_trained = bool(float(np.asarray(meta["head_trained"]).reshape(-1)[0])) if "head_trained" in meta else ("gauss_head/w" in blob)
         # archives written before an auxiliary weight existed (the sample() head "gauss_head/*" came with round 2): complete them
         # with the values init_weights draws, so an older checkpoint still loads
         d0 = dims_from_args(args, 1, True)

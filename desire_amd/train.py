@@ -66,10 +66,14 @@ def build_parser() -> argparse.ArgumentParser:
                    help="with --bf16 x3: two-piece operands in the forward pass's sample generation too (DESIRE_FLAG_TRAIN_FWD_3P: ~4 %% faster "
                         "steps, gradients within 5e-4 instead of 2e-4 of float64 autograd)")
     p.add_argument("--skip_padding", action="store_true",
-                   help="DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC: run the step on the agents that are present only -- the per-row stages on "
-                        "present rows, the IOC on slot classes (include/desire_hip.h).  On SDD windows most of max_num_obj is padding "
-                        "(utils/data_loader.py:209-229): 2.3x faster steps on bookstore/video6 at max_num_obj 32; gradients equal the padded step's "
-                        "to fp32 reduction noise.  Not with --bn batch")
+                   help="(the default since round 6; kept so that older command lines still parse) DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC: "
+                        "run the step on the agents that are present only -- the per-row stages on present rows, the IOC on slot classes "
+                        "(include/desire_hip.h).  On SDD windows most of max_num_obj is padding (utils/data_loader.py:209-229): 2.3x faster steps on "
+                        "bookstore/video6 at max_num_obj 32; gradients equal the padded step's to fp32 reduction noise")
+    p.add_argument("--keep_padding", action="store_true",
+                   help="run every one of the max_num_obj slots of every window like the reference does (it masks id-0 objects in the cost only, "
+                        "model/model.py:351-366): the opt-out of the default above.  The compacted step reads the present-agent counts back once per "
+                        "step (one host wait on an event, include/desire_hip.h)")
     p.add_argument("--head_loss_weight", type=float, default=0.0,
                    help="weight of the reference's own loss for the 5-wide Gaussian output layer (model/model.py:494-550: -log N(next position | "
                         "mux, muy, sx, sy, rho), teacher-forced over the observed frames) added to the training loss; > 0 trains gauss_head/w|b "
@@ -234,13 +238,9 @@ def _train_overlapped(args, data_loader, model, log, rank, world, t_obs, t_pred,
 
 def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
-    args.dims_flags = 0
-    if args.two_piece_forward:
-        from desire_amd.spec import FLAG_TRAIN_FWD_3P
-        args.dims_flags |= FLAG_TRAIN_FWD_3P
-    if args.skip_padding:
-        from desire_amd.spec import FLAG_COMPACT_IOC, FLAG_COMPACT_ROWS
-        args.dims_flags |= FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC
+    if args.skip_padding and args.keep_padding:
+        raise SystemExit("--skip_padding and --keep_padding exclude each other")
+    # (dims.flags are derived in desire_amd/model.py: _flags_from_args -- padding skipped unless --keep_padding)
     import torch
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

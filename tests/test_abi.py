@@ -92,6 +92,19 @@ def test_dims_from_args_reference_defaults():
     d = dims_from_args(args, 10)
     assert (d.S, d.V, d.mno, d.H, d.L, d.T_obs, d.T_pred, d.grid_size, d.B) == (32, 1024, 64, 128, 128, 8, 8, 4, 16)
     d.validate()
+    # round 6: padding is skipped by default on the drop-in surface (max_num_obj 60 against ~8 objects per SDD frame, train.py:74); the opt-outs
+    from desire_amd.spec import FLAG_COMPACT_IOC, FLAG_COMPACT_ROWS, FLAG_TRAIN_FWD_3P
+    both = FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC
+    assert d.flags == both
+    assert dims_from_args(argparse.Namespace(**vars(args), keep_padding=True), 10).flags == 0
+    assert dims_from_args(argparse.Namespace(**vars(args), dims_flags=0), 10).flags == 0                       # an explicit value is taken literally
+    assert dims_from_args(argparse.Namespace(**vars(args), dims_flags=0, skip_padding=True), 10).flags == both
+    assert dims_from_args(argparse.Namespace(**vars(args), batch_norm="batch"), 10).flags == 0                 # whole-batch statistics see the padding rows
+    assert dims_from_args(argparse.Namespace(**vars(args), batch_norm="per_object", two_piece_forward=True), 10).flags == both | FLAG_TRAIN_FWD_3P
+    assert dims_from_args(args, 10, ref_compat=True).flags == 0
+    from desire_amd.train import build_parser
+    assert dims_from_args(build_parser().parse_args([]), 10).flags == both
+    assert dims_from_args(build_parser().parse_args(["--keep_padding"]), 10).flags == 0
 
 
 def test_one_hip_runtime_in_the_process_whatever_the_import_order():

@@ -190,6 +190,13 @@ def test_default_mode_is_the_trained_path_and_old_checkpoints_load():
             warnings.simplefilter("always")
             m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
         assert not any("gauss_head" in str(r.message) for r in rec)
+        # an archive of rounds 2-4 (head inside, no marker): the rule it was written under still applies -- the head counts as given
+        save_weights(os.path.join(td, "legacy.npz"), {k: v for k, v in blob.items() if not k.startswith("meta/")})
+        m6 = DESIREModel.restore(args, os.path.join(td, "legacy.npz"))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m6.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout")
+        assert m6._head_given and not any("gauss_head" in str(r.message) for r in rec)
         nrm = np.random.default_rng(1).standard_normal((6, 16, 2)).astype(np.float32)
         np.testing.assert_array_equal(m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, normals=nrm),
                                       m5.sample(None, traj, None, (1400.0, 1100.0), truth, num=6, mode="rollout", normals=nrm))

@@ -47,7 +47,7 @@ def _synthetic_video(n_frames, mno, n_ids, rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("operands", ["", "x3", "skip", "x3+skip"])      # fp32; split-bf16 operands (dims.bf16 = 2); --skip_padding (DESIRE_FLAG_COMPACT_*)
+@pytest.mark.parametrize("operands", ["", "x3", "keep", "x3+keep"])      # fp32; split-bf16 operands (dims.bf16 = 2); padding skipped (the default: DESIRE_FLAG_COMPACT_*) / --keep_padding
 def test_training_loop_runs_saves_and_learns(tmp_path, operands):
     from desire_amd.data_loader import DataLoader
     from desire_amd.model import DESIREModel
@@ -57,7 +57,7 @@ def test_training_loop_runs_saves_and_learns(tmp_path, operands):
                                      "--d_dim", "64", "--latent_size", "64", "--num_samples", "3", "--num_epochs", "3",
                                      "--save_every", "5", "--learning_rate", "0.0005", "--neighborhood_size", "256",
                                      "--save_dir", str(tmp_path / "save")] + (["--bf16", "x3"] if "x3" in operands else []) +
-                                    (["--skip_padding"] if "skip" in operands else []))
+                                    (["--keep_padding"] if "keep" in operands else []))
     dl = DataLoader(a.batch_size, a.seq_length + a.pred_length, a.max_num_obj, frames=frames)
     assert dl.num_batches > 0
     import random
