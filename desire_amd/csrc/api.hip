@@ -223,12 +223,17 @@ extern "C" int desire_set_option(desire_handle* h, const char* name, int32_t val
     else if (nm == "ioc_split") d.ioc_split = value;
     else if (nm == "train_fp32_mask") d.train_fp32_mask = value;
     else if (nm == "flags") d.flags = value;
+    else if (nm == "compact_host_counts") {    // DESIRE_FLAG_COMPACT_*, inference: 1 = read the scans' counts back and size the launches exactly (one host wait per
+        h->cp_host_counts = value != 0;        // desire_encode, not capturable -- what training always does); 0 (default) = device-side counts (kernels.h: DynCount)
+        h->cp_pending = false; h->cp_enc = false;
+        return DESIRE_OK;
+    }
     else if (nm == "compact_min_rows") {       // DESIRE_FLAG_COMPACT_IOC: a slot class with fewer rows than this is folded into the next larger one (default 8192)
         if (value < 0) return fail(DESIRE_ERR_ARG, "compact_min_rows must be >= 0");
         h->ci_min_rows = value;
         return DESIRE_OK;
     }
-    else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags, compact_min_rows)");
+    else return fail(DESIRE_ERR_ARG, "unknown option: " + nm + " (ioc_form, ioc_split, train_fp32_mask, flags, compact_min_rows, compact_host_counts)");
     if (int rc = check_options(d)) return rc;
     if ((d.flags ^ h->d.flags) & (DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC)) {
         h->cp_pending = false; h->cp_enc = false;       // the maps of the last desire_encode were built for the other setting: a new desire_encode comes first

@@ -37,15 +37,35 @@ int compact_classes(const desire_ctx* h, int* m4) {         // slot classes: the
     for (int i = n; i < 4; ++i) m4[i] = h->d.mno;
     return n;
 }
+// DEVICE-SIDE COUNTS (round 6): in inference with frozen batch-norm the host never learns how many agents are present -- every compacted launch is
+// sized for the worst case and reads its count from the scans' device words (kernels.h: DynCount), so a compacted call has no host wait and can be
+// captured in a hipGraph.  Training keeps the read-back (its backward sizes two dozen reductions from P), and so do per-sample batch statistics
+// (bn_mode 1: the normalisation kernels are not count-aware) and desire_set_option("compact_host_counts", 1) -- the A/B switch.
+bool compact_dyn(const desire_ctx* h) { return !h->training && h->d.bn_mode == 0 && !h->cp_host_counts; }
+// worst case of one slot class: every window of the batch seated in it
+static size_t class_rows_worst(const desire_ctx* h, int m_c) {
+    const int gpt = (m_c <= 32 && 32 % m_c) ? 32 / m_c : 0;
+    const size_t ngrp = (size_t)h->d.n_scenes * h->d.K;
+    return gpt ? ((ngrp + gpt - 1) / gpt) * 32 : ngrp * m_c;
+}
 int compact_setup(desire_ctx* h) {
     const desire_dims& d = h->d;
     const size_t A = h->A, R = h->R, f = sizeof(float);
+    // slot-class buffers: with device-side counts a class's region starts at a STATIC offset (the sum of the worst cases of the classes before it)
+    size_t Ac = A, Rc = R + 128, Wc = (size_t)d.n_scenes;
+    if (d.flags & DESIRE_FLAG_COMPACT_IOC) {
+        int m4[4];
+        const int n_cls = compact_classes(h, m4);
+        Ac = 0; Rc = 0; Wc = 0;
+        for (int c = 0; c < n_cls; ++c) { Ac += (size_t)d.n_scenes * m4[c]; Rc += class_rows_worst(h, m4[c]); Wc += (size_t)d.n_scenes; }
+        Ac = std::max(Ac, A); Rc = std::max(Rc, R + 128);
+    }
     struct WS { const char* n; size_t bytes; };
     const WS list[] = {{"cp_amap", A * sizeof(int32_t)}, {"cp_inv", A * sizeof(int32_t)}, {"cp_count", 8 * sizeof(int32_t)}, {"cp_HxHy", A * 2 * d.H * f},
                        {"cp_plast", A * 2 * f}, {"cp_params", A * 2 * d.L * f}, {"cp_Y0", R * (size_t)d.T_pred * 2 * f},
                        {"cp_past", A * (size_t)d.T_obs * 3 * f}, {"cp_fut", A * (size_t)d.T_pred * 3 * f}, {"cp_valid2", A}};
-    const WS list_ioc[] = {{"ci_win", 4 * (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_map", 4 * A * sizeof(int32_t)}, {"ci_Hx", A * 2 * d.H * f}, {"ci_pl", A * 2 * f},
-                           {"ci_valid", A}, {"ci_gos", (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_Y", (R + 128) * (size_t)d.T_pred * 2 * f}, {"ci_score", (R + 128) * f}};      // (+ a partial padded tile per class)
+    const WS list_ioc[] = {{"ci_win", 4 * (size_t)d.n_scenes * sizeof(int32_t)}, {"ci_map", 4 * A * sizeof(int32_t)}, {"ci_Hx", Ac * 2 * d.H * f}, {"ci_pl", Ac * 2 * f},
+                           {"ci_valid", Ac}, {"ci_gos", Wc * sizeof(int32_t)}, {"ci_Y", Rc * (size_t)d.T_pred * 2 * f}, {"ci_score", Rc * f}};      // (+ a partial padded tile per class)
     for (const WS& w : list)
         if (!h->ws[w.n].p && h->ws[w.n].alloc(w.bytes)) return fail(DESIRE_ERR_HIP, std::string("hipMalloc failed for ") + w.n);
     if (h->d.flags & DESIRE_FLAG_COMPACT_IOC)
@@ -72,13 +92,14 @@ static int compact_scans(desire_ctx* h, hipStream_t s) {
         launch_class_scan(static_cast<const uint8_t*>(h->ws["valid"].p), d.n_scenes, d.mno, n_cls, m4, d.K, h->ci_min_rows, static_cast<int32_t*>(h->ws["ci_win"].p),
                           static_cast<int32_t*>(h->ws["ci_map"].p), static_cast<int32_t*>(h->ws["cp_count"].p) + 4, h->cp_host + 4, s);
     }
-    HIPCHK(hipEventRecord(h->cp_ev, s));
+    if (!compact_dyn(h)) HIPCHK(hipEventRecord(h->cp_ev, s));             // (device-side counts: nobody waits, and the call stays capturable)
     h->cp_pending = true;
     return DESIRE_OK;
 }
 // waits (once per desire_encode) for the scans' counts to reach the host
 static int compact_wait(desire_ctx* h, hipStream_t s) {
     if (!h->cp_pending) return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_*: desire_encode comes first (it builds the present-agent maps)");
+    if (compact_dyn(h)) return DESIRE_OK;                                // the kernels read the counts themselves
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
         return fail(DESIRE_ERR_STATE, "DESIRE_FLAG_COMPACT_* read the present-agent counts back: not capturable in a hipGraph");
@@ -99,6 +120,8 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     // (not while the Gaussian-head loss is on: that term counts every (object, observed frame) pair, including objects that have left by the last
     //  observed frame, which the present-agent map does not hold)
     const bool enc_c = compact_rows(h) && !(h->training && h->head_loss_w > 0.f);
+    const bool dyn = enc_c && compact_dyn(h);
+    const int32_t* dynP = nullptr;                                       // the present-agent count on the device (cp_count[0]) when `dyn`
     h->cp_enc = false;
     int Ae = A;
     const float* pastE = dev_past; const float* futE = dev_fut;
@@ -107,18 +130,22 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     const int32_t* amap = nullptr;
     if (enc_c) {
         if (int rc = compact_setup(h)) return rc;
+        if (dyn) dynP = static_cast<const int32_t*>(h->ws["cp_count"].p);
         launch_valid_from_frames(dev_past, d.n_scenes, d.T_obs, d.mno, validE, s);
         if (int rc = compact_scans(h, s)) return rc;
         if (int rc = compact_wait(h, s)) return rc;
-        const int P = *static_cast<volatile int32_t*>(h->cp_host);
-        if (P < 0 || P > A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
-        h->cp_P = P; h->cp_enc = true; Ae = P;
+        int P = A;                                                       // device-side counts: the worst case sizes the launches
+        if (!dyn) {
+            P = *static_cast<volatile int32_t*>(h->cp_host);
+            if (P < 0 || P > A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
+        }
+        h->cp_P = dyn ? -1 : P; h->cp_enc = true; Ae = P;
         launch_fill_f32(W(h, "HxHy"), (size_t)A * 2 * H, 0.f, s); launch_fill_f32(W(h, "p_last"), (size_t)A * 2, 0.f, s);
         if (d.posterior) launch_fill_f32(W(h, "params"), (size_t)A * 2 * d.L, 0.f, s);
         if (P == 0) { HIPCHK(hipGetLastError()); return DESIRE_OK; }
         amap = static_cast<const int32_t*>(h->ws["cp_amap"].p);
-        launch_gather_frames(dev_past, W(h, "cp_past"), amap, P, d.T_obs, d.mno, s);
-        if (d.posterior) launch_gather_frames(dev_fut, W(h, "cp_fut"), amap, P, d.T_pred, d.mno, s);
+        launch_gather_frames(dev_past, W(h, "cp_past"), amap, P, d.T_obs, d.mno, s, dynP);
+        if (d.posterior) launch_gather_frames(dev_fut, W(h, "cp_fut"), amap, P, d.T_pred, d.mno, s, dynP);
         pastE = W(h, "cp_past"); futE = W(h, "cp_fut");
         HxE = W(h, "cp_HxHy"); plE = W(h, "cp_plast"); validE = static_cast<uint8_t*>(h->ws["cp_valid2"].p); paramsE = W(h, "cp_params");
     }
@@ -128,6 +155,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
     e.out = HxE; e.ldo = 2 * H; e.p_last = plE; e.valid = validE;
+    e.dyn = DynCount{dynP, 1};
     if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
     const EncArgs ex = e;
     if (d.posterior) {
@@ -146,8 +174,8 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         Timer t(h, s, "encoder_xy"); launch_encoder_pair(ex, e, s);
     } else { Timer t(h, s, "encoder_x"); launch_encoder(ex, s); }
     if (enc_c) {          // back to the caller's layout for the IOC stage (absent agents: zeros, filled above)
-        launch_scatter_agents(HxE, W(h, "HxHy"), amap, Ae, 2 * H, s);
-        launch_scatter_agents(plE, W(h, "p_last"), amap, Ae, 2, s);
+        launch_scatter_agents(HxE, W(h, "HxHy"), amap, Ae, 2 * H, s, dynP);
+        launch_scatter_agents(plE, W(h, "p_last"), amap, Ae, 2, s, dynP);
     } else if (compact_rows(h) || compact_ioc(h)) {
         // DESIRE_FLAG_COMPACT_IOC alone: the slot-class maps are built behind the encoder that writes `valid`; their sizes reach the host through a
         // mapped word while the CVAE encoder below keeps the device busy, and desire_ioc_refine waits on the event before it sizes its launches
@@ -158,9 +186,10 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         GemmArgs g{};
         g.A = HxE; g.lda = 2 * H; g.M = Ae; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
         g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");
+        g.dyn = DynCount{dynP, 1};
         { Timer t(h, s, "fc_c"); launch_gemm_rows(g, EPI_BIAS_RELU, s); }
         ConvArgs c{};
-        c.n = Ae;
+        c.n = Ae; c.dyn = DynCount{dynP, 1};
         c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
         const bool pobn = d.bn_mode != 0;                 // batch statistics: linear conv epilogue, then a normalise + activate pass per layer
@@ -184,8 +213,9 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = Ae; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
         g.NT = (2 * d.L + 31) / 32; g.out = paramsE; g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
+        g.dyn = DynCount{dynP, 1};
         { Timer t(h, s, "vae_enc_fc"); launch_gemm_rows(g, EPI_BIAS, s); }
-        if (enc_c) launch_scatter_agents(paramsE, W(h, "params"), amap, Ae, 2 * d.L, s);       // desire_losses / the reparam backward read them per agent
+        if (enc_c) launch_scatter_agents(paramsE, W(h, "params"), amap, Ae, 2 * d.L, s, dynP);       // desire_losses / the reparam backward read them per agent
     }
     HIPCHK(hipGetLastError());
     return DESIRE_OK;
@@ -202,12 +232,17 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     int R = h->R, mno = d.mno;
     const float* HxS = W(h, "HxHy"); const float* plS = W(h, "p_last"); float* Yout = W(h, "Y0");
     const bool compact = compact_rows(h);
+    const bool dyn = compact && compact_dyn(h);
+    const int32_t* dynP = dyn ? static_cast<const int32_t*>(h->ws["cp_count"].p) : nullptr;      // device-side count: launches sized for P = A
     h->cp_last = compact;
     if (compact) {
         if (int rc = compact_wait(h, s)) return rc;
-        const int P = *static_cast<volatile int32_t*>(h->cp_host);
-        if (P < 0 || P > h->A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
-        h->cp_P = P;
+        int P = h->A;
+        if (!dyn) {
+            P = *static_cast<volatile int32_t*>(h->cp_host);
+            if (P < 0 || P > h->A) return fail(DESIRE_ERR_HIP, "present-agent scan returned a count out of range");
+        }
+        h->cp_P = dyn ? -1 : P;
         R = P * d.K; mno = P;
         const size_t RT2 = (size_t)h->R * d.T_pred * 2;
         if (P == 0) {       // nothing present: every row is padding
@@ -218,13 +253,13 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         const int32_t* amap = static_cast<const int32_t*>(h->ws["cp_amap"].p);
         Timer t(h, s, "compact_gather");
         if (!h->cp_enc) {           // (an encoder stack that ran compact has left all three in place)
-            launch_gather_agents(W(h, "HxHy"), W(h, "cp_HxHy"), amap, P, 2 * H, s);
-            launch_gather_agents(W(h, "p_last"), W(h, "cp_plast"), amap, P, 2, s);
-            if (d.posterior) launch_gather_agents(W(h, "params"), W(h, "cp_params"), amap, P, 2 * d.L, s);
+            launch_gather_agents(W(h, "HxHy"), W(h, "cp_HxHy"), amap, P, 2 * H, s, dynP);
+            launch_gather_agents(W(h, "p_last"), W(h, "cp_plast"), amap, P, 2, s, dynP);
+            if (d.posterior) launch_gather_agents(W(h, "params"), W(h, "cp_params"), amap, P, 2 * d.L, s, dynP);
         }
         HxS = W(h, "cp_HxHy"); plS = W(h, "cp_plast"); Yout = W(h, "cp_Y0");
     }
-    if (compact) { Timer t(h, s, "reparam"); launch_reparam_c(W(h, "cp_params"), dev_eps, W(h, "z"), static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.L, d.posterior, s); }
+    if (compact) { Timer t(h, s, "reparam"); launch_reparam_c(W(h, "cp_params"), dev_eps, W(h, "z"), static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.L, d.posterior, s, dynP); }
     else { Timer t(h, s, "reparam"); launch_reparam(W(h, "params"), dev_eps, W(h, "z"), R, d.L, d.K, d.mno, d.posterior, s); }
     auto normd = [&](const char* layer, float* x, int P, int C, int sig) {          // batch statistics of the decoder layers (see desire_encode)
         const float* ga = D(h, (std::string(layer) + "/gamma").c_str()); const float* be = D(h, (std::string(layer) + "/beta").c_str());
@@ -237,6 +272,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
+    g.dyn = DynCount{dynP, d.K};
     // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
     // two-piece operands are an IOC-kernel matter (sample generation must not move Y0 by more than fp32 rounding)
     const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask(h) & 8)))) && d.bn_mode == 0 && !d.ref_compat;
@@ -248,7 +284,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     }
     else { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
     ConvArgs c{};
-    c.n = R;
+    c.n = R; c.dyn = DynCount{dynP, d.K};
     const bool pobn = d.bn_mode != 0;
     if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
@@ -280,6 +316,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = HxS; m.ldhx = 2 * H; m.xz = W(h, "xz");
+    m.dyn = DynCount{dynP, 1};
     if (h->training) m.sv_p = W(h, "mask_sv_p");
     if (d.bf16 == 1) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
     else if (x6gen && (H == 64 || H == 128) && h->V % 128 == 0) { m.Wp = D4(h, "mask/W6"); Timer t(h, s, "mask_fc"); launch_mask_x6(m, s); }
@@ -289,7 +326,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.R = R; a.K = d.K; a.mno = mno; a.H = H; a.T = d.T_pred;
     a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
-    a.Y = Yout; a.hdump = nullptr;
+    a.Y = Yout; a.hdump = nullptr; a.dyn = DynCount{dynP, 1};
     if (d.ref_compat) { a.T = d.n_dec; a.hdump = W(h, "dec_states"); }       // model/model.py:280-285: 7 steps, the states are the output
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
     if (d.bf16 == 1) {
@@ -307,7 +344,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
         Timer t(h, s, "compact_scatter");
         const size_t RT2 = (size_t)h->R * d.T_pred * 2;
         launch_fill_f32(W(h, "Y0"), RT2, 0.f, s); launch_fill_f32(dev_Yhat, RT2, 0.f, s);
-        launch_scatter_rows(Yout, W(h, "Y0"), dev_Yhat, static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.T_pred * 2, s);
+        launch_scatter_rows(Yout, W(h, "Y0"), dev_Yhat, static_cast<const int32_t*>(h->ws["cp_amap"].p), mno, d.K, d.mno, d.T_pred * 2, s, dynP);
     } else
         launch_copy_f32(dev_Yhat, W(h, "Y0"), (size_t)R * d.T_pred * 2, s);
     HIPCHK(hipGetLastError());
@@ -318,6 +355,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
 // n_scenes windows of mno slots each with their own agent-level inputs; training-mode saves go to the view's row offset in the shared buffers.
 struct IocView {
     int R, mno, n_scenes; float* Y; float* score; const float* Hx; int ldhx; const float* p_last; const uint8_t* valid; const int32_t* gos; size_t row_off;
+    const int32_t* dynN = nullptr;   // the view's window count on the device (a slot class under device-side counts): R / n_scenes / ngrp above are the worst case
     int gpt = 0, ngrp = 0;       // padded tiles (slot classes that do not divide 32; kernels.h: IocArgs.gpt): groups per 32-row tile, real groups; R = tiles * 32
 };
 static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
@@ -336,6 +374,7 @@ static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     a.variant = d.ioc_form;
     a.gpt = v.gpt; a.ngrp = v.ngrp;
+    a.dyn = DynCount{v.dynN, 1};
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
     // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
     // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count
@@ -508,6 +547,8 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         // DESIRE_FLAG_COMPACT_IOC: one launch sequence per slot class over the windows seated in it; windows without a present agent are not run
         // (their rows keep the Y they came with and score 0)
         if (int rc = compact_wait(h, s)) return rc;
+        const bool dyn = compact_dyn(h);
+        const int32_t* cnt_dev = static_cast<const int32_t*>(h->ws["cp_count"].p) + 4;
         int m4[4];
         const int n_cls = compact_classes(h, m4);
         const int32_t* cnt = h->cp_host + 4;
@@ -516,7 +557,9 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
         launch_fill_f32(dev_score, (size_t)h->R, 0.f, s);
         h->ci_n = 0;
         for (int c = 0; c < n_cls; ++c) {
-            const int n_c = static_cast<volatile const int32_t*>(cnt)[c], m_c = m4[c];
+            // device-side counts: every class is launched for the worst case (all windows in it) at a static offset; an empty class's grids exit
+            const int n_c = dyn ? d.n_scenes : static_cast<volatile const int32_t*>(cnt)[c], m_c = m4[c];
+            const int32_t* dynN = dyn ? cnt_dev + c : nullptr;
             if (n_c < 0 || n_c > d.n_scenes) return fail(DESIRE_ERR_HIP, "slot-class scan returned a count out of range");
             if (n_c == 0) continue;
             const int32_t* cmap = static_cast<const int32_t*>(h->ws["ci_map"].p) + (size_t)c * h->A;
@@ -525,18 +568,18 @@ extern "C" int desire_ioc_refine(desire_handle* h, float* dev_Yhat, float* dev_s
             const int R_c = gpt ? ((ngrp + gpt - 1) / gpt) * 32 : n_c * d.K * m_c;
             IocView v{R_c, m_c, n_c, W(h, "ci_Y") + roff * T2, W(h, "ci_score") + roff, W(h, "ci_Hx") + aoff * 2 * d.H, 2 * d.H, W(h, "ci_pl") + aoff * 2,
                       static_cast<const uint8_t*>(h->ws["ci_valid"].p) + aoff, static_cast<const int32_t*>(h->ws["ci_gos"].p) + woff, roff};
-            v.gpt = gpt; v.ngrp = ngrp;
+            v.gpt = gpt; v.ngrp = ngrp; v.dynN = dynN;
             {
                 Timer t(h, s, "ioc_repack");
                 launch_cls_gather_agents(W(h, "HxHy"), 2 * d.H, W(h, "p_last"), static_cast<const int32_t*>(h->ws["grid_of_scene"].p), cmap, win, n_c, m_c,
-                                         const_cast<float*>(v.Hx), const_cast<float*>(v.p_last), const_cast<uint8_t*>(v.valid), const_cast<int32_t*>(v.gos), s);
-                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 0, s, gpt);
+                                         const_cast<float*>(v.Hx), const_cast<float*>(v.p_last), const_cast<uint8_t*>(v.valid), const_cast<int32_t*>(v.gos), s, dynN);
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 0, s, gpt, dynN);
             }
             if (int rc = ioc_core(h, v, s)) return rc;
             {
                 Timer t(h, s, "ioc_repack");
-                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 1, s, gpt);
-                launch_cls_rows(dev_score, v.score, cmap, n_c, m_c, d.K, d.mno, 1, 1, s, gpt);
+                launch_cls_rows(dev_Yhat, v.Y, cmap, n_c, m_c, d.K, d.mno, (int)T2, 1, s, gpt, dynN);
+                launch_cls_rows(dev_score, v.score, cmap, n_c, m_c, d.K, d.mno, 1, 1, s, gpt, dynN);
             }
             h->ci_cls[h->ci_n] = c; h->ci_cnt[h->ci_n] = n_c; ++h->ci_n;
             aoff += (size_t)n_c * m_c; roff += (size_t)R_c; woff += (size_t)n_c;

@@ -342,6 +342,29 @@ __device__ __forceinline__ void nb_publish_occ(unsigned long long oc, unsigned* 
 
 // the same for the IOC kernels' padded tiles (IocArgs.gpt > 0): -1 = a dead row
 __device__ __forceinline__ int ioc_agent_of_row(int r, int K, int mno, int gpt, int ngrp);
+
+// ---- device-side row counts (kernels.h: DynCount) ----------------------------------------------------------------------------------------------
+// DYN_N(a, field, first): a.field = cnt[0] * mul when the launch carries a device-side count; the workgroup returns when its first unit `first` lies
+// beyond it (wave-uniform, before any barrier).  DYN_P: the per-row stages' pseudo-scene of P present agents (mno = P, R = P * K).
+#define DYN_N(a, field, first)                                                                     \
+    if ((a).dyn.cnt) {                                                                             \
+        (a).field = __builtin_amdgcn_readfirstlane((a).dyn.cnt[0]) * (a).dyn.mul;                  \
+        if ((long)(first) >= (long)(a).field) return;                                              \
+    }
+#define DYN_P(a, first_row)                                                                        \
+    if ((a).dyn.cnt) {                                                                             \
+        (a).mno = __builtin_amdgcn_readfirstlane((a).dyn.cnt[0]);                                  \
+        (a).R = (a).mno * (a).K;                                                                   \
+        if ((long)(first_row) >= (long)(a).R) return;                                              \
+    }
+// an IOC launch over the windows of a slot class: returns false when the class is empty (the whole grid exits)
+#define IOC_DYN(a)                                                                                 \
+    if ((a).dyn.cnt) {                                                                             \
+        const int n_c_ = __builtin_amdgcn_readfirstlane((a).dyn.cnt[0]);                           \
+        (a).ngrp = n_c_ * (a).K;                                                                   \
+        (a).R = (a).gpt ? (((a).ngrp + (a).gpt - 1) / (a).gpt) * 32 : (a).ngrp * (a).mno;          \
+        if (n_c_ <= 0) return;                                                                     \
+    }
 // row r = (scene*K + k)*mno + slot  ->  agent = scene*mno + slot
 __device__ __forceinline__ int agent_of_row(int r, int K, int mno) {
     const int per_scene = K * mno;

@@ -71,6 +71,7 @@ struct desire_ctx {
     int32_t* cp_host = nullptr; hipEvent_t cp_ev = nullptr; bool cp_pending = false; int cp_P = -1;
     int ci_n = 0, ci_cls[4] = {0, 0, 0, 0}, ci_cnt[4] = {0, 0, 0, 0}; bool ci_last = false; int ci_min_rows = 8192;     // DESIRE_FLAG_COMPACT_IOC: the classes the last IOC stage ran (class index, windows)
     bool cp_enc = false;                                     // the last desire_encode ran its stack on the present agents only (saves in compact agent order)
+    bool cp_host_counts = false;                             // desire_set_option("compact_host_counts", 1): inference reads the counts back like training does (A/B)
     bool cp_last = false;                                    // the last desire_sample ran compacted (desire_backward follows it, not the flag)
     // desire_build_windows*: plain pointers, cached at creation -- a feeder thread may run the builder while the owner thread runs a forward or a backward on
     // the same handle (desire_amd/prefetch.py: DeviceWindowFeeder), and those insert workspace entries lazily: the builder must not walk the map
@@ -131,6 +132,7 @@ int desire_upload(desire_ctx* h, const std::string& name, const std::vector<floa
 int desire_ready(desire_handle* h);
 bool compact_rows(const desire_ctx* h);                        // DESIRE_FLAG_COMPACT_ROWS set
 bool compact_ioc(const desire_ctx* h);                         // DESIRE_FLAG_COMPACT_IOC set and the shape is served
+bool compact_dyn(const desire_ctx* h);                         // compacted launches take their counts from device words (inference, frozen batch-norm): no host wait
 bool compact_padded_ok(const desire_ctx* h);                   // the padded-tile IOC kernels serve this handle (slot class 10)
 int compact_classes(const desire_ctx* h, int* m4);             // its slot classes (ascending, the handle's mno last): returns how many
 int compact_setup(desire_ctx* h);                              // its buffers, event and mapped count word (idempotent)

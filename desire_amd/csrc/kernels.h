@@ -13,6 +13,12 @@ inline void allow_big_lds(F* f) {
     }
 }
 
+// A launch whose row count is known on the DEVICE only (DESIRE_FLAG_COMPACT_*, inference: the present agents of a batch / the windows seated in a
+// slot class, counted by kernels_compact.hip's scans).  The host sizes the grid -- and picks the kernel variant -- for the worst case and the kernel
+// replaces its count by cnt[0] * mul in its first instructions; workgroups beyond it exit before they touch memory.  No read-back, no host wait, the
+// call is hipGraph-capturable.  cnt == nullptr (every other launch): the count in the argument block stands.
+struct DynCount { const int32_t* cnt; int mul; };
+
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_SCALE_SHIFT_ELU = 2, EPI_NONE = 3, EPI_ELUGRAD = 4, EPI_SIGGRAD = 5 };
 
 // out[M, N] = epi(A[M, K] @ W[K, N]); W in packed fragment order [NT][G][64] float4.
@@ -22,6 +28,7 @@ struct GemmArgs {
     float* out; int ldo; int N;
     const float* p0; const float* p1; int chmod;
     const float* aux;                              // [M, ldo] saved activation for the gradient epilogues
+    DynCount dyn;                                  // M = cnt[0] * mul on the device (see DynCount)
 };
 void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s);
 
@@ -33,6 +40,7 @@ struct MaskArgs {
     int Hl;                                        // logical width: the softmax runs over columns [0, Hl) (Hl < H: zero-padded tile)
     const float4* Wp; const float* bias; const float* Hx; int ldhx; float* xz;
     float* sv_p;                                   // optional [R,H]: relu(xhat W + b) kept for the backward softmax
+    DynCount dyn;                                  // one pseudo-scene of P = cnt[0] present agents: mno = P, R = P * K (DynCount)
 };
 void launch_mask(const MaskArgs& a, hipStream_t s);
 // six-product forms of deconv1 and the mask fc (kernels_x6.hip; weight pointers = three-piece packs)
@@ -47,6 +55,7 @@ struct ConvArgs {
     const float* scale; const float* shift;        // folded bias + frozen batch-norm
     int mode; const float* yprev;                  // epilogue mode (common.h:conv_epilogue); saved activation of the
                                                    // destination layer for the backward modes
+    DynCount dyn;                                  // n = cnt[0] * mul on the device (see DynCount)
 };
 void launch_conv1(const ConvArgs& a, hipStream_t s);     // [n,32,32,1]  -> [n,16,16,32]
 void launch_conv2(const ConvArgs& a, hipStream_t s);     // [n,16,16,32] -> [n,8,8,64]
@@ -72,6 +81,7 @@ struct EncArgs {
     // the position drawn from the bivariate Gaussian the 5-wide head reads off the current state
     int n_roll; const float* w5; const float* b5;          // head [H,5], [5]
     const float* normals; float* roll_out;                 // [n_roll, A, 2] N(0,1) draws in, sampled positions (clipped <= 1) out
+    DynCount dyn;                                          // one pseudo-scene of mno = cnt[0] present agents (n_scenes = 1; DynCount)
 };
 void launch_encoder(const EncArgs& a, hipStream_t s);
 void launch_encoder_pair(const EncArgs& past, const EncArgs& fut, hipStream_t s);   // both encoders, one launch (same H)
@@ -86,6 +96,7 @@ struct DecArgs {
     float* Y;                                              // [R, T, 2]
     float* hdump;                                          // optional [R, T, H] hidden states h_t
     float* sv_r; float* sv_u; float* sv_c;                 // optional [R, T, H] gate values (training mode)
+    DynCount dyn;                                          // one pseudo-scene of P = cnt[0] present agents: mno = P, R = P * K (DynCount)
 };
 void launch_decoder(const DecArgs& a, hipStream_t s);
 void launch_decoder_bf16(const DecArgs& a, hipStream_t s);    // kernels_bf16.hip; Whg / Whc = bf16 packs
@@ -112,6 +123,9 @@ struct IocArgs {
     // gpt whole groups of mno slots (gpt * mno <= 32) followed by dead rows; group G = tile * gpt + (row & 31) / mno, ngrp real groups; R = tiles * 32.
     // gpt = 0: rows are packed, r = (scene * K + k) * mno + slot (mno divides 32).
     int gpt; int ngrp;
+    // windows of this launch counted on the device (a slot class of DESIRE_FLAG_COMPACT_IOC, inference): n_c = dyn.cnt[0] windows of mno slots ->
+    // ngrp = n_c * K, R = gpt ? ceil(ngrp / gpt) * 32 : ngrp * mno (ioc_dyn_rows, common.h); the arguments hold the worst case (every window in this class)
+    DynCount dyn;
 };
 void launch_ioc(const IocArgs& a, hipStream_t s);
 // Which IOC form serves (mno, H, bins): the cluster form (32-row tiles exchanging hidden states through global memory) takes every
@@ -288,20 +302,20 @@ int launch_ioc_bwd_cluster(const IocBwdArgs& a, int* grp_cnt, int* err, hipStrea
 
 // ---- present-row compaction (kernels_compact.hip; DESIRE_FLAG_COMPACT_ROWS) ----
 void launch_present_scan(const uint8_t* valid, int A, int32_t* amap, int32_t* inv, int32_t* count_dev, int32_t* count_host, hipStream_t s);
-void launch_gather_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s);
+void launch_gather_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s, const int32_t* dynP = nullptr);     // dynP / dynN: the count on the device (DynCount)
 void launch_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* amap, int P, int n, hipStream_t s);
-void launch_reparam_c(const float* params_c, const float* eps, float* z, const int32_t* amap, int P, int K, int mno, int L, int posterior, hipStream_t s);
-void launch_scatter_rows(const float* comp, float* full0, float* full1, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);
+void launch_reparam_c(const float* params_c, const float* eps, float* z, const int32_t* amap, int P, int K, int mno, int L, int posterior, hipStream_t s, const int32_t* dynP = nullptr);
+void launch_scatter_rows(const float* comp, float* full0, float* full1, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s, const int32_t* dynP = nullptr);
 void launch_gather_rows(const float* full, float* comp, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s);
 // IOC class repacking (DESIRE_FLAG_COMPACT_IOC)
 void launch_class_scan(const uint8_t* valid, int n_scenes, int mno, int n_cls, const int* m4, int K, int min_rows, int32_t* cls_win, int32_t* cmap,
                        int32_t* cnt_dev, int32_t* cnt_host, hipStream_t s);
 void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
-                              float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s);
-void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s, int gpt = 0);
+                              float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s, const int32_t* dynN = nullptr);
+void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s, int gpt = 0, const int32_t* dynN = nullptr);
 void launch_cls_scatter_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* cmap, int NA, int n, hipStream_t s);
 // encoder-stage compaction
 void launch_valid_from_frames(const float* past, int n_scenes, int T, int mno, uint8_t* valid, hipStream_t s);
-void launch_gather_frames(const float* frames, float* out, const int32_t* amap, int P, int T, int mno, hipStream_t s);
-void launch_scatter_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s);
+void launch_gather_frames(const float* frames, float* out, const int32_t* amap, int P, int T, int mno, hipStream_t s, const int32_t* dynP = nullptr);
+void launch_scatter_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s, const int32_t* dynP = nullptr);
 void launch_gather_add_agents(const float* in, int ldi, float* out, int ldo, const int32_t* amap, int P, int n, hipStream_t s);

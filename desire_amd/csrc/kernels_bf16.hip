@@ -62,6 +62,8 @@ __global__ __launch_bounds__((H / 32) * WM * 64, ((H / 32) * WM <= 4) ? IOC16_OC
     const int cb = w % NT, mt = w / NT;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * TM;
+    IOC_DYN(a)                                          // (a slot class counted on the device: kernels.h DynCount; the grid is the worst case's)
+    if (a.dyn.cnt && row0 >= a.R) return;
     const int col = cb * 32 + c31;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2_bf16(ConvArgs a) {
     const int lane = lane_id(), w = wave_id();
     const int hf = w & 1, sp = w >> 1;
     const int s0 = blockIdx.x * 4 + sp * 2;
+    DYN_N(a, n, blockIdx.x * 4)
     const int c = lane & 31, hi = lane >> 5;
     float* my = out_s16 + (sp * 2) * 4096;
     // this wave's region = [2 samples x 64 px] x its 32 output channels; 8 lanes x float4 cover one row of it
@@ -550,6 +553,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv3_bf16(ConvArgs a) {
     u16* in_s = zero_row + LDP;                                        // [4][64][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * 4;
+    DYN_N(a, n, s0)
     for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
     for (int i = tid; i < 4 * 64 * 8; i += DS_WG) {
         const int pix = i >> 3, c8 = i & 7;
@@ -642,6 +646,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * TM;
+    DYN_P(a, row0)
     const int col = cb * 32 + c31;
     for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
@@ -750,6 +755,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv34_bf16(ConvArgs a, const float
     float* xacc = reinterpret_cast<float*>(in_s + 4 * 64 * LDP);       // [4][1024]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * 4;
+    DYN_N(a, n, s0)
     for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
     for (int i = tid; i < 4 * 1024; i += DS_WG) xacc[i] = 0.f;
     for (int i = tid; i < 4 * 64 * 8; i += DS_WG) {
@@ -879,6 +885,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv1_bf16(GemmArgs a) {
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * 64, ld = a.K + 8, G16 = a.K >> 4;
+    DYN_N(a, M, row0)
     stage16(As, a.A, ld, a.lda, row0, a.M, 0, a.K, tid);
     __syncthreads();
     const uint4* Bp = reinterpret_cast<const uint4*>(a.Bp);
@@ -914,6 +921,7 @@ __global__ __launch_bounds__(DS_WG) void k_mask_bf16(MaskArgs a) {
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * 64;
+    DYN_P(a, row0)
     const int NT = a.H >> 5, G16 = a.V >> 4;
     f32x16 acc[2][1][2] = {{{zero16(), zero16()}}, {{zero16(), zero16()}}};
     const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
@@ -994,6 +1002,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv_gather_bf16(ConvArgs a) {
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
     const int s0 = blockIdx.x * SPW;
+    DYN_N(a, n, s0)
     for (int i = tid; i < LDP / 2; i += DS_WG) reinterpret_cast<unsigned*>(zero_row)[i] = 0u;
     constexpr int Q = CI / 8;
     for (int i = tid; i < SPW * IW * IW * Q; i += DS_WG) {
@@ -1068,6 +1077,7 @@ __global__ __launch_bounds__((H / 32) * 64) void k_encoder_bf16(EncArgs a) {
     float* xs = reinterpret_cast<float*>(rb + TM * LDB);   // [2][32][2] normalised input, double-buffered over t
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
+    DYN_N(a, mno, blockIdx.x * TM)
     const int A = a.n_scenes * a.mno;
     const int a0 = blockIdx.x * TM;
     const int col = cb * 32 + c31;

@@ -77,6 +77,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
     const int col = cb * 32 + c31;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int tile_pos = blockIdx.x % tpg;                             // my tile inside its group
+    IOC_DYN(a)                                                         // (a slot class counted on the device: kernels.h DynCount)
     const int n_tiles = a.R / TM;
     static_assert(NTHR >= CLMAXM, "one thread per group slot for the position loads");
     const agent_buf hexr = agent_buffer(hex16, 2u * (unsigned)n_tiles * (H * TM * 2));

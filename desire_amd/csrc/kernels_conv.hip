@@ -26,6 +26,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv1(ConvArgs a) {
     // aligned 16-byte LDS reads; the lane's 25 weights (its output channel) live in registers
     __shared__ __attribute__((aligned(16))) float in_s[36 * 40];
     const int n = blockIdx.x, tid = threadIdx.x;
+    DYN_N(a, n, n)
     for (int i = tid; i < 36 * 40; i += DS_WG) in_s[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < 1024; i += DS_WG) in_s[((i >> 5) + 1) * 40 + (i & 31) + 1] = a.in[(size_t)n * 1024 + i];
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(DS_WG) void k_conv_gather(ConvArgs a) {
     float* in_s = smem + LDP;                     // [SPW][IW*IW][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * SPW;
+    DYN_N(a, n, s0)
     for (int i = tid; i < LDP; i += DS_WG) zero_row[i] = 0.f;
     constexpr int Q = CI / 4;
     // position of pixel (y, x) in a sample's LDS image.  Stride 2: the four parity classes are kept as separate (IW/2)^2 sub-images -- a tap
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     const int lane = lane_id(), w = wave_id();
     const int hf = w & 1, sp = w >> 1;
     const int s0 = blockIdx.x * 4 + sp * 2;
+    DYN_N(a, n, blockIdx.x * 4)
     const int c = lane & 31, hi = lane >> 5;
     float* my = out_s + (sp * 2) * 4096;
     // zero this wave's region: 2 samples x 64 px x 32 co
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
     float* in_s = smem + 128;                                          // [NS][64][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * NS;
+    DYN_N(a, n, s0)
     for (int i = tid; i < 128; i += NS * 64) zero_row[i] = 0.f;
     for (int i = tid; i < NS * 64 * 16; i += NS * 64) {
         const int pix = i >> 4, c4 = i & 15;
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(DS_WG) void k_deconv4_tp(ConvArgs a) {
     __shared__ float xacc[4 * 1024];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int smp = blockIdx.x * 4 + w;
+    DYN_N(a, n, blockIdx.x * 4)
     for (int i = tid; i < 4 * 1024; i += DS_WG) xacc[i] = 0.f;
     __syncthreads();
     float* xa = xacc + w * 1024;

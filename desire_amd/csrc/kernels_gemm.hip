@@ -17,6 +17,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_gemm_rows(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TMR;
+    DYN_N(a, M, row0)
     f32x16 acc[NTW][MT];
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(DS_WG) void k_mask(MaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * DS_TM;
+    DYN_P(a, row0)
     const int NT = a.H >> 5;                                 // 2, 4 or 8 column tiles; wave w takes w, w+4
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     const float* a_lane = smem + (lane & 31) * LDA_C + 4 * (lane >> 5);

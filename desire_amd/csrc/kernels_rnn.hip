@@ -159,13 +159,22 @@ __device__ __forceinline__ void encoder_tile(const EncArgs& a, int blk) {
     }
 }
 template <int H, int TM, bool ROLL = false>
-__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) { encoder_tile<H, TM, ROLL>(a, blockIdx.x); }
+__global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a) {
+    DYN_N(a, mno, blockIdx.x * TM)                 // (device-side count: one pseudo-scene of mno = P present agents, kernels.h: DynCount)
+    encoder_tile<H, TM, ROLL>(a, blockIdx.x);
+}
 // past and future encoders in ONE launch (they are independent and each is latency-bound: A/32 workgroups stepping through T
 // dependent GRU steps): the first nb0 workgroups run a0, the rest a1
 template <int H, int TM>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder_pair(EncArgs a0, EncArgs a1, int nb0) {
-    if ((int)blockIdx.x < nb0) encoder_tile<H, TM, false>(a0, blockIdx.x);
-    else encoder_tile<H, TM, false>(a1, blockIdx.x - nb0);
+    const int blk = (int)blockIdx.x < nb0 ? (int)blockIdx.x : (int)blockIdx.x - nb0;
+    if (a0.dyn.cnt) {                             // device-side count (both encoders run on the same P present agents; nb0 is the worst case's)
+        const int P = __builtin_amdgcn_readfirstlane(a0.dyn.cnt[0]);
+        a0.mno = P; a1.mno = P;
+        if (blk * TM >= P) return;
+    }
+    if ((int)blockIdx.x < nb0) encoder_tile<H, TM, false>(a0, blk);
+    else encoder_tile<H, TM, false>(a1, blk);
 }
 void launch_encoder_pair(const EncArgs& a0, const EncArgs& a1, hipStream_t s) {
     constexpr int TM = 32;
@@ -208,6 +217,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, 2) void k_decoder(DecArg
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int cb = w % NT, mt = w / NT;
     const int row0 = blockIdx.x * TM;
+    DYN_P(a, row0)
     const bool active = cb < NT;
     const int col = cb * 32 + (lane & 31);
     for (int i = tid; i < TM * (H >> 2); i += NTHR) {
@@ -411,6 +421,8 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
     const int cb = w % NT, mt = w / NT;
     const int tile = NSPL > 1 ? (int)blockIdx.x / NSPL : (int)blockIdx.x, member = NSPL > 1 ? (int)blockIdx.x % NSPL : 0;
     const int row0 = tile * TM;
+    IOC_DYN(a)                                          // (a slot class counted on the device: kernels.h DynCount; the grid is the worst case's)
+    if (a.dyn.cnt && row0 >= a.R) return;
     unsigned long long my_bins = ~0ull;
     if (NSPL > 1) { my_bins = 0ull; for (int b = member; b < 64; b += NSPL) my_bins |= 1ull << b; }
     const bool active = cb < NT;
@@ -938,6 +950,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 1 : 2) void k_ioc_cl
     const int col = cb * 32 + (lane & 31);
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int tile_pos = blockIdx.x % tpg;              // my tile inside its group
+    IOC_DYN(a)                                          // (a slot class counted on the device: kernels.h DynCount; the persistent grid is the worst case's)
     const int n_tiles = a.R / TM;
 
     for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];

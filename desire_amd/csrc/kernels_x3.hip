@@ -61,6 +61,8 @@ __global__ __launch_bounds__((H / 32) * 64, NP == 2 ? 2 : 1) void k_ioc_x3(IocAr
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int hi = lane >> 5, c31 = lane & 31;
     const int row0 = blockIdx.x * TM;
+    IOC_DYN(a)                                          // (a slot class counted on the device: kernels.h DynCount; the grid is the worst case's)
+    if (a.dyn.cnt && row0 >= a.R) return;
     const int col = cb * 32 + c31;
     const int r8 = tid / TPR, q8 = tid % TPR;
     const int my_row = min(row0 + r8, a.R - 1);

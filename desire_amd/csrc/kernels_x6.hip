@@ -34,6 +34,7 @@ __global__ __launch_bounds__((H / 32) * 64, (H / 32) <= 4 ? 2 : 1) void k_decode
     float* xs = reinterpret_cast<float*>(hb);          // [32][LDH]  x_z tile: prologue only, in the space the images take afterwards
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * TM;
+    DYN_P(a, row0)
     const int col = cb * 32 + (lane & 31), hi = lane >> 5;
     for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo)
     const int lane = lane_id(), w = wave_id();
     const int hf = w & 1, sp = w >> 1;
     const int s0 = blockIdx.x * 4 + sp * 2;
+    DYN_N(a, n, blockIdx.x * 4)
     const int c = lane & 31, hi = lane >> 5;
     float* my = out_s6 + (sp * 2) * 4096;
     const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
     u16* img = reinterpret_cast<u16*>(smem);                           // [3][NPX + 1][LDB]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int s0 = blockIdx.x * 2;
+    DYN_N(a, n, s0)
     for (int i = tid; i < NP * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
     for (int i = tid; i < NPX * 16; i += DS_WG) {
         const int pix = i >> 4, c4 = i & 15;
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv1_x6(GemmArgs a) {          
     u16* img = reinterpret_cast<u16*>(smem);
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * 64;
+    DYN_N(a, M, row0)
     const uint4* Bp = reinterpret_cast<const uint4*>(a.Bp);
     const int G16 = a.K >> 4;
     const size_t plo = (size_t)a.NT * G16 * 64;
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(DS_WG, 2) void k_mask_x6(MaskArgs a) {
     u16* img = reinterpret_cast<u16*>(smem);
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int row0 = blockIdx.x * 64;
+    DYN_P(a, row0)
     const int NT = a.H >> 5;                                 // 2 or 4 column tiles: wave w takes tile w
     f32x16 acc[2][1] = {{zero16()}, {zero16()}};
     const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);

@@ -390,6 +390,7 @@ int repack(desire_ctx* h, hipStream_t s) {
 
 extern "C" int desire_set_training(desire_handle* h, int enable) {
     if (int rc = desire_ready(h)) return rc;
+    if ((enable != 0) != h->training) { h->cp_pending = false; h->cp_enc = false; }      // compaction maps: inference and training learn the counts differently (a new desire_encode comes first)
     if (!enable) {
         if (h->training) {          // the trained master copy becomes the handle's weights: desire_get_weight and a later
             std::vector<float> flat(h->n_params);          // desire_set_training(h, 1) start from it (Adam moments restart at zero)

@@ -6,7 +6,8 @@ The loader pads every window to max_num_obj slots (utils/data_loader.py:209-229)
     within 1e-3 of the CPU oracle (normalised coordinates) on the committed real-SDD goldens;
   * rows of absent agents: zeros in "Y0" (the sample-generation output);
   * edge cases: nothing present, everything present, a single agent, prior sampling (no posterior);
-  * the flag is refused where it would change results (bn_mode = 2) and under hipGraph capture."""
+  * the flag is refused where it would change results (bn_mode = 2); the read-back path (training; "compact_host_counts") is refused under hipGraph
+    capture, the default inference path -- device-side counts, round 6 -- is captured and replayed on changing data (end of this file)."""
 import numpy as np
 import pytest
 
@@ -144,6 +145,7 @@ def test_flag_is_refused_where_it_would_change_results(torch_cuda):
     with pytest.raises(_lib.DesireError):
         h.set_option("flags", 64)
     h.set_option("flags", FLAG_COMPACT_ROWS)               # on a live handle
+    h.set_option("compact_host_counts", 1)                 # the read-back path (what training always runs): it is the one that cannot be captured
     w = init_weights(d, 0)
     h.set_weights(w)
     torch = torch_cuda
@@ -410,3 +412,107 @@ def test_training_with_the_gaussian_head_loss_keeps_every_observed_object(torch_
     for k in res[0]:
         ref = np.abs(res[0][k]).max()
         assert ref > 0 and np.abs(res[0][k] - res[1][k]).max() / ref < 3e-5, k
+
+
+# ---- round 6: device-side counts (kernels.h: DynCount) -- inference sizes every compacted launch for the worst case and reads P / the class counts on the device
+@pytest.mark.parametrize("kw", [dict(), dict(bf16=2), dict(bf16=3), dict(bf16=1), dict(H=64, K=3, mno=16), dict(posterior=0), dict(mno=64, n_scenes=5, K=2, n_grids=1),
+                                dict(mno=96, n_scenes=3, K=2, n_grids=1), dict(mno=128, n_scenes=3, K=2, n_grids=1, bf16=1)],
+                         ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
+def test_device_side_counts_equal_the_read_back_counts(torch_cuda, kw):
+    """The default inference path (no host wait) against desire_set_option("compact_host_counts", 1) (the round-5 path: counts read back, launches sized
+    exactly): per-row stages bit-identical; the IOC equal up to which tiling the launcher picks for the worst-case row count (fp32 summation order)."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    d = small_dims(**{**dict(n_scenes=8, K=3, T_obs=6, T_pred=7, n_grids=1), **kw}).replace(flags=FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC)
+    w = init_weights(d, 41)
+    counts = [3, 9, 0, 14, 8, d.mno, 1, 20][: d.n_scenes]
+    past, fut, eps, grids, gos, keep = ragged_counts(d, seed=44, counts=[min(c, d.mno) for c in counts])
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+    res = []
+    for host_counts in (0, 1):
+        h = _lib.Handle(d); h.set_weights(w); h.set_option("compact_min_rows", 0); h.set_option("compact_host_counts", host_counts)
+        h.set_scene_grids(g_t.data_ptr(), gos)
+        Y = torch.full((d.R, d.T_pred, 2), 7.0, device="cuda"); sc = torch.full((d.R,), 3.0, device="cuda")
+        h.forward(p_t.data_ptr(), f_t.data_ptr() if d.posterior else 0, e_t.data_ptr(), Y.data_ptr(), sc.data_ptr())
+        torch.cuda.synchronize()
+        res.append((h.read_buffer("Y0", (d.R, d.T_pred, 2)), Y.cpu().numpy(), sc.cpu().numpy()))
+        h.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])                                  # sample generation: the same kernels on the same rows
+    tol = 2e-2 if d.bf16 == 1 else 2e-6
+    assert np.abs(res[0][1] - res[1][1]).max() <= tol and np.abs(res[0][2] - res[1][2]).max() <= 50 * tol
+    m = row_mask(d, keep)
+    assert np.abs(res[0][0][m]).max() > 0 and not np.abs(res[0][0][~m]).any()
+
+
+@pytest.mark.parametrize("which", ["none", "all", "one"])
+def test_device_side_counts_edge_cases_and_changing_batches(torch_cuda, which):
+    """Nothing / everything / one agent present, then a DIFFERENT presence pattern through the same handle (the counts are per call, nothing is cached on
+    the host): equal to a fresh uncompacted handle on present rows."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    d = small_dims(n_scenes=4, K=3, T_obs=6, T_pred=7, n_grids=1)
+    w = init_weights(d, 9)
+    cnts = {"none": [0, 0, 0, 0], "all": [d.mno] * 4, "one": [0, 1, 0, 0]}[which]
+    cases = [ragged_counts(d, seed=5, counts=cnts), ragged_counts(d, seed=6, counts=[5, 0, d.mno, 11])]
+    hc = _lib.Handle(d.replace(flags=FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC)); hc.set_weights(w); hc.set_option("compact_min_rows", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    for past, fut, eps, grids, gos, keep in cases:
+        _, Yr, sr = run(torch, d, w, past, fut, eps, grids, gos)
+        p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+        hc.set_scene_grids(g_t.data_ptr(), gos)
+        Y = torch.full((d.R, d.T_pred, 2), 7.0, device="cuda"); sc = torch.full((d.R,), 3.0, device="cuda")
+        hc.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr())
+        torch.cuda.synchronize()
+        m = row_mask(d, keep)
+        Yc, scc = Y.cpu().numpy(), sc.cpu().numpy()
+        assert np.isfinite(Yc).all() and np.isfinite(scc).all()
+        if m.any():
+            assert np.abs(Yc[m] - Yr[m]).max() < 2e-6 and np.abs(scc[m] - sr[m]).max() < 1e-4
+        assert not np.abs(Yc[~m]).any() and not np.abs(scc[~m]).any()
+    hc.close()
+
+
+def test_a_compacted_forward_replays_from_a_hipgraph(torch_cuda):
+    """no hipEventSynchronize in the compacted inference call any more, so it can be captured -- and the replayed graph follows the
+    DATA: the same graph run on windows with another presence pattern gives that batch's results (the counts are read on the device at replay time)."""
+    torch = torch_cuda
+    from desire_amd import _lib
+    d = small_dims(n_scenes=6, K=4, T_obs=8, T_pred=12, n_grids=1).replace(flags=FLAG_COMPACT_ROWS | FLAG_COMPACT_IOC)
+    w = init_weights(d, 5)
+    a = ragged_counts(d, seed=6, counts=[9, 3, 0, 14, d.mno, 1])
+    b = ragged_counts(d, seed=7, counts=[0, 20, 7, 2, 0, 11])
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    p, f, e, g = t(a[0]), t(a[1]), t(a[2]), t(a[3])
+    h = _lib.Handle(d); h.set_weights(w); h.set_option("compact_min_rows", 0); h.set_scene_grids(g.data_ptr(), a[4])
+    Y = torch.zeros((d.R, d.T_pred, 2), device="cuda"); sc = torch.zeros((d.R,), device="cuda")
+    side = torch.cuda.Stream(); sp = side.cuda_stream
+    torch.cuda.synchronize()
+    ref = {}
+    for tag, case in (("b", b), ("a", a)):                    # direct calls (the first also warms the lazy allocations up outside capture)
+        p.copy_(t(case[0])); f.copy_(t(case[1])); e.copy_(t(case[2]))
+        h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+        side.synchronize()
+        ref[tag] = (Y.clone(), sc.clone())
+    h.graph_begin(sp)
+    h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+    gid = h.graph_end(sp)
+    for rep in range(6):
+        tag, case = ("a", a) if rep % 2 == 0 else ("b", b)
+        p.copy_(t(case[0])); f.copy_(t(case[1])); e.copy_(t(case[2]))
+        Y.zero_(); sc.zero_()
+        torch.cuda.synchronize()
+        h.graph_launch(gid, sp)
+        side.synchronize()
+        assert torch.equal(Y, ref[tag][0]) and torch.equal(sc, ref[tag][1]), (rep, tag)
+    assert float(ref["a"][0].abs().max()) > 0 and not torch.equal(ref["a"][0], ref["b"][0])
+    # the read-back path still refuses capture
+    h.set_option("compact_host_counts", 1)
+    h.graph_begin(sp)
+    with pytest.raises(_lib.DesireError):
+        h.forward(p.data_ptr(), f.data_ptr(), e.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+    try:
+        h.graph_end(sp)
+    except _lib.DesireError:
+        pass
+    h.close()
