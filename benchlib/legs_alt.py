@@ -643,11 +643,34 @@ def sdd_leg(a, d, w, grids_t, gos, eps_t, Y, score, stream, dev):
     k4 = {}
     for name, ms in h4.get_profile():
         k4.setdefault(name, []).append(ms)
+    # same handle, counts READ BACK (the round-5 path, what training still does): launches sized exactly, one host wait per call -- the same-run A/B of
+    # the device-side counts the default path uses since round 6 (kernels.h: DynCount)
+    h4.set_option("compact_host_counts", 1)
+    for _ in range(2):
+        h4.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yi.data_ptr(), sci.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for _ in range(n2):
+        h4.forward(p2_t.data_ptr(), f2_t.data_ptr(), eps_t.data_ptr(), Yi.data_ptr(), sci.data_ptr(), stream)
+    torch.cuda.synchronize()
+    i_dt_rb = (time.perf_counter() - ts) / n2
+    from desire_amd.spec import flops_per_sample
+    from benchlib.common import FP32_MFMA_PEAK_TFLOPS
+    dense_tf = flops_per_sample(d) * present * d.K * d.n_scenes / i_dt / 1e12
     sdd["compact_rows_and_ioc"] = {"ms_per_step": i_dt * 1e3, "value_present_agents_only": present * d.K * d.n_scenes / i_dt,
+                                   "ms_per_step_with_count_read_back": i_dt_rb * 1e3,
                                    "kernel_ms_per_step": {k: round(float(np.sum(v)) / n2, 4) for k, v in k4.items()},
                                    "max_abs_diff_present_rows_vs_uncompacted": float((Yi[rows_present] - Y[rows_present]).abs().max()),
-                                   "note": "dims.flags = DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC; kernel_ms_per_step sums the launches of one "
-                                           "step (one IOC launch per slot class)"}
+                                   "roofline": {"bound": "mfma", "frac": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "present_rows_dense_formula_tflops": dense_tf, "present_rows_dense_formula_frac": dense_tf / FP32_MFMA_PEAK_TFLOPS,
+                                                "mfma_util_from_profile": {"k_ioc<PAD>": 0.77, "k_deconv2": 0.69, "k_deconv3": 0.80, "source": "profiles/r05_bench_sdd_compact_pmc_per_kernel.json"},
+                                                "note": "frac is null: the dense formula over-credits windows whose social bins are mostly empty (skipped exactly) and "
+                                                        "under-credits the dead rows of the padded slot-class tiles, so flops/time is not a utilisation figure here; "
+                                                        "present_rows_dense_formula_* = SURVEY D4's per-sample flops x present-agent samples / time (a LOWER bound of "
+                                                        "nothing and an UPPER bound of nothing -- reported for continuity); the executed fraction is the SQ MFMA-busy "
+                                                        "counter of the profile named beside it"},
+                                   "note": "dims.flags = DESIRE_FLAG_COMPACT_ROWS | DESIRE_FLAG_COMPACT_IOC, counts read on the device (no host wait; round 6); "
+                                           "kernel_ms_per_step sums the launches of one step (one IOC launch per slot class)"}
     h4.close()
     # ... and the fastest fp32-class form on real data: split operands (dims.bf16 = 2) with both compaction bits
     h5 = _lib.Handle(d2.replace(flags=d2.flags | 4 | 8, bf16=2))

@@ -122,6 +122,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     const bool enc_c = compact_rows(h) && !(h->training && h->head_loss_w > 0.f);
     const bool dyn = enc_c && compact_dyn(h);
     const int32_t* dynP = nullptr;                                       // the present-agent count on the device (cp_count[0]) when `dyn`
+    int hintP = 0;
     h->cp_enc = false;
     int Ae = A;
     const float* pastE = dev_past; const float* futE = dev_fut;
@@ -130,7 +131,13 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     const int32_t* amap = nullptr;
     if (enc_c) {
         if (int rc = compact_setup(h)) return rc;
-        if (dyn) dynP = static_cast<const int32_t*>(h->ws["cp_count"].p);
+        if (dyn) {
+            dynP = static_cast<const int32_t*>(h->ws["cp_count"].p);
+            // a GUESS of P for choices that are about speed only (which variant of a row GEMM): whatever the mapped word holds -- the previous call's count, or
+            // this one's if the scan has already run.  Never a bound: the grids are the worst case's and the kernels read the real count.
+            hintP = *static_cast<volatile int32_t*>(h->cp_host);
+            if (hintP < 0 || hintP > A) hintP = 0;
+        }
         launch_valid_from_frames(dev_past, d.n_scenes, d.T_obs, d.mno, validE, s);
         if (int rc = compact_scans(h, s)) return rc;
         if (int rc = compact_wait(h, s)) return rc;
@@ -186,7 +193,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         GemmArgs g{};
         g.A = HxE; g.lda = 2 * H; g.M = Ae; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
         g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");
-        g.dyn = DynCount{dynP, 1};
+        g.dyn = DynCount{dynP, 1}; g.M_hint = hintP;
         { Timer t(h, s, "fc_c"); launch_gemm_rows(g, EPI_BIAS_RELU, s); }
         ConvArgs c{};
         c.n = Ae; c.dyn = DynCount{dynP, 1};
@@ -213,7 +220,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = Ae; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
         g.NT = (2 * d.L + 31) / 32; g.out = paramsE; g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
-        g.dyn = DynCount{dynP, 1};
+        g.dyn = DynCount{dynP, 1}; g.M_hint = hintP;
         { Timer t(h, s, "vae_enc_fc"); launch_gemm_rows(g, EPI_BIAS, s); }
         if (enc_c) launch_scatter_agents(paramsE, W(h, "params"), amap, Ae, 2 * d.L, s, dynP);       // desire_losses / the reparam backward read them per agent
     }
@@ -273,6 +280,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
     g.dyn = DynCount{dynP, d.K};
+    if (dyn) { const int hp = *static_cast<volatile int32_t*>(h->cp_host); g.M_hint = (hp > 0 && hp <= h->A) ? hp * d.K : 0; }
     // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
     // two-piece operands are an IOC-kernel matter (sample generation must not move Y0 by more than fp32 rounding)
     const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask(h) & 8)))) && d.bn_mode == 0 && !d.ref_compat;

@@ -29,6 +29,7 @@ struct GemmArgs {
     const float* p0; const float* p1; int chmod;
     const float* aux;                              // [M, ldo] saved activation for the gradient epilogues
     DynCount dyn;                                  // M = cnt[0] * mul on the device (see DynCount)
+    int M_hint;                                    // with dyn: a GUESS of the device-side M (the previous call's count) -- picks the kernel variant, never a bound
 };
 void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s);
 

@@ -47,18 +47,22 @@ void launch_present_scan(const uint8_t* valid, int A, int32_t* amap, int32_t* in
 }
 
 // ---- agent-level gathers: out[a', :] = in[amap[a'], :]  (HxHy, p_last, params) ------------------------------------------------------
+// grids of the element-wise kernels that may carry a device-side count: capped, the kernels stride over their elements -- with the worst case as the
+// launch size most of an uncapped grid would be workgroups that exit at once (0.1 ms of dead dispatches per step on 512 SDD windows)
+static inline unsigned cp_grid(long n) { const long b = (n + 255) / 256; return (unsigned)(b < 8192 ? (b < 1 ? 1 : b) : 8192); }
+#define CP_FOR(i, total) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)(total); i += (long)gridDim.x * blockDim.x)
 // (dynP, here and below: the count on the DEVICE -- the host passes the worst case as P for the grid and the kernel reads the real one; kernels.h: DynCount)
 __global__ void k_gather_agents(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ amap, int P, int ld, const int32_t* __restrict__ dynP) {
     if (dynP) P = dynP[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * ld) return;
-    const int ap = (int)(i / ld), c = (int)(i - (long)ap * ld);
-    out[i] = in[(size_t)amap[ap] * ld + c];
+    CP_FOR(i, (long)P * ld) {
+        const int ap = (int)(i / ld), c = (int)(i - (long)ap * ld);
+        out[i] = in[(size_t)amap[ap] * ld + c];
+    }
 }
 void launch_gather_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s, const int32_t* dynP) {
     const long n = (long)P * ld;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_gather_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, amap, P, ld, dynP);
+    hipLaunchKernelGGL(k_gather_agents, dim3(cp_grid(n)), dim3(256), 0, s, in, out, amap, P, ld, dynP);
 }
 // out[amap[a'], c0 + c] += in[a', c]  (the compact domain's share of d loss / d Hx back onto the agents; one writer per element)
 __global__ void k_scatter_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ amap, int P, int n) {
@@ -84,22 +88,22 @@ __device__ __forceinline__ size_t full_row_of(int rp, int P, int K, int mno, con
 __global__ void k_reparam_c(const float* __restrict__ params_c, const float* __restrict__ eps, float* __restrict__ z,
                             const int32_t* __restrict__ amap, int P, int K, int mno, int L, int posterior, const int32_t* __restrict__ dynP) {
     if (dynP) P = dynP[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * K * L) return;
-    const int rp = (int)(i / L), l = (int)(i - (long)rp * L);
-    const size_t r = full_row_of(rp, P, K, mno, amap);
-    float e = eps[r * L + l];
-    if (posterior) {
-        const int ap = rp % P;
-        const float mu = params_c[(size_t)ap * 2 * L + l], ls = params_c[(size_t)ap * 2 * L + L + l];
-        e = mu + sqrtf(expf(ls)) * e;
+    CP_FOR(i, (long)P * K * L) {
+        const int rp = (int)(i / L), l = (int)(i - (long)rp * L);
+        const size_t r = full_row_of(rp, P, K, mno, amap);
+        float e = eps[r * L + l];
+        if (posterior) {
+            const int ap = rp % P;
+            const float mu = params_c[(size_t)ap * 2 * L + l], ls = params_c[(size_t)ap * 2 * L + L + l];
+            e = mu + sqrtf(expf(ls)) * e;
+        }
+        z[i] = e;
     }
-    z[i] = e;
 }
 void launch_reparam_c(const float* params_c, const float* eps, float* z, const int32_t* amap, int P, int K, int mno, int L, int posterior, hipStream_t s, const int32_t* dynP) {
     const long n = (long)P * K * L;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_reparam_c, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, params_c, eps, z, amap, P, K, mno, L, posterior, dynP);
+    hipLaunchKernelGGL(k_reparam_c, dim3(cp_grid(n)), dim3(256), 0, s, params_c, eps, z, amap, P, K, mno, L, posterior, dynP);
 }
 
 // ---- rows between the domains: n floats per row ---------------------------------------------------------------------------------------
@@ -107,18 +111,18 @@ void launch_reparam_c(const float* params_c, const float* eps, float* z, const i
 __global__ void k_scatter_rows(const float* __restrict__ comp, float* __restrict__ full0, float* __restrict__ full1,
                                const int32_t* __restrict__ amap, int P, int K, int mno, int n, const int32_t* __restrict__ dynP) {
     if (dynP) P = dynP[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * K * n) return;
-    const int rp = (int)(i / n), c = (int)(i - (long)rp * n);
-    const size_t r = full_row_of(rp, P, K, mno, amap);
-    const float v = comp[i];
-    full0[r * n + c] = v;
-    if (full1) full1[r * n + c] = v;
+    CP_FOR(i, (long)P * K * n) {
+        const int rp = (int)(i / n), c = (int)(i - (long)rp * n);
+        const size_t r = full_row_of(rp, P, K, mno, amap);
+        const float v = comp[i];
+        full0[r * n + c] = v;
+        if (full1) full1[r * n + c] = v;
+    }
 }
 void launch_scatter_rows(const float* comp, float* full0, float* full1, const int32_t* amap, int P, int K, int mno, int n, hipStream_t s, const int32_t* dynP) {
     const long t = (long)P * K * n;
     if (t <= 0) return;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, comp, full0, full1, amap, P, K, mno, n, dynP);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(cp_grid(t)), dim3(256), 0, s, comp, full0, full1, amap, P, K, mno, n, dynP);
 }
 // gather: compact[r', :] = full[r, :]
 __global__ void k_gather_rows(const float* __restrict__ full, float* __restrict__ comp, const int32_t* __restrict__ amap, int P, int K, int mno, int n) {
@@ -216,25 +220,25 @@ __global__ void k_cls_gather_agents(const float* __restrict__ Hx, int ld, const 
                                     float* __restrict__ Hx_c, float* __restrict__ p_c, uint8_t* __restrict__ valid_c, int32_t* __restrict__ gos_c,
                                     const int32_t* __restrict__ dynN) {
     if (dynN) n_c = dynN[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long NA = (long)n_c * m_c;
-    if (i < n_c) gos_c[i] = gos[win[i]];
-    if (i < NA) {
-        const int a = cmap[i];
-        valid_c[i] = a >= 0 ? 1 : 0;
-        p_c[2 * i] = a >= 0 ? p_last[2 * (size_t)a] : 0.f;
-        p_c[2 * i + 1] = a >= 0 ? p_last[2 * (size_t)a + 1] : 0.f;
+    CP_FOR(i, NA * ld) {
+        if (i < n_c) gos_c[i] = gos[win[i]];
+        if (i < NA) {
+            const int a = cmap[i];
+            valid_c[i] = a >= 0 ? 1 : 0;
+            p_c[2 * i] = a >= 0 ? p_last[2 * (size_t)a] : 0.f;
+            p_c[2 * i + 1] = a >= 0 ? p_last[2 * (size_t)a + 1] : 0.f;
+        }
+        const long ia = i / ld; const int c = (int)(i - ia * ld);
+        const int a = cmap[ia];
+        Hx_c[i] = a >= 0 ? Hx[(size_t)a * ld + c] : 0.f;
     }
-    if (i >= NA * ld) return;
-    const long ia = i / ld; const int c = (int)(i - ia * ld);
-    const int a = cmap[ia];
-    Hx_c[i] = a >= 0 ? Hx[(size_t)a * ld + c] : 0.f;
 }
 void launch_cls_gather_agents(const float* Hx, int ld, const float* p_last, const int32_t* gos, const int32_t* cmap, const int32_t* win, int n_c, int m_c,
                               float* Hx_c, float* p_c, uint8_t* valid_c, int32_t* gos_c, hipStream_t s, const int32_t* dynN) {
     const long n = (long)n_c * m_c * ld;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_cls_gather_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Hx, ld, p_last, gos, cmap, win, n_c, m_c, Hx_c, p_c, valid_c, gos_c, dynN);
+    hipLaunchKernelGGL(k_cls_gather_agents, dim3(cp_grid(n)), dim3(256), 0, s, Hx, ld, p_last, gos, cmap, win, n_c, m_c, Hx_c, p_c, valid_c, gos_c, dynN);
 }
 // rows: dir = 0 gather  comp[class row of (w', k, j), :] = full[row(cmap, k), :] (zeros for padding);  dir = 1 scatter back (padding rows dropped).
 // Class row of (w', k, j): packed (gpt = 0) (w'*K + k)*m_c + j; padded tiles (gpt > 0) tile*32 + (G % gpt)*m_c + j with G = w'*K + k, tile = G / gpt.
@@ -245,28 +249,28 @@ __global__ void k_cls_rows(float* __restrict__ full, float* __restrict__ comp, c
         const long ngrp = (long)n_c * K;
         rows = gpt ? ((ngrp + gpt - 1) / gpt) * 32 : ngrp * m_c;
     }
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * n) return;
-    const long rc = i / n; const int c = (int)(i - rc * n);
-    int j; long g;
-    if (gpt) {
-        const int il = (int)(rc & 31), gi = il / m_c;
-        j = il - gi * m_c; g = (rc >> 5) * gpt + gi;
-        if (gi >= gpt || g >= (long)n_c * K) { if (!dir) comp[i] = 0.f; return; }
-    } else { j = (int)(rc % m_c); g = rc / m_c; }
-    const int k = (int)(g % K); const int wp = (int)(g / K);
-    const int a = cmap[(size_t)wp * m_c + j];
-    if (a < 0) { if (!dir) comp[i] = 0.f; return; }
-    const int sc = a / mno, slot = a - sc * mno;
-    const size_t r = ((size_t)sc * K + k) * mno + slot;
-    if (dir) full[r * n + c] = comp[i]; else comp[i] = full[r * n + c];
+    CP_FOR(i, rows * n) {
+        const long rc = i / n; const int c = (int)(i - rc * n);
+        int j; long g;
+        if (gpt) {
+            const int il = (int)(rc & 31), gi = il / m_c;
+            j = il - gi * m_c; g = (rc >> 5) * gpt + gi;
+            if (gi >= gpt || g >= (long)n_c * K) { if (!dir) comp[i] = 0.f; continue; }
+        } else { j = (int)(rc % m_c); g = rc / m_c; }
+        const int k = (int)(g % K); const int wp = (int)(g / K);
+        const int a = cmap[(size_t)wp * m_c + j];
+        if (a < 0) { if (!dir) comp[i] = 0.f; continue; }
+        const int sc = a / mno, slot = a - sc * mno;
+        const size_t r = ((size_t)sc * K + k) * mno + slot;
+        if (dir) full[r * n + c] = comp[i]; else comp[i] = full[r * n + c];
+    }
 }
 void launch_cls_rows(float* full, float* comp, const int32_t* cmap, int n_c, int m_c, int K, int mno, int n, int dir, hipStream_t s, int gpt, const int32_t* dynN) {
     const long ngrp = (long)n_c * K;
     const long rows = gpt ? ((ngrp + gpt - 1) / gpt) * 32 : ngrp * m_c;
     const long t = rows * n;
     if (t <= 0) return;
-    hipLaunchKernelGGL(k_cls_rows, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir, gpt, rows, dynN);
+    hipLaunchKernelGGL(k_cls_rows, dim3(cp_grid(t)), dim3(256), 0, s, full, comp, cmap, n_c, m_c, K, mno, n, dir, gpt, rows, dynN);
 }
 // out[cmap[i], c] += in[i, c] for the seated agents of a class (cmap[i] >= 0; one writer per element: an agent sits in exactly one class slot)
 __global__ void k_cls_scatter_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ cmap, int NA, int n) {
@@ -300,32 +304,32 @@ void launch_valid_from_frames(const float* past, int n_scenes, int T, int mno, u
 // frames_c[0, t, a', :] = frames[scene, t, slot, :]
 __global__ void k_gather_frames(const float* __restrict__ frames, float* __restrict__ out, const int32_t* __restrict__ amap, int P, int T, int mno, const int32_t* __restrict__ dynP) {
     if (dynP) P = dynP[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)T * P) return;
-    const int t = (int)(i / P), ap = (int)(i - (long)t * P);
-    const int a = amap[ap];
-    const int sc = a / mno, slot = a - sc * mno;
-    const float* src = frames + (((size_t)sc * T + t) * mno + slot) * 3;
-    float* dst = out + (size_t)i * 3;
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    CP_FOR(i, (long)T * P) {
+        const int t = (int)(i / P), ap = (int)(i - (long)t * P);
+        const int a = amap[ap];
+        const int sc = a / mno, slot = a - sc * mno;
+        const float* src = frames + (((size_t)sc * T + t) * mno + slot) * 3;
+        float* dst = out + (size_t)i * 3;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
 }
 void launch_gather_frames(const float* frames, float* out, const int32_t* amap, int P, int T, int mno, hipStream_t s, const int32_t* dynP) {
     const long n = (long)T * P;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_gather_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frames, out, amap, P, T, mno, dynP);
+    hipLaunchKernelGGL(k_gather_frames, dim3(cp_grid(n)), dim3(256), 0, s, frames, out, amap, P, T, mno, dynP);
 }
 // out[amap[a'], c] = in[a', c]   (rows of absent agents untouched: the caller zero-fills)
 __global__ void k_scatter_agents(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ amap, int P, int ld, const int32_t* __restrict__ dynP) {
     if (dynP) P = dynP[0];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * ld) return;
-    const int ap = (int)(i / ld), c = (int)(i - (long)ap * ld);
-    out[(size_t)amap[ap] * ld + c] = in[i];
+    CP_FOR(i, (long)P * ld) {
+        const int ap = (int)(i / ld), c = (int)(i - (long)ap * ld);
+        out[(size_t)amap[ap] * ld + c] = in[i];
+    }
 }
 void launch_scatter_agents(const float* in, float* out, const int32_t* amap, int P, int ld, hipStream_t s, const int32_t* dynP) {
     const long n = (long)P * ld;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_scatter_agents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, amap, P, ld, dynP);
+    hipLaunchKernelGGL(k_scatter_agents, dim3(cp_grid(n)), dim3(256), 0, s, in, out, amap, P, ld, dynP);
 }
 // out[a', c] += in[amap[a'], c]   (n columns; agent-level gradient from the caller's layout into the compact one)
 __global__ void k_gather_add_agents(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, const int32_t* __restrict__ amap, int P, int n) {

@@ -90,7 +90,8 @@ static void launch_gemm_rows_n(const GemmArgs& a, int epi, hipStream_t s) {
 // windows per call) that leaves most CUs idle behind one long dependent MFMA chain, so small launches give every wave ONE
 // 32 x 32 output tile instead (same k order per output: the results are bit-identical either way).
 void launch_gemm_rows(const GemmArgs& a, int epi, hipStream_t s) {
-    const long wgs = (long)((a.M + DS_TM - 1) / DS_TM) * ((a.NT + 15) / 16);
+    const int Msel = (a.dyn.cnt && a.M_hint > 0) ? a.M_hint : a.M;       // (device-side count: a.M is the worst case, which sizes the grid inside launch_gemm_rows_n)
+    const long wgs = (long)((Msel + DS_TM - 1) / DS_TM) * ((a.NT + 15) / 16);
     if (wgs < 128) launch_gemm_rows_n<1, 1>(a, epi, s); else launch_gemm_rows_n<4, 2>(a, epi, s);
 }
 

@@ -167,12 +167,18 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
 // dependent GRU steps): the first nb0 workgroups run a0, the rest a1
 template <int H, int TM>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder_pair(EncArgs a0, EncArgs a1, int nb0) {
-    const int blk = (int)blockIdx.x < nb0 ? (int)blockIdx.x : (int)blockIdx.x - nb0;
-    if (a0.dyn.cnt) {                             // device-side count (both encoders run on the same P present agents; nb0 is the worst case's)
+    if (a0.dyn.cnt) {
+        // device-side count: both encoders run on the same P present agents and the grid is the worst case's 2 * nb0 -- tiles are dealt alternately
+        // (block b = encoder b & 1, tile b >> 1), so that the live tiles of BOTH encoders are the first blocks dispatched (behind the worst case's
+        // dead blocks of the first encoder the second one started 0.18 ms late on 512 SDD windows)
         const int P = __builtin_amdgcn_readfirstlane(a0.dyn.cnt[0]);
         a0.mno = P; a1.mno = P;
+        const int blk = (int)blockIdx.x >> 1;
         if (blk * TM >= P) return;
+        if (blockIdx.x & 1) encoder_tile<H, TM, false>(a1, blk); else encoder_tile<H, TM, false>(a0, blk);
+        return;
     }
+    const int blk = (int)blockIdx.x < nb0 ? (int)blockIdx.x : (int)blockIdx.x - nb0;
     if ((int)blockIdx.x < nb0) encoder_tile<H, TM, false>(a0, blk);
     else encoder_tile<H, TM, false>(a1, blk);
 }

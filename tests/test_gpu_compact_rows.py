@@ -11,7 +11,7 @@ The loader pads every window to max_num_obj slots (utils/data_loader.py:209-229)
 import numpy as np
 import pytest
 
-from desire_amd.spec import FLAG_COMPACT_ROWS, init_weights
+from desire_amd.spec import FLAG_COMPACT_IOC, FLAG_COMPACT_ROWS, init_weights
 from tests.helpers import make_case, small_dims
 from tests.test_golden_e2e import load_case
 
