@@ -31,12 +31,6 @@
 #endif
 // TPGT: tiles per group as a compile-time constant (2, 3, 4: the neighbour-chunk loops of the pooling chains are then branch-free), or 0 = read
 // it from the arguments
-#ifndef CL_EARLY_COPY
-#define CL_EARLY_COPY 0
-#endif
-#ifndef CL_HRING
-#define CL_HRING 0
-#endif
 #ifndef IOC16CL_OCC
 #define IOC16CL_OCC 2
 #endif
@@ -169,11 +163,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 TICKC(0)
                 // 16-byte loads (sc1) of the peers' h_{t-1} tiles (published at the end of step t-1, parity (t-1)&1), all of a thread's
                 // chunks in flight: chunk i of a tile = column i >> 2, exchange positions 8 (i & 3) .. + 7 = lane half (i & 1), accumulator
-                // elements 8 (i >> 1 & 1) .. + 7 (publish_h).  CL_EARLY_COPY: requested BEFORE the position-only phase and stored to LDS
-                // after it (the wait for the peers then comes first; it is short: they run in step)
+                // elements 8 (i >> 1 & 1) .. + 7 (publish_h).  (Requesting them BEFORE the position-only phase was measured twice -- rounds 2 and 5: 4.73 ->
+                // 5.1 ms, 90 spilled registers -- and is gone.)
                 const unsigned pbyte = (unsigned)((t + 1) & 1) * (unsigned)n_tiles * (H * TM * 2);
                 constexpr int CPT = (H * 4 + NTHR - 1) / NTHR;                 // chunks per thread and peer tile
-                constexpr bool EARLY = CL_EARLY_COPY && TPGT > 0;
                 uint4 xv[TPGT > 0 ? (TPGT - 1) * CPT : 1];
                 auto request_peers = [&]() {
                     if constexpr (TPGT > 0) {
@@ -186,10 +179,6 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         }
                     }
                 };
-                if (EARLY && t > 0) {
-                    group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
-                    request_peers();
-                }
                 // ---- P1: e_v, e_s, neighbour bits of my rows against the whole group (positions only: no hidden state needed) ----
                 {
                     const float px = pg[my_slot * 2], py = pg[my_slot * 2 + 1];
@@ -254,10 +243,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 TICKC(1)
                 // ---- neighbours' h_{t-1} into the group's Ht ----
                 if (t > 0) {
-                    if (!EARLY) group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
+                    group_wait_wt(cnt, tpg * (it * (a.T + 1) + t), a.err);
                     TICKC(2)
                     if constexpr (TPGT > 0) {
-                        if (!EARLY) request_peers();
+                        request_peers();
 #pragma unroll
                         for (int pi = 0; pi < TPGT - 1; ++pi) {
                             const int tp = pi + (pi >= tile_pos ? 1 : 0);
@@ -341,30 +330,11 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         const int nb = mine ? __ffsll((long long)mine) - 1 : b;
                         uint4 mf[JGM];
                         frag_bits(b, mf);
-                        // the group's h^T fragments of a bin's NT link-1 chains as ONE stream through a ring of CL_HRING registers sets: the
-                        // chain is a dependent MFMA sequence whose A operand comes from LDS, and with one fragment register (what the
-                        // allocator leaves it) every MFMA waits a full LDS round trip -- ~1 100 cycles per chain of 8 instead of 256
-                        constexpr int JGc = TPGT > 0 ? 2 * TPGT : 1, NGc = NT * JGc, RDH = (CL_HRING > 0 && TPGT > 0) ? CL_HRING : 1;
-                        const u16* hq = Ht + c31 * LDT + 8 * hi;
-                        auto hread = [&](int g) { return *reinterpret_cast<const uint4*>(hq + (g / JGc) * 32 * LDT + 16 * (g % JGc)); };
-                        uint4 ar[RDH];
-                        if constexpr (CL_HRING > 0 && TPGT > 0) {
-#pragma unroll
-                            for (int g = 0; g < RDH; ++g) ar[g] = hread(g);
-                        }
+                        // (the chain's h^T fragments through a ring of 3 / 4 / 6 register sets instead of one was measured neutral in round 5 -- the CU's
+                        //  other workgroup already covers that LDS latency -- and is gone)
 #pragma unroll
                         for (int hb = 0; hb < NT; ++hb) {
-                            f32x16 da;
-                            if constexpr (CL_HRING > 0 && TPGT > 0) {
-                                da = zero16();
-#pragma unroll
-                                for (int jg = 0; jg < JGc; ++jg) {
-                                    const int g = hb * JGc + jg;
-                                    da = mfma16(ar[g % RDH], mf[jg], da);
-                                    if (g + RDH < NGc) ar[g % RDH] = hread(g + RDH);
-                                }
-                            } else
-                                da = chain(hb, mf);
+                            const f32x16 da = chain(hb, mf);
                             const uint4 p0 = make_uint4(pk_bf16(da[0], da[1]), pk_bf16(da[2], da[3]), pk_bf16(da[4], da[5]), pk_bf16(da[6], da[7]));
                             const uint4 p1 = make_uint4(pk_bf16(da[8], da[9]), pk_bf16(da[10], da[11]), pk_bf16(da[12], da[13]), pk_bf16(da[14], da[15]));
 #pragma unroll

@@ -447,15 +447,9 @@ __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v
 // the piece images take 8-byte writes, and the per-element stream offsets shrink to four per stream (the row-major kernel of round 3
 // spilled 54 dwords of them and took 4.3 ms longer per 81 920-row step).  Bias column sums by a butterfly over the rows (colsum16).
 // ------------------------------------------------------------------------------------------------------------------
-// gate / candidate contractions of the BPTT step: BWDX3_RD k-groups of pack fragments in flight (0 = mmax_groups: one group ahead)
-#ifndef BWDX3_RD
-#define BWDX3_RD 0
-#endif
-#if BWDX3_RD > 0
-#define BWDX3_MM(NB) mmax_groups_ring<NB, 2, true, BWDX3_RD>
-#else
+// gate / candidate contractions of the BPTT step: one k-group of pack fragments ahead (a deeper ring was measured in round 5 and was not faster:
+// docs/DESIGN_DETAIL.md section 13 item 3)
 #define BWDX3_MM(NB) mmax_groups<NB, 2, true>
-#endif
 #ifdef DESIRE_IOC_TIMING
 #define TICKB(k) { const long long now_ = clock64(); tacc[k] += now_ - tprev; tprev = now_; }
 #else

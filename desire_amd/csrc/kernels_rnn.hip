@@ -1369,13 +1369,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
         if constexpr (NP == 0) mma1(soc, AB + buf * TM * LDB + (lane & 31) * LDB + 4 * (lane >> 5), a.Wsoc + ((size_t)(b * NT + cb) * GH) * 64 + lane, GH);
         else {
             f32x16 t1[1] = {soc};
-            if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
-                const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
-                mma6_ring<1, NP, STEP_RING>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), reinterpret_cast<const uint4*>(a.Wsoc), t0, a.plo_soc, H / 16);
-            } else {
-                const uint4* bl[1] = {reinterpret_cast<const uint4*>(a.Wsoc) + ((size_t)(b * NT + cb) * (H / 16)) * 64 + lane};
-                mma6_groups<1, NP>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), bl, a.plo_soc, H / 16);
-            }
+            // (three pieces: one k-group ahead; a deeper fragment ring measured slower here, 13.55 vs 12.64 ms -- 96 more registers of fragments.  Two pieces run
+            //  k_ioc_step_x2 below)
+            const uint4* bl[1] = {reinterpret_cast<const uint4*>(a.Wsoc) + ((size_t)(b * NT + cb) * (H / 16)) * 64 + lane};
+            mma6_groups<1, NP>(t1, AB + buf * TM * LDB + (lane & 31) * LDB + 8 * (lane >> 5), bl, a.plo_soc, H / 16);
             soc = t1[0];
         }
         __syncthreads();
@@ -1392,13 +1389,8 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
     } else {
         f32x16 t2[2] = {rh, u};
         const uint4* wg = reinterpret_cast<const uint4*>(a.Wg);
-        if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
-            const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
-            mma6_ring<2, NP, (STEP_RING > 4 ? 4 : STEP_RING)>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), wg, t0, a.plo_g, KX / 16);
-        } else {
-            const uint4* bl[2] = {wg + ((size_t)cb * (KX / 16)) * 64 + lane, wg + ((size_t)(cb + NT) * (KX / 16)) * 64 + lane};
-            mma6_groups<2, NP>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), bl, a.plo_g, KX / 16);
-        }
+        const uint4* bl[2] = {wg + ((size_t)cb * (KX / 16)) * 64 + lane, wg + ((size_t)(cb + NT) * (KX / 16)) * 64 + lane};
+        mma6_groups<2, NP>(t2, XH + (lane & 31) * LDX + 8 * (lane >> 5), bl, a.plo_g, KX / 16);
         rh = t2[0]; u = t2[1];
     }
 #pragma unroll
@@ -1416,16 +1408,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
     } else {
         f32x16 t1[1] = {ac};
         const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
-        if constexpr (STEP_RING > 0 && NP == 2) {         // (three pieces: the ring measured slower, 13.55 vs 12.64 ms -- 96 more registers of fragments)
-            const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
-            mma6_ring<1, NP, STEP_RING>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), wc, tx, a.plo_c, E / 16);
-            mma6_ring<1, NP, STEP_RING>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), wc, th, a.plo_c, H / 16);
-        } else {
-            const uint4* bx[1] = {wc + ((size_t)cb * (KX / 16)) * 64 + lane};
-            mma6_groups<1, NP>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), bx, a.plo_c, E / 16);
-            const uint4* bh[1] = {wc + ((size_t)cb * (KX / 16) + E / 16) * 64 + lane};
-            mma6_groups<1, NP>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), bh, a.plo_c, H / 16);
-        }
+        const uint4* bx[1] = {wc + ((size_t)cb * (KX / 16)) * 64 + lane};
+        mma6_groups<1, NP>(t1, XH + (lane & 31) * LDX + 8 * (lane >> 5), bx, a.plo_c, E / 16);
+        const uint4* bh[1] = {wc + ((size_t)cb * (KX / 16) + E / 16) * 64 + lane};
+        mma6_groups<1, NP>(t1, AB + (lane & 31) * LDB + 8 * (lane >> 5), bh, a.plo_c, H / 16);
         ac = t1[0];
     }
 #pragma unroll
@@ -1462,23 +1448,21 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4 || NP != 0) ? 1 : 2) 
 // Same pieces (splitp) and the same products per accumulator as k_ioc_step<H, EV, C, 2>; measured against it (profiles/ab/ab_x2b.sh, three shapes): positions
 // within 1.5e-6, scores within 5e-6 -- the fp32 rounding class, not bit-identical.  configs[3]'s per-GPU shape: IOC 8.6 -> 8.0 ms, step 12.75 -> 12.16 ms.
 // ------------------------------------------------------------------------------------------------
-// PW > 0: PW extra PRODUCER waves per workgroup build the pooled operand of bin b + 1 (the neighbour gather: an L2 / Infinity-Cache round trip per batch
-// of rows) while the NT consumer waves contract bin b -- two instruction streams, so the gather's loads no longer sit in front of the weight-fragment
-// loads in the consumers' in-order vmcnt queue (the single-stream attempt to overlap them lost for exactly that reason).
-template <int H, int EV, int C, int PW>
-__global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepArgs a) {
+// (Round 5 also built this kernel with extra PRODUCER waves gathering bin b + 1 while the others contract bin b: bit-identical, 8.0 -> 10.5 ms at configs[3]'s
+//  shape -- twelve waves at H = 256 leave 168 registers each -- and removed in round 6; docs/DESIGN_DETAIL.md section 13 item 7 has the numbers.)
+template <int H, int EV, int C>
+__global__ __launch_bounds__((H / 32) * 64, 1) void k_ioc_step_x2(IocStepArgs a) {
 #ifdef STEP_TIMING
     long long tk[10]; int nk = 0; tk[nk++] = clock64();
     long long tbl = 0, tmm = 0, tbar = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int TM = 32, NP = 2, RD = STEP_RING > 0 ? ((PW && (H / 32) > 4 && STEP_RING > 4) ? 4 : STEP_RING) : 1;      // (twelve waves at H = 256: 168 registers each)
+    constexpr int TM = 32, NP = 2, RD = STEP_RING > 0 ? STEP_RING : 1;
     const int MW = (a.m_loc * a.nranks + 63) >> 6;
     constexpr int NT = H >> 5, E = EV + C + H, KX = E + H, LDXB = KX + 8, LDBB = H + 8;      // bf16 elements; (ld / 2) = 4 mod 8 dwords: conflict-free b128 reads
     constexpr int XLO = TM * LDXB, BLO = TM * LDBB;                                            // elements between the two piece images of a tile
     constexpr int NTHR = NT * 64, TPR = NTHR / TM;
-    constexpr int NALL = (NT + PW) * 64;                                  // all threads (consumers + producers)
-    constexpr int NBT = PW ? PW * 64 : NTHR, TPB = NBT / TM;               // threads that build the pooled operand, per row
+    constexpr int TPB = TPR;                                               // threads per row in the pooled-operand build
     constexpr int NCH = H / (4 * TPB);
     const int B = a.G * a.G;
     u16* Xb = reinterpret_cast<u16*>(smem_raw);                         // [NP][TM][LDXB]   e_v | e_s | e_r | h
@@ -1488,12 +1472,9 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
     float* red = wv + 3 * EV;                                           // [NT][TM]
     unsigned* occ = reinterpret_cast<unsigned*>(red + NT * TM);
     const int lane = lane_id(), cb = wave_id(), tid = threadIdx.x;
-    const bool consumer = tid < NTHR;                                      // (wave-uniform)
-    const int col = (consumer ? cb : 0) * 32 + (lane & 31);
-    const int r8 = consumer ? tid / TPR : 0, q8 = tid % TPR;
-    const int tb = PW ? tid - NTHR : tid;                                  // builder index
-    const bool builder = PW ? !consumer : true;
-    const int rb = builder ? tb / TPB : 0, qb = builder ? tb % TPB : 0;
+    const int col = cb * 32 + (lane & 31);
+    const int r8 = tid / TPR, q8 = tid % TPR;
+    const int rb = r8, qb = q8;                                            // row / quarter of this thread in the pooled-operand build
     const int row0 = blockIdx.x * TM;
     const int mall = a.m_loc * a.nranks;
     const int n_groups = a.R / a.m_loc;
@@ -1506,10 +1487,10 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
         splitp<2>(v0, v1, pp);
         *reinterpret_cast<unsigned*>(img) = pp[0]; *reinterpret_cast<unsigned*>(img + plo) = pp[1];
     };
-    for (int i = tid; i < 3 * EV; i += NALL) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
-    for (int i = tid; i < TM * B * MW; i += NALL) masks[i] = 0ull;
+    for (int i = tid; i < 3 * EV; i += NTHR) wv[i] = (i < 2 * EV) ? a.w_vel[i] : a.b_vel[i - 2 * EV];
+    for (int i = tid; i < TM * B * MW; i += NTHR) masks[i] = 0ull;
     if (tid < 2) occ[tid] = 0;
-    for (int i = tid; i < TM * (H >> 2); i += NALL) {
+    for (int i = tid; i < TM * (H >> 2); i += NTHR) {
         const int r = i / (H >> 2), c4 = i - r * (H >> 2);
         const float* sp = a.st_h + (size_t)min(row0 + r, a.R - 1) * H + c4 * 4;
         const float4 v = a.peer ? ld_sys_f4(sp) : *reinterpret_cast<const float4*>(sp);
@@ -1521,7 +1502,7 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
     const int grp = my_row / a.m_loc, sl = my_row - grp * a.m_loc;
     const int scene = grp / a.K;
     const int my_gslot = a.rank * a.m_loc + sl;
-    const int grp_b = min(row0 + rb, a.R - 1) / a.m_loc;                   // the builder's row may differ from the thread's P1 row
+    const int grp_b = min(row0 + rb, a.R - 1) / a.m_loc;
     auto pos_of = [&](int j, int t) {
         const int rk = j / a.m_loc, s = j - rk * a.m_loc;
         if (t < 0) {
@@ -1533,14 +1514,14 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
     };
     // h_{t-1} of my accumulator elements straight from the state (the LDS tile holds pieces only)
     f32x16 h = zero16();
-    if (consumer) {
+    {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float* sp = a.st_h + (size_t)min(row0 + acc_row(i), a.R - 1) * H + col;
             h[i] = a.peer ? __uint_as_float(ld_sys_u32(sp)) : *sp;
         }
     }
-    if (consumer) {
+    {
         const float2 pcur = pos_of(my_gslot, a.t), pprev = pos_of(my_gslot, a.t - 1);
         const float px = pcur.x, py = pcur.y;
         const float vx = px - pprev.x, vy = py - pprev.y;
@@ -1626,7 +1607,7 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
     unsigned long long om = (unsigned long long)__builtin_amdgcn_readfirstlane((int)occ[0]) & 0xffffffffull;
     om |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)occ[1]) << 32;
     int buf = 0;
-    if (om && builder) build(ffs_(om) - 1, 0);
+    if (om) build(ffs_(om) - 1, 0);
     __syncthreads();
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
@@ -1638,11 +1619,11 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
 #ifdef STEP_TIMING
         const long long c0 = clock64();
 #endif
-        if (om && builder) build(ffs_(om) - 1, buf ^ 1);
+        if (om) build(ffs_(om) - 1, buf ^ 1);
 #ifdef STEP_TIMING
         const long long c1 = clock64();
 #endif
-        if (consumer) {
+        {
             f32x16 t1[1] = {soc};
             const unsigned t0[1] = {(unsigned)((b * NT + cb) * (H / 16)) * 64u};
             mmaxp_ring<1, NP, RD>(t1, ABb + buf * NP * BLO + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, Wsoc, t0, a.plo_soc, H / 16);
@@ -1660,19 +1641,19 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
 #ifdef STEP_TIMING
     tk[nk++] = clock64();
 #endif
-    if (consumer) {
+    {
 #pragma unroll
         for (int i = 0; i < 16; ++i) st1(Xb + acc_row(i) * LDXB + EV + C + col, XLO, fmaxf(soc[i] + bso, 0.f));
     }
     __syncthreads();
     f32x16 rh = zero16(), u = zero16();
-    if (consumer) {
+    {
         f32x16 t2[2] = {rh, u};
         const unsigned t0[2] = {(unsigned)(cb * (KX / 16)) * 64u, (unsigned)((cb + NT) * (KX / 16)) * 64u};
         mmaxp_ring<2, NP, (RD > 4 ? 4 : RD)>(t2, x_lane, XLO, reinterpret_cast<const uint4*>(a.Wg), t0, a.plo_g, KX / 16);
         rh = t2[0]; u = t2[1];
     }
-    if (consumer) {
+    {
 #pragma unroll
         for (int i = 0; i < 16; ++i) rh[i] = sigmoidf_(rh[i] + bgr) * h[i];
 #pragma unroll
@@ -1685,7 +1666,7 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
     tk[nk++] = clock64();
 #endif
     f32x16 ac = zero16();
-    if (consumer) {
+    {
         f32x16 t1[1] = {ac};
         const uint4* wc = reinterpret_cast<const uint4*>(a.Wc);
         const unsigned tx[1] = {(unsigned)(cb * (KX / 16)) * 64u}, th[1] = {(unsigned)(cb * (KX / 16) + E / 16) * 64u};
@@ -1693,7 +1674,7 @@ __global__ __launch_bounds__((H / 32 + PW) * 64, 1) void k_ioc_step_x2(IocStepAr
         mmaxp_ring<1, NP, RD>(t1, ABb + (lane & 31) * LDBB + 8 * (lane >> 5), BLO, wc, th, a.plo_c, H / 16);
         ac = t1[0];
     }
-    if (consumer) {
+    {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         h[i] = gru_blend(u[i], h[i], tanhf_(ac[i] + bcc));
@@ -1735,23 +1716,13 @@ void launch_ioc_step(const IocStepArgs& a, hipStream_t s) {
     const dim3 grid((a.R + 31) / 32), block((a.H / 32) * 64);
     const size_t lds = ioc_step_lds(a);
 #define STEP_LAUNCH(HH, NPP) { allow_big_lds(k_ioc_step<HH, 16, 32, NPP>); hipLaunchKernelGGL((k_ioc_step<HH, 16, 32, NPP>), grid, block, lds, s, a); }
-    if (a.np == 2) {                 // two-piece operands: the piece-image form (STEP_X2_IMAGES = 0: the fp32-tile form of round 4, for the A/B)
-#ifndef STEP_X2_IMAGES
-#define STEP_X2_IMAGES 1
-#endif
-        if (STEP_X2_IMAGES) {
-            const size_t l2 = ioc_step_x2_lds(a);
-#ifndef STEP_PW
-#define STEP_PW 0                 // producer waves per workgroup building the pooled operand of the next bin (0: the consumers build it themselves).
-                                  // Measured at configs[3]'s shape (profiles/ab/ab_pw.sh, results bit-identical): 0 -> IOC 8.0 ms, 4 -> 10.5 ms (twelve waves at H = 256
-                                  // leave 168 registers each: 292 B of scratch per lane), 2 -> 26 ms
-#endif
-#define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32, STEP_PW>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32, STEP_PW>), grid, dim3(block.x + STEP_PW * 64), l2, s, a); }
-            if (a.H == 256) STEP2_LAUNCH(256) else if (a.H == 128) STEP2_LAUNCH(128) else STEP2_LAUNCH(64)
+    if (a.np == 2) {                 // two-piece operands: the piece-image form (the fp32-tile form of round 4, k_ioc_step<.., 2>, measured slower and is gone)
+        const size_t l2 = ioc_step_x2_lds(a);
+#define STEP2_LAUNCH(HH) { allow_big_lds(k_ioc_step_x2<HH, 16, 32>); hipLaunchKernelGGL((k_ioc_step_x2<HH, 16, 32>), grid, block, l2, s, a); }
+        if (a.H == 256) STEP2_LAUNCH(256) else if (a.H == 128) STEP2_LAUNCH(128) else STEP2_LAUNCH(64)
 #undef STEP2_LAUNCH
-            return;
-        }
-        if (a.H == 256) STEP_LAUNCH(256, 2) else if (a.H == 128) STEP_LAUNCH(128, 2) else STEP_LAUNCH(64, 2) return; }
+        return;
+    }
     if (a.np == 3) { if (a.H == 256) STEP_LAUNCH(256, 3) else if (a.H == 128) STEP_LAUNCH(128, 3) else STEP_LAUNCH(64, 3) return; }
     if (a.H == 256) STEP_LAUNCH(256, 0) else if (a.H == 128) STEP_LAUNCH(128, 0) else STEP_LAUNCH(64, 0)
 #undef STEP_LAUNCH

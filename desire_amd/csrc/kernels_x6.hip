@@ -397,9 +397,7 @@ void launch_deconv3_x6(const ConvArgs& a, hipStream_t s, int np) {
 // 128-column chunk of it is staged: three bf16 images [64][136] in LDS (52 KB: two workgroups per CU), every A fragment read feeds
 // all of a wave's n-tiles; weights are [p0 | p1 | p2] packs ("vae_dec/deconv1/W6", "mask/W6").  Same k order as the fp32 kernels.
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef X6_ROWS2_RD
-#define X6_ROWS2_RD 2
-#endif
+constexpr int X6_ROWS2_RD = 2;          // k-groups of weight fragments in flight in the two-row-block ring (1.66 / 0.73 ms at 2; 4 and 8 measured slower)
 namespace {
 constexpr int KC6 = 128, LDB6 = KC6 + 8, ILO6 = 64 * LDB6;
 // stages columns [k0, k0 + KC6) of 64 rows (row0..) of A [M, lda] into the three images
@@ -434,19 +432,12 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv1_x6(GemmArgs a) {          
         const int nt = (blockIdx.y * NTW + j) * 4 + w;
         if (nt >= a.NT) continue;
         f32x16 acc2[2] = {zero16(), zero16()};
-#if X6_ROWS2_RD > 0
         // both row blocks per fetched weight fragment, X6_ROWS2_RD k-groups in flight (was: the blocks one after the other, each streaming the
         // n-tile's fragments again).  Same-box A/B, 327 680 rows: deconv1 1.67 (old) / 1.66 (2 in flight) / 1.86 (4, 8) ms -- the kernel waits for its
         // 2.7 GB of output stores, not for fragments; the mask fc 0.79 / 0.73 / 0.70 ms.  (Also measured: the ring run ACROSS the wave's n-tiles, so that
         // no fragment is requested behind a tile's 32 stores per lane -- vmcnt retires in order -- 1.60 -> 1.90 ms.  More loads in flight only hurt here.)
         mmax_rows2_ring<3, X6_ROWS2_RD>(acc2, a8, 32 * LDB6, ILO6, Bp + ((size_t)nt * G16) * 64 + lane, plo, G16);
         f32x16 acc[2][1] = {{acc2[0]}, {acc2[1]}};
-#else
-        f32x16 acc[2][1] = {{zero16()}, {zero16()}};
-        const uint4* bl[1] = {Bp + ((size_t)nt * G16) * 64 + lane};
-#pragma unroll
-        for (int m = 0; m < 2; ++m) mmax_groups<1, 3>(acc[m], a8 + m * 32 * LDB6, ILO6, bl, plo, G16);
-#endif
         const int col = nt * 32 + (lane & 31);
         if (col >= a.N) continue;
         const int ch = col % a.chmod;
@@ -477,15 +468,9 @@ __global__ __launch_bounds__(DS_WG, 2) void k_mask_x6(MaskArgs a) {
         stage6(img, a.xhat, a.V, a.R, row0, k0, KC6, tid);
         __syncthreads();
         if (w < NT) {
-#if X6_ROWS2_RD > 0
             f32x16 acc2[2] = {acc[0][0], acc[1][0]};
             mmax_rows2_ring<3, X6_ROWS2_RD>(acc2, a8, 32 * LDB6, ILO6, Wp + ((size_t)w * G16 + (k0 >> 4)) * 64 + lane, plo, KC6 >> 4);
             acc[0][0] = acc2[0]; acc[1][0] = acc2[1];
-#else
-            const uint4* bl[1] = {Wp + ((size_t)w * G16 + (k0 >> 4)) * 64 + lane};
-#pragma unroll
-            for (int m = 0; m < 2; ++m) mmax_groups<1, 3>(acc[m], a8 + m * 32 * LDB6, ILO6, bl, plo, KC6 >> 4);
-#endif
         }
         __syncthreads();
     }

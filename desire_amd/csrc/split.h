@@ -91,44 +91,6 @@ __device__ __forceinline__ void mma6_groups(f32x16 (&acc)[NB], const float* ap, 
     if (g < G16) run(b0, g);
 }
 
-// The same contraction with D k-groups of B fragments in flight (ring slot = g % D).  One group is only NB * (3 | 6) MFMAs -- 100 to 400 matrix cycles
-// against the >= 1000 cycles a fragment takes to arrive from L2 / the Infinity Cache under load -- so with ONE group ahead (mma6_groups) every group
-// waits for its fragments: the step-wise IOC kernel at H = 256 streams 4 MB of W_soc per tile and step and ran its MFMAs at ~13 % (round 5).
-// Same products in the same order per accumulator as mma6_groups: results are bit-identical.  The ring loop stays ROLLED (see mmax_ring).
-// W = uniform base of the pack, t0[nb] = uint4 index of n-tile nb's group 0 / piece 0 (WITHOUT the lane), plo = piece stride: all wave-uniform.
-template <int NB, int NP, int D>
-__device__ __forceinline__ void mma6_ring(f32x16 (&acc)[NB], const float* ap, const uint4* W, const unsigned (&t0)[NB], size_t plo, int G16) {
-    uint4 b[D][NB][NP];
-    const unsigned lane16 = (unsigned)lane_id() * 16u;
-    auto ld = [&](uint4 (&bb)[NB][NP], int g) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const char* base = reinterpret_cast<const char*>(W + ((size_t)t0[nb] + (size_t)i * plo + (size_t)g * 64));
-                bb[nb][i] = *reinterpret_cast<const uint4*>(base + lane16);
-            }
-    };
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) if (dd < G16) ld(b[dd], dd);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma clang loop unroll(disable)
-    for (int g0 = 0; g0 < G16; g0 += D) {
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-            if (g0 + dd < G16) {                                   // (wave-uniform)
-                const FragP<NP> a = fragp<NP>(ap + (g0 + dd) * 16);
-#pragma unroll
-                for (int pr = 0; pr < Pairs<NP>::N; ++pr)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(a.p[Pairs<NP>::A[pr]], b[dd][nb][Pairs<NP>::B[pr]], acc[nb]);
-                if (g0 + dd + D < G16) ld(b[dd], g0 + dd + D);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 // acc[nb] += A[32 x 16G] . B_nb[16G x 32]: piece i of A = the image at ap + i * alo (bf16 elements); piece i of B = the pack at
 // bl[nb] + i * blo (uint4 units; bl already + lane).  One k-group at a time, the next group's fragments in flight (used by the
 // regression head only: G = H/16 groups once per pass).
@@ -167,37 +129,6 @@ __device__ __forceinline__ void mmax_groups(f32x16 (&acc)[NB], const u16* ap, in
         __builtin_amdgcn_sched_barrier(0);
     }
     if (g < G) run(b0, g);
-}
-
-// mmax_groups with D k-groups of pack fragments in flight (ring slot = g % D, the loop over rings stays rolled; per-lane pack pointers as in
-// mmax_groups; the same products in the same order per accumulator: bit-identical results).
-template <int NB, int NP, bool SWAP, int D>
-__device__ __forceinline__ void mmax_groups_ring(f32x16 (&acc)[NB], const u16* ap, int alo, const uint4* const (&bl)[NB], size_t blo, int G) {
-    uint4 b[D][NB][NP];
-    auto ld = [&](uint4 (&bb)[NB][NP], int g) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) bb[nb][i] = bl[nb][i * blo + (size_t)g * 64];
-    };
-#pragma unroll
-    for (int d = 0; d < D; ++d) if (d < G) ld(b[d], d);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma clang loop unroll(disable)
-    for (int g0 = 0; g0 < G; g0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (g0 + d < G) {                                      // (wave-uniform)
-                uint4 av[NP];
-#pragma unroll
-                for (int i = 0; i < NP; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * alo + (g0 + d) * 16);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = SWAP ? mfma_xp<NP>(b[d][nb], av, acc[nb]) : mfma_xp<NP>(av, b[d][nb], acc[nb]);
-                if (g0 + d + D < G) ld(b[d], g0 + d + D);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
 }
 
 // TWO row blocks against ONE n-tile of a pack: acc[m] += A_m[32 x 16G] . B[16G x 32], m = 0, 1 (images of block m at ap + m * amo), every pack
