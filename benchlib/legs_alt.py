@@ -161,6 +161,52 @@ def few_windows_leg(d_full, seed, dev):
         out["windows_%d" % n_w] = {"ms_per_call": dtw * 1e3, "value": dw.R / dtw, "unit": "samples/s", "samples_per_call": dw.R}
         h.close()
     out["note"] = "one call = encode + sample + refine for this many 32-agent windows (K = 20), back-to-back launches, no hipGraph"
+    # the same one-window call on a REAL window (bookstore/video6: ~9 of the 32 slots present, 32-px neighbourhood), padded and with both
+    # compaction bits (device-side counts: no host wait), back-to-back launches and replayed from a hipGraph
+    try:
+        from benchlib.common import sdd_windows
+        W_IMG, H_IMG = 1424.0, 1088.0
+        dr = d_full.replace(n_scenes=1, n_grids=1, nb_w=32.0 / W_IMG, nb_h=32.0 / H_IMG, sx=1.0 / W_IMG, sy=1.0 / H_IMG)
+        wr = init_weights(dr, seed)
+        past, fut, _ = sdd_windows(1, dr.mno)
+        _, _, eps, grids, gos = make_case(dr, seed=seed + 1)
+        p_t, f_t, e_t, g_t = t(past), t(fut), t(eps), t(grids)
+        present = int((past[0, -1, :, 0] != 0).sum())
+        real = {"present_agents": present, "slots": dr.mno}
+        side = torch.cuda.Stream()
+        for tag, fl in (("padded", 0), ("compact_rows_and_ioc", 12)):
+            h = _lib.Handle(dr.replace(flags=fl))
+            h.set_weights(wr)
+            h.set_scene_grids(g_t.data_ptr(), gos)
+            Y = torch.zeros((dr.R, dr.T_pred, 2), device=dev); sc = torch.zeros((dr.R,), device=dev)
+            for _ in range(5):
+                h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), stream)
+            torch.cuda.synchronize()
+            direct = (time.perf_counter() - t0) / 50
+            sp = side.cuda_stream
+            h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+            side.synchronize()
+            h.graph_begin(sp)
+            h.forward(p_t.data_ptr(), f_t.data_ptr(), e_t.data_ptr(), Y.data_ptr(), sc.data_ptr(), sp)
+            gid = h.graph_end(sp)
+            for _ in range(5):
+                h.graph_launch(gid, sp)
+            side.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                h.graph_launch(gid, sp)
+            side.synchronize()
+            graph = (time.perf_counter() - t0) / 50
+            assert bool(torch.isfinite(Y).all())
+            real[tag] = {"ms_per_call": direct * 1e3, "ms_per_call_hipgraph": graph * 1e3, "present_agent_samples_per_s": present * dr.K / min(direct, graph)}
+            h.close()
+        out["real_sdd_window_1"] = real
+    except Exception as e:                                      # noqa: BLE001 -- an extra figure must not cost the leg
+        out["real_sdd_window_1"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 

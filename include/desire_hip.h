@@ -117,9 +117,12 @@ typedef struct desire_dims {
                                       windows gathered into one pseudo-scene; "Hx" / "Hy" / "z_mean" of absent agents read back as zeros; not while
                                       desire_set_head_loss is on, whose term also counts objects that left before the last observed frame); rows of absent
                                       agents come back as zeros in dev_Yhat / "Y0" instead
-                                      of the decode of an all-zero track.  The IOC stage keeps its scene-shaped tiles.  Costs one host wait per desire_sample
-                                      (the present count is read back through a mapped word, overlapped with the CVAE encoder), so a compacted
-                                      desire_sample / desire_forward cannot be captured in a hipGraph.  Not with bn_mode = 2 (whole-batch statistics would
+                                      of the decode of an all-zero track.  The IOC stage keeps its scene-shaped tiles.  COUNTS: in inference with frozen
+                                      batch-norm (bn_mode 0) the host never learns how many agents are present -- every compacted launch is sized for the
+                                      worst case and reads its count from a device word the scan kernels wrote (round 6), so there is NO host wait and a compacted
+                                      desire_forward can be captured in a hipGraph and replayed on other data.  In training, with bn_mode 1, or after
+                                      desire_set_option(h, "compact_host_counts", 1) the count is read back through a mapped word instead (one host wait per
+                                      desire_encode, launches sized exactly, not capturable).  Not with bn_mode = 2 (whole-batch statistics would
                                       change) or ref_compat.  The intermediates "vae_in", "z", "d1".."d3", "xhat", "xz" of desire_read_buffer are then in the COMPACT
                                       row order r' = k*P + a' (P = present agents, a' = rank of the agent among them). */
 
@@ -129,8 +132,9 @@ typedef struct desire_dims {
                                       same kernels, and windows without a present agent are not run (their dev_Yhat rows are left as they came, score 0); rows of
                                       absent agents inside a window likewise keep their incoming dev_Yhat and get score 0.  A class too small to fill the device
                                       (< 8192 rows) is folded into the next larger one, so -- like dims.ioc_split -- the summation order of a window's social
-                                      pooling, i.e. the last bits of its result (<= 2e-6 on trajectories), depends on what else is in the batch.  Same host wait
-                                      and hipGraph restriction as DESIRE_FLAG_COMPACT_ROWS; shapes on the step-wise IOC (mno > 128; split operands at H = 256)
+                                      pooling, i.e. the last bits of its result (<= 2e-6 on trajectories), depends on what else is in the batch.  Counts as for
+                                      DESIRE_FLAG_COMPACT_ROWS (device-side in inference: every class is launched for the worst case at a static offset of the
+                                      class buffers and an empty class's grids exit); shapes on the step-wise IOC (mno > 128; split operands at H = 256)
                                       ignore the bit. */
 
 typedef struct desire_ctx desire_handle;
@@ -145,8 +149,9 @@ int desire_dims_size(void);
 const char* desire_build_hash(void);
 /* Changes one of the behavioural switches of desire_dims on a live handle: name = "ioc_form", "ioc_split", "train_fp32_mask" or
  * "flags"; takes effect at the next call (a flag that changes what desire_encode prepares -- DESIRE_FLAG_COMPACT_* -- at the next
- * desire_encode).  "compact_min_rows" (not a desire_dims field): the fold threshold of DESIRE_FLAG_COMPACT_IOC.  Unknown name or value
- * out of range: DESIRE_ERR_ARG. */
+ * desire_encode).  "compact_min_rows" (not a desire_dims field): the fold threshold of DESIRE_FLAG_COMPACT_IOC.  "compact_host_counts" (not a
+ * desire_dims field): 1 = inference reads the compaction counts back like training does (see DESIRE_FLAG_COMPACT_ROWS), 0 = device-side counts (default).
+ * Unknown name or value out of range: DESIRE_ERR_ARG. */
 int desire_set_option(desire_handle* h, const char* name, int32_t value);
 
 /* Replaces DESIREModel.__init__/build_model graph construction (model/model.py:36-77). */
