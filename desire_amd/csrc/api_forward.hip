@@ -162,7 +162,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
     e.wx_g = D(h, "enc_x/gk"); e.b_g = D(h, "enc_x/gb"); e.wx_c = D(h, "enc_x/ck"); e.b_c = D(h, "enc_x/cb");
     e.Whg = D4(h, "enc_x/Whg"); e.Whc = D4(h, "enc_x/Whc");
     e.out = HxE; e.ldo = 2 * H; e.p_last = plE; e.valid = validE;
-    e.dyn = DynCount{dynP, 1};
+    e.dyn = DynCount{dynP, 1, hintP};
     if (h->training) { e.sv_r = W(h, "ex_sv_r"); e.sv_u = W(h, "ex_sv_u"); e.sv_c = W(h, "ex_sv_c"); e.sv_h = W(h, "ex_sv_h"); e.sv_x = W(h, "ex_sv_x"); }
     const EncArgs ex = e;
     if (d.posterior) {
@@ -193,10 +193,10 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         GemmArgs g{};
         g.A = HxE; g.lda = 2 * H; g.M = Ae; g.K = 2 * H; g.Bp = D4(h, "fc_c/W"); g.G = 2 * H / 8;
         g.NT = h->V / 32; g.out = W(h, "vae_in"); g.ldo = h->V; g.N = h->V; g.p0 = D(h, "fc_c/b");
-        g.dyn = DynCount{dynP, 1}; g.M_hint = hintP;
+        g.dyn = DynCount{dynP, 1, hintP}; g.M_hint = hintP;
         { Timer t(h, s, "fc_c"); launch_gemm_rows(g, EPI_BIAS_RELU, s); }
         ConvArgs c{};
-        c.n = Ae; c.dyn = DynCount{dynP, 1};
+        c.n = Ae; c.dyn = DynCount{dynP, 1, hintP};
         c.in = W(h, "vae_in"); c.out = W(h, "c1"); c.w_raw = D(h, "vae_enc/conv1/raw");
         c.scale = D(h, "vae_enc/conv1/scale"); c.shift = D(h, "vae_enc/conv1/shift");
         const bool pobn = d.bn_mode != 0;                 // batch statistics: linear conv epilogue, then a normalise + activate pass per layer
@@ -220,7 +220,7 @@ extern "C" int desire_encode(desire_handle* h, const float* dev_past, const floa
         g = GemmArgs{};
         g.A = W(h, "c3"); g.lda = 2048; g.M = Ae; g.K = 2048; g.Bp = D4(h, "vae_enc/fc/W"); g.G = 2048 / 8;
         g.NT = (2 * d.L + 31) / 32; g.out = paramsE; g.ldo = 2 * d.L; g.N = 2 * d.L; g.p0 = D(h, "vae_enc/fc/b");
-        g.dyn = DynCount{dynP, 1}; g.M_hint = hintP;
+        g.dyn = DynCount{dynP, 1, hintP}; g.M_hint = hintP;
         { Timer t(h, s, "vae_enc_fc"); launch_gemm_rows(g, EPI_BIAS, s); }
         if (enc_c) launch_scatter_agents(paramsE, W(h, "params"), amap, Ae, 2 * d.L, s, dynP);       // desire_losses / the reparam backward read them per agent
     }
@@ -279,8 +279,9 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     g.A = W(h, "z"); g.lda = d.L; g.M = R; g.K = d.L; g.Bp = D4(h, "vae_dec/deconv1/W"); g.G = d.L / 8;
     g.NT = 64; g.out = W(h, "d1"); g.ldo = 2048; g.N = 2048;
     g.p0 = D(h, "vae_dec/deconv1/scale"); g.p1 = D(h, "vae_dec/deconv1/shift"); g.chmod = 128;
-    g.dyn = DynCount{dynP, d.K};
-    if (dyn) { const int hp = *static_cast<volatile int32_t*>(h->cp_host); g.M_hint = (hp > 0 && hp <= h->A) ? hp * d.K : 0; }
+    int hintS = 0;                                                       // count hint for this call's launches (see desire_encode)
+    if (dyn) { const int hp = *static_cast<volatile int32_t*>(h->cp_host); hintS = (hp > 0 && hp <= h->A) ? hp : 0; }
+    g.dyn = DynCount{dynP, d.K, hintS}; g.M_hint = hintS * d.K;
     // six-product sample generation (the fp32 kernels' accuracy class on the bf16 matrix pipe): dims.bf16 = 3, and dims.bf16 = 2 as well --
     // two-piece operands are an IOC-kernel matter (sample generation must not move Y0 by more than fp32 rounding)
     const bool x6gen = ((d.bf16 == 3 && !h->training) || (d.bf16 == 2 && (!h->training || (train_x3_mask(h) & 8)))) && d.bn_mode == 0 && !d.ref_compat;
@@ -292,7 +293,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     }
     else { Timer t(h, s, "deconv1"); launch_gemm_rows(g, EPI_SCALE_SHIFT_ELU, s); }
     ConvArgs c{};
-    c.n = R; c.dyn = DynCount{dynP, d.K};
+    c.n = R; c.dyn = DynCount{dynP, d.K, hintS};
     const bool pobn = d.bn_mode != 0;
     if (pobn) c.mode = 3;
     c.in = W(h, "d1"); c.out = W(h, "d2"); c.Wp = D4(h, "vae_dec/deconv2/W");
@@ -324,7 +325,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     MaskArgs m{};
     m.xhat = W(h, "xhat"); m.R = R; m.V = h->V; m.H = H; m.Hl = h->Hl; m.K = d.K; m.mno = mno;
     m.Wp = D4(h, "mask/W"); m.bias = D(h, "mask/b"); m.Hx = HxS; m.ldhx = 2 * H; m.xz = W(h, "xz");
-    m.dyn = DynCount{dynP, 1};
+    m.dyn = DynCount{dynP, 1, hintS};
     if (h->training) m.sv_p = W(h, "mask_sv_p");
     if (d.bf16 == 1) { m.Wp = D4(h, "mask/W16"); Timer t(h, s, "mask_fc"); launch_mask_bf16(m, s); }
     else if (x6gen && (H == 64 || H == 128) && h->V % 128 == 0) { m.Wp = D4(h, "mask/W6"); Timer t(h, s, "mask_fc"); launch_mask_x6(m, s); }
@@ -334,7 +335,7 @@ extern "C" int desire_sample(desire_handle* h, const float* dev_eps, float* dev_
     a.R = R; a.K = d.K; a.mno = mno; a.H = H; a.T = d.T_pred;
     a.Wxg = D4(h, "dec/Wxg"); a.Wxc = D4(h, "dec/Wxc"); a.Whg = D4(h, "dec/Whg"); a.Whc = D4(h, "dec/Whc");
     a.b_g = D(h, "dec/gb"); a.b_c = D(h, "dec/cb"); a.w_head = D(h, "head/w"); a.b_head = D(h, "head/b");
-    a.Y = Yout; a.hdump = nullptr; a.dyn = DynCount{dynP, 1};
+    a.Y = Yout; a.hdump = nullptr; a.dyn = DynCount{dynP, 1, hintS};
     if (d.ref_compat) { a.T = d.n_dec; a.hdump = W(h, "dec_states"); }       // model/model.py:280-285: 7 steps, the states are the output
     if (h->training) { a.hdump = W(h, "dec_sv_h"); a.sv_r = W(h, "dec_sv_r"); a.sv_u = W(h, "dec_sv_u"); a.sv_c = W(h, "dec_sv_c"); }
     if (d.bf16 == 1) {
@@ -382,7 +383,7 @@ static int ioc_core(desire_handle* h, const IocView& v, hipStream_t s) {
     a.Wreg = D4(h, "ioc/Wreg"); a.b_reg = D(h, "ioc/reg_b"); a.NTreg = (2 * d.T_pred + 31) / 32;
     a.variant = d.ioc_form;
     a.gpt = v.gpt; a.ngrp = v.ngrp;
-    a.dyn = DynCount{v.dynN, 1};
+    a.dyn = DynCount{v.dynN, 1, 0};
     // bf16: one workgroup holds groups of up to 64 agents; 96 / 128 (and 64 when variant 4 / 6 asks for it) run the cluster form
     // split forms: groups of up to 32 agents on 32-row tiles (also the training-mode forward); inference on groups of 64 agents runs the
     // 64-row tile of kernels_x6r2.hip (one group per tile) in either piece count

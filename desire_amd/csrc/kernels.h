@@ -17,7 +17,16 @@ inline void allow_big_lds(F* f) {
 // slot class, counted by kernels_compact.hip's scans).  The host sizes the grid -- and picks the kernel variant -- for the worst case and the kernel
 // replaces its count by cnt[0] * mul in its first instructions; workgroups beyond it exit before they touch memory.  No read-back, no host wait, the
 // call is hipGraph-capturable.  cnt == nullptr (every other launch): the count in the argument block stands.
-struct DynCount { const int32_t* cnt; int mul; };
+// hint: a GUESS of cnt[0] (the previous call's count, read from the scans' mapped word without waiting; 0 = none).  It only ever shrinks a GRID: launchers of
+// kernels that stride over their tiles (k_encoder_pair, k_deconv2/3 and their six-product forms) size the grid for hint * 1.25 + slack instead of the worst case,
+// and a count above that is still served -- more slowly -- by the stride loop.
+struct DynCount { const int32_t* cnt; int mul; int hint; };
+// units (rows / samples / agents) a strided launch is sized for: the worst case in the arguments, or the hinted count with a quarter of slack
+inline int dyn_units(int worst, const DynCount& d) {
+    if (!d.cnt || d.hint <= 0) return worst;
+    const long g = (long)d.hint * d.mul, want = g + g / 4 + 256;
+    return (int)(want < (long)worst ? want : (long)worst);
+}
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_SCALE_SHIFT_ELU = 2, EPI_NONE = 3, EPI_ELUGRAD = 4, EPI_SIGGRAD = 5 };
 

@@ -153,96 +153,100 @@ __global__ __launch_bounds__(DS_WG) void k_deconv2(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float out_s[];     // [4][64 px][64 co]
     const int lane = lane_id(), w = wave_id();
     const int hf = w & 1, sp = w >> 1;
-    const int s0 = blockIdx.x * 4 + sp * 2;
+    // tiles bx, bx + gridDim.x, ..: one per workgroup unless the grid was sized from a count HINT (kernels.h: DynCount.hint) that the real count exceeds
     DYN_N(a, n, blockIdx.x * 4)
-    const int c = lane & 31, hi = lane >> 5;
-    float* my = out_s + (sp * 2) * 4096;
-    // zero this wave's region: 2 samples x 64 px x 32 co
-    // this wave's region = [2 samples x 64 px] x its 32 output channels; 8 lanes x float4 cover one row of it
-    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
-    for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // A fragments: row = lane&31 -> (s = row>>4, p = row&15)
-    float4 af[16];
-    {
-        const int row = lane & 31;
-        const int smp = min(s0 + (row >> 4), a.n - 1);
-        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 4 * hi;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
-    }
-    // taps: B fragments of tap t+1 are fetched while tap t contracts (two register sets, loop unrolled
-    // by 2 so the sets are addressed statically).  The scatter is a plain LDS read-add-write: this wave
-    // is the only writer of its region (deterministic), and ds_add_f32 measured 1.4x SLOWER on the whole
-    // kernel (LDS atomics retire at a fraction of the plain ds_read/ds_write rate).
-    auto load_b = [&](float4 (&b)[16], int tap) {
-        const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16) * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) b[g] = bp[g * 64];
-    };
-    auto do_tap = [&](const float4 (&b)[16], int tap) {
-        const int ky = tap / 5, kx = tap - ky * 5;
-        f32x16 acc = zero16();
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            acc = mfma32(af[g].x, b[g].x, acc);
-            acc = mfma32(af[g].y, b[g].y, acc);
-            acc = mfma32(af[g].z, b[g].z, acc);
-            acc = mfma32(af[g].w, b[g].w, acc);
+    for (int bx = blockIdx.x; bx * 4 < a.n; bx += gridDim.x) {
+        const int s0 = bx * 4 + sp * 2;
+        const int c = lane & 31, hi = lane >> 5;
+        float* my = out_s + (sp * 2) * 4096;
+        // zero this wave's region: 2 samples x 64 px x 32 co
+        // this wave's region = [2 samples x 64 px] x its 32 output channels; 8 lanes x float4 cover one row of it
+        const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // A fragments: row = lane&31 -> (s = row>>4, p = row&15)
+        float4 af[16];
+        {
+            const int row = lane & 31;
+            const int smp = min(s0 + (row >> 4), a.n - 1);
+            const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 4 * hi;
+    #pragma unroll
+            for (int g = 0; g < 16; ++g) af[g] = *reinterpret_cast<const float4*>(src + g * 8);
         }
-        // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column:
-        // read all, then add and write all -- written as one dependent chain the compiler serialises 16 LDS round trips
-        float* dst[16]; float old[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = acc_row(i);
-            const int s = rr >> 4, p = rr & 15;
-            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-            dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) old[i] = *dst[i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) *dst[i] = old[i] + acc[i];
-    };
-    float4 b0[16], b1[16];
-    load_b(b0, 0);
-#pragma clang loop unroll(disable)
-    for (int tap = 0; tap < 24; tap += 2) {
-        load_b(b1, tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        do_tap(b0, tap);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(b0, tap + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        do_tap(b1, tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    do_tap(b0, 24);
-    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
-    for (int i = 0; i < 16; ++i) {
-        const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
-        const int smp = s0 + (sp_px >> 6);
-        if (smp < a.n) {
-            const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
-            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
-            float4 o;
-            if (FWD) {                                                 // forward: BN + ELU, nothing else in the loop
-                o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);
-                o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
-            } else {
-                o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
-                o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
-                o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
-                o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+        // taps: B fragments of tap t+1 are fetched while tap t contracts (two register sets, loop unrolled
+        // by 2 so the sets are addressed statically).  The scatter is a plain LDS read-add-write: this wave
+        // is the only writer of its region (deterministic), and ds_add_f32 measured 1.4x SLOWER on the whole
+        // kernel (LDS atomics retire at a fraction of the plain ds_read/ds_write rate).
+        auto load_b = [&](float4 (&b)[16], int tap) {
+            const float4* bp = a.Wp + ((size_t)(tap * 2 + hf) * 16) * 64 + lane;
+    #pragma unroll
+            for (int g = 0; g < 16; ++g) b[g] = bp[g * 64];
+        };
+        auto do_tap = [&](const float4 (&b)[16], int tap) {
+            const int ky = tap / 5, kx = tap - ky * 5;
+            f32x16 acc = zero16();
+    #pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc = mfma32(af[g].x, b[g].x, acc);
+                acc = mfma32(af[g].y, b[g].y, acc);
+                acc = mfma32(af[g].z, b[g].z, acc);
+                acc = mfma32(af[g].w, b[g].w, acc);
             }
-            *reinterpret_cast<float4*>(a.out + ix) = o;
+            // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column:
+            // read all, then add and write all -- written as one dependent chain the compiler serialises 16 LDS round trips
+            float* dst[16]; float old[16];
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = acc_row(i);
+                const int s = rr >> 4, p = rr & 15;
+                const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+                dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
+            }
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) old[i] = *dst[i];
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) *dst[i] = old[i] + acc[i];
+        };
+        float4 b0[16], b1[16];
+        load_b(b0, 0);
+    #pragma clang loop unroll(disable)
+        for (int tap = 0; tap < 24; tap += 2) {
+            load_b(b1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            do_tap(b0, tap);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(b0, tap + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            do_tap(b1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        do_tap(b0, 24);
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
+        for (int i = 0; i < 16; ++i) {
+            const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
+            const int smp = s0 + (sp_px >> 6);
+            if (smp < a.n) {
+                const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
+                const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
+                float4 o;
+                if (FWD) {                                                 // forward: BN + ELU, nothing else in the loop
+                    o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);
+                    o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
+                } else {
+                    o.x = conv_epilogue(v.x, sc4.x, sh4.x, a.mode, false, a.yprev, ix);
+                    o.y = conv_epilogue(v.y, sc4.y, sh4.y, a.mode, false, a.yprev, ix + 1);
+                    o.z = conv_epilogue(v.z, sc4.z, sh4.z, a.mode, false, a.yprev, ix + 2);
+                    o.w = conv_epilogue(v.w, sc4.w, sh4.w, a.mode, false, a.yprev, ix + 3);
+                }
+                *reinterpret_cast<float4*>(a.out + ix) = o;
+            }
         }
     }
 }
 void launch_deconv2(const ConvArgs& a, hipStream_t s) {
     allow_big_lds(k_deconv2<true>); allow_big_lds(k_deconv2<false>);
-    if (a.mode == 0) hipLaunchKernelGGL(k_deconv2<true>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
-    else hipLaunchKernelGGL(k_deconv2<false>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+    const int ng = dyn_units(a.n, a.dyn);                  // (device-side count: the grid follows the count hint, the kernel strides over what is left)
+    if (a.mode == 0) hipLaunchKernelGGL(k_deconv2<true>, dim3((ng + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
+    else hipLaunchKernelGGL(k_deconv2<false>, dim3((ng + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,75 +267,80 @@ __global__ __launch_bounds__(NS * 64) void k_deconv3(ConvArgs a) {
     float* zero_row = smem;                                            // [96] floats, 256-byte aligned (dynamic LDS base)
     float* in_s = smem + 128;                                          // [NS][64][LDP]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int s0 = blockIdx.x * NS;
-    DYN_N(a, n, s0)
-    for (int i = tid; i < 128; i += NS * 64) zero_row[i] = 0.f;
-    for (int i = tid; i < NS * 64 * 16; i += NS * 64) {
-        const int pix = i >> 4, c4 = i & 15;
-        const int smp = s0 + (pix >> 6);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
-        *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
-    }
-    __syncthreads();
-    const int smp = s0 + w;
-    const float* mine = in_s + w * 64 * LDP;
-    const int c = lane & 31, hi = lane >> 5;
-    // transposed contraction (weights as the A operand): the accumulators hold D[co][pixel] with lane = pixel and the 16
-    // registers = output channels in runs of four, so the epilogue stores float4 (4x fewer store instructions)
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
-        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
-    }
-    int qy[2], qx[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
-    for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-            f32x16 acc[2] = {zero16(), zero16()};
-            for (int ky = 1 - py; ky < 5; ky += 2)
-                for (int kx = 1 - px; kx < 5; kx += 2) {
-                    const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
-                    const float* ap[2];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int iy = qy[m] + dy, ix = qx[m] + dx;
-                        const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
-                        ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row + ((((w * 64 + iy * 8 + ix + 64) * LDP + 128) & 63))) + 4 * hi;
-                    }
-                    mma_groups_ptr<2, true>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
-                }
-            if (smp < a.n) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
-                    const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const size_t ix = base + 8 * q;
-                        float4 o;
-                        if (FWD) {
-                            o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
-                            o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
-                        } else {
-                            o.x = conv_epilogue(acc[m][4 * q], sc[q].x, sh[q].x, a.mode, false, a.yprev, ix);
-                            o.y = conv_epilogue(acc[m][4 * q + 1], sc[q].y, sh[q].y, a.mode, false, a.yprev, ix + 1);
-                            o.z = conv_epilogue(acc[m][4 * q + 2], sc[q].z, sh[q].z, a.mode, false, a.yprev, ix + 2);
-                            o.w = conv_epilogue(acc[m][4 * q + 3], sc[q].w, sh[q].w, a.mode, false, a.yprev, ix + 3);
+    // tiles bx, bx + gridDim.x, ..: one per workgroup unless the grid was sized from a count HINT (kernels.h: DynCount.hint) that the real count exceeds
+    DYN_N(a, n, blockIdx.x * NS)
+    for (int bx = blockIdx.x; bx * NS < a.n; bx += gridDim.x) {
+        const int s0 = bx * NS;
+        for (int i = tid; i < 128; i += NS * 64) zero_row[i] = 0.f;
+        for (int i = tid; i < NS * 64 * 16; i += NS * 64) {
+            const int pix = i >> 4, c4 = i & 15;
+            const int smp = s0 + (pix >> 6);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
+            *reinterpret_cast<float4*>(in_s + pix * LDP + c4 * 4) = v;
+        }
+        __syncthreads();
+        const int smp = s0 + w;
+        const float* mine = in_s + w * 64 * LDP;
+        const int c = lane & 31, hi = lane >> 5;
+        // transposed contraction (weights as the A operand): the accumulators hold D[co][pixel] with lane = pixel and the 16
+        // registers = output channels in runs of four, so the epilogue stores float4 (4x fewer store instructions)
+        float4 sc[4], sh[4];
+    #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
+            sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
+        }
+        int qy[2], qx[2];
+    #pragma unroll
+        for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                f32x16 acc[2] = {zero16(), zero16()};
+                for (int ky = 1 - py; ky < 5; ky += 2)
+                    for (int kx = 1 - px; kx < 5; kx += 2) {
+                        const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+                        const float* ap[2];
+    #pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int iy = qy[m] + dy, ix = qx[m] + dx;
+                            const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                            ap[m] = (ok ? mine + (iy * 8 + ix) * LDP : zero_row + ((((w * 64 + iy * 8 + ix + 64) * LDP + 128) & 63))) + 4 * hi;
                         }
-                        *reinterpret_cast<float4*>(a.out + ix) = o;
+                        mma_groups_ptr<2, true>(acc, ap, a.Wp + ((size_t)(ky * 5 + kx) * 8) * 64 + lane, 8);
+                    }
+                if (smp < a.n) {
+    #pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
+                        const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const size_t ix = base + 8 * q;
+                            float4 o;
+                            if (FWD) {
+                                o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
+                                o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
+                            } else {
+                                o.x = conv_epilogue(acc[m][4 * q], sc[q].x, sh[q].x, a.mode, false, a.yprev, ix);
+                                o.y = conv_epilogue(acc[m][4 * q + 1], sc[q].y, sh[q].y, a.mode, false, a.yprev, ix + 1);
+                                o.z = conv_epilogue(acc[m][4 * q + 2], sc[q].z, sh[q].z, a.mode, false, a.yprev, ix + 2);
+                                o.w = conv_epilogue(acc[m][4 * q + 3], sc[q].w, sh[q].w, a.mode, false, a.yprev, ix + 3);
+                            }
+                            *reinterpret_cast<float4*>(a.out + ix) = o;
+                        }
                     }
                 }
             }
-        }
+        __syncthreads();                                   // (the next tile of this workgroup restages the LDS tiles)
+    }
 }
 void launch_deconv3(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (128 + (size_t)4 * 64 * 68) * sizeof(float);
     allow_big_lds(k_deconv3<true, 4>); allow_big_lds(k_deconv3<false, 4>);
-    if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_deconv3<false, 4>), dim3((a.n + 3) / 4), dim3(256), lds, s, a);
+    const int ng = dyn_units(a.n, a.dyn);
+    if (a.mode == 0) hipLaunchKernelGGL((k_deconv3<true, 4>), dim3((ng + 3) / 4), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_deconv3<false, 4>), dim3((ng + 3) / 4), dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -168,14 +168,17 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder(EncArgs a
 template <int H, int TM>
 __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder_pair(EncArgs a0, EncArgs a1, int nb0) {
     if (a0.dyn.cnt) {
-        // device-side count: both encoders run on the same P present agents and the grid is the worst case's 2 * nb0 -- tiles are dealt alternately
-        // (block b = encoder b & 1, tile b >> 1), so that the live tiles of BOTH encoders are the first blocks dispatched (behind the worst case's
-        // dead blocks of the first encoder the second one started 0.18 ms late on 512 SDD windows)
+        // device-side count: both encoders run on the same P present agents; the grid is 2 * nb0 with nb0 sized from the count hint (kernels.h: DynCount.hint) or,
+        // without one, for the worst case -- a workgroup strides over its encoder's tiles.  First half of the grid = past encoder, second half = future encoder,
+        // as in the plain launch: consecutive workgroups go to consecutive XCDs, and dealing the two encoders' tiles alternately (tried) put every 40-step tile
+        // of the future encoder on four of the eight XCDs
         const int P = __builtin_amdgcn_readfirstlane(a0.dyn.cnt[0]);
         a0.mno = P; a1.mno = P;
-        const int blk = (int)blockIdx.x >> 1;
-        if (blk * TM >= P) return;
-        if (blockIdx.x & 1) encoder_tile<H, TM, false>(a1, blk); else encoder_tile<H, TM, false>(a0, blk);
+        const bool second = (int)blockIdx.x >= nb0;
+        for (int blk = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x; blk * TM < P; blk += nb0) {
+            if (second) encoder_tile<H, TM, false>(a1, blk); else encoder_tile<H, TM, false>(a0, blk);
+            __syncthreads();                              // the next tile re-initialises the LDS state
+        }
         return;
     }
     const int blk = (int)blockIdx.x < nb0 ? (int)blockIdx.x : (int)blockIdx.x - nb0;
@@ -184,7 +187,8 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64) void k_encoder_pair(EncA
 }
 void launch_encoder_pair(const EncArgs& a0, const EncArgs& a1, hipStream_t s) {
     constexpr int TM = 32;
-    const int nb0 = (a0.n_scenes * a0.mno + TM - 1) / TM, nb1 = (a1.n_scenes * a1.mno + TM - 1) / TM;
+    int nb0 = (a0.n_scenes * a0.mno + TM - 1) / TM, nb1 = (a1.n_scenes * a1.mno + TM - 1) / TM;
+    if (a0.dyn.cnt) nb0 = nb1 = (dyn_units(a0.n_scenes * a0.mno, a0.dyn) + TM - 1) / TM;       // (device-side count: tiles dealt alternately, grid = 2 * nb0, strided)
     const size_t lds = (TM * (a0.H + 4) + TM * 2) * sizeof(float);
     const dim3 grid(nb0 + nb1);
     if (a0.H == 256) hipLaunchKernelGGL((k_encoder_pair<256, TM>), grid, dim3(512), lds, s, a0, a1, nb0);

@@ -183,73 +183,76 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv2_x6(ConvArgs a, size_t plo)
     constexpr int RD = 4;
     const int lane = lane_id(), w = wave_id();
     const int hf = w & 1, sp = w >> 1;
-    const int s0 = blockIdx.x * 4 + sp * 2;
+    // tiles bx, bx + gridDim.x, ..: one per workgroup unless the grid was sized from a count HINT (kernels.h: DynCount.hint) that the real count exceeds
     DYN_N(a, n, blockIdx.x * 4)
-    const int c = lane & 31, hi = lane >> 5;
-    float* my = out_s6 + (sp * 2) * 4096;
-    const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
-    for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 af[8][NP];
-    {
-        const int row = lane & 31;
-        const int smp = min(s0 + (row >> 4), a.n - 1);
-        const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const FragP<NP> f = fragp<NP>(src + g * 16);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) af[g][i] = f.p[i];
-        }
-    }
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    uint4 rb[RD][NP];
-    auto req = [&](int tap, int g) {                       // g: compile-time after unrolling; the slot is g % RD (8 % RD == 0)
-        const uint4* bp = Wp + ((size_t)(min(tap, 24) * 2 + hf) * 8 + g) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) rb[g % RD][i] = bp[i * plo];
-    };
-#pragma unroll
-    for (int g = 0; g < RD; ++g) req(0, g);
-#pragma clang loop unroll(disable)
-    for (int tap = 0; tap < 25; ++tap) {
-        const int ky = tap / 5, kx = tap - ky * 5;
-        f32x16 accA = zero16(), accB = zero16();
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int sl = g % RD;
-#pragma unroll
-            for (int pr = 0; pr < Pairs<NP>::N; ++pr) {             // two accumulator chains, alternating
-                if (pr & 1) accB = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accB);
-                else accA = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accA);
+    for (int bx = blockIdx.x; bx * 4 < a.n; bx += gridDim.x) {
+        const int s0 = bx * 4 + sp * 2;
+        const int c = lane & 31, hi = lane >> 5;
+        float* my = out_s6 + (sp * 2) * 4096;
+        const int er = lane >> 3, ec = hf * 32 + (lane & 7) * 4;
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(my + (i * 8 + er) * 64 + ec) = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 af[8][NP];
+        {
+            const int row = lane & 31;
+            const int smp = min(s0 + (row >> 4), a.n - 1);
+            const float* src = a.in + ((size_t)smp * 16 + (row & 15)) * 128 + 8 * hi;
+    #pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const FragP<NP> f = fragp<NP>(src + g * 16);
+    #pragma unroll
+                for (int i = 0; i < NP; ++i) af[g][i] = f.p[i];
             }
-            if (g + RD < 8) req(tap, g + RD); else req(tap + 1, g + RD - 8);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column
-        float* dst[16]; float old[16];
-#pragma unroll
+        const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+        uint4 rb[RD][NP];
+        auto req = [&](int tap, int g) {                       // g: compile-time after unrolling; the slot is g % RD (8 % RD == 0)
+            const uint4* bp = Wp + ((size_t)(min(tap, 24) * 2 + hf) * 8 + g) * 64 + lane;
+    #pragma unroll
+            for (int i = 0; i < NP; ++i) rb[g % RD][i] = bp[i * plo];
+        };
+    #pragma unroll
+        for (int g = 0; g < RD; ++g) req(0, g);
+    #pragma clang loop unroll(disable)
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap - ky * 5;
+            f32x16 accA = zero16(), accB = zero16();
+    #pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int sl = g % RD;
+    #pragma unroll
+                for (int pr = 0; pr < Pairs<NP>::N; ++pr) {             // two accumulator chains, alternating
+                    if (pr & 1) accB = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accB);
+                    else accA = mfma16(af[g][Pairs<NP>::A[pr]], rb[sl][Pairs<NP>::B[pr]], accA);
+                }
+                if (g + RD < 8) req(tap, g + RD); else req(tap + 1, g + RD - 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the 16 targets of a lane are distinct (different input pixels, same tap) and no other lane touches its column
+            float* dst[16]; float old[16];
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                const int s = rr >> 4, p = rr & 15;
+                const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
+                dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
+            }
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) old[i] = *dst[i];
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) *dst[i] = old[i] + (accA[i] + accB[i]);
+        }
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
         for (int i = 0; i < 16; ++i) {
-            const int rr = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            const int s = rr >> 4, p = rr & 15;
-            const int o = ((p >> 2) + ky) * 8 + (p & 3) + kx;
-            dst[i] = my + (s * 64 + o) * 64 + hf * 32 + c;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) old[i] = *dst[i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) *dst[i] = old[i] + (accA[i] + accB[i]);
-    }
-    const float4 sc4 = *reinterpret_cast<const float4*>(a.scale + ec), sh4 = *reinterpret_cast<const float4*>(a.shift + ec);
-    for (int i = 0; i < 16; ++i) {
-        const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
-        const int smp = s0 + (sp_px >> 6);
-        if (smp < a.n) {
-            const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
-            const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
-            float4 o;
-            o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);      // inference only: BN + ELU
-            o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
-            *reinterpret_cast<float4*>(a.out + ix) = o;
+            const int sp_px = i * 8 + er;                                  // 0..127 = (sample, pixel)
+            const int smp = s0 + (sp_px >> 6);
+            if (smp < a.n) {
+                const float4 v = *reinterpret_cast<const float4*>(my + sp_px * 64 + ec);
+                const size_t ix = ((size_t)smp * 64 + (sp_px & 63)) * 64 + ec;
+                float4 o;
+                o.x = eluf_(v.x * sc4.x + sh4.x); o.y = eluf_(v.y * sc4.y + sh4.y);      // inference only: BN + ELU
+                o.z = eluf_(v.z * sc4.z + sh4.z); o.w = eluf_(v.w * sc4.w + sh4.w);
+                *reinterpret_cast<float4*>(a.out + ix) = o;
+            }
         }
     }
 }
@@ -257,11 +260,11 @@ void launch_deconv2_x6(const ConvArgs& a, hipStream_t s, int np) {
     const size_t plo = (size_t)25 * 2 * 8 * 64;                        // uint4 per piece: 25 taps x 2 n-tiles x 8 k-groups x 64 lanes
     if (np == 2) {
         allow_big_lds(k_deconv2_x6<2>);
-        hipLaunchKernelGGL(k_deconv2_x6<2>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
+        hipLaunchKernelGGL(k_deconv2_x6<2>, dim3((dyn_units(a.n, a.dyn) + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
         return;
     }
     allow_big_lds(k_deconv2_x6<3>);
-    hipLaunchKernelGGL(k_deconv2_x6<3>, dim3((a.n + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
+    hipLaunchKernelGGL(k_deconv2_x6<3>, dim3((dyn_units(a.n, a.dyn) + 3) / 4), dim3(DS_WG), 4 * 4096 * sizeof(float), s, a, plo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -283,99 +286,103 @@ __global__ __launch_bounds__(DS_WG, 2) void k_deconv3_x6i(ConvArgs a, size_t plo
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u16* img = reinterpret_cast<u16*>(smem);                           // [3][NPX + 1][LDB]
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
-    const int s0 = blockIdx.x * 2;
-    DYN_N(a, n, s0)
-    for (int i = tid; i < NP * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
-    for (int i = tid; i < NPX * 16; i += DS_WG) {
-        const int pix = i >> 4, c4 = i & 15;
-        const int smp = s0 + (pix >> 6);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
-        unsigned p0[NP], p1[NP];
-        splitp<NP>(v.x, v.y, p0); splitp<NP>(v.z, v.w, p1);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
-    }
-    __syncthreads();
-    const int ls = w >> 1, half = w & 1, smp = s0 + ls;
-    const int hi = lane >> 5;
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
-        sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
-    }
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
-    int qy[2], qx[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
-    for (int cls = 0; cls < 2; ++cls) {
-        const int py = cls, px = half ? 1 - cls : cls;                 // half 0: (0,0), (1,1);  half 1: (0,1), (1,0)
-        f32x16 acc[2] = {zero16(), zero16()};
-        const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
-        auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
-        uint4 bc[4][NP], bn[4][NP];
-        auto ldw = [&](uint4 (&b)[4][NP], int tap) {
-            const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < NP; ++i) b[g][i] = bp[i * plo + g * 64];
-        };
-        auto run = [&](const uint4 (&b)[4][NP], int t) {
-            const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
-            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
-            const u16* xp[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int iy = qy[m] + dy, ix = qx[m] + dx;
-                const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
-                xp[m] = img + (ok ? (ls * 64 + iy * 8 + ix) * LDB : ZB + ((((ls * 64 + iy * 8 + ix + 64) * LDB * 2) & 255) >> 1)) + 8 * hi;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint4 f0[NP], f1[NP];
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    f0[i] = *reinterpret_cast<const uint4*>(xp[0] + i * IMG + 16 * g);
-                    f1[i] = *reinterpret_cast<const uint4*>(xp[1] + i * IMG + 16 * g);
-                }
-#pragma unroll
-                for (int pr = 0; pr < Pairs<NP>::N; ++pr) {            // D[co][pixel]: the two row blocks alternate on the pipe
-                    acc[0] = mfma16(b[g][Pairs<NP>::B[pr]], f0[Pairs<NP>::A[pr]], acc[0]);
-                    acc[1] = mfma16(b[g][Pairs<NP>::B[pr]], f1[Pairs<NP>::A[pr]], acc[1]);
-                }
-            }
-        };
-        // weight fragments of the next tap in flight while this tap's 48 MFMAs run: two named register sets, no copies
-        ldw(bc, tap_of(0));
-        int t = 0;
-#pragma clang loop unroll(disable)
-        for (; t + 2 <= ntap; t += 2) {
-            ldw(bn, tap_of(t + 1));
-            __builtin_amdgcn_sched_barrier(0);
-            run(bc, t);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntap) ldw(bc, tap_of(t + 2));
-            __builtin_amdgcn_sched_barrier(0);
-            run(bn, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
+    // tiles bx, bx + gridDim.x, ..: one per workgroup unless the grid was sized from a count HINT (kernels.h: DynCount.hint) that the real count exceeds
+    DYN_N(a, n, blockIdx.x * 2)
+    for (int bx = blockIdx.x; bx * 2 < a.n; bx += gridDim.x) {
+        const int s0 = bx * 2;
+        for (int i = tid; i < NP * 192; i += DS_WG) img[(i / 192) * IMG + ZB + (i % 192)] = 0;
+        for (int i = tid; i < NPX * 16; i += DS_WG) {
+            const int pix = i >> 4, c4 = i & 15;
+            const int smp = s0 + (pix >> 6);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (smp < a.n) v = *reinterpret_cast<const float4*>(a.in + ((size_t)s0 * 64 + pix) * 64 + c4 * 4);
+            unsigned p0[NP], p1[NP];
+            splitp<NP>(v.x, v.y, p0); splitp<NP>(v.z, v.w, p1);
+    #pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<uint2*>(img + k * IMG + pix * LDB + c4 * 4) = make_uint2(p0[k], p1[k]);
         }
-        if (t < ntap) run(bc, t);
-        if (smp < a.n) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
-                const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 o;
-                    o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
-                    o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
-                    *reinterpret_cast<float4*>(a.out + base + 8 * q) = o;
+        __syncthreads();
+        const int ls = w >> 1, half = w & 1, smp = s0 + ls;
+        const int hi = lane >> 5;
+        float4 sc[4], sh[4];
+    #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4 * hi);
+            sh[q] = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4 * hi);
+        }
+        const uint4* Wp = reinterpret_cast<const uint4*>(a.Wp);
+        int qy[2], qx[2];
+    #pragma unroll
+        for (int m = 0; m < 2; ++m) { const int q = m * 32 + (lane & 31); qy[m] = q >> 3; qx[m] = q & 7; }
+        for (int cls = 0; cls < 2; ++cls) {
+            const int py = cls, px = half ? 1 - cls : cls;                 // half 0: (0,0), (1,1);  half 1: (0,1), (1,0)
+            f32x16 acc[2] = {zero16(), zero16()};
+            const int ny = py ? 3 : 2, nx = px ? 3 : 2, ntap = ny * nx;
+            auto tap_of = [&](int t) { const int iy = t / nx, ix = t - iy * nx; return (1 - py + 2 * iy) * 5 + (1 - px + 2 * ix); };
+            uint4 bc[4][NP], bn[4][NP];
+            auto ldw = [&](uint4 (&b)[4][NP], int tap) {
+                const uint4* bp = Wp + ((size_t)tap * 4) * 64 + lane;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g)
+    #pragma unroll
+                    for (int i = 0; i < NP; ++i) b[g][i] = bp[i * plo + g * 64];
+            };
+            auto run = [&](const uint4 (&b)[4][NP], int t) {
+                const int tap = tap_of(t), ky = tap / 5, kx = tap - ky * 5;
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;   // exact: numerators even
+                const u16* xp[2];
+    #pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int iy = qy[m] + dy, ix = qx[m] + dx;
+                    const bool ok = iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+                    xp[m] = img + (ok ? (ls * 64 + iy * 8 + ix) * LDB : ZB + ((((ls * 64 + iy * 8 + ix + 64) * LDB * 2) & 255) >> 1)) + 8 * hi;
+                }
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint4 f0[NP], f1[NP];
+    #pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        f0[i] = *reinterpret_cast<const uint4*>(xp[0] + i * IMG + 16 * g);
+                        f1[i] = *reinterpret_cast<const uint4*>(xp[1] + i * IMG + 16 * g);
+                    }
+    #pragma unroll
+                    for (int pr = 0; pr < Pairs<NP>::N; ++pr) {            // D[co][pixel]: the two row blocks alternate on the pipe
+                        acc[0] = mfma16(b[g][Pairs<NP>::B[pr]], f0[Pairs<NP>::A[pr]], acc[0]);
+                        acc[1] = mfma16(b[g][Pairs<NP>::B[pr]], f1[Pairs<NP>::A[pr]], acc[1]);
+                    }
+                }
+            };
+            // weight fragments of the next tap in flight while this tap's 48 MFMAs run: two named register sets, no copies
+            ldw(bc, tap_of(0));
+            int t = 0;
+    #pragma clang loop unroll(disable)
+            for (; t + 2 <= ntap; t += 2) {
+                ldw(bn, tap_of(t + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                run(bc, t);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < ntap) ldw(bc, tap_of(t + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                run(bn, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t < ntap) run(bc, t);
+            if (smp < a.n) {
+    #pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = 2 * qy[m] + py, ox = 2 * qx[m] + px;       // this lane's output pixel
+                    const size_t base = ((size_t)smp * 256 + oy * 16 + ox) * 32 + 4 * hi;
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 o;
+                        o.x = eluf_(acc[m][4 * q] * sc[q].x + sh[q].x); o.y = eluf_(acc[m][4 * q + 1] * sc[q].y + sh[q].y);
+                        o.z = eluf_(acc[m][4 * q + 2] * sc[q].z + sh[q].z); o.w = eluf_(acc[m][4 * q + 3] * sc[q].w + sh[q].w);
+                        *reinterpret_cast<float4*>(a.out + base + 8 * q) = o;
+                    }
                 }
             }
         }
+        __syncthreads();                                   // (the next tile of this workgroup restages the LDS tiles)
     }
 }
 void launch_deconv3_x6(const ConvArgs& a, hipStream_t s, int np) {
@@ -383,12 +390,12 @@ void launch_deconv3_x6(const ConvArgs& a, hipStream_t s, int np) {
     if (np == 2) {
         const size_t ldsi = (size_t)2 * (2 * 64 * 72 + 192) * sizeof(u16);
         allow_big_lds(k_deconv3_x6i<2>);
-        hipLaunchKernelGGL(k_deconv3_x6i<2>, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
+        hipLaunchKernelGGL(k_deconv3_x6i<2>, dim3((dyn_units(a.n, a.dyn) + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
         return;
     }
     const size_t ldsi = (size_t)3 * (2 * 64 * 72 + 192) * sizeof(u16);
     allow_big_lds(k_deconv3_x6i<3>);
-    hipLaunchKernelGGL(k_deconv3_x6i<3>, dim3((a.n + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
+    hipLaunchKernelGGL(k_deconv3_x6i<3>, dim3((dyn_units(a.n, a.dyn) + 1) / 2), dim3(DS_WG), ldsi, s, a, plo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
