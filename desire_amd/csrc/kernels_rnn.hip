@@ -60,6 +60,15 @@ __device__ __forceinline__ void encoder_tile(const EncArgs& a, int blk) {
     float* my_h = hs + (mt * 32 + 4 * (lane >> 5)) * LDH + col;       // + acc-row offset * LDH
 
     const int n_steps = ROLL ? a.T + a.n_roll : a.T;
+    // frame entries (id, x, y) of this thread's agent, one step ahead of their use: frames [n_scenes, T, mno, 3]
+    const float* fbase = a.frames;
+    float fr0 = 0.f, fr1 = 0.f, fr2 = 0.f;
+    if (tid < TM) {
+        const int ag = min(a0 + tid, A - 1);
+        const int sc = ag / a.mno, slot = ag - sc * a.mno;
+        fbase = a.frames + ((size_t)sc * a.T * a.mno + slot) * 3;
+        if (a.T > 0) { fr0 = fbase[0]; fr1 = fbase[1]; fr2 = fbase[2]; }
+    }
     for (int t = 0; t < n_steps; ++t) {
         if (ROLL && t >= a.T) {
             // sample() prediction step (model/model.py:643-681): the 5-wide head reads (mux, muy, log sx, log sy, corr) off the
@@ -88,15 +97,17 @@ __device__ __forceinline__ void encoder_tile(const EncArgs& a, int blk) {
             }
         } else
         if (tid < TM) {
+            // this step's frame entry was requested a step ahead (fr: the load's round trip -- 1 - 2 us of a dependent chain whose step is 8 us at H = 128 --
+            // used to sit in front of the step's first barrier); the next one is requested now and lands under this step's contractions
             const int ag = min(a0 + tid, A - 1);
-            const int sc = ag / a.mno, slot = ag - sc * a.mno;
-            const float* f = a.frames + (((size_t)sc * a.T + t) * a.mno + slot) * 3;
-            xs[tid * 2 + 0] = __fmul_rn(f[1], a.sx);
-            xs[tid * 2 + 1] = __fmul_rn(f[2], a.sy);
+            const float f0 = fr0, f1 = fr1, f2 = fr2;
+            if (t + 1 < a.T) { const float* fn = fbase + (size_t)(t + 1) * a.mno * 3; fr0 = fn[0]; fr1 = fn[1]; fr2 = fn[2]; }
+            xs[tid * 2 + 0] = __fmul_rn(f1, a.sx);
+            xs[tid * 2 + 1] = __fmul_rn(f2, a.sy);
             if (a.sv_x && a0 + tid < A) { a.sv_x[((size_t)ag * a.T + t) * 2] = xs[tid * 2]; a.sv_x[((size_t)ag * a.T + t) * 2 + 1] = xs[tid * 2 + 1]; }
             if (t == a.T - 1 && a0 + tid < A) {
                 if (a.p_last) { a.p_last[(size_t)ag * 2] = xs[tid * 2]; a.p_last[(size_t)ag * 2 + 1] = xs[tid * 2 + 1]; }
-                if (a.valid) a.valid[ag] = (f[0] != 0.f) ? 1 : 0;
+                if (a.valid) a.valid[ag] = (f0 != 0.f) ? 1 : 0;
             }
         }
         __syncthreads();                                   // xs ready, hs holds h_{t-1}
