@@ -46,6 +46,10 @@ fi
 if want config3; then
   stats bench_config3_shape_split --mno 64 --H 256 --K 50 --windows 4 --split --steps 10 --warmup 3
 fi
+if want x6; then        # the six-product / split sample-generation kernels got tile-stride loops this round (device-side counts): same time as r05 expected
+  stats bench_w512_split --split --steps 5 --warmup 2
+  stats bench_w512_x6 --x6 --steps 5 --warmup 2
+fi
 if want train; then
   stats train_split --train --split --steps 5 --warmup 2
   pmc   train_split --train --split
