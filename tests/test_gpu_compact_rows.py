@@ -416,7 +416,10 @@ def test_training_with_the_gaussian_head_loss_keeps_every_observed_object(torch_
 
 # ---- round 6: device-side counts (kernels.h: DynCount) -- inference sizes every compacted launch for the worst case and reads P / the class counts on the device
 @pytest.mark.parametrize("kw", [dict(), dict(bf16=2), dict(bf16=3), dict(bf16=1), dict(H=64, K=3, mno=16), dict(posterior=0), dict(mno=64, n_scenes=5, K=2, n_grids=1),
-                                dict(mno=96, n_scenes=3, K=2, n_grids=1), dict(mno=128, n_scenes=3, K=2, n_grids=1, bf16=1)],
+                                dict(mno=96, n_scenes=3, K=2, n_grids=1), dict(mno=128, n_scenes=3, K=2, n_grids=1, bf16=1),
+                                dict(mno=192, n_scenes=2, K=2, T_pred=8, n_grids=1),                       # step-wise IOC: the slot classes are ignored, the rows compact
+                                dict(mno=64, H=256, n_scenes=3, K=2, n_grids=1, bf16=2),                   # H = 256 with split operands: step-wise as well
+                                dict(ioc_form=8), dict(ioc_form=2)],                                       # row-compacted pooling / 64-row tiles as the class kernels
                          ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()) or "fp32")
 def test_device_side_counts_equal_the_read_back_counts(torch_cuda, kw):
     """The default inference path (no host wait) against desire_set_option("compact_host_counts", 1) (the round-5 path: counts read back, launches sized
