@@ -684,3 +684,27 @@ def test_scenes_of_more_than_128_agents_run_the_step_wise_ioc(torch_cuda, kw):
         small_dims(mno=288).validate()
     with pytest.raises(ValueError):
         small_dims(mno=160, bf16=1).validate()
+
+
+@pytest.mark.parametrize("G,nb_h,nb_w", [(4, 0.02, 0.3), (4, 0.125, 0.5), (3, 0.05, 0.25), (6, 0.03, 0.45), (2, 0.01, 0.2), (4, 32.0 / 1088.0, 256.0 / 1424.0)])
+def test_library_logpolar_table_equals_an_independent_computation(torch_cuda, G, nb_h, nb_w):
+    """the log-polar parity tests hand the oracle the LIBRARY's constant table (so that two libm's cannot move a bin edge), which left
+    the table itself pinned by four hand-checked radii only.  Here the table the library built (C++ pow / cos / sin in double, rounded to fp32) is compared
+    with numpy's own evaluation of the same closed forms: every one of its 3 G constants within ONE fp32 ulp, the exactly representable ones (cos / sin of
+    multiples of 90 degrees, radii that are exact powers) bit-equal."""
+    from desire_amd import _lib
+    from oracle import desire_oracle as O
+    d = small_dims(n_scenes=1, K=1, bin_mode=1, grid_size=G, nb_h=nb_h, nb_w=nb_w)
+    h = _lib.Handle(d)
+    lib_tab = h.bin_table()
+    h.close()
+    ref = O.logpolar_table(np.float32(nb_h), np.float32(nb_w), G)            # (the library receives fp32 dims)
+    used = list(range(G)) + [8 + 2 * k for k in range(G)] + [9 + 2 * k for k in range(G)]
+    for i in used:
+        a, b = np.float32(lib_tab[i]), np.float32(ref[i])
+        assert a == b or abs(float(a) - float(b)) <= float(np.spacing(np.float32(max(abs(a), abs(b), 1e-30)))), (i, a, b)
+        if abs(float(b)) < 1e-7:                                               # cos / sin of a multiple of 90 degrees: |value| is rounding noise of pi, far below
+            assert abs(float(a)) < 1e-7                                        # any coordinate difference it multiplies (both evaluations agree on that)
+    exact = sum(1 for i in used if np.float32(lib_tab[i]) == np.float32(ref[i]))
+    assert exact >= len(used) - 2, (exact, len(used))                          # at most a couple of last-bit differences between the two libm's
+    assert not np.any(lib_tab[[i for i in range(20) if i not in used]])       # the rest of the 20-float table is zero
