@@ -323,6 +323,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
 #pragma unroll
                         for (int k = 0; k < NT; ++k) { const uint4* p = wptr(b0, 0, k); wq[2 * k] = p[0]; wq[2 * k + 1] = p[64]; }
                     }
+#ifdef CL_SETPRIO
+                    __builtin_amdgcn_s_setprio(CL_SETPRIO);
+#endif
 #pragma clang loop unroll(disable)
                     while (mine) {
                         const int b = __ffsll((long long)mine) - 1;
@@ -348,6 +351,9 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#ifdef CL_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     TICKC(4)
                     if (om) {                                          // (workgroup-uniform)
                         __syncthreads();                               // every wave is done reading Ht: it now carries the exchange slots
