@@ -323,9 +323,10 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
 #pragma unroll
                         for (int k = 0; k < NT; ++k) { const uint4* p = wptr(b0, 0, k); wq[2 * k] = p[0]; wq[2 * k + 1] = p[64]; }
                     }
-#ifdef CL_SETPRIO
-                    __builtin_amdgcn_s_setprio(CL_SETPRIO);
-#endif
+                    // wave priority by phase (round 6): the two workgroups of a CU put two waves on every SIMD, and a wave in its pooling chains (3) or gate
+                    // contraction (2) now wins the issue arbitration against one in a position / exchange phase (0).  Same-box A/B at configs[2]'s shape:
+                    // IOC 4.65 - 4.76 ms without -> 4.34 ms (equal priorities for both contractions: 4.52; the candidate phase raised too: 4.37 - 4.40)
+                    __builtin_amdgcn_s_setprio(3);
 #pragma clang loop unroll(disable)
                     while (mine) {
                         const int b = __ffsll((long long)mine) - 1;
@@ -351,9 +352,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#ifdef CL_SETPRIO
                     __builtin_amdgcn_s_setprio(0);
-#endif
                     TICKC(4)
                     if (om) {                                          // (workgroup-uniform)
                         __syncthreads();                               // every wave is done reading Ht: it now carries the exchange slots
@@ -419,6 +418,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                 // step from wave-uniform bases (the opaque zero keeps ~60 of them from being hoisted out of the time loop into spilled
                 // registers).  (Kept inline in both bf16 IOC kernels: as a shared helper the same code spills three times as much.)
                 f32x16 u, ac = zero16();
+                __builtin_amdgcn_s_setprio(2);
                 {
                     f32x16 g0 = zero16(), g1 = zero16();
                     int z4;
@@ -474,6 +474,7 @@ __global__ __launch_bounds__((H / 32) * 64, ((H / 32) <= 4) ? IOC16CL_OCC : 1) v
                         h[i] = gru_blend(u[i], h[i], c);
                         sp[i] = fmaf(h[i], wsc, sp[i]);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                     publish_h(h, true, (unsigned)((t & 1) * n_tiles + tile) * (H * TM * 2));       // LDS images + exchange buffer, parity t & 1
                 }
                 TICKC(8)

@@ -691,6 +691,11 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 if (om) build(ffs_(om) - 1, 0);
                 __syncthreads();
                 TICK(2)
+                // wave priority by phase (round 6): two workgroups per CU = two waves per SIMD; a wave inside its bin loop (3) or its gate / candidate
+                // contraction (2) wins the issue arbitration against one that builds operands or sits in the position phase (0).  Same-box ABAB on the
+                // headline: k_ioc 78.77 - 79.10 ms without, 78.55 - 78.65 with (the reverse order, 1 / 3: 79.1 - 79.25).  Where it pays properly is the
+                // bf16 cluster kernel (kernels_bf16_cl.hip: -6.5 %); k_ioc_bf16 and k_ioc_x3 measured neutral and carry none.
+                __builtin_amdgcn_s_setprio(3);
                 while (om) {
                     const int b = ffs_(om) - 1;
                     om &= om - 1;
@@ -710,6 +715,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                     TICK(5)
                     buf ^= 1;
                 }
+                __builtin_amdgcn_s_setprio(0);
                 if constexpr (NSPL > 1) {
                     // partial sums of this member's bins -> slot [tile][step parity][member]; total = fixed-order sum over the members
                     const int sidx = it * a.T + t;
@@ -751,6 +757,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                             *reinterpret_cast<const float4*>(XH + r * LDX + c4 * 4);
                 }
             }
+            __builtin_amdgcn_s_setprio(2);
             // ---- P4: gates over [x | h]; r*h goes to its own LDS tile so no "done reading h" barrier is needed ----
             f32x16 rh, u;
             if (active) {
@@ -789,6 +796,7 @@ __global__ __launch_bounds__((H / 32) * (TM / 32) * 64, ((H / 32) * (TM / 32) <=
                 for (int i = 0; i < 16; ++i)                               // h slot: last read by the gates, one barrier ago
                     my_x[((i & 3) + 8 * (i >> 2)) * LDX + E] = h[i];
             }
+            __builtin_amdgcn_s_setprio(0);
             // next step's P0: positions and cleared masks (masks were last read in the bin loop)
             if (tid < TM) {
                 pp[tid * 2] = pc[tid * 2]; pp[tid * 2 + 1] = pc[tid * 2 + 1];
